@@ -1,0 +1,80 @@
+"""Build libeavsr_hip.so in-tree with hipcc for gfx950 (no GPU needed: hipcc cross-compiles).
+
+    python -m eavsr_amd.build [--force] [--verbose]
+
+The shared object lands in eavsr_amd/lib/ (git-ignored, but it travels with gpurun snapshots).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libeavsr_hip.so")
+OBJDIR = os.path.join(LIBDIR, "obj")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fno-gpu-rdc",
+         "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the native library cannot be built")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "eavsr_hip.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build_native(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    dig = _digest() + "|" + " ".join(extra_flags)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

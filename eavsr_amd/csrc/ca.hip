@@ -1,0 +1,96 @@
+// Channel attention of the residual channel-attention blocks (a11).
+//
+// Reference: CALayer.forward models/networks.py:444-447 (AdaptiveAvgPool2d(1) -> 1x1 conv c -> c/16
+// -> ReLU -> 1x1 conv -> Sigmoid -> x * y) and RCABlock.forward :461-464 (res * y + x).
+// The global mean needs a grid-wide reduction between conv2 and the scale; the conv kernel leaves
+// per-tile channel sums (no atomics, fixed order), ca_scale finishes the mean + the 64->4->64 MLP for
+// every sample in one tiny launch, scale_residual applies `r * y + x` as a float4 stream.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(64) void ca_scale_kernel(const float* __restrict__ partial, int tiles, float inv_hw,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ scale, int c, int cr) {
+  extern __shared__ float sm[];  // mean[c] then hidden[cr]
+  float* mean = sm;
+  float* hid = sm + c;
+  const int bn = blockIdx.x;
+  for (int ch = threadIdx.x; ch < c; ch += 64) {
+    const float* p = partial + (size_t)bn * tiles * c + ch;
+    float s = 0.f;
+    for (int t = 0; t < tiles; ++t) s += p[(size_t)t * c];
+    mean[ch] = s * inv_hw;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < cr; j += 64) {
+    float v = b1[j];
+    for (int ch = 0; ch < c; ++ch) v += w1[j * c + ch] * mean[ch];
+    hid[j] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += 64) {
+    float v = b2[ch];
+    for (int j = 0; j < cr; ++j) v += w2[ch * cr + j] * hid[j];
+    scale[(size_t)bn * c + ch] = 1.f / (1.f + expf(-v));
+  }
+}
+
+// out = r * scale[n,c] + x ; hw % 4 == 0 fast path with 16-B accesses
+template <bool VEC>
+__global__ __launch_bounds__(256) void scale_residual_kernel(const float* __restrict__ r,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ x, float* __restrict__ out,
+                                                             int hw) {
+  const int nc = blockIdx.y;
+  const float s = scale[nc];
+  const size_t base = (size_t)nc * hw;
+  if (VEC) {
+    const int hw4 = hw >> 2;
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(r + base);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + base);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out + base);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
+      const f32x4 a = r4[i], b = x4[i];
+      f32x4 o;
+      o[0] = a[0] * s + b[0]; o[1] = a[1] * s + b[1]; o[2] = a[2] * s + b[2]; o[3] = a[3] * s + b[3];
+      o4[i] = o;
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256)
+      out[base + i] = r[base + i] * s + x[base + i];
+  }
+}
+
+}  // namespace
+
+extern "C" int eavsr_ca_scale_f32(const float* chan_partial, int32_t tiles, int32_t hw, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, float* scale, int32_t n,
+                                  int32_t c, int32_t cr, void* stream) {
+  EAVSR_REQUIRE(chan_partial && w1 && b1 && w2 && b2 && scale, -1, "ca_scale: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c > 0 && cr > 0 && tiles > 0 && hw > 0, -1, "ca_scale: bad dims");
+  EAVSR_REQUIRE((size_t)(c + cr) * sizeof(float) <= 48 * 1024, -1, "ca_scale: c too large");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(64), (c + cr) * sizeof(float), eavsr::as_stream(stream),
+                     chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, scale, c, cr);
+  return eavsr::launch_status("ca_scale");
+}
+
+extern "C" int eavsr_scale_residual_f32(const float* r, const float* scale, const float* x, float* out, int32_t n,
+                                        int32_t c, int32_t hw, void* stream) {
+  EAVSR_REQUIRE(r && scale && x && out, -1, "scale_residual: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c >= 0 && hw > 0, -1, "scale_residual: bad dims");
+  EAVSR_REQUIRE((long)n * c <= 65535, -1, "scale_residual: n*c too large");
+  if (n * c == 0) return 0;
+  const bool vec = (hw % 4) == 0 && (((uintptr_t)r | (uintptr_t)x | (uintptr_t)out) & 15) == 0;
+  const int work = vec ? hw / 4 : hw;
+  int bx = eavsr::cdiv(work, 256);
+  if (bx > 64) bx = 64;
+  dim3 grid(bx, n * c);
+  if (vec)
+    hipLaunchKernelGGL(scale_residual_kernel<true>, grid, dim3(256), 0, eavsr::as_stream(stream), r, scale, x, out, hw);
+  else
+    hipLaunchKernelGGL(scale_residual_kernel<false>, grid, dim3(256), 0, eavsr::as_stream(stream), r, scale, x, out, hw);
+  return eavsr::launch_status("scale_residual");
+}

@@ -1,0 +1,37 @@
+// Shared host/device helpers of libeavsr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/eavsr_hip.h"
+
+namespace eavsr {
+
+// thread-local error string behind eavsr_last_error()
+void set_error(const char* fmt, ...);
+void clear_error();
+// hipGetLastError() after a launch: 0 or the hipError_t (also records the message)
+int launch_status(const char* what);
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace eavsr
+
+#define EAVSR_REQUIRE(cond, code, ...)      \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::eavsr::set_error(__VA_ARGS__);      \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// spatial tile of the implicit-GEMM conv kernels: 16 rows x 32 columns per 256-thread workgroup,
+// wave w owns rows 4w..4w+3, one 32-pixel MFMA N-tile per row.
+#define EAVSR_CONV_TH 16
+#define EAVSR_CONV_TW 32

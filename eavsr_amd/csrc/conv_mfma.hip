@@ -1,0 +1,289 @@
+// Dense stride-1 convolution as an implicit GEMM on the fp32 matrix cores (a9, a10,
+// a11 convs, predictor heads of a3/a4/a6; also the 7x7 / encoder / upsample convs either side).
+//
+// Reference: torch.nn.Conv2d forward at eavsrp_model.py:146,313-314,381 and networks.py:293-295,
+// 330-331,456-458,478,568 (cuDNN / MKLDNN behind PyTorch).
+//
+// GEMM view per image: out[co, px] = sum_{ci,tap} W[co, ci, tap] * in[ci, px + tap],
+//   M = cout (32 or 64 per workgroup), N = pixels (16 x 32 tile per workgroup), K = cin * k * k.
+// v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD = the fp32 vector peak but with
+// one operand VGPR per 4096 FLOP): lane l supplies A[i = l & 31][k = l >> 5] = weight of output
+// channel i for input channel (2 cp + (l >> 5)) at one tap, and B[k = l >> 5][j = l & 31] = the
+// input pixel j of that channel shifted by the tap.  The accumulator holds
+// D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+//
+// Per workgroup (256 threads = 4 waves, one per SIMD; 2 workgroups per CU):
+//   for each chunk of CK input channels:
+//     stage the (16 + k - 1) x (32 + k - 1) x CK input patch (zero padded at the image border) and the
+//     CK x k*k x CO weight slab into LDS with coalesced global loads            (HBM / L2 -> LDS)
+//     every wave: for tap, channel pair: 2*MT + 4 ds_read_b32, MT*4 MFMAs       (LDS -> MFMA)
+//   epilogue from the accumulators: + bias, activation, + residual, coalesced 128-B row stores,
+//   optional per-tile channel sums for the channel attention (deterministic, no atomics).
+// LDS reads are conflict-free by construction: the 32 lanes of a half-wave read 32 consecutive floats.
+// The input is the virtual concatenation of up to 5 sources, so torch.cat never materialises.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* src[5];
+  int src_c[5];
+  int n_src;
+  const float* wp;
+  const float* bias;
+  const float* residual;
+  float* out;
+  float* chan_partial;
+  int n, h, w, cin, cout, cin_pad, tiles_x, tiles_y;
+  int act;
+  float slope;
+};
+
+template <int KS> struct ChunkOf { static constexpr int value = (KS == 1) ? 16 : (KS == 3) ? 8 : 4; };
+
+template <int KS, int MT>
+__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
+  constexpr int CK = ChunkOf<KS>::value;
+  constexpr int NT = 4;
+  constexpr int TH = EAVSR_CONV_TH, TW = EAVSR_CONV_TW;
+  constexpr int PAD = KS / 2, KK = KS * KS;
+  constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  constexpr int CO = 32 * MT;
+  constexpr int IN_ELEMS = CK * IH * IW;
+  constexpr int W_ELEMS = CK * KK * CO;
+  __shared__ float s_in[IN_ELEMS];
+  __shared__ __attribute__((aligned(16))) float s_w[W_ELEMS];
+  __shared__ float s_red[4 * CO];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int bn = bid / a.tiles_y;
+  const int cot = blockIdx.y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  const float* bin = s_in + half * (IH * IW) + (wave * NT) * IW + l31;
+  const float* ain = s_w + half * (KK * CO) + l31;
+
+  int cbase = 0;
+  for (int s = 0; s < a.n_src; ++s) {
+    const int sc = a.src_c[s];
+    const float* sp = a.src[s] + (size_t)bn * sc * plane;
+    for (int c0 = 0; c0 < sc; c0 += CK) {
+      __syncthreads();  // everyone is done reading the previous chunk
+      // ---- stage the input patch -----------------------------------------------------------
+      for (int e = tid; e < IN_ELEMS; e += 256) {
+        const int ci = e / (IH * IW);
+        const int rem = e - ci * (IH * IW);
+        const int r = rem / IW;
+        const int cc = rem - r * IW;
+        const int gy = y0 - PAD + r, gx = x0 - PAD + cc;
+        float v = 0.f;
+        if ((c0 + ci) < sc && gy >= 0 && gy < h && gx >= 0 && gx < w)
+          v = sp[(size_t)(c0 + ci) * plane + (size_t)gy * w + gx];
+        s_in[e] = v;
+      }
+      // ---- stage the weight slab (contiguous in the packed layout) --------------------------
+      {
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(
+            a.wp + ((size_t)cot * a.cin_pad + (size_t)(cbase + c0)) * (KK * CO));
+        f32x4* wdst = reinterpret_cast<f32x4*>(s_w);
+        for (int e = tid; e < W_ELEMS / 4; e += 256) wdst[e] = wsrc[e];
+      }
+      __syncthreads();
+      // ---- MFMA over the chunk --------------------------------------------------------------
+#pragma unroll(KS <= 3 ? KS : 1)
+      for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int tap = ky * KS + kx;
+#pragma unroll
+          for (int cp = 0; cp < CK / 2; ++cp) {
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[m] = ain[(cp * 2 * KK + tap) * CO + m * 32];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[t] = bin[cp * 2 * (IH * IW) + (t + ky) * IW + kx];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int t = 0; t < NT; ++t)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[m][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    cbase += sc;
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  const int gx = x0 + l31;
+  const bool xok = gx < w;
+  float csum[MT][16];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool cok = co < a.cout;
+      const float b = (cok && a.bias) ? a.bias[co] : 0.f;
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int gy = y0 + wave * NT + t;
+        float v = acc[m][t][r] + b;
+        if (a.act == EAVSR_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (a.act == EAVSR_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+        if (cok && xok && gy < h) {
+          const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
+          sum += v;
+          if (a.residual) v += a.residual[o];
+          a.out[o] = v;
+        }
+      }
+      csum[m][r] = sum;
+    }
+  }
+  if (a.chan_partial) {
+    // reduce over the 32 pixel lanes of each half-wave, then over the 4 waves (fixed order)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = csum[m][r];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if (l31 == 0) s_red[wave * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = v;
+      }
+    __syncthreads();
+    if (tid < CO) {
+      const int co = cot * CO + tid;
+      if (co < a.cout) {
+        const float v = ((s_red[tid] + s_red[CO + tid]) + s_red[2 * CO + tid]) + s_red[3 * CO + tid];
+        const int tile = ty * a.tiles_x + tx;
+        a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + tile) * a.cout + co] = v;
+      }
+    }
+  }
+}
+
+// weight (cout,cin,k,k) -> [cout_tile][cin_pad][k*k][CO], zero padded
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ p, int cout, int cin,
+                                   int kk, int cin_pad, int CO, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % CO);
+  long r = i / CO;
+  const int tap = (int)(r % kk);
+  r /= kk;
+  const int ci = (int)(r % cin_pad);
+  const int cot = (int)(r / cin_pad);
+  const int co = cot * CO + col;
+  p[i] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * kk + tap] : 0.f;
+}
+
+inline int chunk_of(int ks) { return ks == 1 ? 16 : ks == 3 ? 8 : 4; }
+inline int co_tile_of(int cout) { return cout <= 32 ? 32 : 64; }
+
+template <int KS>
+void launch_ks(const ConvArgs& a, dim3 grid, int CO, hipStream_t st) {
+  if (CO == 32)
+    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, 1>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, 2>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" int32_t eavsr_conv2d_ck(int32_t ksize) { return chunk_of(ksize); }
+
+extern "C" int32_t eavsr_conv2d_tiles(int32_t h, int32_t w) {
+  return eavsr::cdiv(h, EAVSR_CONV_TH) * eavsr::cdiv(w, EAVSR_CONV_TW);
+}
+
+extern "C" int64_t eavsr_packed_weight_elems(int32_t cout, int32_t cin, int32_t ksize) {
+  if (cout <= 0 || cin <= 0 || !(ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7)) return -1;
+  const int CO = co_tile_of(cout), ck = chunk_of(ksize);
+  const int64_t cots = eavsr::cdiv(cout, CO), cin_pad = (int64_t)eavsr::cdiv(cin, ck) * ck;
+  return cots * cin_pad * ksize * ksize * CO;
+}
+
+extern "C" int eavsr_pack_conv_weight_f32(const float* weight, float* packed, int32_t cout, int32_t cin,
+                                          int32_t ksize, void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight: NULL pointer");
+  const int64_t total = eavsr_packed_weight_elems(cout, cin, ksize);
+  EAVSR_REQUIRE(total > 0, -1, "pack_conv_weight: bad shape cout=%d cin=%d k=%d", cout, cin, ksize);
+  const int CO = co_tile_of(cout), ck = chunk_of(ksize);
+  const int cin_pad = eavsr::cdiv(cin, ck) * ck;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     eavsr::as_stream(stream), weight, packed, cout, cin, ksize * ksize, cin_pad, CO, (long)total);
+  return eavsr::launch_status("pack_conv_weight");
+}
+
+extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
+  EAVSR_REQUIRE(d != nullptr, -1, "conv2d: NULL descriptor");
+  EAVSR_REQUIRE(d->n_src >= 1 && d->n_src <= 5, -1, "conv2d: n_src %d not in 1..5", d->n_src);
+  EAVSR_REQUIRE(d->ksize == 1 || d->ksize == 3 || d->ksize == 5 || d->ksize == 7, -2,
+                "conv2d: kernel size %d unsupported (1,3,5,7)", d->ksize);
+  EAVSR_REQUIRE(d->weight_packed && d->out, -1, "conv2d: NULL weight/out");
+  EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv2d: bad dims");
+  EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv2d: act %d", d->act);
+  const int ck = chunk_of(d->ksize);
+  ConvArgs a;
+  int csum = 0;
+  for (int s = 0; s < 5; ++s) {
+    a.src[s] = s < d->n_src ? d->src[s] : nullptr;
+    a.src_c[s] = s < d->n_src ? d->src_c[s] : 0;
+    if (s < d->n_src) {
+      EAVSR_REQUIRE(d->src[s] != nullptr && d->src_c[s] > 0, -1, "conv2d: source %d is empty", s);
+      EAVSR_REQUIRE(s == d->n_src - 1 || d->src_c[s] % ck == 0, -2,
+                    "conv2d: source %d has %d channels, not a multiple of %d (only the last may be ragged)", s,
+                    d->src_c[s], ck);
+      csum += d->src_c[s];
+    }
+  }
+  EAVSR_REQUIRE(csum == d->cin, -1, "conv2d: sources sum to %d channels, cin = %d", csum, d->cin);
+  if (d->n == 0) return 0;
+  const int CO = co_tile_of(d->cout);
+  a.n_src = d->n_src;
+  a.wp = d->weight_packed;
+  a.bias = d->bias;
+  a.residual = d->residual;
+  a.out = d->out;
+  a.chan_partial = d->chan_partial;
+  a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
+  a.cin_pad = eavsr::cdiv(d->cin, ck) * ck;
+  a.tiles_x = eavsr::cdiv(d->w, EAVSR_CONV_TW);
+  a.tiles_y = eavsr::cdiv(d->h, EAVSR_CONV_TH);
+  a.act = d->act;
+  a.slope = d->slope;
+  const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
+  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv2d: too many tiles");
+  dim3 grid((unsigned)blocks, eavsr::cdiv(d->cout, CO));
+  hipStream_t st = eavsr::as_stream(stream);
+  switch (d->ksize) {
+    case 1: launch_ks<1>(a, grid, CO, st); break;
+    case 3: launch_ks<3>(a, grid, CO, st); break;
+    case 5: launch_ks<5>(a, grid, CO, st); break;
+    default: launch_ks<7>(a, grid, CO, st); break;
+  }
+  return eavsr::launch_status("conv2d");
+}

@@ -1,0 +1,111 @@
+// flow_warp: bilinear warp of a feature map by a pixel-unit flow (a1, a2).
+//
+// Reference: models/networks.py:699-739 (flow NCHW) and models/eavsrp_model.py:587-626 (flow
+// NHWC) -> torch.nn.functional.grid_sample(mode='bilinear', align_corners=True,
+// padding_mode in {'zeros','border'}).  The reference builds a meshgrid on the host, adds the
+// flow, normalises to [-1,1] and lets grid_sample un-normalise again; here the coordinate
+// arithmetic is done in registers with the SAME sequence of fp32 operations so the sampling
+// positions round identically, and nothing but x, flow and out touches HBM.
+//
+// HBM-bound: (c + 2 + c) * 4 bytes per pixel.  One thread per pixel column (64 lanes along W so
+// every load/store row segment is coalesced), 16 channels per thread; the 4 corner weights and
+// indices are computed once per pixel and reused across channels.
+#include "common.h"
+
+namespace {
+
+constexpr int kChanPerThread = 16;
+
+template <int PADMODE>
+__global__ __launch_bounds__(256) void flow_warp_kernel(
+    const float* __restrict__ x, const float* __restrict__ flow, const float* __restrict__ flow2,
+    float* __restrict__ out, int n, int c, int h, int w, long fs_n, long fs_c, long fs_y, long fs_x,
+    int c_chunks) {
+  const int px = blockIdx.x * 64 + threadIdx.x;
+  const int py = blockIdx.y * 4 + threadIdx.y;
+  const int bn = blockIdx.z / c_chunks;
+  const int c0 = (blockIdx.z % c_chunks) * kChanPerThread;
+  if (px >= w || py >= h) return;
+
+  const long fo = (long)bn * fs_n + (long)py * fs_y + (long)px * fs_x;
+  float fx = flow[fo];
+  float fy = flow[fo + fs_c];
+  if (flow2 != nullptr) {
+    fx += flow2[fo];
+    fy += flow2[fo + fs_c];
+  }
+  // reference: grid + flow, then 2*g/max(size-1,1) - 1   (networks.py:727-731)
+  const float gx = (float)px + fx;
+  const float gy = (float)py + fy;
+  const float nx = 2.0f * gx / (float)max(w - 1, 1) - 1.0f;
+  const float ny = 2.0f * gy / (float)max(h - 1, 1) - 1.0f;
+  // grid_sample, align_corners=True: ((coord + 1) / 2) * (size - 1)
+  float ix = ((nx + 1.0f) / 2.0f) * (float)(w - 1);
+  float iy = ((ny + 1.0f) / 2.0f) * (float)(h - 1);
+  if (PADMODE == EAVSR_PAD_BORDER) {
+    ix = fminf((float)(w - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(h - 1), fmaxf(iy, 0.0f));
+  }
+  // keep the int conversion defined for wild flows (everything out of range reads as zero)
+  ix = fminf(fmaxf(ix, -4.0f), (float)w + 4.0f);
+  iy = fminf(fmaxf(iy, -4.0f), (float)h + 4.0f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const int x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx0, wy1 = iy - fy0;
+  const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+  const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x1 >= 0) & (x1 < w);
+  const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y1 >= 0) & (y1 < h);
+  const float w_nw = (vx0 & vy0) ? wx0 * wy0 : 0.0f;
+  const float w_ne = (vx1 & vy0) ? wx1 * wy0 : 0.0f;
+  const float w_sw = (vx0 & vy1) ? wx0 * wy1 : 0.0f;
+  const float w_se = (vx1 & vy1) ? wx1 * wy1 : 0.0f;
+  const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+  const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+  const int i_nw = cy0 * w + cx0, i_ne = cy0 * w + cx1, i_sw = cy1 * w + cx0, i_se = cy1 * w + cx1;
+
+  const size_t plane = (size_t)h * w;
+  const float* xp = x + ((size_t)bn * c + c0) * plane;
+  float* op = out + ((size_t)bn * c + c0) * plane + (size_t)py * w + px;
+  const int cend = min(kChanPerThread, c - c0);
+#pragma unroll 4
+  for (int cc = 0; cc < cend; ++cc) {
+    const float* p = xp + (size_t)cc * plane;
+    float v = p[i_nw] * w_nw;
+    v += p[i_ne] * w_ne;
+    v += p[i_sw] * w_sw;
+    v += p[i_se] * w_se;
+    op[(size_t)cc * plane] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int eavsr_flow_warp_f32(const float* x, const float* flow, const float* flow2, float* out,
+                                   int32_t n, int32_t c, int32_t h, int32_t w, int32_t flow_layout,
+                                   int32_t padding_mode, void* stream) {
+  EAVSR_REQUIRE(x && flow && out, -1, "flow_warp: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c >= 0 && h >= 0 && w >= 0, -1, "flow_warp: negative dimension");
+  EAVSR_REQUIRE(flow_layout == EAVSR_FLOW_NCHW || flow_layout == EAVSR_FLOW_NHWC, -1,
+                "flow_warp: flow_layout %d", flow_layout);
+  EAVSR_REQUIRE(padding_mode == EAVSR_PAD_ZEROS || padding_mode == EAVSR_PAD_BORDER, -2,
+                "flow_warp: padding_mode %d unsupported (the reference uses zeros and border)", padding_mode);
+  EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "flow_warp: plane too large");
+  if (n == 0 || c == 0 || h == 0 || w == 0) return 0;
+  long fs_n, fs_c, fs_y, fs_x;
+  if (flow_layout == EAVSR_FLOW_NCHW) {
+    fs_n = 2L * h * w; fs_c = (long)h * w; fs_y = w; fs_x = 1;
+  } else {
+    fs_n = 2L * h * w; fs_c = 1; fs_y = 2L * w; fs_x = 2;
+  }
+  const int c_chunks = eavsr::cdiv(c, kChanPerThread);
+  EAVSR_REQUIRE((long)n * c_chunks <= 65535, -1, "flow_warp: n * ceil(c/16) = %ld exceeds grid.z", (long)n * c_chunks);
+  dim3 grid(eavsr::cdiv(w, 64), eavsr::cdiv(h, 4), n * c_chunks), block(64, 4, 1);
+  if (padding_mode == EAVSR_PAD_ZEROS)
+    hipLaunchKernelGGL(flow_warp_kernel<EAVSR_PAD_ZEROS>, grid, block, 0, eavsr::as_stream(stream), x, flow,
+                       flow2, out, n, c, h, w, fs_n, fs_c, fs_y, fs_x, c_chunks);
+  else
+    hipLaunchKernelGGL(flow_warp_kernel<EAVSR_PAD_BORDER>, grid, block, 0, eavsr::as_stream(stream), x, flow,
+                       flow2, out, n, c, h, w, fs_n, fs_c, fs_y, fs_x, c_chunks);
+  return eavsr::launch_status("flow_warp");
+}

@@ -1,0 +1,158 @@
+/*
+ * eavsr_hip.h -- C ABI of libeavsr_hip.so: MI355X (gfx950) kernels for the EAVSR inter-frame
+ * alignment + feature-propagation hot path.
+ *
+ * Boundary contract:
+ *   - plain C: raw DEVICE pointers, sizes, a hipStream_t passed as void*; no torch types.
+ *   - the caller allocates and owns every buffer (inputs, outputs, workspaces); the library
+ *     never allocates or frees device memory and keeps no pointer after return.
+ *   - every call is asynchronous on the given stream; no internal synchronisation, no
+ *     default-stream use.  Safe from several host threads (no mutable global state besides a
+ *     thread-local error string).
+ *   - return value: 0 = OK, <0 = argument / shape / unsupported-configuration error found on
+ *     the host (nothing was launched), >0 = hipError_t of the failed launch.
+ *     eavsr_last_error() returns the message of the last failing call on this thread.
+ *   - all tensors are contiguous fp32 NCHW unless a parameter says otherwise.
+ *
+ * Each entry point names the reference interface (file:line under /root/reference) it replaces.
+ */
+#ifndef EAVSR_HIP_H
+#define EAVSR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAVSR_ABI_VERSION 1
+
+/* activation codes for eavsr_conv2d_f32 */
+#define EAVSR_ACT_NONE 0
+#define EAVSR_ACT_RELU 1
+#define EAVSR_ACT_LRELU 2 /* negative slope in desc.slope */
+
+/* padding modes of eavsr_flow_warp_f32 (torch grid_sample padding_mode) */
+#define EAVSR_PAD_ZEROS 0
+#define EAVSR_PAD_BORDER 1
+
+/* flow layouts of eavsr_flow_warp_f32 */
+#define EAVSR_FLOW_NCHW 0 /* networks.py:699-739      (n,2,h,w): ch0 = x disp, ch1 = y disp */
+#define EAVSR_FLOW_NHWC 1 /* eavsrp_model.py:587-626  (n,h,w,2): [..,0] = x,  [..,1] = y     */
+
+int eavsr_abi_version(void);
+/* "eavsr-hip <semver> gfx950" */
+const char* eavsr_version(void);
+/* message of the last failing call on the calling thread ("" if none) */
+const char* eavsr_last_error(void);
+
+/* Verifies on the device that v_mfma_f32_32x32x2_f32 has the operand / accumulator lane layout the
+ * kernels assume (asymmetric integer data).  scratch: >= 8192 floats of device memory.  The result
+ * (0 = layout OK, otherwise the number of mismatching elements) is written to scratch[0] as float;
+ * the caller synchronises and reads it. */
+int eavsr_selftest_mfma_f32(float* scratch, void* stream);
+
+/* ---- a1 / a2: flow_warp -------------------------------------------------------------------
+ * replaces networks.flow_warp (models/networks.py:699-739) and eavsrp_model.flow_warp
+ * (models/eavsrp_model.py:587-626): bilinear grid_sample, align_corners=True, of x by a pixel-unit
+ * flow.  out[n,c,y,x] = bilinear(x[n,c], y + fy, x + fx), corner-wise zero padding (ZEROS) or
+ * coordinate clamping (BORDER).  flow2 (nullable, same layout) is added to flow first
+ * (networks.py:610,615 warp by a sum of two flows).                                            */
+int eavsr_flow_warp_f32(const float* x, const float* flow, const float* flow2, float* out,
+                        int32_t n, int32_t c, int32_t h, int32_t w,
+                        int32_t flow_layout, int32_t padding_mode, void* stream);
+
+/* ---- a7: DCNv2 ------------------------------------------------------------------------------
+ * replaces mmcv.ops.modulated_deform_conv2d as called at models/networks.py:627-630 (module
+ * parameters from the ModulatedDeformConv2d base class, networks.py:575-583).
+ * Fused sampler + modulation + (cout x cin*9) contraction + bias; no column buffer in HBM.
+ * offset: (n, dg*18, h, w) channel g*18 + 2k + {0: dy, 1: dx};  mask: (n, dg*9, h, w) channel g*9+k.
+ * weight_packed: from eavsr_pack_conv_weight_f32(weight(cout,cin,3,3)).
+ * Supported: 3x3, stride 1, pad 1, dilation 1, groups 1, (cin/dg) % 8 == 0, cout <= 64 per launch
+ * tile (any cout; tiles of 64).  Anything else returns -2.                                       */
+int eavsr_dcnv2_f32(const float* x, const float* offset, const float* mask,
+                    const float* weight_packed, const float* bias, float* out,
+                    int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                    int32_t deform_groups, void* stream);
+
+/* ---- dense convolution (a9, a10, a11 convs; predictor heads a3/a4/a6; callers f1/f2) ----------
+ * replaces torch.nn.Conv2d forward (stride 1, padding k/2, dilation 1, groups 1) as used at
+ * eavsrp_model.py:146,313-314 (fusion 1x1), :381 (input conv), networks.py:456-458 (RCAB convs),
+ * :293-295,:330-331 (predictor heads), :568 (TransOffsetworelu), SPyNet 7x7 convs
+ * (eavsrp_model.py:534-574), encoder / upsample convs.  Implicit GEMM on v_mfma_f32_32x32x2_f32
+ * (exact fp32 fma chain).
+ * The input is the virtual channel-concatenation of up to 5 NCHW sources (replaces torch.cat at
+ * eavsrp_model.py:313,322,353): every source but the last must have channels % eavsr_conv2d_ck(ksize) == 0.
+ * out = act(conv + bias) + residual.                                                           */
+typedef struct eavsr_conv2d_desc {
+  const float* src[5];
+  int32_t src_c[5];
+  int32_t n_src;
+  int32_t ksize; /* 1, 3, 5 or 7 */
+  const float* weight_packed; /* eavsr_pack_conv_weight_f32 */
+  const float* bias;          /* [cout] or NULL */
+  const float* residual;      /* (n,cout,h,w) or NULL, added after the activation */
+  float* out;                 /* (n,cout,h,w) */
+  /* optional: per-tile channel sums of `out` for the channel attention (networks.py:444-445):
+   * chan_partial[(n * tiles + tile) * cout + co], tiles = eavsr_conv2d_tiles(h,w); NULL = off */
+  float* chan_partial;
+  int32_t n, h, w, cin, cout;
+  int32_t act;
+  float slope;
+} eavsr_conv2d_desc;
+
+int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);
+/* input-channel chunk the kernel for this kernel size works in (sources must be multiples of it) */
+int32_t eavsr_conv2d_ck(int32_t ksize);
+/* number of spatial tiles per image (rows of chan_partial per sample) */
+int32_t eavsr_conv2d_tiles(int32_t h, int32_t w);
+/* number of floats of the packed weight buffer for (cout, cin, ksize) */
+int64_t eavsr_packed_weight_elems(int32_t cout, int32_t cin, int32_t ksize);
+/* weight (cout,cin,k,k) -> packed [cout_tile][cin_pad][k*k][co_in_tile], zero padded */
+int eavsr_pack_conv_weight_f32(const float* weight, float* packed, int32_t cout, int32_t cin,
+                               int32_t ksize, void* stream);
+
+/* ---- a11: channel attention -----------------------------------------------------------------
+ * CALayer (models/networks.py:432-447): scale[n,c] = sigmoid(W2 . relu(W1 . mean_hw(r) + b1) + b2)
+ * from the per-tile sums produced by eavsr_conv2d_f32(chan_partial).  w1 (cr,c), w2 (c,cr).      */
+int eavsr_ca_scale_f32(const float* chan_partial, int32_t tiles, int32_t hw,
+                       const float* w1, const float* b1, const float* w2, const float* b2,
+                       float* scale, int32_t n, int32_t c, int32_t cr, void* stream);
+/* RCABlock tail (networks.py:447,464): out = r * scale[n,c] + x */
+int eavsr_scale_residual_f32(const float* r, const float* scale, const float* x, float* out,
+                             int32_t n, int32_t c, int32_t hw, void* stream);
+
+/* ---- a3 / a6 front end ----------------------------------------------------------------------
+ * AdaptBlock2_3x3 / AdaptBlockOffset `concat` + `concat2` (models/networks.py:290-291,300 and
+ * :327-328,336): cat(x,h_hr) -> depthwise 3x3 + LeakyReLU(0.2) -> grouped 3x3 (2 in / 1 out,
+ * groups=c) + LeakyReLU(0.2), fused in one pass.  w1 (2c,1,3,3) b1 (2c) w2 (c,2,3,3) b2 (c).       */
+int eavsr_adapt_frontend_f32(const float* x, const float* h_hr, const float* w1, const float* b1,
+                             const float* w2, const float* b2, float* out,
+                             int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+
+/* affine -> sampling offsets (models/networks.py:302-311 and :338-346) and mask sigmoid (:313-314).
+ * heads: (n, 6*D [+ 9*D], h, w) = [transform 4D | translation 2D | mask logits 9D] (the three head
+ * convs run as one conv with concatenated weights).  offset: (n, 18*D, h, w) in mmcv order;
+ * mask: (n, 9*D, h, w) = sigmoid, or NULL when the heads carry no mask logits (D = 1 blocks).      */
+int eavsr_affine_offsets_f32(const float* heads, float* offset, float* mask,
+                             int32_t n, int32_t D, int32_t h, int32_t w, void* stream);
+
+/* ---- a5 / a12 resampling glue ---------------------------------------------------------------
+ * out = scale * bilinear_align_corners(in [+ in2]) [+ addend]   (F.interpolate(..., align_corners=True)
+ * at models/networks.py:600-601,608,613 with the /4, /2, *2 factors and the adds at :610,:613).   */
+int eavsr_resize_bilinear_ac_f32(const float* in, const float* in2, const float* addend, float* out,
+                                 int32_t n, int32_t c, int32_t hin, int32_t win,
+                                 int32_t hout, int32_t wout, float scale, void* stream);
+/* feature pyramid (models/eavsrp_model.py:218-220): F.interpolate(scale 0.5 / 0.25, bilinear,
+ * align_corners=False) == 2x2 box means of pixels (2d,2d+1) and (4d+1,4d+2).  h % 4 == w % 4 == 0. */
+int eavsr_pyramid_f32(const float* in, float* down2, float* down4,
+                      int32_t nc, int32_t h, int32_t w, void* stream);
+/* out = a + b [+ c] elementwise (flow sums at networks.py:619, eavsrp_model.py:309,323) */
+int eavsr_add_f32(const float* a, const float* b, const float* c, float* out, int64_t count,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAVSR_HIP_H */
