@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- SR frames/s of the EAVSR x4 forward on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one `EAVSRP.forward` over one batch of synthetic clips already resident in HBM:
+BASELINE.json configs[1] = 4 clips x 7 frames x 3 x 180 x 320 fp32 per GPU, x4 -> 720 x 1280
+(weak scaling: every rank owns its own 4 clips; clips are independent, there is no data-path
+collective).  Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      the dominant kernel (3x3 64->64 MFMA conv) against the fp32 MFMA peak, and
+  kernels       the same for DCNv2 / flow_warp (HBM-bound) -- durations measured with HIP events on the
+                launch stream during one extra, untimed, instrumented step,
+  cpu_baseline  the CPU oracle timed on this box's host cores on a bounded crop of the workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=4, help="clips per GPU (configs[1]: 4)")
+    ap.add_argument("--frames", type=int, default=7)
+    ap.add_argument("--height", type=int, default=180)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--preset", default="trained_like", choices=["default", "trained_like"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[96, 128], help="h w of the CPU-baseline crop")
+    return ap.parse_args()
+
+
+def build_model(device, preset):
+    from argparse import Namespace
+    from eavsr_amd.eavsrp_model import EAVSRP
+    from eavsr_amd.utils.synthetic import fill_state_dict, shapes_of
+    net = EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale=4), None)
+    sd0 = net.state_dict()
+    sd = fill_state_dict(shapes_of(sd0), preset, fixed=sd0)
+    net.load_state_dict(sd, strict=True)
+    return net.to(device).eval(), sd
+
+
+def cpu_baseline(sd, frames, crop_h, crop_w, full_h, full_w):
+    """The oracle (a port of the reference's algorithm, oracle/eavsr_oracle.py) on the host cores."""
+    from oracle import eavsr_oracle as O
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    clip = synthetic_clip(1, frames, crop_h, crop_w, seed=0)
+    t0 = time.time()
+    with torch.no_grad():
+        O.eavsrp_forward(sd, clip, 4)
+    dt = time.time() - t0
+    fps_crop = frames / dt
+    return {
+        "value": fps_crop * (crop_h * crop_w) / float(full_h * full_w),
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"1 clip x {frames} frames x 3 x {crop_h} x {crop_w} (crop of the {full_h}x{full_w} workload) "
+                  f"in {dt:.1f} s = {fps_crop:.3f} frames/s at the crop size; value is scaled by the pixel ratio "
+                  f"to {full_h}x{full_w} (per-pixel work is size-independent); torch {torch.__version__} CPU, "
+                  f"{cores} threads",
+    }
+
+
+def main():
+    args = parse()
+    from eavsr_amd import ops, shard
+    rank, local_rank, world = shard.init_process_group()
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("[bench] no GPU visible: eavsr_amd has no CPU path", file=sys.stderr)
+        sys.exit(2)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    ops.lib()  # fail loudly if the HIP extension is missing
+
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    net, sd = build_model(device, args.preset)
+    n, t, h, w = args.clips, args.frames, args.height, args.width
+    clips = synthetic_clip(n, t, h, w, seed=rank).to(device)   # resident in HBM before the timed region
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(clips)
+        torch.cuda.synchronize()
+        shard.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(clips)
+        torch.cuda.synchronize()
+        shard.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed, device=device if world > 1 else None)
+    frames_total = world * n * t * args.steps
+    value = frames_total / elapsed
+
+    line = {
+        "metric": "SR frames/sec at 4x 7-frame 180x320->720x1280",
+        "value": value,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"eavsrp x4 inference, {n} clips/GPU x {t} frames x 3 x {h} x {w} fp32 "
+                               f"(BASELINE.json configs[1]), weights: seeded '{args.preset}' init",
+                   "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "scale": 4, "sharding": "clips across ranks, no collective"},
+    }
+
+    if rank == 0 and not args.no_kernel_profile:
+        # one extra untimed step with HIP events around every launch (events on the launch stream)
+        with torch.no_grad(), ops.profile() as prof:
+            net(clips)
+        summ = prof.summary()
+        total_ms = sum(v["ms"] for v in summ.values())
+
+        def entry(name, bound):
+            v = summ.get(name)
+            if not v:
+                return None
+            avg_ms = v["ms"] / v["calls"]
+            if bound == "mfma":
+                ach = v["flops"] / v["calls"] / (avg_ms * 1e-3) / 1e12
+                return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
+                        "share_of_step": v["ms"] / total_ms}
+            ach = v["bytes"] / v["calls"] / (avg_ms * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
+                    "share_of_step": v["ms"] / total_ms}
+
+        dom = entry("conv3x3_64to64", "mfma")
+        if dom is not None:
+            line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+            line["roofline"]["kernel"] = "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)"
+            line["roofline"]["avg_ms"] = dom["avg_ms"]
+            line["roofline"]["share_of_step"] = dom["share_of_step"]
+        line["kernels"] = [e for e in (entry("dcnv2", "hbm"), entry("flow_warp", "hbm"),
+                                       entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
+                                       entry("scale_residual", "hbm"), entry("conv5x5_64to120", "mfma")) if e]
+        line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        line["step_device_ms_instrumented"] = total_ms
+        pmc = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(pmc) and "roofline" in line:
+            try:
+                line["roofline"]["traffic"] = json.load(open(pmc)).get("conv3x3_64to64")
+            except Exception:
+                pass
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd_cpu = {k: v.cpu() for k, v in sd.items()}
+        line["cpu_baseline"] = cpu_baseline(sd_cpu, t, args.cpu_crop[0], args.cpu_crop[1], h, w)
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        shard.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""ctypes binding of libeavsr_hip.so (the C ABI declared in include/eavsr_hip.h).
+
+There is no CPU path and no PyTorch fallback: if the shared object is missing or an entry
+point is absent, the first use raises.  Build it with ``python -m eavsr_amd.build`` (or
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
+
+ABI_VERSION = 1
+
+p_f32 = C.c_void_p  # device pointers travel as integers
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+vp = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """struct eavsr_conv2d_desc"""
+    _fields_ = [
+        ("src", vp * 5),
+        ("src_c", i32 * 5),
+        ("n_src", i32),
+        ("ksize", i32),
+        ("weight_packed", vp),
+        ("bias", vp),
+        ("residual", vp),
+        ("out", vp),
+        ("chan_partial", vp),
+        ("n", i32), ("h", i32), ("w", i32), ("cin", i32), ("cout", i32),
+        ("act", i32),
+        ("slope", f32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/eavsr_hip.h declares
+SIGNATURES = {
+    "eavsr_abi_version": (C.c_int, []),
+    "eavsr_version": (C.c_char_p, []),
+    "eavsr_last_error": (C.c_char_p, []),
+    "eavsr_selftest_mfma_f32": (C.c_int, [vp, vp]),
+    "eavsr_flow_warp_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_dcnv2_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), vp]),
+    "eavsr_conv2d_ck": (i32, [i32]),
+    "eavsr_conv2d_tiles": (i32, [i32, i32]),
+    "eavsr_packed_weight_elems": (i64, [i32, i32, i32]),
+    "eavsr_pack_conv_weight_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "eavsr_ca_scale_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "eavsr_scale_residual_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "eavsr_adapt_frontend_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_affine_offsets_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_resize_bilinear_ac_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "eavsr_pyramid_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+    "eavsr_add_f32": (C.c_int, [vp, vp, vp, vp, i64, vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes library with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m eavsr_amd.build`). eavsr_amd has no CPU or PyTorch fallback.")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 not found
+            raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        if lib.eavsr_abi_version() != ABI_VERSION:
+            raise NativeLibraryError(
+                f"ABI mismatch: library {lib.eavsr_abi_version()} vs binding {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().eavsr_last_error().decode(errors="replace")
+        kind = "argument error" if code < 0 else "hipError"
+        raise RuntimeError(f"{what} failed ({kind} {code}): {msg}")

@@ -1,0 +1,357 @@
+"""Drop-in counterparts of models/eavsrp_model.py (x4) and models/eavsrpx2_model.py (x2).
+
+`EAVSRP(opt, spynet_pretrained=None).forward(lrs)` keeps the reference signature
+((n,t,3,h,w) in [0,1] -> (n,t,3,s*h,s*w), eavsrp_model.py:202-240) and state_dict keys, and runs
+the whole forward on libeavsr_hip.so kernels: the alignment / propagation hot path (MultiAdSTN,
+DCNv2, flow_warp, fusion, 30-RCAB backbones) and, on the same conv kernel, the callers either
+side of it (SPyNet, encoder, upsampling tail).  torch is used for memory, views, and a few
+elementwise / pooling glue ops outside the hot loop.
+
+One process drives one GPU (no nn.DataParallel: networks.init_net here does not wrap).
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import networks as N
+from . import ops
+
+Tensor = torch.Tensor
+
+
+# ---------------------------------------------------------------------------------------------
+# flow_warp with the flow in NHWC (eavsrp_model.py:587-626)
+# ---------------------------------------------------------------------------------------------
+def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_corners=True):
+    """Warp `x` (n,c,h,w) by `flow` (n,h,w,2): [...,0] = x displacement, [...,1] = y, in pixels."""
+    if interpolation != "bilinear" or not align_corners:
+        raise NotImplementedError("the reference path only uses bilinear, align_corners=True")
+    return ops.flow_warp(x, flow, padding_mode=padding_mode, flow_layout="nhwc")
+
+
+# ---------------------------------------------------------------------------------------------
+# residual backbone (eavsrp_model.py:366-400)
+# ---------------------------------------------------------------------------------------------
+class ResidualBlocksWithInputConv(nn.Module):
+    """conv3x3(in -> out) + LeakyReLU(0.1) -> RCAGroup(nb=num_blocks).  `feat` may be a tensor or a
+    list of tensors standing for their channel concatenation (the cat at eavsrp_model.py:322,353 is
+    never materialised)."""
+
+    def __init__(self, in_channels, out_channels=64, num_blocks=30):
+        super().__init__()
+        self.main = nn.Sequential(
+            N.Conv2d(in_channels, out_channels, 3, 1, 1, bias=True),
+            N._Act("lrelu", 0.1),
+            N.RCAGroup(out_channels, out_channels, nb=num_blocks))
+
+    def forward(self, feat):
+        x = self.main[0](feat, act="lrelu", slope=0.1)
+        return self.main[2](x)
+
+
+# ---------------------------------------------------------------------------------------------
+# SPyNet (eavsrp_model.py:402-585) -- caller of the path ("next" row f1); uses flow_warp(border)
+# ---------------------------------------------------------------------------------------------
+class ConvModule(nn.Module):
+    """Key-compatible with mmcv.cnn.ConvModule(norm_cfg=None): .conv (+ fused ReLU)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, norm_cfg=None,
+                 act_cfg=dict(type="ReLU")):
+        super().__init__()
+        assert norm_cfg is None and stride == 1 and padding == kernel_size // 2
+        self.conv = N.Conv2d(in_channels, out_channels, kernel_size, stride, padding)
+        self.with_activation = act_cfg is not None
+        if self.with_activation:
+            assert act_cfg["type"] == "ReLU"
+            self.activate = N._Act("relu")
+
+    def forward(self, x):
+        return self.conv(x, act="relu" if self.with_activation else None)
+
+
+class SPyNetBasicModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        chans = [(8, 32), (32, 64), (64, 32), (32, 16), (16, 2)]
+        self.basic_module = nn.Sequential(*[
+            ConvModule(ci, co, 7, 1, 3, norm_cfg=None, act_cfg=dict(type="ReLU") if i < 4 else None)
+            for i, (ci, co) in enumerate(chans)])
+
+    def forward(self, tensor_input):
+        return self.basic_module(tensor_input)
+
+
+def load_checkpoint(module: nn.Module, path: str, strict: bool = True):
+    """Reader for mmcv-style checkpoints ({'state_dict': ...} or a bare state dict), as
+    mmcv.runner.load_checkpoint is used at eavsrp_model.py:421."""
+    ck = torch.load(path, map_location="cpu")
+    sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck
+    sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+    module.load_state_dict(sd, strict=strict)
+    return ck
+
+
+class SPyNet(nn.Module):
+    def __init__(self, pretrained):
+        super().__init__()
+        self.basic_module = nn.ModuleList([SPyNetBasicModule() for _ in range(6)])
+        if isinstance(pretrained, str):
+            load_checkpoint(self, pretrained, strict=True)
+        elif pretrained is not None:
+            raise TypeError(f"[pretrained] should be str or None, but got {type(pretrained)}.")
+        self.register_buffer("mean", torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+
+    def compute_flow(self, ref, supp):
+        """eavsrp_model.py:433-488"""
+        n, _, h, w = ref.size()
+        ref = [(ref - self.mean) / self.std]
+        supp = [(supp - self.mean) / self.std]
+        for _ in range(5):
+            ref.append(F.avg_pool2d(ref[-1], kernel_size=2, stride=2, count_include_pad=False))
+            supp.append(F.avg_pool2d(supp[-1], kernel_size=2, stride=2, count_include_pad=False))
+        ref, supp = ref[::-1], supp[::-1]
+        flow = ref[0].new_zeros(n, 2, h // 32, w // 32)
+        for level in range(len(ref)):
+            if level == 0:
+                flow_up = flow
+            else:
+                flow_up = ops.resize_bilinear_ac(flow, (flow.shape[2] * 2, flow.shape[3] * 2), 2.0)
+            warped = ops.flow_warp(supp[level], flow_up, padding_mode="border")
+            res = self.basic_module[level](torch.cat([ref[level], warped, flow_up], 1))
+            flow = ops.add(flow_up, res)
+        return flow
+
+    def forward(self, ref, supp):
+        """eavsrp_model.py:490-523"""
+        h, w = ref.shape[2:4]
+        w_up = w if (w % 32) == 0 else 32 * (w // 32 + 1)
+        h_up = h if (h % 32) == 0 else 32 * (h // 32 + 1)
+        ref = F.interpolate(ref, size=(h_up, w_up), mode="bilinear", align_corners=False)
+        supp = F.interpolate(supp, size=(h_up, w_up), mode="bilinear", align_corners=False)
+        flow = F.interpolate(self.compute_flow(ref, supp), size=(h, w), mode="bilinear", align_corners=False)
+        flow[:, 0, :, :] *= float(w) / float(w_up)
+        flow[:, 1, :, :] *= float(h) / float(h_up)
+        return flow
+
+
+# ---------------------------------------------------------------------------------------------
+# EAVSRP
+# ---------------------------------------------------------------------------------------------
+_PYR = ("spatial", "spatial_d2", "spatial_d4")
+
+
+class EAVSRP(nn.Module):
+    """eavsrp_model.py:121-364 (scale 4) / eavsrpx2_model.py:124-365 (scale 2, selected by
+    opt.scale or the `scale` argument)."""
+
+    def __init__(self, opt, spynet_pretrained=None, scale=None):
+        super().__init__()
+        self.opt = opt
+        self.predict = getattr(opt, "predict", False)
+        self.n_resblock = 30
+        self.n_frame = getattr(opt, "n_frame", 7)
+        self.n_feats = 64
+        self.n_flow = getattr(opt, "n_flow", 5)
+        self.scale = int(scale if scale is not None else getattr(opt, "scale", 4))
+        if self.scale not in (2, 4):
+            raise NotImplementedError("EAVSRP exists for x4 (eavsrp_model) and x2 (eavsrpx2_model)")
+
+        self.spynet = SPyNet(pretrained=spynet_pretrained)
+        for p in self.spynet.parameters():
+            p.requires_grad = False
+        self.encoder = N.ContrasExtractorLayer(self.n_feats)
+
+        self.deform_align = nn.ModuleDict()
+        self.backbone = nn.ModuleDict()
+        self.fusion = nn.ModuleDict()
+        for i, module in enumerate(["backward_1", "forward_1", "backward_2", "forward_2"]):
+            self.deform_align[module] = N.MultiAdSTN(opt, self.n_feats, self.n_feats, deformable_groups=8)
+            self.backbone[module] = ResidualBlocksWithInputConv((2 + i) * self.n_feats, self.n_feats, self.n_resblock)
+            self.fusion[module] = N.Conv2d(self.n_feats * 3, self.n_feats, 1, 1, 0, bias=True)
+
+        self.reconstruction = ResidualBlocksWithInputConv(5 * self.n_feats, self.n_feats, 5)
+        self.upsample1 = N.seq([N.conv(self.n_feats, self.n_feats * 4, mode="C"), nn.PixelShuffle(2)])
+        if self.scale == 4:
+            self.upsample2 = N.seq([N.conv(self.n_feats, self.n_feats * 4, mode="C"), nn.PixelShuffle(2)])
+        self.conv_hr = N.Conv2d(64, 64, 3, 1, 1)
+        self.conv_last = N.Conv2d(64, 3, 3, 1, 1)
+        self.img_upsample = nn.Upsample(scale_factor=self.scale, mode="bilinear", align_corners=False)
+        self.lrelu = N._Act("lrelu", 0.1)
+
+    # -- flows -----------------------------------------------------------------------------
+    def compute_flow(self, lrs):
+        """eavsrp_model.py:179-200.  Both directions go through SPyNet as one batch."""
+        n, t, c, h, w = lrs.shape
+        lrs_1 = lrs[:, :-1].reshape(-1, c, h, w)
+        lrs_2 = lrs[:, 1:].reshape(-1, c, h, w)
+        both = self.spynet(torch.cat([lrs_1, lrs_2], 0), torch.cat([lrs_2, lrs_1], 0))
+        m = n * (t - 1)
+        flows_backward = both[:m].view(n, t - 1, 2, h, w)
+        flows_forward = both[m:].view(n, t - 1, 2, h, w)
+        return flows_forward, flows_backward
+
+    # -- forward ---------------------------------------------------------------------------
+    def forward(self, lrs):
+        n, t, c, h, w = lrs.shape
+        assert h >= 64 and w >= 64, (
+            'The height and width of inputs should be at least 64, '
+            f'but got {h} and {w}.')
+        if not lrs.is_cuda:
+            raise RuntimeError("eavsr_amd.EAVSRP runs on the GPU only (no CPU path); for a CPU reference use "
+                               "the original repository with --gpu_ids -1")
+        with torch.no_grad():
+            flows_forward, flows_backward = self.compute_flow(lrs)
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training needs the backward kernels, which are not part of this round: "
+                                      "call .eval() / run under torch.no_grad()")
+
+        # frame-major feature tensors so every per-frame slice is contiguous
+        lr_tm = lrs.transpose(0, 1).reshape(t * n, c, h, w)
+        f1 = self.encoder(lr_tm)                                   # :216
+        f2, f4 = ops.pyramid(f1)                                   # :218-220
+        feats: Dict[str, List[Tensor]] = {
+            "spatial": [f1[i * n:(i + 1) * n] for i in range(t)],
+            "spatial_d2": [f2[i * n:(i + 1) * n] for i in range(t)],
+            "spatial_d4": [f4[i * n:(i + 1) * n] for i in range(t)],
+        }
+        for iter_ in (1, 2):
+            for direction in ("backward", "forward"):
+                module = f"{direction}_{iter_}"
+                feats[module] = []
+                flows = flows_backward if direction == "backward" else flows_forward
+                feats = self.propagate(feats, flows, module)
+        return self.upsample(lrs, feats)
+
+    def propagate(self, feats, flows, module_name):
+        """eavsrp_model.py:242-329."""
+        n, t, _, h, w = flows.size()
+        frame_idx = list(range(0, t + 1))
+        flow_idx = list(range(-1, t))
+        mapping_idx = list(range(0, len(feats["spatial"])))
+        mapping_idx += mapping_idx[::-1]
+        backward = "backward" in module_name
+        if backward:
+            frame_idx = frame_idx[::-1]
+            flow_idx = frame_idx
+        step = 1 if backward else -1
+        align, fusion, backbone = self.deform_align[module_name], self.fusion[module_name], self.backbone[module_name]
+        feat_prop = flows.new_zeros(n, self.n_feats, h, w)
+        zeros = None
+        for i, idx in enumerate(frame_idx):
+            cur = [feats[k][mapping_idx[idx]] for k in _PYR]
+            if i > 0:
+                nbr = [feats[k][mapping_idx[idx + step]] for k in _PYR]
+                flow_n1 = flows[:, flow_idx[i]].contiguous()
+                cond_n1 = align(nbr, cur, feat_prop, flow_n1)
+                if i > 1:
+                    feat_n2 = feats[module_name][-2]
+                    nbr2 = [feats[k][mapping_idx[idx + 2 * step]] for k in _PYR]
+                    flow_n2 = flows[:, flow_idx[i - 1]].contiguous()
+                    flow_n2 = ops.add(flow_n1, ops.flow_warp(flow_n2, flow_n1))          # :309-310
+                    cond_n2 = align(nbr2, cur, feat_n2, flow_n2)
+                else:
+                    if zeros is None:
+                        zeros = torch.zeros_like(cond_n1)
+                    cond_n2 = zeros
+                feat_prop = fusion([cond_n1, cur[0], cond_n2])                          # :313-314
+            others = [feats[k][idx] for k in feats if k not in _PYR and k != module_name]
+            res = backbone([cur[0]] + others + [feat_prop])                             # :317-323
+            feat_prop = ops.add(feat_prop, res)
+            feats[module_name].append(feat_prop)
+        if backward:
+            feats[module_name] = feats[module_name][::-1]
+        return feats
+
+    def upsample(self, lqs, feats):
+        """eavsrp_model.py:331-364, all t frames as one batch."""
+        n, t = lqs.shape[:2]
+        branches = [k for k in feats if k not in _PYR]
+        srcs = [torch.cat(feats["spatial"], 0)] + [torch.cat(feats[k], 0) for k in branches]   # frame-major
+        hr = self.reconstruction(srcs)
+        hr = F.pixel_shuffle(self.upsample1[0](hr, act="lrelu", slope=0.1), 2)     # lrelu commutes with the shuffle
+        if self.scale == 4:
+            hr = F.pixel_shuffle(self.upsample2[0](hr, act="lrelu", slope=0.1), 2)
+        hr = self.conv_hr(hr, act="lrelu", slope=0.1)
+        lq_tm = lqs.transpose(0, 1).reshape(t * n, *lqs.shape[2:])
+        skip = self.img_upsample(lq_tm)
+        out = self.conv_last(hr, residual=skip)                                      # :359-360
+        return out.view(t, n, *out.shape[1:]).transpose(0, 1).contiguous()
+
+
+class EAVSRPx2(EAVSRP):
+    """eavsrpx2_model.py's network (class EAVSRP there): one pixel-shuffle stage, x2 bilinear skip."""
+
+    def __init__(self, opt, spynet_pretrained=None):
+        super().__init__(opt, spynet_pretrained, scale=2)
+
+
+# ---------------------------------------------------------------------------------------------
+# model wrapper (eavsrp_model.py:18-119), inference side
+# ---------------------------------------------------------------------------------------------
+class EAVSRPModel:
+    """Inference-side stand-in of EAVSRPModel / EAVSRPx2Model: set_input / test / forward /
+    get_current_visuals / load_networks / save_networks with the reference's checkpoint format
+    ({'state_dict': ...}, base_model.py:159-217).  Training (optimize_parameters) needs the
+    backward kernels, which are a later row of SURVEY.md section 8."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.scale = opt.scale
+        self.isTrain = getattr(opt, "isTrain", False)
+        gpu_ids = list(getattr(opt, "gpu_ids", [0]))
+        if len(gpu_ids) == 0:
+            raise RuntimeError("eavsr_amd has no CPU path (--gpu_ids -1 is the reference's CPU mode)")
+        self.device = torch.device("cuda", gpu_ids[0])
+        self.visual_names = ["data_lr_seq", "data_hr_seq", "data_sr_seq"]
+        self.model_names = ["EAVSRP"]
+        self.netEAVSRP = N.init_net(EAVSRP(opt, getattr(opt, "spynet_pretrained", None)), gpu_ids=gpu_ids)
+        self.time, self.isfirst, self.num = 0.0, True, 0
+
+    def eval(self):
+        self.netEAVSRP.eval()
+
+    def set_input(self, input, epoch=0):
+        self.data_lr_seq = input["lr_seq"].to(self.device)
+        self.data_hr_seq = input["hr_seq"].to(self.device) if "hr_seq" in input else None
+        self.image_name = input.get("fname")
+        self.idx = min(self.opt.n_frame // 2, self.data_lr_seq.shape[1] - 1)
+        self.epoch = epoch
+
+    def forward(self):
+        start = time.time()
+        self.data_sr_seq = self.netEAVSRP(self.data_lr_seq)
+        self.data_sr = self.data_sr_seq[:, self.idx]
+        end = time.time()
+        if not self.isfirst:
+            self.time += end - start
+            self.num += 1
+        self.isfirst = False
+
+    def test(self):
+        with torch.no_grad():
+            self.forward()
+
+    def optimize_parameters(self):
+        raise NotImplementedError("training needs the backward kernels (SURVEY.md 8: config 4, not in this round)")
+
+    def get_current_visuals(self):
+        out = {}
+        for name in self.visual_names:
+            v = getattr(self, name, None)
+            if v is not None:
+                out[name] = torch.clamp(v.detach() * 255.0, 0, 255).round()
+        return out
+
+    def save_networks(self, path):
+        torch.save({"state_dict": {k: v.cpu() for k, v in self.netEAVSRP.state_dict().items()}}, path)
+
+    def load_networks(self, path):
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        self.netEAVSRP.load_state_dict(sd, strict=True)

@@ -1,0 +1,348 @@
+"""Drop-in counterparts of the hot-path classes of the reference's models/networks.py.
+
+Same class names, constructor arguments, forward() signatures and state_dict keys as the
+reference (so `load_networks`, which exits on any key mismatch -- base_model.py:193-213 -- keeps
+working), but every forward() runs hand-written HIP kernels from libeavsr_hip.so through
+eavsr_amd.ops.  The modules can be *constructed* and (de)serialised on any device; calling them
+needs fp32 tensors on a MI355X -- there is no CPU or PyTorch-op fallback.
+
+Only what EAVSRP instantiates is here (rows 2-6, 8); the dead classes of
+networks.py (PatchSelect, ResBlock*, Flownet, SPYAdaSTN, ...) are out of scope.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import List, Sequence, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+Tensor = torch.Tensor
+TensorOrList = Union[Tensor, Sequence[Tensor]]
+
+
+# --------------------------------------------------------------------------------------------
+# layer-string builder (networks.py:84-95 `seq`, :108-190 `conv`): only the modes the hot path uses
+# --------------------------------------------------------------------------------------------
+def seq(*args):
+    if len(args) == 1:
+        args = args[0]
+    if isinstance(args, nn.Module):
+        return args
+    return nn.Sequential(*[seq(a) for a in args])
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d parameter container (same keys / default init) whose forward is the MFMA conv.
+    Dense stride-1 "same" convolutions only; `act` fuses the activation that follows it in the
+    reference's nn.Sequential."""
+
+    def forward(self, x: TensorOrList, act=None, slope=0.0, residual=None, chan_partial=False):
+        if self.groups != 1 or self.stride != (1, 1) or self.dilation != (1, 1) or \
+                self.padding != (self.kernel_size[0] // 2,) * 2 or self.padding_mode != "zeros":
+            raise NotImplementedError("eavsr_amd Conv2d: dense stride-1 same-padding convolutions only")
+        return ops.conv2d(x, self.weight, self.bias, act=act, slope=slope, residual=residual,
+                          chan_partial=chan_partial)
+
+
+class _Act(nn.Module):
+    """Placeholder that keeps nn.Sequential indices (hence state_dict keys) identical to the
+    reference; the activation itself is fused into the preceding conv's epilogue."""
+
+    def __init__(self, kind: str, slope: float = 0.0):
+        super().__init__()
+        self.kind, self.slope = kind, slope
+
+    def extra_repr(self):
+        return f"{self.kind}, slope={self.slope} (fused)"
+
+
+def conv(in_channels=64, out_channels=64, kernel_size=3, stride=1, padding=1, bias=True, groups=1, mode="CBR"):
+    """networks.py:108-190 for the modes EAVSRP uses: 'C', 'R', 'L' (LeakyReLU 0.2)."""
+    L = []
+    for t in mode:
+        if t == "C":
+            L.append(Conv2d(in_channels, out_channels, kernel_size, stride, padding, groups=groups, bias=bias))
+        elif t in "Rr":
+            L.append(_Act("relu"))
+        elif t in "Ll":
+            L.append(_Act("lrelu", 0.2))
+        else:
+            raise NotImplementedError(f"conv mode {t!r} is not used on the EAVSR hot path")
+    return seq(*L)
+
+
+def _run_fused(seq_mod: nn.Sequential, x: TensorOrList, residual=None, chan_partial=False):
+    """Run a Sequential of Conv2d / _Act with each activation fused into the conv before it."""
+    mods = list(seq_mod) if isinstance(seq_mod, nn.Sequential) else [seq_mod]
+    i, out = 0, x
+    while i < len(mods):
+        m = mods[i]
+        if not isinstance(m, Conv2d):
+            raise NotImplementedError(type(m))
+        act, slope = None, 0.0
+        if i + 1 < len(mods) and isinstance(mods[i + 1], _Act):
+            act, slope = mods[i + 1].kind, mods[i + 1].slope
+            i += 1
+        last = i == len(mods) - 1
+        out = m(out, act=act, slope=slope, residual=residual if last else None,
+                chan_partial=chan_partial and last)
+        i += 1
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# flow_warp  (networks.py:699-739)
+# --------------------------------------------------------------------------------------------
+def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_corners=True):
+    """Warp `x` (n,c,h,w) by `flow` (n,2,h,w; channel 0 = x displacement, 1 = y, in pixels)."""
+    if interpolation != "bilinear" or not align_corners:
+        raise NotImplementedError("the reference path only uses bilinear, align_corners=True")
+    return ops.flow_warp(x, flow, padding_mode=padding_mode, flow_layout="nchw")
+
+
+# --------------------------------------------------------------------------------------------
+# DCNv2 (mmcv.ops stand-ins: networks.py:573)
+# --------------------------------------------------------------------------------------------
+modulated_deform_conv2d = ops.modulated_deform_conv2d
+
+
+class ModulatedDeformConv2d(nn.Module):
+    """Parameter-compatible with mmcv.ops.ModulatedDeformConv2d (weight, bias; mmcv's default init
+    uniform(+-1/sqrt(cin*kh*kw)), zero bias)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deform_groups=1, bias=True):
+        super().__init__()
+        ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, ks
+        self.stride = (stride, stride) if isinstance(stride, int) else tuple(stride)
+        self.padding = (padding, padding) if isinstance(padding, int) else tuple(padding)
+        self.dilation = (dilation, dilation) if isinstance(dilation, int) else tuple(dilation)
+        self.groups, self.deform_groups = groups, deform_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels // groups, *ks))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.init_weights()
+
+    def init_weights(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1.0 / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv2d(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                       self.dilation, self.groups, self.deform_groups)
+
+
+# --------------------------------------------------------------------------------------------
+# offset predictors (networks.py:280-348, 566-571)
+# --------------------------------------------------------------------------------------------
+_REGULAR = [[-1, -1, -1, 0, 0, 0, 1, 1, 1], [-1, 0, 1, -1, 0, 1, -1, 0, 1]]
+
+
+class _AdaptBase(nn.Module):
+    def __init__(self, inplanes):
+        super().__init__()
+        self.register_buffer("regular_matrix", torch.tensor(_REGULAR).float())
+        self.concat = conv(inplanes * 2, inplanes * 2, groups=inplanes * 2, mode="CL")
+        self.concat2 = conv(inplanes * 2, inplanes, groups=inplanes, mode="CL")
+
+    def _frontend(self, x, h_hr):
+        c1, c2 = self.concat[0], self.concat2[0]
+        return ops.adapt_frontend(x, h_hr, c1.weight, c1.bias, c2.weight, c2.bias)
+
+
+class AdaptBlock2_3x3(_AdaptBase):
+    """networks.py:318-348: (x, h_hr) -> 18 sampling offsets of one 3x3 grid."""
+
+    def __init__(self, opt, inplanes=64, outplanes=64, stride=1, dilation=1, deformable_groups=64):
+        super().__init__(inplanes)
+        self.opt = opt
+        self.mask = True
+        self.transform_matrix_conv = Conv2d(inplanes, 4, 3, 1, 1, bias=True)
+        self.translation_conv = Conv2d(inplanes, 2, 3, 1, 1, bias=True)
+
+    def forward(self, x, h_hr):
+        f = self._frontend(x, h_hr)
+        heads = ops.conv2d(f, [self.transform_matrix_conv.weight, self.translation_conv.weight],
+                           [self.transform_matrix_conv.bias, self.translation_conv.bias])
+        return ops.affine_offsets(heads, 1, with_mask=False)[0]
+
+
+class AdaptBlockOffset(_AdaptBase):
+    """networks.py:280-315: (x, h_hr) -> (offset (n,18D,h,w) in mmcv order, mask (n,9D,h,w))."""
+
+    def __init__(self, opt, inplanes=64, outplanes=64, stride=1, dilation=1, deformable_groups=64):
+        super().__init__(inplanes)
+        self.D = deformable_groups
+        self.opt = opt
+        self.transform_matrix_conv = Conv2d(inplanes, 4 * self.D, 5, 1, 2, bias=True)
+        self.translation_conv = Conv2d(inplanes, 2 * self.D, 5, 1, 2, bias=True)
+        self.mask_conv = Conv2d(inplanes, 9 * self.D, 5, 1, 2, bias=True)
+        self.relu = _Act("lrelu", 0.2)  # unused by forward in the reference as well
+
+    def forward(self, x, h_hr):
+        f = self._frontend(x, h_hr)
+        heads = ops.conv2d(f, [self.transform_matrix_conv.weight, self.translation_conv.weight, self.mask_conv.weight],
+                           [self.transform_matrix_conv.bias, self.translation_conv.bias, self.mask_conv.bias])
+        return ops.affine_offsets(heads, self.D, with_mask=True)
+
+
+class TransOffsetworelu(nn.Module):
+    """networks.py:566-571: 3x3 conv 18 -> 2 ("offsets -> residual flow"), no activation."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv_first = conv(18, 2, mode="C")
+
+    def forward(self, offset):
+        return self.conv_first(offset)
+
+
+class MultiAdSTN(ModulatedDeformConv2d):
+    """networks.py:575-631.  forward(nbr_feat_l, ref_feat_l, feat_prop, offset, flag=False)."""
+
+    def __init__(self, opt, inplanes=64, outplanes=64, stride=1, dilation=1, deformable_groups=64):
+        super().__init__(inplanes, outplanes, kernel_size=3, padding=1, stride=stride, dilation=dilation,
+                         deform_groups=deformable_groups)
+        self.opt = opt
+        kw = dict(inplanes=inplanes, outplanes=outplanes, stride=stride, dilation=dilation,
+                  deformable_groups=deformable_groups)
+        self.flow_l1 = AdaptBlock2_3x3(opt, **kw)
+        self.flow_l2 = AdaptBlock2_3x3(opt, **kw)
+        self.flow_l3 = AdaptBlock2_3x3(opt, **kw)
+        self.adastn = AdaptBlockOffset(opt, **kw)
+        self.trans_l3 = TransOffsetworelu()
+        self.trans_l2 = TransOffsetworelu()
+        self.trans_l1 = TransOffsetworelu()
+        self.center = getattr(opt, "n_frame", 7) // 2
+
+    def forward(self, nbr_feat_l, ref_feat_l, feat_prop, offset, flag=False):
+        n, _, h, w = offset.shape
+        if not flag:
+            h4, w4 = int(math.floor(h * 0.25)), int(math.floor(w * 0.25))
+            h2, w2 = int(math.floor(h * 0.5)), int(math.floor(w * 0.5))
+            off_d4 = ops.resize_bilinear_ac(offset, (h4, w4), 0.25)            # :600
+            off_d2 = ops.resize_bilinear_ac(offset, (h2, w2), 0.5)             # :601
+            # level 3 (:604-608)
+            warp4 = ops.flow_warp(nbr_feat_l[2], off_d4)
+            p1 = self.trans_l3(self.flow_l3(warp4, ref_feat_l[2]))
+            p1_up = ops.resize_bilinear_ac(p1, (2 * h4, 2 * w4), 2.0)
+            # level 2 (:609-613)
+            warp2 = ops.flow_warp(nbr_feat_l[1], off_d2, flow2=p1_up)
+            p2 = self.trans_l2(self.flow_l2(warp2, ref_feat_l[1]))
+            p2_up = ops.resize_bilinear_ac(p2, (2 * h2, 2 * w2), 2.0, pre_add=p1_up)
+            # level 1 (:614-619)
+            warp1 = ops.flow_warp(nbr_feat_l[0], offset, flow2=p2_up)
+            p3 = self.trans_l1(self.flow_l1(warp1, ref_feat_l[0]))
+            offset = ops.add(p3, p2_up, offset)
+        nbr = ops.flow_warp(nbr_feat_l[0], offset)                             # :621
+        feat = ops.flow_warp(feat_prop, offset)                                # :623
+        de_offset, mask = self.adastn(nbr, ref_feat_l[0])                      # :625
+        return modulated_deform_conv2d(feat, de_offset, mask, self.weight, self.bias, self.stride, self.padding,
+                                       self.dilation, self.groups, self.deform_groups)   # :627-630
+
+
+# --------------------------------------------------------------------------------------------
+# residual channel-attention backbone (networks.py:432-482)
+# --------------------------------------------------------------------------------------------
+class CALayer(nn.Module):
+    def __init__(self, channel=64, reduction=16):
+        super().__init__()
+        self.conv_du = nn.Sequential(
+            nn.Conv2d(channel, channel // reduction, 1, padding=0, bias=True), _Act("relu"),
+            nn.Conv2d(channel // reduction, channel, 1, padding=0, bias=True), _Act("sigmoid"))
+
+    def scale_from_partial(self, partial: Tensor, hw: int) -> Tensor:
+        a, b = self.conv_du[0], self.conv_du[2]
+        return ops.ca_scale(partial, hw, a.weight, a.bias, b.weight, b.bias)
+
+    def forward(self, x):
+        """x * sigmoid(MLP(mean_hw(x))).  Stand-alone form (RCABlock uses the fused path where the
+        channel sums come out of the conv epilogue)."""
+        n, c, h, w = x.shape
+        partial = x.sum(dim=(2, 3)).view(n, 1, c)
+        return ops.scale_residual(x, self.scale_from_partial(partial, h * w), torch.zeros_like(x))
+
+
+class RCABlock(nn.Module):
+    def __init__(self, in_channels=64, out_channels=64, kernel_size=3, stride=1, padding=1, bias=True,
+                 mode="CRC", reduction=16):
+        super().__init__()
+        assert in_channels == out_channels
+        if mode[0] in "RL":
+            mode = mode[0].lower() + mode[1:]
+        self.res = conv(in_channels, out_channels, kernel_size, stride, padding, bias=bias, mode=mode)
+        self.ca = CALayer(out_channels, reduction)
+
+    def forward(self, x):
+        r, partial = _run_fused(self.res, x, chan_partial=True)     # conv-ReLU-conv, + channel sums
+        scale = self.ca.scale_from_partial(partial, x.shape[2] * x.shape[3])
+        return ops.scale_residual(r, scale, x)                      # res * y + x  (:463-464)
+
+
+class RCAGroup(nn.Module):
+    def __init__(self, in_channels=64, out_channels=64, kernel_size=3, stride=1, padding=1, bias=True,
+                 mode="CRC", reduction=16, nb=12):
+        super().__init__()
+        assert in_channels == out_channels
+        if mode[0] in "RL":
+            mode = mode[0].lower() + mode[1:]
+        RG = [RCABlock(in_channels, out_channels, kernel_size, stride, padding, bias, mode, reduction)
+              for _ in range(nb)]
+        RG.append(conv(out_channels, out_channels, mode="C"))
+        self.rg = nn.Sequential(*RG)
+
+    def forward(self, x):
+        r = x
+        for blk in list(self.rg)[:-1]:
+            r = blk(r)
+        return self.rg[-1](r, residual=x)                           # conv, + x  (:480-482)
+
+
+# --------------------------------------------------------------------------------------------
+# encoder (networks.py:522-552) -- a caller of the path ("next" row f2), run on the same conv kernel
+# --------------------------------------------------------------------------------------------
+class ContrasExtractorLayer(nn.Module):
+    """VGG16 conv1_1 .. conv3_1 without the two pools + tail conv.  The reference pulls
+    torchvision's pretrained VGG16 at construction; torchvision is not part of this image, so the
+    convs start from PyTorch's default init and real weights arrive through load_state_dict
+    (same keys: encoder.model.conv{1_1,1_2,2_1,2_2,3_1}.*, encoder.tail.*)."""
+
+    def __init__(self, n_feat=64):
+        super().__init__()
+        cfg = [("conv1_1", 3, 64), ("conv1_2", 64, 64), ("conv2_1", 64, 128), ("conv2_2", 128, 128),
+               ("conv3_1", 128, 256)]
+        od = OrderedDict()
+        for i, (name, ci, co) in enumerate(cfg):
+            od[name] = Conv2d(ci, co, 3, 1, 1)
+            if i < len(cfg) - 1:
+                od[name.replace("conv", "relu")] = _Act("relu")
+        self.tail = Conv2d(256, n_feat, 3, 1, 1)
+        self.model = nn.Sequential(od)
+        self.register_buffer("mean", torch.Tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1))
+        self.register_buffer("std", torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
+
+    def forward(self, batch):
+        batch = (batch - self.mean) / self.std
+        return self.tail(_run_fused(self.model, batch))
+
+
+def init_net(net, init_type="default", init_gain=0.02, gpu_ids=()):
+    """networks.py:67-74 replacement: one process per GPU, so no DataParallel wrapper -- the module
+    moves to gpu_ids[0] (or the current device) and is returned as is."""
+    if init_type not in ("default", None):
+        raise NotImplementedError("only init_type='default' (what the EAVSR scripts use) is supported")
+    if len(gpu_ids) > 0:
+        net.to(torch.device("cuda", gpu_ids[0]))
+    return net

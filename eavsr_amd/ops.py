@@ -1,0 +1,444 @@
+"""Functional host-side wrappers over the C ABI (include/eavsr_hip.h).
+
+PyTorch is plumbing here: it owns device memory (outputs come from torch.empty on the caching
+allocator) and the stream (torch.cuda.current_stream()).  Every function launches HIP kernels
+from libeavsr_hip.so asynchronously on that stream and raises on any error.  Inputs must be
+fp32 CUDA(HIP) tensors; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _native as N
+
+Tensor = torch.Tensor
+
+ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2}
+
+
+def _chk(t: Tensor, name: str) -> Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; eavsr_amd runs on the GPU only (no CPU path)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: dtype {t.dtype} unsupported (fp32 only in this round)")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _DeviceOf:
+    """Make sure launches go to the device that owns the tensors."""
+
+    def __init__(self, t: Tensor):
+        self.idx = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+def lib():
+    return N.load()
+
+
+# ------------------------------------------------------------------------------------------
+# optional per-launch timing (HIP events on the launch stream); off unless `with profile():`
+# ------------------------------------------------------------------------------------------
+class Profile:
+    """Collects (kernel name, algorithmic flops, algorithmic bytes, start/end event) per launch.
+    Events are recorded on the stream the kernel is launched on, so the elapsed time is the
+    device-side duration of that launch (plus ~1 us of event overhead)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+_prof: Optional[Profile] = None
+
+
+class profile:
+    def __enter__(self):
+        global _prof
+        _prof = Profile()
+        return _prof
+
+    def __exit__(self, *a):
+        global _prof
+        _prof = None
+
+
+def _launch(name: str, flops: float, nbytes: float, t: Tensor, fn, what: str):
+    """Run `fn()` (a C-ABI call returning an int status) on t's device and check it."""
+    with _DeviceOf(t):
+        if _prof is None:
+            code = fn()
+        else:
+            st = torch.cuda.current_stream(t.device)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            code = fn()
+            e1.record(st)
+            _prof.records.append((name, flops, nbytes, e0, e1))
+    N.check(code, what)
+
+
+def selftest_mfma(device="cuda:0") -> int:
+    """Number of accumulator elements that disagree with the assumed MFMA lane layout (0 = OK)."""
+    s = torch.zeros(8192, device=device, dtype=torch.float32)
+    with _DeviceOf(s):
+        N.check(lib().eavsr_selftest_mfma_f32(s.data_ptr(), _stream(s)), "selftest_mfma")
+    return int(s[0].item())
+
+
+# ------------------------------------------------------------------------------------------
+# flow_warp  (networks.py:699-739, eavsrp_model.py:587-626)
+# ------------------------------------------------------------------------------------------
+def flow_warp(x: Tensor, flow: Tensor, padding_mode: str = "zeros", flow2: Optional[Tensor] = None,
+              flow_layout: str = "nchw") -> Tensor:
+    x = _chk(x, "x")
+    n, c, h, w = x.shape
+    if flow_layout == "nchw":
+        if tuple(flow.shape) != (n, 2, h, w):
+            raise ValueError(f"The spatial sizes of input ({(h, w)}) and flow ({tuple(flow.shape)}) are not the same.")
+        layout = 0
+    elif flow_layout == "nhwc":
+        if tuple(flow.shape) != (n, h, w, 2):
+            raise ValueError(f"The spatial sizes of input ({(h, w)}) and flow ({tuple(flow.shape)}) are not the same.")
+        # a permuted view of an NCHW tensor (the reference passes flow.permute(0,2,3,1)) is used in place
+        if not flow.is_contiguous() and flow.permute(0, 3, 1, 2).is_contiguous():
+            flow = flow.permute(0, 3, 1, 2)
+            layout = 0
+        else:
+            layout = 1
+    else:
+        raise ValueError(flow_layout)
+    pm = {"zeros": 0, "border": 1}.get(padding_mode)
+    if pm is None:
+        raise NotImplementedError(f"padding_mode={padding_mode!r}: the reference path uses 'zeros' and 'border'")
+    flow = _chk(flow, "flow")
+    if flow2 is not None:
+        flow2 = _chk(flow2, "flow2")
+        if flow2.shape != flow.shape:
+            raise ValueError("flow2 must have the shape/layout of flow")
+    out = torch.empty_like(x)
+    st = _stream(x)
+    _launch("flow_warp", 8.0 * n * c * h * w, 4.0 * n * h * w * (2 * c + 2 + (2 if flow2 is not None else 0)), x,
+            lambda: lib().eavsr_flow_warp_f32(_p(x), _p(flow), _p(flow2), _p(out), n, c, h, w, layout, pm, st),
+            "flow_warp")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# packed conv weights (cached per parameter version)
+# ------------------------------------------------------------------------------------------
+class _PackCache:
+    """Packed weights, cached per weight *object* and version.  Entries hold weak references to the
+    source tensors and are verified by identity, so a freed tensor whose id / address is reused
+    can never produce a stale hit; nn.Parameters live as long as their module, so the hot path
+    always hits."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, weights: Sequence[Tensor]) -> Tensor:
+        key = tuple((id(w), w._version) for w in weights)
+        hit = self._d.get(key)
+        if hit is not None:
+            refs, packed = hit
+            if all(r() is w for r, w in zip(refs, weights)):
+                return packed
+        w = weights[0] if len(weights) == 1 else torch.cat([x.detach() for x in weights], 0)
+        w = _chk(w.detach(), "weight")
+        cout, cin, kh, kw = w.shape
+        if kh != kw:
+            raise NotImplementedError("square kernels only")
+        elems = lib().eavsr_packed_weight_elems(cout, cin, kh)
+        if elems <= 0:
+            raise NotImplementedError(f"conv weight shape {tuple(w.shape)} unsupported")
+        packed = torch.empty(elems, device=w.device, dtype=torch.float32)
+        with _DeviceOf(w):
+            N.check(lib().eavsr_pack_conv_weight_f32(_p(w), _p(packed), cout, cin, kh, _stream(w)), "pack_conv_weight")
+        d = self._d
+        # drop stale versions of the same objects and dead entries
+        ids = {id(x) for x in weights}
+        for k in [k for k in d if any(i in ids for i, _ in k)]:
+            d.pop(k, None)
+        refs = tuple(weakref.ref(x, lambda _r, k=key, d=d: d.pop(k, None)) for x in weights)
+        d[key] = (refs, packed)
+        return packed
+
+    def clear(self):
+        self._d.clear()
+
+
+pack_cache = _PackCache()
+
+
+def _cat_bias(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
+    if biases[0] is None:
+        return None
+    return biases[0] if len(biases) == 1 else torch.cat([b.detach() for b in biases], 0)
+
+
+_bias_cache = {}
+
+
+def _bias_of(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
+    if len(biases) == 1:
+        return None if biases[0] is None else _chk(biases[0].detach(), "bias")
+    key = tuple((id(b), b._version) for b in biases)
+    hit = _bias_cache.get(key)
+    if hit is not None and all(r() is b for r, b in zip(hit[0], biases)):
+        return hit[1]
+    cat = _chk(_cat_bias(biases), "bias")
+    refs = tuple(weakref.ref(b, lambda _r, k=key: _bias_cache.pop(k, None)) for b in biases)
+    _bias_cache[key] = (refs, cat)
+    return cat
+
+
+# ------------------------------------------------------------------------------------------
+# dense conv  (nn.Conv2d, stride 1, "same" padding)
+# ------------------------------------------------------------------------------------------
+def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence[Tensor]],
+           bias: Union[None, Tensor, Sequence[Optional[Tensor]]] = None, act: Optional[str] = None,
+           slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False):
+    """conv over the virtual channel-concatenation of `srcs`; `weight` may be a list of weights
+    that are concatenated along cout (several heads in one launch).
+    Returns out, or (out, partial) with the per-tile channel sums when chan_partial=True."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    weights = [weight] if isinstance(weight, torch.Tensor) else list(weight)
+    biases = [bias] if (bias is None or isinstance(bias, torch.Tensor)) else list(bias)
+    srcs = [_chk(s, f"src{i}") for i, s in enumerate(srcs)]
+    if not 1 <= len(srcs) <= 5:
+        raise ValueError("1..5 sources")
+    n, _, h, w = srcs[0].shape
+    for s in srcs:
+        if s.shape[0] != n or tuple(s.shape[2:]) != (h, w):
+            raise ValueError("all sources must share n,h,w")
+    cin = sum(int(s.shape[1]) for s in srcs)
+    cout = sum(int(x.shape[0]) for x in weights)
+    k = int(weights[0].shape[-1])
+    if any(int(x.shape[1]) != cin for x in weights):
+        raise ValueError(f"weight expects {[int(x.shape[1]) for x in weights]} input channels, sources give {cin}")
+    ck = lib().eavsr_conv2d_ck(k)
+    if any(int(s.shape[1]) % ck for s in srcs[:-1]):
+        srcs = [torch.cat(srcs, 1)]  # ragged middle source: materialise (tiny SPyNet inputs only)
+    wp = pack_cache.get(weights)
+    b = _bias_of(biases)
+    out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
+    part = None
+    if chan_partial:
+        tiles = lib().eavsr_conv2d_tiles(h, w)
+        part = torch.empty((n, tiles, cout), device=out.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _chk(residual, "residual")
+        if residual.shape != out.shape:
+            raise ValueError("residual shape mismatch")
+    d = N.ConvDesc()
+    for i in range(5):
+        d.src[i] = _p(srcs[i]) if i < len(srcs) else None
+        d.src_c[i] = int(srcs[i].shape[1]) if i < len(srcs) else 0
+    d.n_src = len(srcs)
+    d.ksize = k
+    d.weight_packed = _p(wp)
+    d.bias = _p(b)
+    d.residual = _p(residual)
+    d.out = _p(out)
+    d.chan_partial = _p(part)
+    d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
+    d.act = ACT[act]
+    d.slope = float(slope)
+    st = _stream(out)
+    px = float(n) * h * w
+    _launch(f"conv{k}x{k}_{cin}to{cout}", 2.0 * cin * cout * k * k * px,
+            4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+            lambda: lib().eavsr_conv2d_f32(C.byref(d), st), "conv2d")
+    return (out, part) if chan_partial else out
+
+
+# ------------------------------------------------------------------------------------------
+# DCNv2  (mmcv.ops.modulated_deform_conv2d as called at networks.py:627-630)
+# ------------------------------------------------------------------------------------------
+def _one(v):
+    return int(v[0]) if isinstance(v, (tuple, list)) else int(v)
+
+
+def modulated_deform_conv2d(input: Tensor, offset: Tensor, mask: Tensor, weight: Tensor,
+                            bias: Optional[Tensor] = None, stride=1, padding=0, dilation=1, groups=1,
+                            deform_groups=1) -> Tensor:
+    """Same signature as mmcv.ops.modulated_deform_conv2d.  Supported configuration: 3x3 kernel,
+    stride 1, padding 1, dilation 1, groups 1, (cin / deform_groups) % 8 == 0 (the reference uses
+    64 channels, 8 groups).  Anything else raises NotImplementedError -- there is no fallback."""
+    x = _chk(input, "input")
+    cout, cin_g, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or _one(stride) != 1 or _one(padding) != 1 or _one(dilation) != 1 or groups != 1:
+        raise NotImplementedError(
+            f"modulated_deform_conv2d: kernel {(kh, kw)}, stride {stride}, padding {padding}, dilation {dilation}, "
+            f"groups {groups} unsupported (reference configuration: 3x3, 1, 1, 1, 1)")
+    n, cin, h, w = x.shape
+    if cin_g != cin:
+        raise ValueError("weight / input channel mismatch")
+    offset = _chk(offset, "offset")
+    mask = _chk(mask, "mask")
+    if tuple(offset.shape) != (n, deform_groups * 18, h, w):
+        raise ValueError(f"offset shape {tuple(offset.shape)} != {(n, deform_groups * 18, h, w)}")
+    if tuple(mask.shape) != (n, deform_groups * 9, h, w):
+        raise ValueError(f"mask shape {tuple(mask.shape)} != {(n, deform_groups * 9, h, w)}")
+    wp = pack_cache.get([weight])
+    b = None if bias is None else _chk(bias.detach(), "bias")
+    out = torch.empty((n, cout, h, w), device=x.device, dtype=torch.float32)
+    if (cin // deform_groups) % 8 != 0:
+        raise NotImplementedError(f"modulated_deform_conv2d: {cin // deform_groups} channels per deformable group "
+                                  "unsupported (must be a multiple of 8; the reference uses 64 channels / 8 groups)")
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch("dcnv2", 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * deform_groups + cout), x,
+            lambda: lib().eavsr_dcnv2_f32(_p(x), _p(offset), _p(mask), _p(wp), _p(b), _p(out), n, cin, h, w, cout,
+                                          deform_groups, st), "dcnv2")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# predictor pieces
+# ------------------------------------------------------------------------------------------
+def adapt_frontend(x: Tensor, h_hr: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    x, h_hr = _chk(x, "x"), _chk(h_hr, "h_hr")
+    if x.shape != h_hr.shape:
+        raise ValueError("x and h_hr must have the same shape")
+    n, c, h, w = x.shape
+    if tuple(w1.shape) != (2 * c, 1, 3, 3) or tuple(w2.shape) != (c, 2, 3, 3):
+        raise ValueError("adapt_frontend weight shapes")
+    out = torch.empty_like(x)
+    w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
+    st = _stream(x)
+    _launch("adapt_frontend", 2.0 * 27 * c * n * h * w, 4.0 * 3 * c * n * h * w, x,
+            lambda: lib().eavsr_adapt_frontend_f32(_p(x), _p(h_hr), _p(w1), _p(b1), _p(w2), _p(b2), _p(out),
+                                                   n, c, h, w, st), "adapt_frontend")
+    return out
+
+
+def affine_offsets(heads: Tensor, D: int, with_mask: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    heads = _chk(heads, "heads")
+    n, hc, h, w = heads.shape
+    if hc != (15 * D if with_mask else 6 * D):
+        raise ValueError(f"heads has {hc} channels, expected {15 * D if with_mask else 6 * D}")
+    off = torch.empty((n, 18 * D, h, w), device=heads.device, dtype=torch.float32)
+    mask = torch.empty((n, 9 * D, h, w), device=heads.device, dtype=torch.float32) if with_mask else None
+    st = _stream(heads)
+    _launch("affine_offsets", 60.0 * D * n * h * w, 4.0 * n * h * w * (hc + 18 * D + (9 * D if with_mask else 0)), heads,
+            lambda: lib().eavsr_affine_offsets_f32(_p(heads), _p(off), _p(mask), n, D, h, w, st), "affine_offsets")
+    return off, mask
+
+
+# ------------------------------------------------------------------------------------------
+# resampling glue
+# ------------------------------------------------------------------------------------------
+def resize_bilinear_ac(x: Tensor, size: Tuple[int, int], scale: float = 1.0, pre_add: Optional[Tensor] = None,
+                       post_add: Optional[Tensor] = None) -> Tensor:
+    """scale * F.interpolate(x [+ pre_add], size, bilinear, align_corners=True) [+ post_add]"""
+    x = _chk(x, "x")
+    n, c, hin, win = x.shape
+    hout, wout = int(size[0]), int(size[1])
+    if pre_add is not None:
+        pre_add = _chk(pre_add, "pre_add")
+        if pre_add.shape != x.shape:
+            raise ValueError("pre_add shape")
+    out = torch.empty((n, c, hout, wout), device=x.device, dtype=torch.float32)
+    if post_add is not None:
+        post_add = _chk(post_add, "post_add")
+        if post_add.shape != out.shape:
+            raise ValueError("post_add shape")
+    st = _stream(x)
+    _launch("resize_bilinear_ac", 0.0, 4.0 * n * c * (hin * win + hout * wout), x,
+            lambda: lib().eavsr_resize_bilinear_ac_f32(_p(x), _p(pre_add), _p(post_add), _p(out), n, c, hin, win, hout,
+                                                       wout, float(scale), st), "resize_bilinear_ac")
+    return out
+
+
+def pyramid(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """(down2, down4) of eavsrp_model.py:218-220"""
+    x = _chk(x, "x")
+    n, c, h, w = x.shape
+    if h % 4 or w % 4:
+        raise ValueError(f"h={h}, w={w} must be divisible by 4 (eavsrp_model.py:223-224)")
+    d2 = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.float32)
+    d4 = torch.empty((n, c, h // 4, w // 4), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    _launch("pyramid", 0.0, 4.0 * n * c * h * w * (1 + 0.25 + 0.0625), x,
+            lambda: lib().eavsr_pyramid_f32(_p(x), _p(d2), _p(d4), n * c, h, w, st), "pyramid")
+    return d2, d4
+
+
+def add(a: Tensor, b: Tensor, c: Optional[Tensor] = None) -> Tensor:
+    a, b = _chk(a, "a"), _chk(b, "b")
+    if a.shape != b.shape or (c is not None and c.shape != a.shape):
+        raise ValueError("add: shape mismatch")
+    if c is not None:
+        c = _chk(c, "c")
+    out = torch.empty_like(a)
+    st = _stream(a)
+    _launch("add", float(a.numel()), 4.0 * a.numel() * (3 if c is None else 4), a,
+            lambda: lib().eavsr_add_f32(_p(a), _p(b), _p(c), _p(out), a.numel(), st), "add")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# channel attention
+# ------------------------------------------------------------------------------------------
+def ca_scale(partial: Tensor, hw: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """partial (n, tiles, c) channel sums -> sigmoid(W2 relu(W1 mean + b1) + b2), shape (n, c)"""
+    partial = _chk(partial, "partial")
+    n, tiles, c = partial.shape
+    cr = int(w1.shape[0])
+    scale = torch.empty((n, c), device=partial.device, dtype=torch.float32)
+    w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
+    st = _stream(partial)
+    _launch("ca_scale", 0.0, 4.0 * partial.numel(), partial,
+            lambda: lib().eavsr_ca_scale_f32(_p(partial), tiles, hw, _p(w1), _p(b1), _p(w2), _p(b2), _p(scale), n, c,
+                                             cr, st), "ca_scale")
+    return scale
+
+
+def scale_residual(r: Tensor, scale: Tensor, x: Tensor) -> Tensor:
+    """r * scale[n,c] + x"""
+    r, x, scale = _chk(r, "r"), _chk(x, "x"), _chk(scale, "scale")
+    n, c, h, w = r.shape
+    if x.shape != r.shape or tuple(scale.shape) != (n, c):
+        raise ValueError("scale_residual: shape mismatch")
+    out = torch.empty_like(r)
+    st = _stream(r)
+    _launch("scale_residual", 2.0 * r.numel(), 12.0 * r.numel(), r,
+            lambda: lib().eavsr_scale_residual_f32(_p(r), _p(scale), _p(x), _p(out), n, c, h * w, st), "scale_residual")
+    return out

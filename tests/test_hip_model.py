@@ -1,0 +1,163 @@
+"""GPU parity tests, module level: the drop-in modules (eavsr_amd.networks / eavsrp_model) against
+the golden vectors produced by the reference and against the CPU oracle.  `pytest -m gpu`."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from oracle import eavsr_oracle as O
+from tests import helpers as H
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+OPT = Namespace(predict=False, n_frame=7, n_flow=5, scale=4)
+
+
+@pytest.fixture(scope="module")
+def nets(cuda):
+    from eavsr_amd import networks, eavsrp_model, ops
+    ops.lib()
+    return networks, eavsrp_model
+
+
+def load(module, sd, prefix, dev):
+    module.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}, strict=True)
+    return module.to(dev).eval()
+
+
+def dev(ts, d):
+    return [t.to(d) for t in ts]
+
+
+@pytest.mark.parametrize("preset", ["default", "trained_like"])
+def test_adapt_blocks_golden(nets, cuda, preset):
+    Nw, _ = nets
+    g2 = H.golden(f"g2_adapt3x3_{preset}")
+    sd = H.filled({**H.adapt3x3_shapes("g2.flow."), **H.trans_shapes("g2.trans.")}, preset)
+    blk = load(Nw.AdaptBlock2_3x3(OPT, 64, 64, deformable_groups=8), sd, "g2.flow.", cuda)
+    tr = load(Nw.TransOffsetworelu(), sd, "g2.trans.", cuda)
+    x, h = dev(cases.g2_inputs(), cuda)
+    with torch.no_grad():
+        off = blk(x, h)
+        fl = tr(off)
+    assert H.maxabs(off.cpu(), g2["offset18"]) <= 2e-5
+    assert H.maxabs(fl.cpu(), g2["flow2"]) <= 2e-5
+
+    g3 = H.golden(f"g3_adaptoffset_{preset}")
+    sd = H.filled(H.adaptoffset_shapes("g3.adastn."), preset)
+    blk = load(Nw.AdaptBlockOffset(OPT, 64, 64, deformable_groups=8), sd, "g3.adastn.", cuda)
+    x, h = dev(cases.g3_inputs(), cuda)
+    with torch.no_grad():
+        off, mask = blk(x, h)
+    assert H.maxabs(off.cpu(), g3["offset"]) <= 2e-5
+    assert H.maxabs(mask.cpu(), g3["mask"]) <= 1e-5
+
+
+@pytest.mark.parametrize("preset", ["default", "trained_like"])
+def test_multiadstn_golden(nets, cuda, preset):
+    Nw, _ = nets
+    gold = H.golden(f"g5_multiadstn_{preset}")
+    sd = H.filled(H.multiadstn_shapes("g5.align."), preset)
+    m = load(Nw.MultiAdSTN(OPT, 64, 64, deformable_groups=8), sd, "g5.align.", cuda)
+    nbr, ref, fp, flow = cases.g5_inputs()
+    with torch.no_grad():
+        out = m(dev(nbr, cuda), dev(ref, cuda), fp.to(cuda), flow.to(cuda))
+    assert H.maxabs(out.cpu(), gold["out"]) <= 1e-4
+
+
+@pytest.mark.parametrize("preset", ["default", "trained_like"])
+def test_backbone_blocks_golden(nets, cuda, preset):
+    Nw, Mw = nets
+    gold = H.golden(f"g6_backbone_{preset}")
+    x64, x128 = cases.g6_inputs()
+    sd = H.filled({**H.rcab_shapes("g6.rcab."), **H.rcagroup_shapes("g6.group.", 2),
+                   **H.rbic_shapes("g6.rbic.", 128, 2)}, preset)
+    a = load(Nw.RCABlock(64, 64), sd, "g6.rcab.", cuda)
+    b = load(Nw.RCAGroup(64, 64, nb=2), sd, "g6.group.", cuda)
+    c = load(Mw.ResidualBlocksWithInputConv(128, 64, 2), sd, "g6.rbic.", cuda)
+    with torch.no_grad():
+        assert H.maxabs(a(x64.to(cuda)).cpu(), gold["rcab"]) <= 2e-5
+        assert H.maxabs(b(x64.to(cuda)).cpu(), gold["group"]) <= 2e-5
+        assert H.maxabs(c(x128.to(cuda)).cpu(), gold["rbic"]) <= 2e-5
+        # a list of tensors stands for their concatenation
+        assert H.maxabs(c([x128[:, :64].to(cuda), x128[:, 64:].to(cuda)]).cpu(), gold["rbic"]) <= 2e-5
+        # stand-alone CALayer
+        ca = a.ca(x64.to(cuda)).cpu()
+    assert H.maxabs(ca, O.ca_layer(sd, "g6.rcab.ca.", x64)) <= 1e-5
+
+
+def _model(nets, cuda, tag, preset):
+    _, Mw = nets
+    scale = 4 if tag == "x4" else 2
+    net = Mw.EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale=scale), None)
+    sd = H.filled(H.model_shapes(tag), preset)
+    net.load_state_dict(sd, strict=True)
+    return net.to(cuda).eval(), sd
+
+
+@pytest.mark.parametrize("preset", ["default", "trained_like"])
+def test_propagate_golden(nets, cuda, preset):
+    gold = H.golden(f"g7_propagate_{preset}")
+    net, _ = _model(nets, cuda, "x4", preset)
+    feats, flows, prev = cases.g7_inputs()
+    with torch.no_grad():
+        f1 = {k: dev(v, cuda) for k, v in feats.items()}
+        f1["backward_1"] = []
+        r1 = torch.stack(net.propagate(f1, flows.to(cuda), "backward_1")["backward_1"], 1).cpu()
+        f2 = {k: dev(v, cuda) for k, v in feats.items()}
+        for k in ("backward_1", "forward_1", "backward_2"):
+            f2[k] = dev(prev[k], cuda)
+        f2["forward_2"] = []
+        r2 = torch.stack(net.propagate(f2, flows.to(cuda), "forward_2")["forward_2"], 1).cpu()
+    assert H.maxabs(r1, gold["backward_1"]) <= 2e-4
+    assert H.maxabs(r2, gold["forward_2"]) <= 2e-4
+
+
+@pytest.mark.parametrize("tag", ["x4", "x2"])
+@pytest.mark.parametrize("preset", ["default", "trained_like"])
+def test_end_to_end_golden(nets, cuda, tag, preset):
+    """BASELINE.json configs[0]: 1 x 7 x 3 x 64 x 64 clip, fp32; north-star tolerance 1e-3 max-abs
+    against the reference CPU path (here: the golden output of the real reference modules)."""
+    gold = H.golden(f"g8_e2e_{tag}_{preset}")
+    net, _ = _model(nets, cuda, tag, preset)
+    clip = cases.g8_clip().to(cuda)
+    caps = []
+    hook = net.reconstruction.register_forward_pre_hook(lambda m, inp: caps.append(inp[0]))
+    with torch.no_grad():
+        ff, fb = net.compute_flow(clip)
+        y = net(clip)
+    hook.remove()
+    assert tuple(y.shape) == tuple(gold["shape"].tolist())
+    assert H.maxabs(ff.cpu(), gold["flows_forward"]) <= 1e-4
+    assert H.maxabs(fb.cpu(), gold["flows_backward"]) <= 1e-4
+    err = H.maxabs(cases.subsample(y.cpu()), gold["sub"])
+    assert err <= 1e-3, err
+    assert H.maxabs(y.cpu().mean(dim=(-1, -2)), gold["mean"]) <= 1e-4
+    # the propagated branch features (input of `reconstruction`), far more sensitive than the output
+    n, t = 1, 7
+    srcs = caps[0]  # list of 5 frame-major tensors (t*n,64,h,w)
+    cat = torch.cat([s.view(t, n, 64, 64, 64) for s in srcs], 2)  # (t,n,320,h,w)
+    got = torch.stack([cases.subsample(cat[i].cpu()) for i in (0, 3, 6)], 1)
+    scale = max(1.0, gold["branch_feats"].abs().max().item())
+    assert H.maxabs(got, gold["branch_feats"]) <= 1e-3 * scale
+    assert O.psnr_255(y.cpu(), y.cpu()) == float("inf")
+
+
+def test_batch_of_clips_equals_single_clips(nets, cuda):
+    """clips are independent units: a batch must equal its clips run one by one."""
+    net, _ = _model(nets, cuda, "x4", "trained_like")
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    clips = synthetic_clip(2, 3, 64, 64, seed=5).to(cuda)
+    with torch.no_grad():
+        both = net(clips)
+        one = torch.cat([net(clips[i:i + 1]) for i in range(2)], 0)
+    assert H.maxabs(both.cpu(), one.cpu()) <= 1e-5
+
+
+def test_model_rejects_cpu_and_small_inputs(nets, cuda):
+    net, _ = _model(nets, cuda, "x4", "default")
+    with pytest.raises(AssertionError):
+        net(torch.zeros(1, 3, 3, 32, 32, device=cuda))
+    with pytest.raises(RuntimeError):
+        net.cpu()(torch.zeros(1, 3, 3, 64, 64))

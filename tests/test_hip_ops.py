@@ -1,0 +1,264 @@
+"""GPU parity tests, op level: every HIP kernel behind the C ABI against the CPU oracle and the
+golden vectors.  Run with `pytest -m gpu` on a MI355X."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import eavsr_oracle as O
+from tests import helpers as H
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(cuda):
+    from eavsr_amd import ops as _ops
+    _ops.lib()  # fails loudly if the HIP extension is missing
+    return _ops
+
+
+def g(t, dev):
+    return t.to(dev).contiguous()
+
+
+def rel_err(a, b):
+    return H.maxabs(a, b) / max(1e-6, b.abs().max().item())
+
+
+def test_mfma_layout_selftest(ops):
+    assert ops.selftest_mfma("cuda:0") == 0
+
+
+# ------------------------------------------------------------------------------------------ a1/a2
+def test_flow_warp_golden(ops, cuda):
+    gold = H.golden("g1_flow_warp")
+    for name, (x, flow, pad) in cases.g1_flow_warp_cases().items():
+        a = ops.flow_warp(g(x, cuda), g(flow, cuda), padding_mode=pad).cpu()
+        assert H.maxabs(a, gold[name + "__nchw"]) <= 2e-5 * max(1.0, x.abs().max().item()), name
+        b = ops.flow_warp(g(x, cuda), g(flow.permute(0, 2, 3, 1), cuda), padding_mode=pad, flow_layout="nhwc").cpu()
+        assert H.maxabs(b, gold[name + "__nhwc"]) <= 2e-5 * max(1.0, x.abs().max().item()), name
+        # a permuted NCHW view is accepted without a copy
+        c = ops.flow_warp(g(x, cuda), g(flow, cuda).permute(0, 2, 3, 1), padding_mode=pad, flow_layout="nhwc").cpu()
+        assert torch.equal(a, c), name
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 45, 80), (2, 64, 90, 160), (3, 7, 33, 70), (1, 1, 1, 1), (2, 3, 6, 10)])
+@pytest.mark.parametrize("pad", ["zeros", "border"])
+def test_flow_warp_vs_oracle(ops, cuda, shape, pad):
+    n, c, h, w = shape
+    x = cases.randn(1, n, c, h, w)
+    f1 = cases.randn(2, n, 2, h, w, scale=2.5)
+    f2 = cases.randn(3, n, 2, h, w, scale=1.0)
+    ref = O.flow_warp(x, f1 + f2, pad)
+    out = ops.flow_warp(g(x, cuda), g(f1, cuda), padding_mode=pad, flow2=g(f2, cuda)).cpu()
+    assert H.maxabs(out, ref) <= 5e-5
+
+
+def test_flow_warp_identity_and_integer_shift_exact(ops, cuda):
+    x = cases.randn(5, 2, 16, 20, 24)
+    z = torch.zeros(2, 2, 20, 24)
+    assert torch.equal(ops.flow_warp(g(x, cuda), g(z, cuda)).cpu(), x)
+    f = torch.zeros(2, 2, 20, 24)
+    f[:, 0] = 3.0
+    f[:, 1] = -2.0
+    out = ops.flow_warp(g(x, cuda), g(f, cuda)).cpu()
+    ref = torch.zeros_like(x)
+    ref[:, :, 2:, :-3] = x[:, :, :-2, 3:]
+    assert H.maxabs(out, ref) <= 1e-5
+
+
+def test_flow_warp_rejects_bad_inputs(ops, cuda):
+    x = torch.zeros(1, 2, 8, 8, device=cuda)
+    with pytest.raises(ValueError):
+        ops.flow_warp(x, torch.zeros(1, 2, 8, 9, device=cuda))
+    with pytest.raises(NotImplementedError):
+        ops.flow_warp(x, torch.zeros(1, 2, 8, 8, device=cuda), padding_mode="reflection")
+    with pytest.raises(RuntimeError):
+        ops.flow_warp(torch.zeros(1, 2, 8, 8), torch.zeros(1, 2, 8, 8))  # CPU tensor: no CPU path
+
+
+# ------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # k, srcs channels, cout, n, h, w, act, residual, partial
+    (3, [64], 64, 2, 37, 45, "relu", False, False),
+    (3, [64], 64, 1, 16, 32, None, True, True),
+    (3, [64, 64, 64], 64, 1, 20, 40, "lrelu", False, False),
+    (3, [64, 64, 64, 64, 64], 64, 1, 18, 33, "lrelu", False, False),
+    (3, [18], 2, 2, 23, 31, None, False, False),
+    (3, [3], 64, 1, 19, 21, "relu", False, False),
+    (3, [64], 6, 1, 12, 16, None, False, False),
+    (3, [64], 256, 1, 17, 35, "lrelu", False, False),
+    (3, [256], 64, 1, 9, 40, None, False, False),
+    (3, [64], 3, 1, 33, 65, None, True, False),
+    (1, [64, 64, 64], 64, 2, 21, 37, None, False, False),
+    (5, [64], 120, 1, 22, 36, None, False, False),
+    (7, [8], 32, 2, 12, 20, "relu", False, False),
+    (7, [32], 64, 1, 24, 40, "relu", False, False),
+    (7, [64], 32, 1, 6, 10, "relu", False, False),
+    (7, [16], 2, 1, 48, 80, None, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"k{c[0]}_c{'+'.join(map(str, c[1]))}_o{c[2]}_{c[4]}x{c[5]}")
+def test_conv2d_vs_torch_cpu(ops, cuda, case):
+    k, chans, cout, n, h, w, act, use_res, use_part = case
+    cin = sum(chans)
+    srcs = [cases.randn(10 + i, n, c, h, w) for i, c in enumerate(chans)]
+    wt = cases.randn(20, cout, cin, k, k, scale=1.0 / (cin * k * k) ** 0.5)
+    b = cases.randn(21, cout, scale=0.1)
+    res = cases.randn(22, n, cout, h, w) if use_res else None
+    ref = F.conv2d(torch.cat(srcs, 1), wt, b, 1, k // 2)
+    if act == "relu":
+        ref = F.relu(ref)
+    elif act == "lrelu":
+        ref = F.leaky_relu(ref, 0.1)
+    pre = ref
+    if use_res:
+        ref = ref + res
+    out = ops.conv2d([g(s, cuda) for s in srcs], g(wt, cuda), g(b, cuda), act=act, slope=0.1,
+                     residual=None if res is None else g(res, cuda), chan_partial=use_part)
+    if use_part:
+        out, part = out
+        sums = part.sum(dim=1).cpu()
+        assert H.maxabs(sums, pre.sum(dim=(2, 3))) <= 2e-3
+    assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv2d_multi_head_weights(ops, cuda):
+    x = cases.randn(1, 1, 64, 14, 18)
+    ws = [cases.randn(2 + i, co, 64, 3, 3, scale=0.05) for i, co in enumerate((4, 2))]
+    bs = [cases.randn(5 + i, co, scale=0.1) for i, co in enumerate((4, 2))]
+    out = ops.conv2d(g(x, cuda), [g(w_, cuda) for w_ in ws], [g(b_, cuda) for b_ in bs]).cpu()
+    ref = F.conv2d(x, torch.cat(ws), torch.cat(bs), 1, 1)
+    assert H.maxabs(out, ref) <= 2e-5
+
+
+def test_conv2d_weight_cache_tracks_inplace_updates(ops, cuda):
+    x = g(cases.randn(1, 1, 64, 16, 16), cuda)
+    w_ = torch.nn.Parameter(g(cases.randn(2, 64, 64, 3, 3, scale=0.05), cuda))
+    a = ops.conv2d(x, w_, None).cpu()
+    with torch.no_grad():
+        w_.mul_(2.0)
+    b = ops.conv2d(x, w_, None).cpu()
+    assert H.maxabs(b, 2 * a) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------ a7
+def _dcn_inputs(n, c, h, w, cout, dg, sigma, seed=0):
+    x = cases.randn(seed + 1, n, c, h, w)
+    off = cases.randn(seed + 2, n, dg * 18, h, w, scale=sigma)
+    mask = cases.rand(seed + 3, n, dg * 9, h, w)
+    wt = cases.randn(seed + 4, cout, c, 3, 3, scale=1.0 / (c * 9) ** 0.5)
+    b = cases.randn(seed + 5, cout, scale=0.1)
+    return x, off, mask, wt, b
+
+
+@pytest.mark.parametrize("sigma", [0.0, 0.5, 2.0, 8.0])
+@pytest.mark.parametrize("shape", [(1, 64, 24, 40, 64, 8), (2, 64, 13, 37, 64, 8), (1, 64, 10, 12, 64, 1),
+                                   (1, 16, 9, 33, 32, 2), (1, 64, 7, 5, 40, 8)])
+def test_dcnv2_vs_oracle(ops, cuda, shape, sigma):
+    n, c, h, w, cout, dg = shape
+    x, off, mask, wt, b = _dcn_inputs(n, c, h, w, cout, dg, sigma)
+    ref = O.dcnv2(x, off, mask, wt, b, 1, 1, 1, 1, dg)
+    out = ops.modulated_deform_conv2d(g(x, cuda), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), 1, 1, 1, 1, dg)
+    assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_dcnv2_zero_offset_unit_mask_is_conv2d(ops, cuda):
+    x, off, mask, wt, b = _dcn_inputs(1, 64, 20, 30, 64, 8, 0.0)
+    out = ops.modulated_deform_conv2d(g(x, cuda), g(off * 0, cuda), g(torch.ones_like(mask), cuda), g(wt, cuda),
+                                      g(b, cuda), 1, 1, 1, 1, 8).cpu()
+    assert H.maxabs(out, F.conv2d(x, wt, b, 1, 1)) <= 2e-5
+
+
+def test_dcnv2_integer_offsets_shift_the_taps(ops, cuda):
+    """offset (dy, dx) = (+1, -2) for every tap == conv2d of the image shifted by (-1, +2) with zero fill."""
+    x, off, mask, wt, b = _dcn_inputs(1, 64, 12, 16, 64, 8, 0.0)
+    off = torch.zeros_like(off)
+    off[:, 0::2] = 1.0
+    off[:, 1::2] = -2.0
+    out = ops.modulated_deform_conv2d(g(x, cuda), g(off, cuda), g(torch.ones_like(mask), cuda), g(wt, cuda),
+                                      g(b, cuda), 1, 1, 1, 1, 8).cpu()
+    xs = torch.zeros(1, 64, 12 + 8, 16 + 8)
+    xs[:, :, 4:-4, 4:-4] = x
+    # sample at (y-1+i+1, x-1+j-2): correlate the zero-extended image, then crop with the shift
+    full = F.conv2d(xs, wt, b, 1, 1)
+    ref = full[:, :, 4 + 1:4 + 1 + 12, 4 - 2:4 - 2 + 16]
+    assert H.maxabs(out, ref) <= 2e-5
+
+
+def test_dcnv2_unsupported_configs_raise(ops, cuda):
+    x = torch.zeros(1, 12, 8, 8, device=cuda)
+    with pytest.raises(NotImplementedError):  # 12/3 = 4 channels per group
+        ops.modulated_deform_conv2d(x, torch.zeros(1, 54, 8, 8, device=cuda), torch.zeros(1, 27, 8, 8, device=cuda),
+                                    torch.zeros(8, 12, 3, 3, device=cuda), None, 1, 1, 1, 1, 3)
+    with pytest.raises(NotImplementedError):  # stride 2
+        ops.modulated_deform_conv2d(torch.zeros(1, 64, 8, 8, device=cuda), torch.zeros(1, 144, 8, 8, device=cuda),
+                                    torch.zeros(1, 72, 8, 8, device=cuda), torch.zeros(64, 64, 3, 3, device=cuda),
+                                    None, 2, 1, 1, 1, 8)
+
+
+# ------------------------------------------------------------------------------------------ a3/a6 pieces
+@pytest.mark.parametrize("shape", [(1, 64, 12, 16), (2, 64, 45, 80), (1, 64, 33, 130)])
+def test_adapt_frontend_vs_oracle(ops, cuda, shape):
+    n, c, h, w = shape
+    sd = H.filled(H.adapt_front_shapes("f."), "trained_like")
+    x, hh = cases.randn(1, n, c, h, w), cases.randn(2, n, c, h, w)
+    ref = O.adapt_frontend(sd, "f.", x, hh)
+    out = ops.adapt_frontend(g(x, cuda), g(hh, cuda), g(sd["f.concat.0.weight"], cuda), g(sd["f.concat.0.bias"], cuda),
+                             g(sd["f.concat2.0.weight"], cuda), g(sd["f.concat2.0.bias"], cuda)).cpu()
+    assert H.maxabs(out, ref) <= 1e-5
+
+
+@pytest.mark.parametrize("D,with_mask", [(1, False), (8, True)])
+def test_affine_offsets_vs_oracle(ops, cuda, D, with_mask):
+    n, h, w = 2, 11, 19
+    heads = cases.randn(1, n, (15 if with_mask else 6) * D, h, w)
+    off, mask = ops.affine_offsets(g(heads, cuda), D, with_mask)
+    ref = O.affine_offsets(heads[:, :4 * D], heads[:, 4 * D:6 * D], D)
+    assert H.maxabs(off.cpu(), ref) <= 1e-5
+    if with_mask:
+        assert H.maxabs(mask.cpu(), torch.sigmoid(heads[:, 6 * D:])) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------ a5/a12 glue
+@pytest.mark.parametrize("hin,win,hout,wout,scale", [(32, 48, 8, 12, 0.25), (32, 48, 16, 24, 0.5), (8, 12, 16, 24, 2.0),
+                                                      (45, 80, 90, 160, 2.0), (6, 10, 12, 20, 2.0)])
+def test_resize_bilinear_ac(ops, cuda, hin, win, hout, wout, scale):
+    x = cases.randn(1, 2, 2, hin, win)
+    pre = cases.randn(2, 2, 2, hin, win)
+    post = cases.randn(3, 2, 2, hout, wout)
+    ref = F.interpolate(x + pre, size=(hout, wout), mode="bilinear", align_corners=True) * scale + post
+    out = ops.resize_bilinear_ac(g(x, cuda), (hout, wout), scale, pre_add=g(pre, cuda), post_add=g(post, cuda)).cpu()
+    assert H.maxabs(out, ref) <= 1e-5
+    ref2 = F.interpolate(x, size=(hout, wout), mode="bilinear", align_corners=True) * scale
+    assert H.maxabs(ops.resize_bilinear_ac(g(x, cuda), (hout, wout), scale).cpu(), ref2) <= 1e-5
+
+
+def test_pyramid_matches_interpolate(ops, cuda):
+    x = cases.randn(1, 3, 64, 36, 52)
+    d2, d4 = ops.pyramid(g(x, cuda))
+    r2, r4 = O.feature_pyramid(x)
+    assert H.maxabs(d2.cpu(), r2) <= 1e-6 and H.maxabs(d4.cpu(), r4) <= 1e-6
+    with pytest.raises(ValueError):
+        ops.pyramid(torch.zeros(1, 2, 10, 12, device=cuda))
+
+
+def test_add(ops, cuda):
+    a, b, c = (cases.randn(i, 3, 2, 17, 19) for i in range(3))
+    assert torch.equal(ops.add(g(a, cuda), g(b, cuda)).cpu(), a + b)
+    assert torch.equal(ops.add(g(a, cuda), g(b, cuda), g(c, cuda)).cpu(), a + b + c)
+
+
+# ------------------------------------------------------------------------------------------ a11
+def test_channel_attention_pieces(ops, cuda):
+    sd = H.filled(H.rcab_shapes("b."), "trained_like")
+    x = cases.randn(1, 2, 64, 20, 28)
+    r = cases.randn(2, 2, 64, 20, 28)
+    part = r.view(2, 64, 4, -1).sum(-1).permute(0, 2, 1).contiguous()  # 4 fake tiles
+    scale = ops.ca_scale(g(part, cuda), 20 * 28, g(sd["b.ca.conv_du.0.weight"], cuda), g(sd["b.ca.conv_du.0.bias"], cuda),
+                         g(sd["b.ca.conv_du.2.weight"], cuda), g(sd["b.ca.conv_du.2.bias"], cuda))
+    ref = O.ca_layer(sd, "b.ca.", r) + x
+    out = ops.scale_residual(g(r, cuda), scale, g(x, cuda)).cpu()
+    assert H.maxabs(out, ref) <= 1e-5

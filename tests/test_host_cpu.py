@@ -1,0 +1,94 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol the header
+declares, the drop-in modules construct with the reference's state_dict keys, and the product path
+fails loudly instead of falling back when it is given CPU tensors."""
+import os
+import re
+from argparse import Namespace
+
+import pytest
+import torch
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from eavsr_amd import _native, build
+    build.build_native()
+    lib = _native.load()
+    header = open(os.path.join(ROOT, "include", "eavsr_hip.h")).read()
+    declared = set(re.findall(r"\b(eavsr_[a-z0-9_]+)\s*\(", header))
+    declared -= {"eavsr_conv2d_desc"}
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.eavsr_abi_version() == _native.ABI_VERSION
+    assert b"gfx950" in lib.eavsr_version()
+    # pure host helpers (no device work)
+    assert lib.eavsr_conv2d_ck(3) == 8 and lib.eavsr_conv2d_ck(7) == 4 and lib.eavsr_conv2d_ck(1) == 16
+    assert lib.eavsr_conv2d_tiles(180, 320) == 12 * 10
+    assert lib.eavsr_packed_weight_elems(64, 64, 3) == 64 * 64 * 9
+    assert lib.eavsr_packed_weight_elems(120, 64, 5) == 2 * 64 * 25 * 64
+    assert lib.eavsr_packed_weight_elems(2, 18, 3) == 24 * 9 * 32
+
+
+def test_host_side_argument_errors_are_reported_without_a_gpu():
+    from eavsr_amd import _native
+    lib = _native.load()
+    assert lib.eavsr_flow_warp_f32(None, None, None, None, 1, 1, 1, 1, 0, 0, None) == -1
+    assert b"NULL" in lib.eavsr_last_error()
+    assert lib.eavsr_dcnv2_f32(1, 1, 1, 1, None, 1, 1, 12, 8, 8, 8, 3, None) == -2  # 4 channels / group
+    assert b"multiple of 8" in lib.eavsr_last_error()
+    assert lib.eavsr_pyramid_f32(16, 16, 16, 1, 10, 12, None) == -2
+
+
+@pytest.mark.parametrize("tag", ["x4", "x2"])
+def test_drop_in_state_dict_contract(tag):
+    from eavsr_amd.eavsrp_model import EAVSRP
+    from eavsr_amd.utils.synthetic import keys_digest, shapes_of
+    net = EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale=4 if tag == "x4" else 2), None)
+    shapes = shapes_of(net.state_dict())
+    assert shapes == H.model_shapes(tag)
+    assert keys_digest(shapes) == H.golden_keys(tag)["digest"]
+    assert not any(p.requires_grad for p in net.spynet.parameters())  # eavsrp_model.py:132-133
+    # round trip through the reference's checkpoint format {'state_dict': ...}
+    sd = H.filled(H.model_shapes(tag), "default")
+    net.load_state_dict(sd, strict=True)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_no_cpu_fallback():
+    from eavsr_amd import networks as N, ops
+    from eavsr_amd.eavsrp_model import EAVSRP
+    x = torch.zeros(1, 2, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.flow_warp(x, torch.zeros(1, 2, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        N.RCABlock(64, 64)(torch.zeros(1, 64, 8, 8))
+    net = EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale=4), None).eval()
+    with pytest.raises(RuntimeError, match="GPU only"):
+        net(torch.zeros(1, 3, 3, 64, 64))
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/"""
+    pkg = os.path.join(ROOT, "eavsr_amd")
+    pat = re.compile(r"^\s*(from|import)\s+[.\w]*oracle|[\"']oracle[\"'/]|liboracle|_oracle", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(src), os.path.join(dirpath, f)
+
+
+def test_synthetic_fill_is_order_independent_and_deterministic():
+    from eavsr_amd.utils.synthetic import fill_state_dict, synthetic_clip
+    shapes = {"b.weight": (4, 3, 3, 3), "a.weight": (2, 2, 1, 1), "a.bias": (2,)}
+    x = fill_state_dict(shapes, "default")
+    y = fill_state_dict(dict(reversed(list(shapes.items()))), "default")
+    assert all(torch.equal(x[k], y[k]) for k in shapes)
+    assert torch.equal(synthetic_clip(1, 2, 64, 64, 3), synthetic_clip(1, 2, 64, 64, 3))
+    c = synthetic_clip(2, 3, 64, 96, 1)
+    assert c.shape == (2, 3, 3, 64, 96) and 0 <= c.min() and c.max() < 1

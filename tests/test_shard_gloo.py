@@ -1,0 +1,66 @@
+"""The N>1 path on CPU: two processes, gloo backend, the same shard / barrier / max-over-ranks code
+bench.py uses on RCCL.  No GPU needed."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from eavsr_amd import shard
+    r, lr, w = shard.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    clips = torch.arange(5 * 2, dtype=torch.float32).view(5, 2, 1, 1, 1)  # 5 "clips" of 2 "frames"
+    mine = shard.shard_clips(clips, r, w)
+    shard.barrier()
+    job_time = shard.max_over_ranks(1.0 + r)          # slowest rank defines the job time
+    frames = shard.sum_over_ranks(float(mine.shape[0] * mine.shape[1]))
+    out = shard.gather_outputs(mine * 2.0, 5, r, w)   # DataParallel-style gather of per-clip results
+    q.put((rank, [int(v) for v in mine[:, 0].flatten()], job_time, frames,
+           None if out is None else out.flatten().tolist()))
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_clip_sharding_over_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, own0, t0, f0, out0), (r1, own1, t1, f1, out1) = res
+    assert own0 == [0, 4, 8] and own1 == [2, 6]         # clips 0,2,4 / 1,3 (first frame ids)
+    assert t0 == t1 == 2.0                               # MAX over ranks
+    assert f0 == f1 == 10.0                              # every frame counted exactly once
+    assert out0 == [2.0 * v for v in range(10)] and out1 is None
+
+
+def test_clip_indices_partition_every_clip_once():
+    from eavsr_amd.shard import clip_indices
+    for n in (0, 1, 7, 8, 33):
+        for world in (1, 2, 4, 8):
+            seen = sorted(i for r in range(world) for i in clip_indices(n, r, world))
+            assert seen == list(range(n))
+            sizes = [len(clip_indices(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        clip_indices(4, 2, 2)
