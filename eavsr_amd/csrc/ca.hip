@@ -9,31 +9,43 @@
 
 namespace {
 
-__global__ __launch_bounds__(64) void ca_scale_kernel(const float* __restrict__ partial, int tiles, float inv_hw,
-                                                      const float* __restrict__ w1, const float* __restrict__ b1,
-                                                      const float* __restrict__ w2, const float* __restrict__ b2,
-                                                      float* __restrict__ scale, int c, int cr) {
-  extern __shared__ float sm[];  // mean[c] then hidden[cr]
-  float* mean = sm;
-  float* hid = sm + c;
+// one workgroup per sample; 256 threads = Q groups of c threads, group q sums tiles q, q+Q, ... of its
+// channel (coalesced over channels), fixed-order LDS reduction over the groups, then the tiny MLP.
+__global__ __launch_bounds__(256) void ca_scale_kernel(const float* __restrict__ partial, int tiles, float inv_hw,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ scale, int c, int cr) {
+  extern __shared__ float sm[];  // part[Q*c] then mean[c] then hidden[cr]
+  const int Q = 256 / c;
+  float* part = sm;
+  float* mean = sm + Q * c;
+  float* hid = mean + c;
   const int bn = blockIdx.x;
-  for (int ch = threadIdx.x; ch < c; ch += 64) {
+  const int tid = threadIdx.x;
+  const int q = tid / c, ch = tid - q * c;
+  if (q < Q) {
     const float* p = partial + (size_t)bn * tiles * c + ch;
     float s = 0.f;
-    for (int t = 0; t < tiles; ++t) s += p[(size_t)t * c];
-    mean[ch] = s * inv_hw;
+    for (int t = q; t < tiles; t += Q) s += p[(size_t)t * c];
+    part[q * c + ch] = s;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < cr; j += 64) {
-    float v = b1[j];
-    for (int ch = 0; ch < c; ++ch) v += w1[j * c + ch] * mean[ch];
-    hid[j] = fmaxf(v, 0.f);
+  if (tid < c) {
+    float s = 0.f;
+    for (int k = 0; k < Q; ++k) s += part[k * c + tid];
+    mean[tid] = s * inv_hw;
   }
   __syncthreads();
-  for (int ch = threadIdx.x; ch < c; ch += 64) {
-    float v = b2[ch];
-    for (int j = 0; j < cr; ++j) v += w2[ch * cr + j] * hid[j];
-    scale[(size_t)bn * c + ch] = 1.f / (1.f + expf(-v));
+  if (tid < cr) {
+    float v = b1[tid];
+    for (int k = 0; k < c; ++k) v += w1[tid * c + k] * mean[k];
+    hid[tid] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  if (tid < c) {
+    float v = b2[tid];
+    for (int j = 0; j < cr; ++j) v += w2[tid * cr + j] * hid[j];
+    scale[(size_t)bn * c + tid] = 1.f / (1.f + expf(-v));
   }
 }
 
@@ -70,9 +82,10 @@ extern "C" int eavsr_ca_scale_f32(const float* chan_partial, int32_t tiles, int3
                                   int32_t c, int32_t cr, void* stream) {
   EAVSR_REQUIRE(chan_partial && w1 && b1 && w2 && b2 && scale, -1, "ca_scale: NULL pointer");
   EAVSR_REQUIRE(n >= 0 && c > 0 && cr > 0 && tiles > 0 && hw > 0, -1, "ca_scale: bad dims");
-  EAVSR_REQUIRE((size_t)(c + cr) * sizeof(float) <= 48 * 1024, -1, "ca_scale: c too large");
+  EAVSR_REQUIRE(c <= 256 && cr <= 256, -2, "ca_scale: c=%d / cr=%d unsupported (<= 256)", c, cr);
   if (n == 0) return 0;
-  hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(64), (c + cr) * sizeof(float), eavsr::as_stream(stream),
+  const int Q = 256 / c;
+  hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(256), (size_t)(Q * c + c + cr) * sizeof(float), eavsr::as_stream(stream),
                      chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, scale, c, cr);
   return eavsr::launch_status("ca_scale");
 }

@@ -13,15 +13,18 @@
 // D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
 //
 // Per workgroup (256 threads = 4 waves, one per SIMD; 2 workgroups per CU):
-//   for each chunk of CK input channels:
-//     stage the (16 + k - 1) x (32 + k - 1) x CK input patch (zero padded at the image border) and the
-//     CK x k*k x CO weight slab into LDS with coalesced global loads            (HBM / L2 -> LDS)
+//   for each chunk of CK input channels, two LDS stages: the LDS-DMA (global_load_lds, no VGPRs, no
+//   ds_write) of chunk i+1 is in flight behind the MFMA loop of chunk i, one barrier per chunk:
+//     the (16 + k - 1) x (32 + k - 1) x CK input patch (zero padded at the image border) and the
+//     CK x k*k x CO weight slab (contiguous in the packed layout)               (HBM / L2 -> LDS)
 //     every wave: for tap, channel pair: 2*MT + 4 ds_read_b32, MT*4 MFMAs       (LDS -> MFMA)
 //   epilogue from the accumulators: + bias, activation, + residual, coalesced 128-B row stores,
 //   optional per-tile channel sums for the channel attention (deterministic, no atomics).
 // LDS reads are conflict-free by construction: the 32 lanes of a half-wave read 32 consecutive floats.
 // The input is the virtual concatenation of up to 5 sources, so torch.cat never materialises.
 #include "common.h"
+
+#include <mutex>
 
 namespace {
 
@@ -39,27 +42,60 @@ struct ConvArgs {
   float slope;
 };
 
-template <int KS> struct ChunkOf { static constexpr int value = (KS == 1) ? 16 : (KS == 3) ? 8 : 4; };
+// Lanes of the input-patch DMA that fall outside the image (zero padding) or outside the channel
+// range read this zero word instead (an LDS-DMA cannot produce a constant by itself).
+__device__ float g_zero_word[4];
+
+template <int KS> struct ChunkOf { static constexpr int value = (KS == 1) ? 16 : (KS == 3) ? 8 : (KS == 5) ? 4 : 2; };
+
+template <int KS, int MT>
+struct ConvCfg {
+  static constexpr int CK = ChunkOf<KS>::value;
+  static constexpr int NT = 4;
+  static constexpr int TH = EAVSR_CONV_TH, TW = EAVSR_CONV_TW;
+  static constexpr int PAD = KS / 2, KK = KS * KS;
+  static constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  static constexpr int CO = 32 * MT;
+  static constexpr int IN_ELEMS = CK * IH * IW;
+  static constexpr int IN_SEGS = (IN_ELEMS + 63) / 64;   // one wave-level dword DMA = 64 floats
+  static constexpr int IN_PAD = IN_SEGS * 64;
+  static constexpr int W_ELEMS = CK * KK * CO;
+  static constexpr int W_SEGS = (W_ELEMS + 255) / 256;   // one wave-level dwordx4 DMA = 256 floats
+  static constexpr int W_PAD = W_SEGS * 256;
+  static constexpr int BUF = IN_PAD + W_PAD;             // floats per pipeline stage
+  static constexpr int LDS_FLOATS = 2 * BUF + 4 * CO;
+  static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// bijective XCD-aware remap of the linear block id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give every XCD a contiguous run of tiles (neighbouring tiles share halo rows in L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + pos;
+}
 
 template <int KS, int MT>
 __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
-  constexpr int CK = ChunkOf<KS>::value;
-  constexpr int NT = 4;
-  constexpr int TH = EAVSR_CONV_TH, TW = EAVSR_CONV_TW;
-  constexpr int PAD = KS / 2, KK = KS * KS;
-  constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
-  constexpr int CO = 32 * MT;
-  constexpr int IN_ELEMS = CK * IH * IW;
-  constexpr int W_ELEMS = CK * KK * CO;
-  __shared__ float s_in[IN_ELEMS];
-  __shared__ __attribute__((aligned(16))) float s_w[W_ELEMS];
-  __shared__ float s_red[4 * CO];
+  using Cfg = ConvCfg<KS, MT>;
+  constexpr int CK = Cfg::CK, NT = Cfg::NT, TH = Cfg::TH, TW = Cfg::TW, PAD = Cfg::PAD, KK = Cfg::KK;
+  constexpr int IH = Cfg::IH, IW = Cfg::IW, CO = Cfg::CO;
+  constexpr int IN_ELEMS = Cfg::IN_ELEMS, IN_SEGS = Cfg::IN_SEGS, IN_PAD = Cfg::IN_PAD;
+  constexpr int W_ELEMS = Cfg::W_ELEMS, W_SEGS = Cfg::W_SEGS, BUF = Cfg::BUF;
+  // ALL LDS in one array: [stage 0: input patch | weight slab][stage 1: ...][channel-sum scratch]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_red = smem + 2 * BUF;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
@@ -77,58 +113,87 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
 
-  const float* bin = s_in + half * (IH * IW) + (wave * NT) * IW + l31;
-  const float* ain = s_w + half * (KK * CO) + l31;
+  // chunk cursor over the virtual concatenation of the sources
+  int cs = 0, cc0 = 0, cbase = 0;
+  int total_chunks = 0;
+  for (int s = 0; s < a.n_src; ++s) total_chunks += (a.src_c[s] + CK - 1) / CK;
 
-  int cbase = 0;
-  for (int s = 0; s < a.n_src; ++s) {
-    const int sc = a.src_c[s];
-    const float* sp = a.src[s] + (size_t)bn * sc * plane;
-    for (int c0 = 0; c0 < sc; c0 += CK) {
-      __syncthreads();  // everyone is done reading the previous chunk
-      // ---- stage the input patch -----------------------------------------------------------
-      for (int e = tid; e < IN_ELEMS; e += 256) {
+  // ---- LDS-DMA of one chunk (input patch + weight slab) into pipeline stage `stage` ----------------
+  // global_load_lds: per-lane global address, LDS destination = wave-uniform base + lane * size, no
+  // VGPR staging and no ds_write.  Wave w moves segments w, w+4, w+8, ...
+  auto issue_chunk = [&](int stage) {
+    float* s_in = smem + stage * BUF;
+    float* s_w = s_in + IN_PAD;
+    const int sc = a.src_c[cs];
+    const float* sp = a.src[cs] + ((size_t)bn * sc + cc0) * plane;
+    const int nvalid = min(CK, sc - cc0);
+    // rolled on purpose: unrolling makes hipcc materialise every lane address / mask up front (spills)
+#pragma unroll 1
+    for (int i = 0; i < (IN_SEGS + 3) / 4; ++i) {
+      const int seg = i * 4 + wave;
+      if (seg < IN_SEGS) {  // wave-uniform
+        const int e = seg * 64 + lane;
         const int ci = e / (IH * IW);
         const int rem = e - ci * (IH * IW);
         const int r = rem / IW;
         const int cc = rem - r * IW;
         const int gy = y0 - PAD + r, gx = x0 - PAD + cc;
-        float v = 0.f;
-        if ((c0 + ci) < sc && gy >= 0 && gy < h && gx >= 0 && gx < w)
-          v = sp[(size_t)(c0 + ci) * plane + (size_t)gy * w + gx];
-        s_in[e] = v;
+        const bool ok = e < IN_ELEMS && ci < nvalid && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const float* p = ok ? sp + ((size_t)ci * plane + (size_t)gy * w + gx) : g_zero_word;
+        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(s_in + seg * 64), 4, 0, 0);
       }
-      // ---- stage the weight slab (contiguous in the packed layout) --------------------------
-      {
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(
-            a.wp + ((size_t)cot * a.cin_pad + (size_t)(cbase + c0)) * (KK * CO));
-        f32x4* wdst = reinterpret_cast<f32x4*>(s_w);
-        for (int e = tid; e < W_ELEMS / 4; e += 256) wdst[e] = wsrc[e];
+    }
+    const float* wsrc = a.wp + ((size_t)cot * a.cin_pad + (size_t)(cbase + cc0)) * (KK * CO);
+#pragma unroll 1
+    for (int i = 0; i < (W_SEGS + 3) / 4; ++i) {
+      const int seg = i * 4 + wave;
+      if (seg < W_SEGS) {  // wave-uniform
+        const int e4 = min(seg * 64 + lane, W_ELEMS / 4 - 1);  // the tail of a ragged slab re-reads its last 16 B
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)e4 * 4), (lptr_t)(s_w + seg * 256), 16, 0, 0);
       }
-      __syncthreads();
-      // ---- MFMA over the chunk --------------------------------------------------------------
+    }
+  };
+  auto advance = [&]() {
+    cc0 += CK;
+    if (cc0 >= a.src_c[cs]) {
+      cbase += a.src_c[cs];
+      ++cs;
+      cc0 = 0;
+    }
+  };
+
+  issue_chunk(0);
+  for (int it = 0; it < total_chunks; ++it) {
+    // chunk `it` has landed (this wave's DMAs: vmcnt; the other waves': the barrier); everyone is also
+    // done computing on the stage that the next DMA overwrites.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 1 < total_chunks) {
+      advance();
+      issue_chunk((it + 1) & 1);  // in flight behind the MFMA loop below
+    }
+    const float* bin = smem + (it & 1) * BUF + half * (IH * IW) + (wave * NT) * IW + l31;
+    const float* ain = smem + (it & 1) * BUF + IN_PAD + half * (KK * CO) + l31;
 #pragma unroll(KS <= 3 ? KS : 1)
-      for (int ky = 0; ky < KS; ++ky) {
+    for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          const int tap = ky * KS + kx;
+      for (int kx = 0; kx < KS; ++kx) {
+        const int tap = ky * KS + kx;
 #pragma unroll
-          for (int cp = 0; cp < CK / 2; ++cp) {
-            float av[MT], bv[NT];
+        for (int cp = 0; cp < CK / 2; ++cp) {
+          float av[MT], bv[NT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) av[m] = ain[(cp * 2 * KK + tap) * CO + m * 32];
+          for (int m = 0; m < MT; ++m) av[m] = ain[(cp * 2 * KK + tap) * CO + m * 32];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bv[t] = bin[cp * 2 * (IH * IW) + (t + ky) * IW + kx];
+          for (int t = 0; t < NT; ++t) bv[t] = bin[cp * 2 * (IH * IW) + (t + ky) * IW + kx];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-              for (int t = 0; t < NT; ++t)
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[m][t], 0, 0, 0);
-          }
+            for (int t = 0; t < NT; ++t)
+              acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[m][t], 0, 0, 0);
         }
       }
     }
-    cbase += sc;
   }
 
   // ---- epilogue ---------------------------------------------------------------------------
@@ -200,15 +265,29 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   p[i] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * kk + tap] : 0.f;
 }
 
-inline int chunk_of(int ks) { return ks == 1 ? 16 : ks == 3 ? 8 : 4; }
+inline int chunk_of(int ks) { return ks == 1 ? 16 : ks == 3 ? 8 : ks == 5 ? 4 : 2; }
 inline int co_tile_of(int cout) { return cout <= 32 ? 32 : 64; }
 
+template <int KS, int MT>
+int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  using Cfg = ConvCfg<KS, MT>;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<KS, MT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("conv2d: hipFuncSetAttribute(%zu B of LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, MT>), grid, dim3(256), Cfg::LDS_BYTES, st, a);
+  return eavsr::launch_status("conv2d");
+}
+
 template <int KS>
-void launch_ks(const ConvArgs& a, dim3 grid, int CO, hipStream_t st) {
-  if (CO == 32)
-    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, 1>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, 2>), grid, dim3(256), 0, st, a);
+int launch_ks(const ConvArgs& a, dim3 grid, int CO, hipStream_t st) {
+  return CO == 32 ? launch_one<KS, 1>(a, grid, st) : launch_one<KS, 2>(a, grid, st);
 }
 
 }  // namespace
@@ -277,13 +356,13 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
   a.slope = d->slope;
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv2d: too many tiles");
+  EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv2d: image plane too large for 32-bit tile offsets");
   dim3 grid((unsigned)blocks, eavsr::cdiv(d->cout, CO));
   hipStream_t st = eavsr::as_stream(stream);
   switch (d->ksize) {
-    case 1: launch_ks<1>(a, grid, CO, st); break;
-    case 3: launch_ks<3>(a, grid, CO, st); break;
-    case 5: launch_ks<5>(a, grid, CO, st); break;
-    default: launch_ks<7>(a, grid, CO, st); break;
+    case 1: return launch_ks<1>(a, grid, CO, st);
+    case 3: return launch_ks<3>(a, grid, CO, st);
+    case 5: return launch_ks<5>(a, grid, CO, st);
+    default: return launch_ks<7>(a, grid, CO, st);
   }
-  return eavsr::launch_status("conv2d");
 }

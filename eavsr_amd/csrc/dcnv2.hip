@@ -4,8 +4,8 @@
 // ModulatedDeformConv2d parameters of networks.py:575-583 (64 -> 64, 3x3, stride 1, pad 1,
 // dilation 1, groups 1, deform_groups 8).  mmcv runs a per-sample im2col into a (cin*9, h*w) column
 // buffer in HBM (132.7 MB at 180x320), an SGEMM and a bias pass.  Here the column tile never leaves
-// the CU: per 4x32-pixel tile and per 8-channel chunk the sampler writes col[c][tap][px] into LDS and
-// the 64 x (8*9) x 128 contraction runs on v_mfma_f32_32x32x2_f32 straight from LDS.
+// the CU: per 4x32-pixel tile and per 4-channel chunk the sampler writes col[c][tap][px] into LDS and
+// the 64 x (4*9) x 128 contraction runs on v_mfma_f32_32x32x2_f32 straight from LDS.
 //
 // Semantics restated from the published mmcv 1.x algorithm (modulated_deformable_im2col):
 //   tap k = 3 i + j samples at p = (y - 1 + i + dy, x - 1 + j + dx), dy = offset[g*18 + 2k],
@@ -15,8 +15,7 @@
 //
 // HBM traffic per pixel (fp32, cin = cout = 64, dg = 8): 64 + 144 + 72 + 64 floats = 1376 B; the input
 // patch is re-read through L1/L2 by the 9 taps (data-dependent gathers, neighbouring lanes hit the
-// same lines).  The per-(pixel, tap) corner indices / weights are computed once and reused by the 8
-// channels of the deformable group.
+// same lines).  The per-(pixel, tap) corner indices / weights are computed once per 4-channel chunk.
 #include "common.h"
 
 namespace {
@@ -31,18 +30,33 @@ struct DcnArgs {
   int n, cin, h, w, cout, dg, cpg, cin_pad, tiles_x, tiles_y;
 };
 
-constexpr int DT_H = 4, DT_W = 32, DT_PX = DT_H * DT_W;  // 128 pixels per workgroup, one row per wave
-constexpr int DCK = 8;                                   // channels per chunk
-constexpr int DKK = 9;
+// load through a wave-uniform base + 32-bit BYTE offset: lowers to `global_load_dword v, v_off, s[base]`
+// (an element index would have to be shifted in 64 bits, which forces per-lane 64-bit addresses)
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
+__device__ __forceinline__ float ld_b(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+constexpr int DT_H = 4, DT_W = 32, DT_PX = DT_H * DT_W;  // 128 pixels per workgroup, one row per wave
+constexpr int DCK = 4;                                   // channels per chunk (half a deformable group at cpg = 8)
+constexpr int DKK = 9;
+constexpr int TAPS_PER_THREAD = 5;                       // 9 taps x 128 px over 256 threads: taps h, h+2, .. (h = tid >> 7)
+
+// Small LDS footprint (27.6 KB) and few VGPRs on purpose: 4-5 workgroups per CU, so that the sampler
+// (latency-bound gathers) of some workgroups runs under the MFMA contraction of the others.
 template <int MT>
-__global__ __launch_bounds__(256, 2) void dcnv2_kernel(DcnArgs a) {
+__global__ __launch_bounds__(256, 4) void dcnv2_kernel(DcnArgs a) {
   constexpr int CO = 32 * MT;
-  __shared__ float s_col[DCK * DKK * DT_PX];                             // 36,864 B
-  __shared__ __attribute__((aligned(16))) float s_w[DCK * DKK * CO];    // 18,432 B (MT = 2)
+  constexpr int W4 = DCK * DKK * CO / 4;
+  constexpr int W_SEGS = (DCK * DKK * CO + 255) / 256;  // 1 KiB (one wave-level dwordx4 DMA) each
+  __shared__ float s_col[DCK * DKK * DT_PX];                            // 18,432 B
+  __shared__ __attribute__((aligned(16))) float s_w[W_SEGS * 256];      //  9,216 B (MT = 2)
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   int bid = blockIdx.x;
   const int tx = bid % a.tiles_x;
@@ -63,64 +77,85 @@ __global__ __launch_bounds__(256, 2) void dcnv2_kernel(DcnArgs a) {
   const float* bcol = s_col + half * (DKK * DT_PX) + wave * 32 + l31;
   const float* acol = s_w + half * (DKK * CO) + l31;
 
+  // this thread samples pixel p for the taps tap0, tap0 + 2, ...
+  const int p = tid & (DT_PX - 1);
+  const int tap0 = tid >> 7;
+  const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
+  const bool pix_ok = gy < h && gx < w;
+  const unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
+  const unsigned uplane = (unsigned)plane;
+
   for (int c0 = 0; c0 < a.cin; c0 += DCK) {
     const int g = c0 / a.cpg;
-    __syncthreads();
-    // ---- sampler: col[c][tap][px] for the 8 channels of this chunk ---------------------------
-    for (int item = tid; item < DKK * DT_PX; item += 256) {
-      const int tap = item >> 7;  // wave-uniform
-      const int p = item & (DT_PX - 1);
-      const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
-      float vals[DCK];
+    // ---- sampler: issue every offset / mask load of this thread first, then the gathers ----------
+    float oy[TAPS_PER_THREAD], ox[TAPS_PER_THREAD], mk[TAPS_PER_THREAD];
+    // wave-uniform bases + 32-bit lane offsets: `global_load v, v_off, s[base]` (no 64-bit VALU address math)
+    const float* offb = a.offset + ((size_t)bn * a.dg + g) * 18 * plane;
+    const float* mkb = a.mask + ((size_t)bn * a.dg + g) * 9 * plane;
 #pragma unroll
-      for (int c = 0; c < DCK; ++c) vals[c] = 0.f;
-      if (gy < h && gx < w) {
-        const size_t pix = (size_t)gy * w + gx;
-        const float* offp = a.offset + ((size_t)bn * a.dg * 18 + (size_t)g * 18 + 2 * tap) * plane + pix;
-        const float oy = offp[0];
-        const float ox = offp[plane];
-        const float mk = a.mask[((size_t)bn * a.dg * 9 + (size_t)g * 9 + tap) * plane + pix];
-        const int ti = tap / 3, tj = tap - 3 * ti;
-        const float py = (float)(gy - 1 + ti) + oy;
-        const float px = (float)(gx - 1 + tj) + ox;
-        if (py > -1.f && px > -1.f && py < (float)h && px < (float)w) {
-          const float fy0 = floorf(py), fx0 = floorf(px);
-          const int hl = (int)fy0, wl = (int)fx0;
-          const int hh_i = hl + 1, wh_i = wl + 1;
-          const float lh = py - fy0, lw = px - fx0;
-          const float hh = 1.f - lh, hw = 1.f - lw;
-          const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
-          const float w1 = (t_ok & l_ok) ? hh * hw : 0.f;
-          const float w2 = (t_ok & r_ok) ? hh * lw : 0.f;
-          const float w3 = (b_ok & l_ok) ? lh * hw : 0.f;
-          const float w4 = (b_ok & r_ok) ? lh * lw : 0.f;
-          const int cy0 = max(hl, 0), cy1 = min(hh_i, h - 1);
-          const int cx0 = max(wl, 0), cx1 = min(wh_i, w - 1);
-          const int i1 = cy0 * w + cx0, i2 = cy0 * w + cx1, i3 = cy1 * w + cx0, i4 = cy1 * w + cx1;
-          const float* xp = a.x + ((size_t)bn * a.cin + c0) * plane;
+    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
+      const unsigned tap = (unsigned)min(tap0 + 2 * j, DKK - 1);
+      oy[j] = ld_b(offb, (2u * tap * uplane + pix) * 4u);
+      ox[j] = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
+      mk[j] = ld_b(mkb, (tap * uplane + pix) * 4u);
+    }
+    const float* xp = a.x + ((size_t)bn * a.cin + c0) * plane;
+    __syncthreads();  // the previous chunk's contraction is done with s_col / s_w
+    // weight slab of this chunk: LDS-DMA (no VGPRs, no ds_write); lands before the barrier below
+    {
+      const float* wsrc = a.wp + ((size_t)cot * a.cin_pad + (size_t)c0) * (DKK * CO);
 #pragma unroll
-          for (int c = 0; c < DCK; ++c) {
-            const float* q = xp + (size_t)c * plane;
-            float v = w1 * q[i1];
-            v += w2 * q[i2];
-            v += w3 * q[i3];
-            v += w4 * q[i4];
-            vals[c] = v * mk;
-          }
+      for (int i = 0; i < (W_SEGS + 3) / 4; ++i) {
+        const int seg = i * 4 + wave;
+        if (seg < W_SEGS) {  // wave-uniform
+          const int e4 = min(seg * 64 + lane, W4 - 1);
+          __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)e4 * 4), (lptr_t)(s_w + seg * 256), 16, 0, 0);
         }
       }
+    }
 #pragma unroll
-      for (int c = 0; c < DCK; ++c) s_col[(c * DKK + tap) * DT_PX + p] = vals[c];
+    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
+      const int tap = tap0 + 2 * j;
+      const int ti = tap / 3, tj = tap - 3 * ti;
+      const float py = (float)(gy - 1 + ti) + oy[j];
+      const float px = (float)(gx - 1 + tj) + ox[j];
+      const bool in = pix_ok && tap < DKK && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+      const float fy0 = floorf(py), fx0 = floorf(px);
+      const float lh = py - fy0, lw = px - fx0;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      // clamp before the int conversion so that wild offsets stay defined (they are masked by `in`)
+      const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
+      const int hh_i = hl + 1, wh_i = wl + 1;
+      const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
+      const float w1 = (in & t_ok & l_ok) ? hh * hw : 0.f;
+      const float w2 = (in & t_ok & r_ok) ? hh * lw : 0.f;
+      const float w3 = (in & b_ok & l_ok) ? lh * hw : 0.f;
+      const float w4 = (in & b_ok & r_ok) ? lh * lw : 0.f;
+      const int cy0 = min(max(hl, 0), h - 1), cy1 = min(max(hh_i, 0), h - 1);
+      const int cx0 = min(max(wl, 0), w - 1), cx1 = min(max(wh_i, 0), w - 1);
+      const unsigned i1 = (unsigned)(cy0 * w + cx0) * 4u, i2 = (unsigned)(cy0 * w + cx1) * 4u;  // byte offsets
+      const unsigned i3 = (unsigned)(cy1 * w + cx0) * 4u, i4 = (unsigned)(cy1 * w + cx1) * 4u;
+      float vals[DCK];
+#pragma unroll
+      for (int c = 0; c < DCK; ++c) {
+        const float* q = xp + (size_t)c * plane;  // uniform
+        float v = w1 * ld_b(q, i1);
+        v += w2 * ld_b(q, i2);
+        v += w3 * ld_b(q, i3);
+        v += w4 * ld_b(q, i4);
+        vals[c] = v * mk[j];
+      }
+      if (tap < DKK) {
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) s_col[(c * DKK + tap) * DT_PX + p] = vals[c];
+      }
+      // bound the gathers in flight (2 taps x 4 channels x 4 corners = 32 per lane): without this the
+      // scheduler hoists all 80 gathers of the chunk and the kernel needs > 200 VGPRs
+      if (j & 1) __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- weight slab of this chunk -----------------------------------------------------------
-    {
-      const f32x4* wsrc =
-          reinterpret_cast<const f32x4*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)c0) * (DKK * CO));
-      f32x4* wdst = reinterpret_cast<f32x4*>(s_w);
-      for (int e = tid; e < DCK * DKK * CO / 4; e += 256) wdst[e] = wsrc[e];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's weight DMA has landed
     __syncthreads();
-    // ---- contraction: 36 k-steps of (channel pair, tap) ----------------------------------------
+    // ---- contraction: 18 k-steps of (channel pair, tap) ------------------------------------------
 #pragma unroll
     for (int tap = 0; tap < DKK; ++tap) {
 #pragma unroll
@@ -135,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void dcnv2_kernel(DcnArgs a) {
     }
   }
 
-  const int gy = y0 + wave, gx = x0 + l31;
-  if (gy < h && gx < w) {
+  const int oy_ = y0 + wave, ox_ = x0 + l31;
+  if (oy_ < h && ox_ < w) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -144,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void dcnv2_kernel(DcnArgs a) {
         const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co < a.cout) {
           const float b = a.bias ? a.bias[co] : 0.f;
-          a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = acc[m][r] + b;
+          a.out[((size_t)bn * a.cout + co) * plane + (size_t)oy_ * w + ox_] = acc[m][r] + b;
         }
       }
   }
@@ -161,7 +196,7 @@ extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float*
   EAVSR_REQUIRE(cin % deform_groups == 0, -1, "dcnv2: cin %d not divisible by deform_groups %d", cin,
                 deform_groups);
   const int cpg = cin / deform_groups;
-  EAVSR_REQUIRE(cpg % DCK == 0, -2,
+  EAVSR_REQUIRE(cpg % 8 == 0, -2,
                 "dcnv2: %d channels per deformable group unsupported (must be a multiple of 8; the reference "
                 "uses 64 channels / 8 groups)", cpg);
   EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "dcnv2: plane too large");

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Launch the hot kernels at the bench shapes a few times (for rocprofv3 --pmc passes)."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from eavsr_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+n, h, w = 4, 180, 320
+reps = int(os.environ.get("REPS", 5))
+which = os.environ.get("WHICH", "conv,convhr,dcn,warp").split(",")
+r = lambda *s: torch.randn(*s, device=dev)
+x64 = r(n, 64, h, w)
+w33, b = r(64, 64, 3, 3) * 0.05, r(64) * 0.1
+if "conv" in which:
+    for _ in range(reps):
+        ops.conv2d(x64, w33, b, act="relu")
+if "convhr" in which:
+    hr = r(n, 64, 4 * h, 4 * w)
+    for _ in range(2):
+        ops.conv2d(hr, w33, b, act="relu")
+if "dcn" in which:
+    off = r(n, 144, h, w) * 1.5
+    mask = torch.rand(n, 72, h, w, device=dev)
+    for _ in range(reps):
+        ops.modulated_deform_conv2d(x64, off, mask, w33, b, 1, 1, 1, 1, 8)
+if "warp" in which:
+    flow = r(n, 2, h, w) * 2
+    for _ in range(reps):
+        ops.flow_warp(x64, flow)
+torch.cuda.synchronize()
+print("done")
