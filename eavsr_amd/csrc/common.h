@@ -31,7 +31,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// spatial tile of the implicit-GEMM conv kernels: 16 rows x 32 columns per 256-thread workgroup,
+// spatial tile of the implicit-GEMM conv kernels: 32 rows x 32 columns per 512-thread workgroup,
 // wave w owns rows 4w..4w+3, one 32-pixel MFMA N-tile per row.
-#define EAVSR_CONV_TH 16
+#define EAVSR_CONV_TH 32
 #define EAVSR_CONV_TW 32

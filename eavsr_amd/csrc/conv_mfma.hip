@@ -5,14 +5,14 @@
 // 330-331,456-458,478,568 (cuDNN / MKLDNN behind PyTorch).
 //
 // GEMM view per image: out[co, px] = sum_{ci,tap} W[co, ci, tap] * in[ci, px + tap],
-//   M = cout (32 or 64 per workgroup), N = pixels (16 x 32 tile per workgroup), K = cin * k * k.
+//   M = cout (32 or 64 per workgroup), N = pixels (32 x 32 tile per workgroup), K = cin * k * k.
 // v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD = the fp32 vector peak but with
 // one operand VGPR per 4096 FLOP): lane l supplies A[i = l & 31][k = l >> 5] = weight of output
 // channel i for input channel (2 cp + (l >> 5)) at one tap, and B[k = l >> 5][j = l & 31] = the
 // input pixel j of that channel shifted by the tap.  The accumulator holds
 // D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
 //
-// Per workgroup (256 threads = 4 waves, one per SIMD; 2 workgroups per CU):
+// Per workgroup (512 threads = 8 waves, two per SIMD; one workgroup per CU, 32 x 32 pixel tile):
 //   for each chunk of CK input channels, two LDS stages: the LDS-DMA (global_load_lds, no VGPRs, no
 //   ds_write) of chunk i+1 is in flight behind the MFMA loop of chunk i, one barrier per chunk:
 //     the (16 + k - 1) x (32 + k - 1) x CK input patch (zero padded at the image border) and the
@@ -48,22 +48,32 @@ __device__ float g_zero_word[4];
 
 template <int KS> struct ChunkOf { static constexpr int value = (KS == 1) ? 16 : (KS == 3) ? 8 : (KS == 5) ? 4 : 2; };
 
-template <int KS, int MT>
+// VEC = true : the input patch moves as 16-byte DMA pieces; needs w % 4 == 0, 16-byte aligned sources and
+//              every source a multiple of CK channels.  The patch then starts 4 columns left of the tile
+//              (a whole float4) instead of PAD columns, and its per-lane source offsets are computed once
+//              per workgroup (the patch geometry is the same for every chunk; only the channel base moves).
+// VEC = false: dword pieces with per-piece address arithmetic; any width / alignment / ragged last source.
+template <int KS, int MT, bool VEC>
 struct ConvCfg {
   static constexpr int CK = ChunkOf<KS>::value;
   static constexpr int NT = 4;
   static constexpr int TH = EAVSR_CONV_TH, TW = EAVSR_CONV_TW;
   static constexpr int PAD = KS / 2, KK = KS * KS;
-  static constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  static constexpr int MARG = VEC ? (PAD ? 4 : 0) : PAD;  // columns staged left/right of the tile
+  static constexpr int IH = TH + KS - 1, IW = TW + 2 * MARG;
   static constexpr int CO = 32 * MT;
   static constexpr int IN_ELEMS = CK * IH * IW;
-  static constexpr int IN_SEGS = (IN_ELEMS + 63) / 64;   // one wave-level dword DMA = 64 floats
-  static constexpr int IN_PAD = IN_SEGS * 64;
+  static constexpr int PIECE = VEC ? 256 : 64;            // floats moved by one wave-level DMA
+  static constexpr int IN_SEGS = (IN_ELEMS + PIECE - 1) / PIECE;
+  static constexpr int IN_PAD = IN_SEGS * PIECE;
+  static constexpr int NW = EAVSR_CONV_TH / NT;            // waves per workgroup (one 4-row strip each)
+  static constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;    // pieces per wave
   static constexpr int W_ELEMS = CK * KK * CO;
-  static constexpr int W_SEGS = (W_ELEMS + 255) / 256;   // one wave-level dwordx4 DMA = 256 floats
+  static constexpr int W_SEGS = (W_ELEMS + 255) / 256;     // one wave-level dwordx4 DMA = 256 floats
   static constexpr int W_PAD = W_SEGS * 256;
-  static constexpr int BUF = IN_PAD + W_PAD;             // floats per pipeline stage
-  static constexpr int LDS_FLOATS = 2 * BUF + 4 * CO;
+  static constexpr int BUF = IN_PAD + W_PAD;               // floats per pipeline stage
+  static constexpr int W_IT = (W_SEGS + NW - 1) / NW;
+  static constexpr int LDS_FLOATS = 2 * BUF + NW * CO;
   static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
 };
 
@@ -79,13 +89,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + pos;
 }
 
-template <int KS, int MT>
-__global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
-  using Cfg = ConvCfg<KS, MT>;
+template <int KS, int MT, bool VEC>
+__global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
+  using Cfg = ConvCfg<KS, MT, VEC>;
   constexpr int CK = Cfg::CK, NT = Cfg::NT, TH = Cfg::TH, TW = Cfg::TW, PAD = Cfg::PAD, KK = Cfg::KK;
-  constexpr int IH = Cfg::IH, IW = Cfg::IW, CO = Cfg::CO;
-  constexpr int IN_ELEMS = Cfg::IN_ELEMS, IN_SEGS = Cfg::IN_SEGS, IN_PAD = Cfg::IN_PAD;
-  constexpr int W_ELEMS = Cfg::W_ELEMS, W_SEGS = Cfg::W_SEGS, BUF = Cfg::BUF;
+  constexpr int MARG = Cfg::MARG, IH = Cfg::IH, IW = Cfg::IW, CO = Cfg::CO;
+  constexpr int IN_ELEMS = Cfg::IN_ELEMS, IN_SEGS = Cfg::IN_SEGS, IN_PAD = Cfg::IN_PAD, IN_IT = Cfg::IN_IT;
+  constexpr int W_ELEMS = Cfg::W_ELEMS, W_SEGS = Cfg::W_SEGS, W_IT = Cfg::W_IT, BUF = Cfg::BUF;
+  constexpr int NW = Cfg::NW, NTHR = 64 * NW;
   // ALL LDS in one array: [stage 0: input patch | weight slab][stage 1: ...][channel-sum scratch]
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_red = smem + 2 * BUF;
@@ -118,38 +129,71 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
   int total_chunks = 0;
   for (int s = 0; s < a.n_src; ++s) total_chunks += (a.src_c[s] + CK - 1) / CK;
 
+  // VEC: per-lane byte offsets of this wave's pieces inside one CK-channel slab (0xFFFFFFFF = the piece
+  // lies in the zero padding: never moved, its LDS words stay at the zeros written below)
+  unsigned voff[VEC ? IN_IT : 1];
+  if (VEC) {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < (2 * BUF) / 4; e += NTHR) z[e] = zero;
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int seg = i * NW + wave;
+      const int e4 = seg * 64 + lane;
+      const int ci = e4 / (IH * (IW / 4));
+      const int rem = e4 - ci * (IH * (IW / 4));
+      const int r = rem / (IW / 4);
+      const int c4 = rem - r * (IW / 4);
+      const int gy = y0 - PAD + r, gx = x0 - MARG + 4 * c4;
+      const bool ok = seg < IN_SEGS && e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
+      voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
+    }
+    __syncthreads();  // the zero fill is complete before any DMA may land
+  }
+
   // ---- LDS-DMA of one chunk (input patch + weight slab) into pipeline stage `stage` ----------------
   // global_load_lds: per-lane global address, LDS destination = wave-uniform base + lane * size, no
-  // VGPR staging and no ds_write.  Wave w moves segments w, w+4, w+8, ...
+  // VGPR staging and no ds_write.  Wave w moves pieces w, w+NW, w+2NW, ...
   auto issue_chunk = [&](int stage) {
     float* s_in = smem + stage * BUF;
     float* s_w = s_in + IN_PAD;
     const int sc = a.src_c[cs];
     const float* sp = a.src[cs] + ((size_t)bn * sc + cc0) * plane;
-    const int nvalid = min(CK, sc - cc0);
-    // rolled on purpose: unrolling makes hipcc materialise every lane address / mask up front (spills)
+    if (VEC) {
+#pragma unroll
+      for (int i = 0; i < IN_IT; ++i) {
+        const int seg = i * NW + wave;
+        if (voff[i] != 0xFFFFFFFFu)
+          __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(sp) + voff[i]),
+                                           (lptr_t)(s_in + seg * 256), 16, 0, 0);
+      }
+    } else {
+      const int nvalid = min(CK, sc - cc0);
+      // rolled on purpose: unrolling makes hipcc materialise every lane address / mask up front (spills)
 #pragma unroll 1
-    for (int i = 0; i < (IN_SEGS + 3) / 4; ++i) {
-      const int seg = i * 4 + wave;
-      if (seg < IN_SEGS) {  // wave-uniform
-        const int e = seg * 64 + lane;
-        const int ci = e / (IH * IW);
-        const int rem = e - ci * (IH * IW);
-        const int r = rem / IW;
-        const int cc = rem - r * IW;
-        const int gy = y0 - PAD + r, gx = x0 - PAD + cc;
-        const bool ok = e < IN_ELEMS && ci < nvalid && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        const float* p = ok ? sp + ((size_t)ci * plane + (size_t)gy * w + gx) : g_zero_word;
-        __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(s_in + seg * 64), 4, 0, 0);
+      for (int i = 0; i < IN_IT; ++i) {
+        const int seg = i * NW + wave;
+        if (seg < IN_SEGS) {  // wave-uniform
+          const int e = seg * 64 + lane;
+          const int ci = e / (IH * IW);
+          const int rem = e - ci * (IH * IW);
+          const int r = rem / IW;
+          const int cc = rem - r * IW;
+          const int gy = y0 - PAD + r, gx = x0 - MARG + cc;
+          const bool ok = e < IN_ELEMS && ci < nvalid && gy >= 0 && gy < h && gx >= 0 && gx < w;
+          const float* p = ok ? sp + ((size_t)ci * plane + (size_t)gy * w + gx) : g_zero_word;
+          __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(s_in + seg * 64), 4, 0, 0);
+        }
       }
     }
-    const float* wsrc = a.wp + ((size_t)cot * a.cin_pad + (size_t)(cbase + cc0)) * (KK * CO);
-#pragma unroll 1
-    for (int i = 0; i < (W_SEGS + 3) / 4; ++i) {
-      const int seg = i * 4 + wave;
+    const char* wsrc = reinterpret_cast<const char*>(
+        a.wp + ((size_t)cot * a.cin_pad + (size_t)(cbase + cc0)) * (KK * CO));
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int seg = i * NW + wave;
       if (seg < W_SEGS) {  // wave-uniform
-        const int e4 = min(seg * 64 + lane, W_ELEMS / 4 - 1);  // the tail of a ragged slab re-reads its last 16 B
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)e4 * 4), (lptr_t)(s_w + seg * 256), 16, 0, 0);
+        const unsigned e4 = (unsigned)min(seg * 64 + lane, W_ELEMS / 4 - 1);  // a ragged tail re-reads its last 16 B
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(s_w + seg * 256), 16, 0, 0);
       }
     }
   };
@@ -172,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
       advance();
       issue_chunk((it + 1) & 1);  // in flight behind the MFMA loop below
     }
-    const float* bin = smem + (it & 1) * BUF + half * (IH * IW) + (wave * NT) * IW + l31;
+    const float* bin = smem + (it & 1) * BUF + half * (IH * IW) + (wave * NT) * IW + (MARG - PAD) + l31;
     const float* ain = smem + (it & 1) * BUF + IN_PAD + half * (KK * CO) + l31;
 #pragma unroll(KS <= 3 ? KS : 1)
     for (int ky = 0; ky < KS; ++ky) {
@@ -242,7 +286,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_mfma_kernel(ConvArgs a) {
     if (tid < CO) {
       const int co = cot * CO + tid;
       if (co < a.cout) {
-        const float v = ((s_red[tid] + s_red[CO + tid]) + s_red[2 * CO + tid]) + s_red[3 * CO + tid];
+        float v = s_red[tid];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) v += s_red[k * CO + tid];
         const int tile = ty * a.tiles_x + tx;
         a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + tile) * a.cout + co] = v;
       }
@@ -268,26 +314,27 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 inline int chunk_of(int ks) { return ks == 1 ? 16 : ks == 3 ? 8 : ks == 5 ? 4 : 2; }
 inline int co_tile_of(int cout) { return cout <= 32 ? 32 : 64; }
 
-template <int KS, int MT>
+template <int KS, int MT, bool VEC>
 int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  using Cfg = ConvCfg<KS, MT>;
+  using Cfg = ConvCfg<KS, MT, VEC>;
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<KS, MT>),
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<KS, MT, VEC>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv2d: hipFuncSetAttribute(%zu B of LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, MT>), grid, dim3(256), Cfg::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, MT, VEC>), grid, dim3(64 * Cfg::NW), Cfg::LDS_BYTES, st, a);
   return eavsr::launch_status("conv2d");
 }
 
 template <int KS>
-int launch_ks(const ConvArgs& a, dim3 grid, int CO, hipStream_t st) {
-  return CO == 32 ? launch_one<KS, 1>(a, grid, st) : launch_one<KS, 2>(a, grid, st);
+int launch_ks(const ConvArgs& a, dim3 grid, int CO, bool vec, hipStream_t st) {
+  if (vec) return CO == 32 ? launch_one<KS, 1, true>(a, grid, st) : launch_one<KS, 2, true>(a, grid, st);
+  return CO == 32 ? launch_one<KS, 1, false>(a, grid, st) : launch_one<KS, 2, false>(a, grid, st);
 }
 
 }  // namespace
@@ -359,10 +406,14 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
   EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv2d: image plane too large for 32-bit tile offsets");
   dim3 grid((unsigned)blocks, eavsr::cdiv(d->cout, CO));
   hipStream_t st = eavsr::as_stream(stream);
+  // 16-byte DMA path: whole float4 groups are either inside or outside the image and every piece is aligned
+  bool vec = (d->w % 4) == 0;
+  for (int s = 0; s < d->n_src; ++s)
+    vec = vec && (((uintptr_t)d->src[s]) & 15) == 0 && (d->src_c[s] % ck) == 0;
   switch (d->ksize) {
-    case 1: return launch_ks<1>(a, grid, CO, st);
-    case 3: return launch_ks<3>(a, grid, CO, st);
-    case 5: return launch_ks<5>(a, grid, CO, st);
-    default: return launch_ks<7>(a, grid, CO, st);
+    case 1: return launch_ks<1>(a, grid, CO, vec, st);
+    case 3: return launch_ks<3>(a, grid, CO, vec, st);
+    case 5: return launch_ks<5>(a, grid, CO, vec, st);
+    default: return launch_ks<7>(a, grid, CO, vec, st);
   }
 }
