@@ -185,6 +185,226 @@ __global__ __launch_bounds__(256, 4) void dcnv2_kernel(DcnArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-patch variant (w % 4 == 0, 16-byte aligned input): the (4 + 12) x (32 + 16) input window of the
+// 4 channels of a chunk is brought into LDS once by 16-byte LDS-DMA (two stages: the window of chunk
+// c+1 lands behind the sampling + contraction of chunk c) and the 9 taps gather from LDS (ds_read2_b32,
+// 128 B/clk) instead of from L1 (the gathers through the texture path were the bottleneck of the
+// global-gather kernel: ~27 clk per wave-instruction).  Taps that leave the window -- offsets beyond
+// ~+-6 px, rare after the flow pre-warp of MultiAdSTN -- fall back to a global gather, lane by lane.
+// The window is zero outside the image, which is exactly the corner-wise zero padding of the sampler.
+// Offsets / masks of chunk c+1 are prefetched into registers during chunk c.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PH = 16, PW = 48;           // window rows y0-6 .. y0+9, columns x0-8 .. x0+39
+constexpr int PY0 = 6, PX0 = 8;
+constexpr int PATCH_F = DCK * PH * PW;    // 3072 floats = 12 KiB = 12 one-KiB DMA pieces
+constexpr int PATCH_SEGS = PATCH_F / 256;
+constexpr int PATCH_IT = PATCH_SEGS / 4;  // pieces per wave
+
+template <int MT>
+__global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
+  constexpr int CO = 32 * MT;
+  constexpr int W4 = DCK * DKK * CO / 4;
+  constexpr int W_SEGS = (DCK * DKK * CO + 255) / 256;
+  // one LDS array: [col tile][weight slab][window stage 0][window stage 1]
+  __shared__ __attribute__((aligned(16))) float smem[DCK * DKK * DT_PX + W_SEGS * 256 + 2 * PATCH_F];
+  float* s_col = smem;
+  float* s_w = smem + DCK * DKK * DT_PX;
+  float* s_patch = s_w + W_SEGS * 256;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int bn = bid / a.tiles_y;
+  const int cot = blockIdx.y;
+  const int y0 = ty * DT_H, x0 = tx * DT_W;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+  const unsigned uplane = (unsigned)plane;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  const float* bcol = s_col + half * (DKK * DT_PX) + wave * 32 + l31;
+  const float* acol = s_w + half * (DKK * CO) + l31;
+
+  const int p = tid & (DT_PX - 1);
+  const int tap0 = tid >> 7;
+  const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
+  const bool pix_ok = gy < h && gx < w;
+  const unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
+
+  // zero both window stages once; pieces that lie outside the image are never moved and stay zero
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(s_patch);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < 2 * PATCH_F / 4; e += 256) z[e] = zero;
+  }
+  // per-lane byte offsets of this wave's window pieces within a 4-channel slab (0xFFFFFFFF: outside)
+  unsigned voff[PATCH_IT];
+#pragma unroll
+  for (int i = 0; i < PATCH_IT; ++i) {
+    const int e4 = (i * 4 + wave) * 64 + lane;
+    const int ci = e4 / (PH * (PW / 4));
+    const int rem = e4 - ci * (PH * (PW / 4));
+    const int r = rem / (PW / 4), c4 = rem - r * (PW / 4);
+    const int yy = y0 - PY0 + r, xx = x0 - PX0 + 4 * c4;
+    const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+    voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)yy * w + xx) * 4) : 0xFFFFFFFFu;
+  }
+  auto issue_patch = [&](int c0, int stage) {
+    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin + c0) * plane);
+#pragma unroll
+    for (int i = 0; i < PATCH_IT; ++i)
+      if (voff[i] != 0xFFFFFFFFu)
+        __builtin_amdgcn_global_load_lds((gptr_t)(xb + voff[i]),
+                                         (lptr_t)(s_patch + stage * PATCH_F + (i * 4 + wave) * 256), 16, 0, 0);
+  };
+  float oy[TAPS_PER_THREAD], ox[TAPS_PER_THREAD], mk[TAPS_PER_THREAD];
+  float oyn[TAPS_PER_THREAD], oxn[TAPS_PER_THREAD], mkn[TAPS_PER_THREAD];
+  auto load_offsets = [&](int c0, float* fy, float* fx, float* fm) {
+    const int g = c0 / a.cpg;
+    const float* offb = a.offset + ((size_t)bn * a.dg + g) * 18 * plane;
+    const float* mkb = a.mask + ((size_t)bn * a.dg + g) * 9 * plane;
+#pragma unroll
+    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
+      const unsigned tap = (unsigned)min(tap0 + 2 * j, DKK - 1);
+      fy[j] = ld_b(offb, (2u * tap * uplane + pix) * 4u);
+      fx[j] = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
+      fm[j] = ld_b(mkb, (tap * uplane + pix) * 4u);
+    }
+  };
+
+  __syncthreads();  // zero fill done before the first DMA may land
+  issue_patch(0, 0);
+  load_offsets(0, oy, ox, mk);
+
+  int stage = 0;
+  for (int c0 = 0; c0 < a.cin; c0 += DCK, stage ^= 1) {
+    // window(c0) has landed (vmcnt + barrier of the previous iteration, or here for the first chunk) and
+    // the previous contraction is done with s_col / s_w
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+      const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)c0) * (DKK * CO));
+#pragma unroll
+      for (int i = 0; i < (W_SEGS + 3) / 4; ++i) {
+        const int seg = i * 4 + wave;
+        if (seg < W_SEGS) {
+          const unsigned e4 = (unsigned)min(seg * 64 + lane, W4 - 1);
+          __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(s_w + seg * 256), 16, 0, 0);
+        }
+      }
+    }
+    const bool more = c0 + DCK < a.cin;
+    if (more) {
+      issue_patch(c0 + DCK, stage ^ 1);
+      load_offsets(c0 + DCK, oyn, oxn, mkn);  // first used after the next vmcnt(0): never waited for early
+    }
+    const float* pst = s_patch + stage * PATCH_F;
+    const float* xp = a.x + ((size_t)bn * a.cin + c0) * plane;
+#pragma unroll
+    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
+      const int tap = tap0 + 2 * j;
+      const int ti = tap / 3, tj = tap - 3 * ti;
+      const float py = (float)(gy - 1 + ti) + oy[j];
+      const float px = (float)(gx - 1 + tj) + ox[j];
+      const bool in = pix_ok && tap < DKK && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+      const float fy0 = floorf(py), fx0 = floorf(px);
+      const float lh = py - fy0, lw = px - fx0;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
+      const float m = in ? mk[j] : 0.f;
+      float vals[DCK];
+      // window coordinates of the top-left corner
+      const int ry = hl - (y0 - PY0), rx = wl - (x0 - PX0);
+      const bool in_win = ry >= 0 && ry <= PH - 2 && rx >= 0 && rx <= PW - 2;
+      if (in_win || !in) {
+        // fast path: the window holds zeros outside the image == corner-wise zero padding
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const float* q = pst + (in ? ry * PW + rx : 0);
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) {
+          float v = w1 * q[c * (PH * PW)];
+          v += w2 * q[c * (PH * PW) + 1];
+          v += w3 * q[c * (PH * PW) + PW];
+          v += w4 * q[c * (PH * PW) + PW + 1];
+          vals[c] = v * m;
+        }
+      } else {
+        const int hh_i = hl + 1, wh_i = wl + 1;
+        const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
+        const float w1 = (t_ok & l_ok) ? hh * hw : 0.f;
+        const float w2 = (t_ok & r_ok) ? hh * lw : 0.f;
+        const float w3 = (b_ok & l_ok) ? lh * hw : 0.f;
+        const float w4 = (b_ok & r_ok) ? lh * lw : 0.f;
+        const int cy0 = min(max(hl, 0), h - 1), cy1 = min(max(hh_i, 0), h - 1);
+        const int cx0 = min(max(wl, 0), w - 1), cx1 = min(max(wh_i, 0), w - 1);
+        const unsigned i1 = (unsigned)(cy0 * w + cx0) * 4u, i2 = (unsigned)(cy0 * w + cx1) * 4u;
+        const unsigned i3 = (unsigned)(cy1 * w + cx0) * 4u, i4 = (unsigned)(cy1 * w + cx1) * 4u;
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) {
+          const float* q = xp + (size_t)c * plane;
+          float v = w1 * ld_b(q, i1);
+          v += w2 * ld_b(q, i2);
+          v += w3 * ld_b(q, i3);
+          v += w4 * ld_b(q, i4);
+          vals[c] = v * m;
+        }
+      }
+      if (tap < DKK) {
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) s_col[(c * DKK + tap) * DT_PX + p] = vals[c];
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights(c0), window(c0+4), offsets(c0+4) have landed
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < DKK; ++tap) {
+#pragma unroll
+      for (int cp = 0; cp < DCK / 2; ++cp) {
+        const float b = bcol[(cp * 2 * DKK + tap) * DT_PX];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float av = acol[(cp * 2 * DKK + tap) * CO + m * 32];
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[m], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < TAPS_PER_THREAD; ++j) {
+        oy[j] = oyn[j];
+        ox[j] = oxn[j];
+        mk[j] = mkn[j];
+      }
+    }
+  }
+
+  const int oy_ = y0 + wave, ox_ = x0 + l31;
+  if (oy_ < h && ox_ < w) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < a.cout) {
+          const float b = a.bias ? a.bias[co] : 0.f;
+          a.out[((size_t)bn * a.cout + co) * plane + (size_t)oy_ * w + ox_] = acc[m][r] + b;
+        }
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float* mask,
@@ -211,9 +431,15 @@ extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float*
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "dcnv2: too many tiles");
   const int CO = cout <= 32 ? 32 : 64;
   dim3 grid((unsigned)blocks, eavsr::cdiv(cout, CO));
-  if (CO == 32)
-    hipLaunchKernelGGL(dcnv2_kernel<1>, grid, dim3(256), 0, eavsr::as_stream(stream), a);
-  else
-    hipLaunchKernelGGL(dcnv2_kernel<2>, grid, dim3(256), 0, eavsr::as_stream(stream), a);
+  // LDS-window path: whole 16-byte pieces are inside or outside the image, and aligned
+  const bool patch = (w % 4) == 0 && (((uintptr_t)x) & 15) == 0;
+  hipStream_t st = eavsr::as_stream(stream);
+  if (patch) {
+    if (CO == 32) hipLaunchKernelGGL(dcnv2_patch_kernel<1>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dcnv2_patch_kernel<2>, grid, dim3(256), 0, st, a);
+  } else {
+    if (CO == 32) hipLaunchKernelGGL(dcnv2_kernel<1>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dcnv2_kernel<2>, grid, dim3(256), 0, st, a);
+  }
   return eavsr::launch_status("dcnv2");
 }
