@@ -18,6 +18,9 @@
 // same lines).  The per-(pixel, tap) corner indices / weights are computed once per 4-channel chunk.
 #include "common.h"
 
+#include <mutex>
+#include <stdlib.h>
+
 namespace {
 
 struct DcnArgs {
@@ -405,6 +408,284 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Register-fed variant (the one the hot path runs): no column tile at all.
+// v_mfma_f32_32x32x2_f32 wants B[k = lane >> 5][j = lane & 31]: lane (half, j) therefore samples ITS OWN
+// pixel j of channel 2 cp + half and hands the value to the MFMA straight from a VGPR -- the sampler's
+// output never touches LDS, and the only barrier is the one per 8-channel group that publishes the next
+// LDS window / weight slab (both moved by 16-byte LDS-DMA while the current group computes).
+// Workgroup = 512 threads = 8 waves = 8 rows x 32 pixels; per tap a lane computes the sampling position
+// once (shared by the 4 channels it owns in the group), gathers 4 x 4 corners from the LDS window
+// (ds_read2_b32) and issues 4 x MT MFMAs whose 64-cycle shadows hide the next tap's arithmetic.
+// ---------------------------------------------------------------------------------------------------
+constexpr int RCK = 8;                        // channels per chunk
+constexpr int WW = 48;                        // window columns x0-8 .. x0+39
+
+// R = rows (= waves) per workgroup: R/4 waves per SIMD.  More waves per SIMD hide the sampler's LDS /
+// VALU latency under the other waves' MFMAs; the VGPR budget shrinks accordingly (512 / (R/4)).
+template <int MT, int R>
+struct RegCfg {
+  static constexpr int CO = 32 * MT;
+  static constexpr int WH = R + 12;                         // window rows y0-6 .. y0+R+5
+  static constexpr int WIN_F = RCK * WH * WW;
+  static constexpr int WIN_SEGS = (WIN_F + 255) / 256;
+  static constexpr int WIN_IT = (WIN_SEGS + R - 1) / R;
+  static constexpr int W_F = RCK * DKK * CO;               // weight slab floats
+  static constexpr int W_SEGS = (W_F + 255) / 256;
+  static constexpr int W_IT = (W_SEGS + R - 1) / R;
+  static constexpr int STAGE = WIN_SEGS * 256 + W_SEGS * 256;
+  static constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(float);
+};
+
+template <int MT, int R, bool PREFETCH>
+__global__ __launch_bounds__(64 * R, R / 4) void dcnv2_reg_kernel(DcnArgs a) {
+  using Cfg = RegCfg<MT, R>;
+  constexpr int CO = Cfg::CO, W_F = Cfg::W_F, W_SEGS = Cfg::W_SEGS, W_IT = Cfg::W_IT, STAGE = Cfg::STAGE;
+  constexpr int WH = Cfg::WH, WIN_F = Cfg::WIN_SEGS * 256, WIN_SEGS = Cfg::WIN_SEGS, WIN_IT = Cfg::WIN_IT;
+  constexpr int RT_H = R, NTHR = 64 * R;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [stage][window | weights]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int bn = bid / a.tiles_y;
+  const int cot = blockIdx.y;
+  const int y0 = ty * RT_H, x0 = tx * DT_W;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+  const unsigned uplane = (unsigned)plane;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  const int gy = y0 + wave, gx = x0 + l31;
+  const bool pix_ok = gy < h && gx < w;
+  const unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
+
+  {  // zero both stages once: window pieces outside the image are never moved and stay zero
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < 2 * STAGE / 4; e += NTHR) z[e] = zero;
+  }
+  unsigned voff[WIN_IT];
+#pragma unroll
+  for (int i = 0; i < WIN_IT; ++i) {
+    const int seg = i * R + wave;
+    const int e4 = seg * 64 + lane;
+    const int ci = e4 / (WH * (WW / 4));
+    const int rem = e4 - ci * (WH * (WW / 4));
+    const int r = rem / (WW / 4), c4 = rem - r * (WW / 4);
+    const int yy = y0 - 6 + r, xx = x0 - 8 + 4 * c4;
+    const bool ok = seg < WIN_SEGS && e4 < RCK * WH * WW / 4 && yy >= 0 && yy < h && xx >= 0 && xx < w;
+    voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)yy * w + xx) * 4) : 0xFFFFFFFFu;
+  }
+  auto issue_stage = [&](int c0, int stage) {
+    float* win = smem + stage * STAGE;
+    float* sw = win + WIN_F;
+    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin + c0) * plane);
+#pragma unroll
+    for (int i = 0; i < WIN_IT; ++i)
+      if (voff[i] != 0xFFFFFFFFu)
+        __builtin_amdgcn_global_load_lds((gptr_t)(xb + voff[i]), (lptr_t)(win + (i * R + wave) * 256), 16, 0, 0);
+    const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)c0) * (DKK * CO));
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int seg = i * R + wave;
+      if (seg < W_SEGS) {
+        const unsigned e4 = (unsigned)min(seg * 64 + lane, W_F / 4 - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(sw + seg * 256), 16, 0, 0);
+      }
+    }
+  };
+  float oy[DKK], ox[DKK], mk[DKK], oyn[PREFETCH ? DKK : 1], oxn[PREFETCH ? DKK : 1], mkn[PREFETCH ? DKK : 1];
+  auto load_offsets = [&](int c0, float* fy, float* fx, float* fm) {
+    const int g = c0 / a.cpg;
+    const float* offb = a.offset + ((size_t)bn * a.dg + g) * 18 * plane;
+    const float* mkb = a.mask + ((size_t)bn * a.dg + g) * 9 * plane;
+#pragma unroll
+    for (int t = 0; t < DKK; ++t) {
+      fy[t] = ld_b(offb, (2u * t * uplane + pix) * 4u);
+      fx[t] = ld_b(offb, ((2u * t + 1u) * uplane + pix) * 4u);
+      fm[t] = ld_b(mkb, ((unsigned)t * uplane + pix) * 4u);
+    }
+  };
+
+  __syncthreads();  // zero fill complete before the first DMA may land
+  issue_stage(0, 0);
+  if (PREFETCH) load_offsets(0, oy, ox, mk);
+
+  int stage = 0;
+  for (int c0 = 0; c0 < a.cin; c0 += RCK, stage ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage data + this chunk's offsets have landed
+    __syncthreads();                                   // ... for every wave; the other stage is free
+    const bool more = c0 + RCK < a.cin;
+    if (!PREFETCH) load_offsets(c0, oy, ox, mk);  // issued BEFORE the DMAs: waited for by a counted vmcnt
+    if (more) {
+      issue_stage(c0 + RCK, stage ^ 1);
+      if (PREFETCH) load_offsets(c0 + RCK, oyn, oxn, mkn);  // first used after the next vmcnt(0)
+    }
+    const float* win = smem + stage * STAGE;
+    const float* awt = win + WIN_F + half * (DKK * CO) + l31;
+    const float* xg = a.x + ((size_t)bn * a.cin + c0) * plane;
+    // Does any lane of this wave have a valid tap whose 2x2 footprint leaves the LDS window?  (rare)
+    bool need_fb = false;
+#pragma unroll
+    for (int tap = 0; tap < DKK; ++tap) {
+      const float py = (float)(gy - 1 + tap / 3) + oy[tap];
+      const float px = (float)(gx - 1 + tap % 3) + ox[tap];
+      const bool in = pix_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+      // window rows y0-6 .. y0+WH-7: floor(py) in [y0-6, y0+WH-8]  <=>  py in [y0-6, y0+WH-7)
+      const bool in_win = py >= (float)(y0 - 6) && py < (float)(y0 - 6 + WH - 1) &&
+                          px >= (float)(x0 - 8) && px < (float)(x0 - 8 + WW - 1);
+      need_fb |= in && !in_win;
+    }
+    if (!__any(need_fb)) {
+      // ---- straight-line fast path: no branch inside, so the scheduler can slide the next tap's address
+      // arithmetic and LDS gathers under the current tap's MFMAs
+#pragma unroll
+      for (int tap = 0; tap < DKK; ++tap) {
+        const int ti = tap / 3, tj = tap - 3 * ti;
+        const float py = (float)(gy - 1 + ti) + oy[tap];
+        const float px = (float)(gx - 1 + tj) + ox[tap];
+        const bool in = pix_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+        const float fy0 = floorf(py), fx0 = floorf(px);
+        const float lh = py - fy0, lw = px - fx0;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const float m = in ? mk[tap] : 0.f;
+        // clamped window coordinates (every lane that is `in` is inside the window here)
+        const int ry = (int)fminf(fmaxf(fy0 - (float)(y0 - 6), 0.f), (float)(WH - 2));
+        const int rx = (int)fminf(fmaxf(fx0 - (float)(x0 - 8), 0.f), (float)(WW - 2));
+        const float w1 = hh * hw * m, w2 = hh * lw * m, w3 = lh * hw * m, w4 = lh * lw * m;
+        const float* q = win + half * (WH * WW) + ry * WW + rx;
+        float bval[RCK / 2];
+#pragma unroll
+        for (int cp = 0; cp < RCK / 2; ++cp) {
+          const float* qc = q + cp * 2 * (WH * WW);
+          float v = w1 * qc[0];
+          v += w2 * qc[1];
+          v += w3 * qc[WW];
+          v += w4 * qc[WW + 1];
+          bval[cp] = v;
+        }
+#pragma unroll
+        for (int cp = 0; cp < RCK / 2; ++cp) {
+#pragma unroll
+          for (int mm = 0; mm < MT; ++mm) {
+            const float av = awt[(cp * 2 * DKK + tap) * CO + mm * 32];
+            acc[mm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bval[cp], acc[mm], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+  #pragma unroll
+      for (int tap = 0; tap < DKK; ++tap) {
+        const int ti = tap / 3, tj = tap - 3 * ti;
+        const float py = (float)(gy - 1 + ti) + oy[tap];
+        const float px = (float)(gx - 1 + tj) + ox[tap];
+        const bool in = pix_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+        const float fy0 = floorf(py), fx0 = floorf(px);
+        const float lh = py - fy0, lw = px - fx0;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
+        const float m = in ? mk[tap] : 0.f;
+        const int ry = hl - (y0 - 6), rx = wl - (x0 - 8);
+        const bool in_win = ry >= 0 && ry <= WH - 2 && rx >= 0 && rx <= WW - 2;
+        float bval[RCK / 2];
+        if (in_win || !in) {
+          // the window holds zeros outside the image == the sampler's corner-wise zero padding
+          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+          const float* q = win + half * (WH * WW) + (in ? ry * WW + rx : 0);
+  #pragma unroll
+          for (int cp = 0; cp < RCK / 2; ++cp) {
+            const float* qc = q + cp * 2 * (WH * WW);
+            float v = w1 * qc[0];
+            v += w2 * qc[1];
+            v += w3 * qc[WW];
+            v += w4 * qc[WW + 1];
+            bval[cp] = v * m;
+          }
+        } else {
+          const int hh_i = hl + 1, wh_i = wl + 1;
+          const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
+          const float w1 = (t_ok & l_ok) ? hh * hw : 0.f;
+          const float w2 = (t_ok & r_ok) ? hh * lw : 0.f;
+          const float w3 = (b_ok & l_ok) ? lh * hw : 0.f;
+          const float w4 = (b_ok & r_ok) ? lh * lw : 0.f;
+          const int cy0 = min(max(hl, 0), h - 1), cy1 = min(max(hh_i, 0), h - 1);
+          const int cx0 = min(max(wl, 0), w - 1), cx1 = min(max(wh_i, 0), w - 1);
+          const unsigned i1 = (unsigned)(cy0 * w + cx0) * 4u, i2 = (unsigned)(cy0 * w + cx1) * 4u;
+          const unsigned i3 = (unsigned)(cy1 * w + cx0) * 4u, i4 = (unsigned)(cy1 * w + cx1) * 4u;
+          const unsigned hoff = (unsigned)half * uplane * 4u;
+  #pragma unroll
+          for (int cp = 0; cp < RCK / 2; ++cp) {
+            const float* qc = xg + (size_t)(2 * cp) * plane;  // uniform; + half * plane via the lane offset
+            float v = w1 * ld_b(qc, i1 + hoff);
+            v += w2 * ld_b(qc, i2 + hoff);
+            v += w3 * ld_b(qc, i3 + hoff);
+            v += w4 * ld_b(qc, i4 + hoff);
+            bval[cp] = v * m;
+          }
+        }
+  #pragma unroll
+        for (int cp = 0; cp < RCK / 2; ++cp) {
+  #pragma unroll
+          for (int mm = 0; mm < MT; ++mm) {
+            const float av = awt[(cp * 2 * DKK + tap) * CO + mm * 32];
+            acc[mm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bval[cp], acc[mm], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (PREFETCH && more) {
+#pragma unroll
+      for (int t = 0; t < DKK; ++t) {
+        oy[t] = oyn[t];
+        ox[t] = oxn[t];
+        mk[t] = mkn[t];
+      }
+    }
+  }
+
+  if (pix_ok) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co < a.cout) {
+          const float b = a.bias ? a.bias[co] : 0.f;
+          a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = acc[m][r] + b;
+        }
+      }
+  }
+}
+
+template <int MT, int R, bool PREFETCH>
+int launch_reg(const DcnArgs& a, dim3 grid, hipStream_t st) {
+  using Cfg = RegCfg<MT, R>;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnv2_reg_kernel<MT, R, PREFETCH>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("dcnv2: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  hipLaunchKernelGGL((dcnv2_reg_kernel<MT, R, PREFETCH>), grid, dim3(64 * R), Cfg::LDS_BYTES, st, a);
+  return eavsr::launch_status("dcnv2");
+}
+
 }  // namespace
 
 extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float* mask,
@@ -434,7 +715,26 @@ extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float*
   // LDS-window path: whole 16-byte pieces are inside or outside the image, and aligned
   const bool patch = (w % 4) == 0 && (((uintptr_t)x) & 15) == 0;
   hipStream_t st = eavsr::as_stream(stream);
-  if (patch) {
+  static const int variant = [] {
+    // A-B switch: "reg" = register-fed B operand (experimental, currently slower: 308 us vs 271 us at
+    // 4x64x180x320), "global" = no LDS window; default = LDS-window kernel
+    const char* e = getenv("EAVSR_DCN_VARIANT");
+    return e == nullptr ? 1 : (e[0] == 'r' ? 0 : (e[0] == 'g' ? 2 : 1));
+  }();
+  static const int rows = [] {
+    const char* e = getenv("EAVSR_DCN_ROWS");  // A-B: 8, 12 or 16 rows (waves) per workgroup
+    return e == nullptr ? 8 : atoi(e);
+  }();
+  if (patch && variant == 0) {
+    const int R = rows == 8 ? 8 : rows == 16 ? 16 : 12;
+    a.tiles_y = eavsr::cdiv(h, R);
+    const long rblocks = (long)a.tiles_x * a.tiles_y * n;
+    dim3 rgrid((unsigned)rblocks, eavsr::cdiv(cout, CO));
+    if (R == 8) return CO == 32 ? launch_reg<1, 8, true>(a, rgrid, st) : launch_reg<2, 8, true>(a, rgrid, st);
+    if (R == 16) return CO == 32 ? launch_reg<1, 16, false>(a, rgrid, st) : launch_reg<2, 16, false>(a, rgrid, st);
+    return CO == 32 ? launch_reg<1, 12, true>(a, rgrid, st) : launch_reg<2, 12, true>(a, rgrid, st);
+  }
+  if (patch && variant == 1) {
     if (CO == 32) hipLaunchKernelGGL(dcnv2_patch_kernel<1>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dcnv2_patch_kernel<2>, grid, dim3(256), 0, st, a);
   } else {
