@@ -130,7 +130,7 @@ def main():
     if not torch.cuda.is_available():
         print("[bench] no GPU visible: eavsr_amd has no CPU path", file=sys.stderr)
         sys.exit(2)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     ops.lib()  # fail loudly if the HIP extension is missing
 
@@ -152,7 +152,8 @@ def main():
         shard.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, device=device if world > 1 else None)
+    on_dev = world > 1 and torch.distributed.get_backend() == "nccl"
+    elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
     frames_total = world * n * t * args.steps
     value = frames_total / elapsed
 
@@ -207,10 +208,16 @@ def main():
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120", "mfma")) if e]
         line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         line["step_device_ms_instrumented"] = total_ms
+        # HBM bytes per launch from the PMC passes of the last profiling visit (profiles/traffic.json:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there)
         pmc = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(pmc) and "roofline" in line:
+        if os.path.exists(pmc):
             try:
-                line["roofline"]["traffic"] = json.load(open(pmc)).get("conv3x3_64to64")
+                tr = json.load(open(pmc))
+                if "roofline" in line:
+                    line["roofline"]["traffic"] = tr.get("conv3x3_64to64")
+                for e in line["kernels"]:
+                    e["traffic"] = tr.get(e["kernel"])
             except Exception:
                 pass
 

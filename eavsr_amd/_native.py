@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -37,6 +37,9 @@ class ConvDesc(C.Structure):
         ("n", i32), ("h", i32), ("w", i32), ("cin", i32), ("cout", i32),
         ("act", i32),
         ("slope", f32),
+        ("ca_scale", vp),
+        ("ca_x", vp),
+        ("ca_out", vp),
     ]
 
 

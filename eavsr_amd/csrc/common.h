@@ -31,6 +31,19 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Bijective XCD-aware remap of a linear workgroup id.  Workgroups are dealt round-robin over the 8 XCDs
+// (b and b+8 share an XCD and its private L2), so consecutive ids -- neighbouring tiles that share halo
+// rows -- would land on 8 different L2s.  The remap gives every XCD a contiguous run of ids.  Placement
+// is a speed hint only; nothing depends on it for correctness.
+#ifdef __HIPCC__
+__device__ __forceinline__ int eavsr_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, pos = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + pos;
+}
+#endif
+
 // spatial tile of the implicit-GEMM conv kernels: 32 rows x 32 columns per 512-thread workgroup,
 // wave w owns rows 4w..4w+3, one 32-pixel MFMA N-tile per row.
 #define EAVSR_CONV_TH 32

@@ -37,6 +37,9 @@ struct ConvArgs {
   const float* residual;
   float* out;
   float* chan_partial;
+  const float* ca_scale;  // FUSE: effective input = src[0] * ca_scale[n, c] + ca_x
+  const float* ca_x;
+  float* ca_out;          // FUSE: optional copy of the effective input (the next residual stream)
   int n, h, w, cin, cout, cin_pad, tiles_x, tiles_y;
   int act;
   float slope;
@@ -53,9 +56,13 @@ template <int KS> struct ChunkOf { static constexpr int value = (KS == 1) ? 16 :
 //              (a whole float4) instead of PAD columns, and its per-lane source offsets are computed once
 //              per workgroup (the patch geometry is the same for every chunk; only the channel base moves).
 // VEC = false: dword pieces with per-piece address arithmetic; any width / alignment / ragged last source.
-template <int KS, int MT, bool VEC>
+// FUSE = true: channel-attention prologue (RCABlock tail, networks.py:447,463-464, fused into the next conv):
+//              two input patches (r, x) per stage and B = r * scale + x formed on the way to the MFMA;
+//              chunks of 4 channels so that two stages still fit the 160 KiB of LDS.
+template <int KS, int MT, bool VEC, bool FUSE = false>
 struct ConvCfg {
-  static constexpr int CK = ChunkOf<KS>::value;
+  static constexpr int CK = FUSE ? 4 : ChunkOf<KS>::value;
+  static constexpr int NIN = FUSE ? 2 : 1;                 // input patches per stage
   static constexpr int NT = 4;
   static constexpr int TH = EAVSR_CONV_TH, TW = EAVSR_CONV_TW;
   static constexpr int PAD = KS / 2, KK = KS * KS;
@@ -71,27 +78,19 @@ struct ConvCfg {
   static constexpr int W_ELEMS = CK * KK * CO;
   static constexpr int W_SEGS = (W_ELEMS + 255) / 256;     // one wave-level dwordx4 DMA = 256 floats
   static constexpr int W_PAD = W_SEGS * 256;
-  static constexpr int BUF = IN_PAD + W_PAD;               // floats per pipeline stage
+  static constexpr int BUF = NIN * IN_PAD + W_PAD;         // floats per pipeline stage
   static constexpr int W_IT = (W_SEGS + NW - 1) / NW;
-  static constexpr int LDS_FLOATS = 2 * BUF + NW * CO;
+  static constexpr int LDS_FLOATS = 2 * BUF + NW * CO + (FUSE ? 256 : 0);
   static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// bijective XCD-aware remap of the linear block id: blocks b and b+8 share an XCD (round-robin
-// dispatch), so give every XCD a contiguous run of tiles (neighbouring tiles share halo rows in L2).
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7;
-  const int xcd = bid & 7, pos = bid >> 3;
-  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + pos;
-}
-
-template <int KS, int MT, bool VEC>
+template <int KS, int MT, bool VEC, bool FUSE>
 __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
-  using Cfg = ConvCfg<KS, MT, VEC>;
+  using Cfg = ConvCfg<KS, MT, VEC, FUSE>;
+  static_assert(!FUSE || VEC, "the fused channel-attention prologue exists for the 16-byte DMA path only");
   constexpr int CK = Cfg::CK, NT = Cfg::NT, TH = Cfg::TH, TW = Cfg::TW, PAD = Cfg::PAD, KK = Cfg::KK;
   constexpr int MARG = Cfg::MARG, IH = Cfg::IH, IW = Cfg::IW, CO = Cfg::CO;
   constexpr int IN_ELEMS = Cfg::IN_ELEMS, IN_SEGS = Cfg::IN_SEGS, IN_PAD = Cfg::IN_PAD, IN_IT = Cfg::IN_IT;
@@ -100,13 +99,15 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
   // ALL LDS in one array: [stage 0: input patch | weight slab][stage 1: ...][channel-sum scratch]
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_red = smem + 2 * BUF;
+  float* s_y = s_red + NW * CO;  // FUSE: ca_scale[bn, 0..cin)
+  constexpr int NIN = Cfg::NIN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
@@ -148,6 +149,9 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
       const bool ok = seg < IN_SEGS && e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
       voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
     }
+    if (FUSE) {
+      for (int c = tid; c < a.cin; c += NTHR) s_y[c] = a.ca_scale[(size_t)bn * a.cin + c];
+    }
     __syncthreads();  // the zero fill is complete before any DMA may land
   }
 
@@ -156,16 +160,22 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
   // VGPR staging and no ds_write.  Wave w moves pieces w, w+NW, w+2NW, ...
   auto issue_chunk = [&](int stage) {
     float* s_in = smem + stage * BUF;
-    float* s_w = s_in + IN_PAD;
+    float* s_w = s_in + NIN * IN_PAD;
     const int sc = a.src_c[cs];
     const float* sp = a.src[cs] + ((size_t)bn * sc + cc0) * plane;
     if (VEC) {
 #pragma unroll
       for (int i = 0; i < IN_IT; ++i) {
         const int seg = i * NW + wave;
-        if (voff[i] != 0xFFFFFFFFu)
+        if (voff[i] != 0xFFFFFFFFu) {
           __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(sp) + voff[i]),
                                            (lptr_t)(s_in + seg * 256), 16, 0, 0);
+          if (FUSE) {
+            const float* xp = a.ca_x + ((size_t)bn * sc + cc0) * plane;
+            __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(xp) + voff[i]),
+                                             (lptr_t)(s_in + IN_PAD + seg * 256), 16, 0, 0);
+          }
+        }
       }
     } else {
       const int nvalid = min(CK, sc - cc0);
@@ -217,7 +227,27 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
       issue_chunk((it + 1) & 1);  // in flight behind the MFMA loop below
     }
     const float* bin = smem + (it & 1) * BUF + half * (IH * IW) + (wave * NT) * IW + (MARG - PAD) + l31;
-    const float* ain = smem + (it & 1) * BUF + IN_PAD + half * (KK * CO) + l31;
+    const float* ain = smem + (it & 1) * BUF + NIN * IN_PAD + half * (KK * CO) + l31;
+    float yv[FUSE ? CK / 2 : 1];
+    if (FUSE) {
+      const int cur_c0 = it * CK;  // single source: chunk `it` covers channels it*CK ..
+#pragma unroll
+      for (int cp = 0; cp < CK / 2; ++cp) yv[cp] = s_y[cur_c0 + 2 * cp + half];
+      if (a.ca_out != nullptr && cot == 0) {
+        // side output: the effective input of this chunk's channels for this wave's 4 x 32 interior pixels
+        const float* rin = smem + (it & 1) * BUF + (wave * NT + PAD) * IW + MARG + l31;
+        const int gxs = x0 + l31;
+#pragma unroll
+        for (int j = 0; j < (CK * NT) / 2; ++j) {
+          const int item = 2 * j + half;
+          const int ci = item / NT, t = item - ci * NT;
+          const int gys = y0 + wave * NT + t;
+          const float v = fmaf(rin[ci * (IH * IW) + t * IW], s_y[cur_c0 + ci], rin[IN_PAD + ci * (IH * IW) + t * IW]);
+          if (gys < h && gxs < w)
+            a.ca_out[((size_t)bn * a.cin + cur_c0 + ci) * plane + (size_t)gys * w + gxs] = v;
+        }
+      }
+    }
 #pragma unroll(KS <= 3 ? KS : 1)
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
@@ -229,7 +259,10 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) av[m] = ain[(cp * 2 * KK + tap) * CO + m * 32];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) bv[t] = bin[cp * 2 * (IH * IW) + (t + ky) * IW + kx];
+          for (int t = 0; t < NT; ++t) {
+            const int o = cp * 2 * (IH * IW) + (t + ky) * IW + kx;
+            bv[t] = FUSE ? fmaf(bin[o], yv[cp], bin[IN_PAD + o]) : bin[o];
+          }
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -314,20 +347,20 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 inline int chunk_of(int ks) { return ks == 1 ? 16 : ks == 3 ? 8 : ks == 5 ? 4 : 2; }
 inline int co_tile_of(int cout) { return cout <= 32 ? 32 : 64; }
 
-template <int KS, int MT, bool VEC>
+template <int KS, int MT, bool VEC, bool FUSE = false>
 int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  using Cfg = ConvCfg<KS, MT, VEC>;
+  using Cfg = ConvCfg<KS, MT, VEC, FUSE>;
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<KS, MT, VEC>),
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<KS, MT, VEC, FUSE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv2d: hipFuncSetAttribute(%zu B of LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, MT, VEC>), grid, dim3(64 * Cfg::NW), Cfg::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, MT, VEC, FUSE>), grid, dim3(64 * Cfg::NW), Cfg::LDS_BYTES, st, a);
   return eavsr::launch_status("conv2d");
 }
 
@@ -395,6 +428,9 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
   a.residual = d->residual;
   a.out = d->out;
   a.chan_partial = d->chan_partial;
+  a.ca_scale = d->ca_scale;
+  a.ca_x = d->ca_x;
+  a.ca_out = d->ca_out;
   a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
   a.cin_pad = eavsr::cdiv(d->cin, ck) * ck;
   a.tiles_x = eavsr::cdiv(d->w, EAVSR_CONV_TW);
@@ -410,6 +446,16 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
   bool vec = (d->w % 4) == 0;
   for (int s = 0; s < d->n_src; ++s)
     vec = vec && (((uintptr_t)d->src[s]) & 15) == 0 && (d->src_c[s] % ck) == 0;
+  if (d->ca_scale != nullptr) {
+    EAVSR_REQUIRE(d->ca_x != nullptr, -1, "conv2d: ca_scale without ca_x");
+    EAVSR_REQUIRE(d->ksize == 3 && d->n_src == 1 && vec && (((uintptr_t)d->ca_x) & 15) == 0 && d->cin % 4 == 0 &&
+                      d->cin <= 256 && CO == 64 && d->cout <= 64,
+                  -2, "conv2d: the fused channel-attention prologue needs a single 16-byte aligned source, k = 3, "
+                      "w %% 4 == 0, cin %% 4 == 0, cin <= 256 and 33..64 output channels; use eavsr_scale_residual_f32 + "
+                      "a plain conv otherwise");
+    return launch_one<3, 2, true, true>(a, grid, st);
+  }
+  EAVSR_REQUIRE(d->ca_x == nullptr && d->ca_out == nullptr, -1, "conv2d: ca_x / ca_out without ca_scale");
   switch (d->ksize) {
     case 1: return launch_ks<1>(a, grid, CO, vec, st);
     case 3: return launch_ks<3>(a, grid, CO, vec, st);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 4) void dcnv2_kernel(DcnArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64 * R, R / 4) void dcnv2_reg_kernel(DcnArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  int bid = blockIdx.x;
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
   const int ty = bid % a.tiles_y;

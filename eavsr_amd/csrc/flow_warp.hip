@@ -20,11 +20,17 @@ template <int PADMODE>
 __global__ __launch_bounds__(256) void flow_warp_kernel(
     const float* __restrict__ x, const float* __restrict__ flow, const float* __restrict__ flow2,
     float* __restrict__ out, int n, int c, int h, int w, long fs_n, long fs_c, long fs_y, long fs_x,
-    int c_chunks) {
-  const int px = blockIdx.x * 64 + threadIdx.x;
-  const int py = blockIdx.y * 4 + threadIdx.y;
-  const int bn = blockIdx.z / c_chunks;
-  const int c0 = (blockIdx.z % c_chunks) * kChanPerThread;
+    int c_chunks, int tiles_x, int tiles_y) {
+  // linear tile id -> XCD-contiguous order: (x tile, y tile, channel chunk, sample), x fastest
+  int lid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = lid % tiles_x;
+  lid /= tiles_x;
+  const int ty = lid % tiles_y;
+  lid /= tiles_y;
+  const int c0 = (lid % c_chunks) * kChanPerThread;
+  const int bn = lid / c_chunks;
+  const int px = tx * 64 + threadIdx.x;
+  const int py = ty * 4 + threadIdx.y;
   if (px >= w || py >= h) return;
 
   const long fo = (long)bn * fs_n + (long)py * fs_y + (long)px * fs_x;
@@ -99,13 +105,15 @@ extern "C" int eavsr_flow_warp_f32(const float* x, const float* flow, const floa
     fs_n = 2L * h * w; fs_c = 1; fs_y = 2L * w; fs_x = 2;
   }
   const int c_chunks = eavsr::cdiv(c, kChanPerThread);
-  EAVSR_REQUIRE((long)n * c_chunks <= 65535, -1, "flow_warp: n * ceil(c/16) = %ld exceeds grid.z", (long)n * c_chunks);
-  dim3 grid(eavsr::cdiv(w, 64), eavsr::cdiv(h, 4), n * c_chunks), block(64, 4, 1);
+  const int tiles_x = eavsr::cdiv(w, 64), tiles_y = eavsr::cdiv(h, 4);
+  const long nblk = (long)tiles_x * tiles_y * c_chunks * n;
+  EAVSR_REQUIRE(nblk < (1L << 31), -1, "flow_warp: too many tiles");
+  dim3 grid((unsigned)nblk), block(64, 4, 1);
   if (padding_mode == EAVSR_PAD_ZEROS)
     hipLaunchKernelGGL(flow_warp_kernel<EAVSR_PAD_ZEROS>, grid, block, 0, eavsr::as_stream(stream), x, flow,
-                       flow2, out, n, c, h, w, fs_n, fs_c, fs_y, fs_x, c_chunks);
+                       flow2, out, n, c, h, w, fs_n, fs_c, fs_y, fs_x, c_chunks, tiles_x, tiles_y);
   else
     hipLaunchKernelGGL(flow_warp_kernel<EAVSR_PAD_BORDER>, grid, block, 0, eavsr::as_stream(stream), x, flow,
-                       flow2, out, n, c, h, w, fs_n, fs_c, fs_y, fs_x, c_chunks);
+                       flow2, out, n, c, h, w, fs_n, fs_c, fs_y, fs_x, c_chunks, tiles_x, tiles_y);
   return eavsr::launch_status("flow_warp");
 }

@@ -291,6 +291,13 @@ class RCABlock(nn.Module):
         return ops.scale_residual(r, scale, x)                      # res * y + x  (:463-464)
 
 
+# Fold `res * y + x` of block k into the first conv of block k+1 (eavsr_conv2d_f32's ca_* fields).  Measured
+# at 4x64x180x320: the fused conv costs +21 us (two input patches, 16 half-size chunks, side output) against
+# the 29 us scale_residual launch it removes, and leaves the step time unchanged -- so it is off by default.
+import os as _os
+FUSE_CA_INTO_CONV = _os.environ.get("EAVSR_FUSE_CA", "0") == "1"
+
+
 class RCAGroup(nn.Module):
     def __init__(self, in_channels=64, out_channels=64, kernel_size=3, stride=1, padding=1, bias=True,
                  mode="CRC", reduction=16, nb=12):
@@ -304,10 +311,28 @@ class RCAGroup(nn.Module):
         self.rg = nn.Sequential(*RG)
 
     def forward(self, x):
-        r = x
-        for blk in list(self.rg)[:-1]:
-            r = blk(r)
-        return self.rg[-1](r, residual=x)                           # conv, + x  (:480-482)
+        blocks, last = list(self.rg)[:-1], self.rg[-1]
+        fuse = FUSE_CA_INTO_CONV and ops.ca_fusable(x, last.weight.shape[0]) and len(blocks) > 0 and all(
+            isinstance(b, RCABlock) and len(b.res) == 3 and isinstance(b.res[1], _Act) and b.res[1].kind == "relu"
+            for b in blocks)
+        if not fuse:
+            r = x
+            for blk in blocks:
+                r = blk(r)
+            return last(r, residual=x)                              # conv, + x  (:480-482)
+        # Fused chain: the tail `res * y + x` of block k (networks.py:463-464) is applied inside the first
+        # conv of block k+1 (and inside the group's last conv), which also emits the new residual stream.
+        hw = x.shape[2] * x.shape[3]
+        xs, r, scale = x, None, None
+        for blk in blocks:
+            c1, c2 = blk.res[0], blk.res[2]
+            if r is None:
+                t = c1(xs, act="relu")
+            else:
+                t, xs = ops.conv2d(r, c1.weight, c1.bias, act="relu", ca=(scale, xs), ca_out=True)
+            r, partial = c2(t, chan_partial=True)
+            scale = blk.ca.scale_from_partial(partial, hw)
+        return ops.conv2d(r, last.weight, last.bias, residual=x, ca=(scale, xs))
 
 
 # --------------------------------------------------------------------------------------------

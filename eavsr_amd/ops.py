@@ -230,12 +230,22 @@ def _bias_of(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
 # ------------------------------------------------------------------------------------------
 # dense conv  (nn.Conv2d, stride 1, "same" padding)
 # ------------------------------------------------------------------------------------------
+def ca_fusable(x: Tensor, cout: int = 64) -> bool:
+    """Can the channel-attention tail `r * scale + x` be folded into the next 3x3 conv (16-byte DMA path)?"""
+    return (x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[1] % 4 == 0 and x.shape[1] <= 256 and 32 < cout <= 64
+            and x.is_contiguous() and x.data_ptr() % 16 == 0)
+
+
 def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence[Tensor]],
            bias: Union[None, Tensor, Sequence[Optional[Tensor]]] = None, act: Optional[str] = None,
-           slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False):
+           slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False,
+           ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False):
     """conv over the virtual channel-concatenation of `srcs`; `weight` may be a list of weights
     that are concatenated along cout (several heads in one launch).
-    Returns out, or (out, partial) with the per-tile channel sums when chan_partial=True."""
+    ca=(scale (n,c), x (n,c,h,w)): the conv input is srcs * scale[n,c] + x (RCABlock tail fused into this
+    conv); with ca_out=True that effective input is also returned.
+    Returns out, then the per-tile channel sums when chan_partial=True, then the effective input when
+    ca_out=True."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     weights = [weight] if isinstance(weight, torch.Tensor) else list(weight)
@@ -280,12 +290,33 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.act = ACT[act]
     d.slope = float(slope)
+    xs = None
+    if ca is not None:
+        scale, cx = _chk(ca[0], "ca scale"), _chk(ca[1], "ca x")
+        if len(srcs) != 1 or cx.shape != srcs[0].shape or tuple(scale.shape) != (n, cin):
+            raise ValueError("ca=(scale, x): one source, x of the same shape, scale (n, cin)")
+        if k != 3 or not ca_fusable(srcs[0], cout) or cx.data_ptr() % 16:
+            raise NotImplementedError("fused channel-attention prologue unavailable for this shape; use "
+                                      "scale_residual + conv2d (see ops.ca_fusable)")
+        d.ca_scale, d.ca_x = _p(scale), _p(cx)
+        if ca_out:
+            xs = torch.empty_like(cx)
+            d.ca_out = _p(xs)
+    elif ca_out:
+        raise ValueError("ca_out needs ca")
     st = _stream(out)
     px = float(n) * h * w
-    _launch(f"conv{k}x{k}_{cin}to{cout}", 2.0 * cin * cout * k * k * px,
-            4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+    _launch(f"conv{k}x{k}_{cin}to{cout}" + ("_ca" if ca is not None else ""), 2.0 * cin * cout * k * k * px,
+            4.0 * px * (cin * (1 if ca is None else (3 if ca_out else 2)) + cout + (cout if residual is not None else 0)), out,
             lambda: lib().eavsr_conv2d_f32(C.byref(d), st), "conv2d")
-    return (out, part) if chan_partial else out
+    if not chan_partial and xs is None:
+        return out
+    res = [out]
+    if chan_partial:
+        res.append(part)
+    if xs is not None:
+        res.append(xs)
+    return tuple(res)
 
 
 # ------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 1
+#define EAVSR_ABI_VERSION 2
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -100,6 +100,14 @@ typedef struct eavsr_conv2d_desc {
   int32_t n, h, w, cin, cout;
   int32_t act;
   float slope;
+  /* optional fused channel-attention prologue (RCABlock tail, networks.py:447,463-464, folded into the
+   * NEXT conv): the effective input is src[0] * ca_scale[n,c] + ca_x; when ca_out != NULL it is also
+   * written there (it is the next block's residual stream).  Needs n_src == 1, ksize == 3, w % 4 == 0,
+   * 16-byte aligned src[0] / ca_x, cin % 4 == 0, 33..64 output channels; otherwise the call returns -2
+   * and the caller uses eavsr_scale_residual_f32 + a plain conv.  NULL = off. */
+  const float* ca_scale; /* (n, cin) */
+  const float* ca_x;     /* (n, cin, h, w) */
+  float* ca_out;         /* (n, cin, h, w) or NULL */
 } eavsr_conv2d_desc;
 
 int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);

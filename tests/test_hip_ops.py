@@ -263,3 +263,24 @@ def test_channel_attention_pieces(ops, cuda):
     ref = O.ca_layer(sd, "b.ca.", r) + x
     out = ops.scale_residual(g(r, cuda), scale, g(x, cuda)).cpu()
     assert H.maxabs(out, ref) <= 1e-5
+
+
+def test_conv2d_fused_channel_attention_prologue(ops, cuda):
+    """conv(r * scale + x) with the side output of the effective input == scale_residual followed by conv"""
+    n, c, h, w = 2, 64, 37, 44
+    r, x = cases.randn(1, n, c, h, w), cases.randn(2, n, c, h, w)
+    scale = cases.rand(3, n, c)
+    wt = cases.randn(4, 64, c, 3, 3, scale=0.05)
+    b = cases.randn(5, 64, scale=0.1)
+    res = cases.randn(6, n, 64, h, w)
+    eff = r * scale.view(n, c, 1, 1) + x
+    ref = F.relu(F.conv2d(eff, wt, b, 1, 1))
+    out, xs = ops.conv2d(g(r, cuda), g(wt, cuda), g(b, cuda), act="relu", ca=(g(scale, cuda), g(x, cuda)), ca_out=True)
+    assert H.maxabs(xs.cpu(), eff) <= 1e-6
+    assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+    out2 = ops.conv2d(g(r, cuda), g(wt, cuda), g(b, cuda), residual=g(res, cuda), ca=(g(scale, cuda), g(x, cuda)))
+    assert H.maxabs(out2.cpu(), F.conv2d(eff, wt, b, 1, 1) + res) <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert not ops.ca_fusable(torch.zeros(1, 64, 8, 10, device=cuda))
+    with pytest.raises(NotImplementedError):
+        ops.conv2d(torch.zeros(1, 64, 8, 10, device=cuda), g(wt, cuda), None,
+                   ca=(torch.zeros(1, 64, device=cuda), torch.zeros(1, 64, 8, 10, device=cuda)))
