@@ -1,0 +1,306 @@
+"""Differentiable front of eavsr_amd.ops (training step).
+
+Every function here has the signature of its namesake in ops.py.  When no input needs a gradient
+(inference, `torch.no_grad()`), it forwards straight to the fused forward kernel.  Otherwise it
+goes through a torch.autograd.Function whose backward launches the HIP backward kernels
+(csrc/backward.hip, backward_dcn.hip, conv_wgrad.hip; dgrad reuses the MFMA conv kernel with the
+transposed, flipped weight).  PyTorch only records the graph -- no gradient is computed by an
+ATen kernel on the hot path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+Tensor = torch.Tensor
+
+
+def _needs_grad(*ts) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    for t in ts:
+        if isinstance(t, (list, tuple)):
+            if _needs_grad(*t):
+                return True
+        elif isinstance(t, torch.Tensor) and t.requires_grad:
+            return True
+    return False
+
+
+# ------------------------------------------------------------------------------------------ conv
+class _ConvFn(Function):
+    @staticmethod
+    def forward(ctx, act, slope, n_w, has_bias, has_res, n_src, *ts):
+        ws = list(ts[:n_w])
+        bs = list(ts[n_w:2 * n_w]) if has_bias else [None] * n_w
+        o = 2 * n_w if has_bias else n_w
+        res = ts[o] if has_res else None
+        o += 1 if has_res else 0
+        srcs = list(ts[o:o + n_src])
+        if act is not None and has_res:
+            raise NotImplementedError("conv2d backward: activation together with a residual is not used on the path")
+        out = ops.conv2d(srcs, ws, bs if has_bias else None, act=act, slope=slope, residual=res)
+        ctx.meta = (act, slope, n_w, has_bias, has_res, n_src)
+        ctx.save_for_backward(*ws, *srcs, *( [out] if act is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        act, slope, n_w, has_bias, has_res, n_src = ctx.meta
+        saved = ctx.saved_tensors
+        ws, srcs = list(saved[:n_w]), list(saved[n_w:n_w + n_src])
+        dout = dout.contiguous()
+        g = ops.act_bwd(dout, saved[-1], act, slope) if act is not None else dout
+        k = int(ws[0].shape[-1])
+        need = ctx.needs_input_grad[6:]
+        need_w = need[:n_w]
+        o = 2 * n_w if has_bias else n_w
+        need_res = need[o] if has_res else False
+        o += 1 if has_res else 0
+        need_src = need[o:o + n_src]
+        W = ws[0] if n_w == 1 else torch.cat(ws, 0)
+        dws: List[Optional[Tensor]] = [None] * n_w
+        if any(need_w):
+            dW = ops.conv_wgrad(g, srcs, k)
+            c0 = 0
+            for i, w_ in enumerate(ws):
+                dws[i] = dW[c0:c0 + w_.shape[0]] if need_w[i] else None
+                c0 += w_.shape[0]
+        dbs: List[Optional[Tensor]] = []
+        if has_bias:
+            db = ops.plane_sum(g).sum(0)
+            c0 = 0
+            for w_ in ws:
+                dbs.append(db[c0:c0 + w_.shape[0]])
+                c0 += w_.shape[0]
+        dsrcs: List[Optional[Tensor]] = []
+        c0 = 0
+        for i, s in enumerate(srcs):
+            cs = int(s.shape[1])
+            if need_src[i]:
+                wt = W[:, c0:c0 + cs].flip(2, 3).transpose(0, 1).contiguous()   # (cs, cout, k, k)
+                dsrcs.append(ops.conv2d(g, wt, None))
+            else:
+                dsrcs.append(None)
+            c0 += cs
+        return (None,) * 6 + tuple(dws) + tuple(dbs) + ((dout if need_res else None,) if has_res else ()) + tuple(dsrcs)
+
+
+def conv2d(srcs, weight, bias=None, act=None, slope=0.0, residual=None, chan_partial=False, ca=None, ca_out=False):
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    ws = [weight] if isinstance(weight, torch.Tensor) else list(weight)
+    bs = [bias] if (bias is None or isinstance(bias, torch.Tensor)) else list(bias)
+    if not _needs_grad(srcs, ws, bs, residual):
+        return ops.conv2d(srcs, weight, bias, act=act, slope=slope, residual=residual, chan_partial=chan_partial,
+                          ca=ca, ca_out=ca_out)
+    if chan_partial or ca is not None:
+        raise NotImplementedError("the fused channel-attention paths are inference-only; training uses rcab_tail")
+    has_bias = bs[0] is not None
+    ts = list(ws) + (list(bs) if has_bias else []) + ([residual] if residual is not None else []) + list(srcs)
+    return _ConvFn.apply(act, float(slope), len(ws), has_bias, residual is not None, len(srcs), *ts)
+
+
+# ------------------------------------------------------------------------------------------ flow_warp
+class _FlowWarpFn(Function):
+    @staticmethod
+    def forward(ctx, x, flow, flow2):
+        ctx.save_for_backward(x, flow, *( [flow2] if flow2 is not None else []))
+        return ops.flow_warp(x, flow, "zeros", flow2=flow2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        x, flow = saved[0], saved[1]
+        flow2 = saved[2] if len(saved) > 2 else None
+        need_dx = ctx.needs_input_grad[0]
+        need_df = ctx.needs_input_grad[1] or (flow2 is not None and ctx.needs_input_grad[2])
+        dx, dflow = ops.flow_warp_bwd(x, flow, flow2, dout.contiguous(), need_dx, need_df)
+        return dx, (dflow if ctx.needs_input_grad[1] else None), (dflow if flow2 is not None and ctx.needs_input_grad[2] else None)
+
+
+def flow_warp(x, flow, padding_mode="zeros", flow2=None, flow_layout="nchw"):
+    if not _needs_grad(x, flow, flow2):
+        return ops.flow_warp(x, flow, padding_mode=padding_mode, flow2=flow2, flow_layout=flow_layout)
+    if padding_mode != "zeros":
+        raise NotImplementedError("flow_warp backward exists for padding_mode='zeros' (border is only used inside the "
+                                  "frozen SPyNet)")
+    if flow_layout == "nhwc":
+        flow = flow.permute(0, 3, 1, 2)
+        flow2 = None if flow2 is None else flow2.permute(0, 3, 1, 2)
+    return _FlowWarpFn.apply(x, flow.contiguous(), None if flow2 is None else flow2.contiguous())
+
+
+# ------------------------------------------------------------------------------------------ DCNv2
+class _DcnFn(Function):
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias, dg):
+        ctx.dg = dg
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, offset, mask, weight)
+        return ops.modulated_deform_conv2d(x, offset, mask, weight, bias, 1, 1, 1, 1, dg)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, offset, mask, weight = ctx.saved_tensors
+        dg = ctx.dg
+        dout = dout.contiguous()
+        cout, cin = weight.shape[0], weight.shape[1]
+        col = ops.dcnv2_im2col(x, offset, mask, dg)                              # (n, cin*9, h, w)
+        dW = ops.conv_wgrad(dout, [col], 1).view(cout, cin, 3, 3) if ctx.needs_input_grad[3] else None
+        wt = weight.reshape(cout, cin * 9).t().contiguous().view(cin * 9, cout, 1, 1)
+        dcol = ops.conv2d(dout, wt, None)                                        # W^T . dOut
+        dx, doff, dmask = ops.dcnv2_col2im(x, offset, mask, dcol, dg, need_dx=ctx.needs_input_grad[0])
+        db = ops.plane_sum(dout).sum(0) if ctx.has_bias and ctx.needs_input_grad[4] else None
+        return dx, doff, dmask, dW, db, None
+
+
+def modulated_deform_conv2d(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1,
+                            deform_groups=1):
+    if not _needs_grad(input, offset, mask, weight, bias):
+        return ops.modulated_deform_conv2d(input, offset, mask, weight, bias, stride, padding, dilation, groups,
+                                           deform_groups)
+    one = lambda v: int(v[0]) if isinstance(v, (tuple, list)) else int(v)
+    if tuple(weight.shape[2:]) != (3, 3) or one(stride) != 1 or one(padding) != 1 or one(dilation) != 1 or groups != 1:
+        raise NotImplementedError("modulated_deform_conv2d: only the reference configuration (3x3, 1, 1, 1, 1)")
+    return _DcnFn.apply(input.contiguous(), offset.contiguous(), mask.contiguous(), weight, bias, int(deform_groups))
+
+
+# ------------------------------------------------------------------------------------------ predictor pieces
+class _GConvFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, cpg, act, slope):
+        out = ops.gconv3x3(x, weight, bias, cpg, act, slope)
+        ctx.meta = (cpg, act, slope)
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cpg, act, slope = ctx.meta
+        x, weight, out = ctx.saved_tensors
+        g = ops.act_bwd(dout.contiguous(), out, act, slope) if act is not None else dout.contiguous()
+        dx, dw, db = ops.gconv3x3_bwd(g, x, weight, cpg)
+        return dx, dw, db, None, None, None
+
+
+def adapt_frontend(x, h_hr, w1, b1, w2, b2):
+    if not _needs_grad(x, h_hr, w1, b1, w2, b2):
+        return ops.adapt_frontend(x, h_hr, w1, b1, w2, b2)
+    t = torch.cat([x, h_hr], 1)                                   # networks.py:300 / :336, un-fused for training
+    t = _GConvFn.apply(t, w1, b1, 1, "lrelu", 0.2)
+    return _GConvFn.apply(t, w2, b2, 2, "lrelu", 0.2)
+
+
+class _AffineFn(Function):
+    @staticmethod
+    def forward(ctx, heads, D, with_mask):
+        off, mask = ops.affine_offsets(heads, D, with_mask)
+        ctx.D = D
+        ctx.save_for_backward(*( [mask] if with_mask else []))
+        if with_mask:
+            return off, mask
+        return off
+
+    @staticmethod
+    def backward(ctx, doff, dmask=None):
+        mask = ctx.saved_tensors[0] if ctx.saved_tensors else None
+        return ops.affine_offsets_bwd(doff.contiguous(), None if dmask is None else dmask.contiguous(), mask, ctx.D), None, None
+
+
+def affine_offsets(heads, D, with_mask):
+    if not _needs_grad(heads):
+        return ops.affine_offsets(heads, D, with_mask)
+    r = _AffineFn.apply(heads, D, with_mask)
+    return r if with_mask else (r, None)
+
+
+# ------------------------------------------------------------------------------------------ resampling glue
+class _ResizeFn(Function):
+    @staticmethod
+    def forward(ctx, x, pre_add, post_add, size, scale):
+        ctx.meta = (tuple(x.shape), scale)
+        return ops.resize_bilinear_ac(x, size, scale, pre_add=pre_add, post_add=post_add)
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, scale = ctx.meta
+        dout = dout.contiguous()
+        din = ops.resize_bilinear_ac_bwd(dout, shape, scale) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        return (din if ctx.needs_input_grad[0] else None, din if ctx.needs_input_grad[1] else None,
+                dout if ctx.needs_input_grad[2] else None, None, None)
+
+
+def resize_bilinear_ac(x, size, scale=1.0, pre_add=None, post_add=None):
+    if not _needs_grad(x, pre_add, post_add):
+        return ops.resize_bilinear_ac(x, size, scale, pre_add=pre_add, post_add=post_add)
+    return _ResizeFn.apply(x, pre_add, post_add, (int(size[0]), int(size[1])), float(scale))
+
+
+class _PyramidFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.pyramid(x)
+
+    @staticmethod
+    def backward(ctx, dd2, dd4):
+        return ops.pyramid_bwd(dd2.contiguous(), dd4.contiguous())
+
+
+def pyramid(x):
+    return _PyramidFn.apply(x) if _needs_grad(x) else ops.pyramid(x)
+
+
+class _AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        return ops.add(a, b, c)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d, (d if ctx.needs_input_grad[2] else None)
+
+
+def add(a, b, c=None):
+    return _AddFn.apply(a, b, c) if _needs_grad(a, b, c) else ops.add(a, b, c)
+
+
+# ------------------------------------------------------------------------------------------ RCAB tail
+class _RcabTailFn(Function):
+    """out = r * sigmoid(W2 relu(W1 mean_hw(r) + b1) + b2) + x   (CALayer + residual, networks.py:444-447,463-464)"""
+
+    @staticmethod
+    def forward(ctx, r, x, w1, b1, w2, b2):
+        n, c, h, w = r.shape
+        mean = ops.plane_sum(r, None, 1.0 / (h * w))
+        scale = ops.ca_scale(mean.view(n, 1, c), 1, w1, b1, w2, b2)
+        ctx.save_for_backward(r, mean, scale, w1, b1, w2, b2)
+        return ops.scale_residual(r, scale, x)
+
+    @staticmethod
+    def backward(ctx, d):
+        r, mean, scale, w1, b1, w2, b2 = ctx.saved_tensors
+        d = d.contiguous()
+        n, c, h, w = r.shape
+        dscale = ops.plane_sum(d, r)
+        dmean, dw1, db1, dw2, db2 = ops.ca_mlp_bwd(mean, w1, b1, w2, b2, dscale)
+        dr = ops.scale_residual_bwd(d, scale, dmean * (1.0 / (h * w)))
+        return dr, d, dw1, db1, dw2, db2
+
+
+def rcab_tail(r, x, w1, b1, w2, b2):
+    return _RcabTailFn.apply(r, x, w1, b1, w2, b2)
+
+
+# the remaining ops have no trainable use on the path: forwarded as is
+selftest_mfma = ops.selftest_mfma
+ca_scale = ops.ca_scale
+scale_residual = ops.scale_residual
+ca_fusable = ops.ca_fusable
+profile = ops.profile
+lib = ops.lib
+needs_grad = _needs_grad

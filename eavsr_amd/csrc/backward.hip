@@ -1,0 +1,333 @@
+// Backward kernels of the streaming / sampling ops of the hot path (config 4, training).
+//
+// Reference: autograd through models/networks.py:597-631 (MultiAdSTN.forward), :432-464 (CALayer,
+// RCABlock), :298-348 (AdaptBlock*), models/eavsrp_model.py:218-220 -- i.e. the ATen backward of
+// grid_sample / interpolate / elementwise ops the reference runs implicitly in loss.backward()
+// (eavsrp_model.py:109-113).  All fp32.  Scatter-type gradients (flow_warp / resize w.r.t. their input)
+// use float atomics (one dword per lane, neighbouring lanes hit neighbouring addresses); they are not
+// bitwise reproducible run to run, like the ATen kernels they replace.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// activation backward: g = dy * act'(y), y = the activation's OUTPUT (relu: y > 0; lrelu: slope)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ g, long count, float slope) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += stride) g[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-(n,c) reduction over the plane: out[nc] = sum_hw a (* b).  One workgroup per (n,c).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ out, int hw, float scale) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * hw;
+  float s = 0.f;
+  if (b != nullptr)
+    for (int i = threadIdx.x; i < hw; i += 256) s += a[base + i] * b[base + i];
+  else
+    for (int i = threadIdx.x; i < hw; i += 256) s += a[base + i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2] + red[3]) * scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scale_residual backward (out = r * s[n,c] + x):  dr = d * s + dmean[n,c] (the mean's broadcast
+// gradient, already divided by hw, or NULL);  dx = d is the caller's alias.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_bwd_kernel(const float* __restrict__ d, const float* __restrict__ s,
+                                                        const float* __restrict__ dmean, float* __restrict__ dr,
+                                                        int hw) {
+  const int nc = blockIdx.y;
+  const float sc = s[nc];
+  const float add = dmean ? dmean[nc] : 0.f;
+  const size_t base = (size_t)nc * hw;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) dr[base + i] = d[base + i] * sc + add;
+}
+
+// ---------------------------------------------------------------------------------------------
+// channel-attention MLP, forward from the mean and backward (networks.py:436-447):
+//   hid = relu(W1 m + b1); s = sigmoid(W2 hid + b2)
+// backward: given ds -> dz2 = ds * s (1 - s); dW2 += dz2 hid^T; db2 += dz2; dhid = W2^T dz2;
+//   dz1 = dhid * (hid > 0); dW1 += dz1 m^T; db1 += dz1; dm = W1^T dz1.   One workgroup, loops over n
+//   (deterministic accumulation order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ca_mlp_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
+                                                         const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, const float* __restrict__ ds,
+                                                         float* __restrict__ dmean, float* __restrict__ dw1,
+                                                         float* __restrict__ db1, float* __restrict__ dw2,
+                                                         float* __restrict__ db2, int n, int c, int cr) {
+  extern __shared__ float sm[];  // m[c] hid[cr] dz2[c] dz1[cr]
+  float* m = sm;
+  float* hid = m + c;
+  float* dz2 = hid + cr;
+  float* dz1 = dz2 + c;
+  const int tid = threadIdx.x;
+  // zero the parameter gradients (this kernel owns them)
+  for (int i = tid; i < cr * c; i += 256) { dw1[i] = 0.f; dw2[i] = 0.f; }
+  for (int i = tid; i < cr; i += 256) db1[i] = 0.f;
+  for (int i = tid; i < c; i += 256) db2[i] = 0.f;
+  __syncthreads();
+  for (int b = 0; b < n; ++b) {
+    for (int i = tid; i < c; i += 256) m[i] = mean[(size_t)b * c + i];
+    __syncthreads();
+    for (int j = tid; j < cr; j += 256) {
+      float v = b1[j];
+      for (int k = 0; k < c; ++k) v += w1[j * c + k] * m[k];
+      hid[j] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    for (int i = tid; i < c; i += 256) {
+      float v = b2[i];
+      for (int j = 0; j < cr; ++j) v += w2[i * cr + j] * hid[j];
+      const float s = 1.f / (1.f + expf(-v));
+      dz2[i] = ds[(size_t)b * c + i] * s * (1.f - s);
+    }
+    __syncthreads();
+    for (int j = tid; j < cr; j += 256) {
+      float v = 0.f;
+      for (int i = 0; i < c; ++i) v += w2[i * cr + j] * dz2[i];
+      dz1[j] = hid[j] > 0.f ? v : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < c * cr; i += 256) {
+      const int ci = i / cr, j = i - ci * cr;   // dw2[ci][j]
+      dw2[i] += dz2[ci] * hid[j];
+      const int j1 = i / c, k = i - j1 * c;      // dw1[j1][k]
+      dw1[i] += dz1[j1] * m[k];
+    }
+    for (int i = tid; i < c; i += 256) {
+      db2[i] += dz2[i];
+      float v = 0.f;
+      for (int j = 0; j < cr; ++j) v += w1[j * c + i] * dz1[j];
+      dmean[(size_t)b * c + i] = v;
+    }
+    for (int j = tid; j < cr; j += 256) db1[j] += dz1[j];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flow_warp backward (zeros padding; the border mode only occurs inside the frozen SPyNet).
+// One thread per pixel, all channels: dx gets 4 atomic adds per channel, dflow is summed in registers.
+// d(sample position)/d(flow) = 1 (the reference's normalise / un-normalise pair cancels).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                            const float* __restrict__ flow2,
+                                                            const float* __restrict__ dout, float* __restrict__ dx,
+                                                            float* __restrict__ dflow, int c, int h, int w) {
+  const int px = blockIdx.x * 64 + threadIdx.x;
+  const int py = blockIdx.y * 4 + threadIdx.y;
+  const int bn = blockIdx.z;
+  if (px >= w || py >= h) return;
+  const size_t plane = (size_t)h * w;
+  const size_t fo = (size_t)bn * 2 * plane + (size_t)py * w + px;
+  float fx = flow[fo], fy = flow[fo + plane];
+  if (flow2) { fx += flow2[fo]; fy += flow2[fo + plane]; }
+  const float gx = (float)px + fx, gy = (float)py + fy;
+  const float nx = 2.0f * gx / (float)max(w - 1, 1) - 1.0f;
+  const float ny = 2.0f * gy / (float)max(h - 1, 1) - 1.0f;
+  float ix = ((nx + 1.0f) / 2.0f) * (float)(w - 1);
+  float iy = ((ny + 1.0f) / 2.0f) * (float)(h - 1);
+  ix = fminf(fmaxf(ix, -4.0f), (float)w + 4.0f);
+  iy = fminf(fmaxf(iy, -4.0f), (float)h + 4.0f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+  const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x1 >= 0) & (x1 < w);
+  const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y1 >= 0) & (y1 < h);
+  const bool v_nw = vx0 & vy0, v_ne = vx1 & vy0, v_sw = vx0 & vy1, v_se = vx1 & vy1;
+  const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+  const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+  const int i_nw = cy0 * w + cx0, i_ne = cy0 * w + cx1, i_sw = cy1 * w + cx0, i_se = cy1 * w + cx1;
+  float gix = 0.f, giy = 0.f;
+  for (int cc = 0; cc < c; ++cc) {
+    const size_t cb = ((size_t)bn * c + cc) * plane;
+    const float g = dout[cb + (size_t)py * w + px];
+    if (dx != nullptr) {
+      if (v_nw) atomicAdd(dx + cb + i_nw, g * wx0 * wy0);
+      if (v_ne) atomicAdd(dx + cb + i_ne, g * wx1 * wy0);
+      if (v_sw) atomicAdd(dx + cb + i_sw, g * wx0 * wy1);
+      if (v_se) atomicAdd(dx + cb + i_se, g * wx1 * wy1);
+    }
+    if (dflow != nullptr) {
+      const float a = v_nw ? x[cb + i_nw] : 0.f, b = v_ne ? x[cb + i_ne] : 0.f;
+      const float cv = v_sw ? x[cb + i_sw] : 0.f, d = v_se ? x[cb + i_se] : 0.f;
+      gix += g * ((b - a) * wy0 + (d - cv) * wy1);
+      giy += g * ((cv - a) * wx0 + (d - b) * wx1);
+    }
+  }
+  if (dflow != nullptr) {
+    dflow[fo] = gix;
+    dflow[fo + plane] = giy;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// resize_bilinear_ac backward: din (+)= scale * scatter(dout)   (din pre-zeroed by the caller)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_ac_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                            int hin, int win, int hout, int wout, float rh, float rw,
+                                                            float scale) {
+  const int ox = blockIdx.x * 64 + threadIdx.x;
+  const int oy = blockIdx.y * 4 + threadIdx.y;
+  const int nc = blockIdx.z;
+  if (ox >= wout || oy >= hout) return;
+  const float sy = rh * (float)oy, sx = rw * (float)ox;
+  const int y0 = min((int)sy, hin - 1), x0 = min((int)sx, win - 1);
+  const int y1 = y0 + (y0 < hin - 1 ? 1 : 0), x1 = x0 + (x0 < win - 1 ? 1 : 0);
+  const float ly1 = sy - (float)y0, lx1 = sx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const float g = dout[(size_t)nc * hout * wout + (size_t)oy * wout + ox] * scale;
+  float* p = din + (size_t)nc * hin * win;
+  atomicAdd(p + y0 * win + x0, g * ly0 * lx0);
+  atomicAdd(p + y0 * win + x1, g * ly0 * lx1);
+  atomicAdd(p + y1 * win + x0, g * ly1 * lx0);
+  atomicAdd(p + y1 * win + x1, g * ly1 * lx1);
+}
+
+// pyramid backward: din = 0.25 * dd2[y/2][x/2] + (inner 2x2 of each 4x4 block) 0.25 * dd4[y/4][x/4]
+__global__ __launch_bounds__(256) void pyramid_bwd_kernel(const float* __restrict__ dd2, const float* __restrict__ dd4,
+                                                          float* __restrict__ din, int h, int w) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int nc = blockIdx.z;
+  if (x >= w || y >= h) return;
+  float v = 0.25f * dd2[(size_t)nc * (h / 2) * (w / 2) + (size_t)(y >> 1) * (w / 2) + (x >> 1)];
+  const int ry = y & 3, rx = x & 3;
+  if ((ry == 1 || ry == 2) && (rx == 1 || rx == 2))
+    v += 0.25f * dd4[(size_t)nc * (h / 4) * (w / 4) + (size_t)(y >> 2) * (w / 4) + (x >> 2)];
+  din[(size_t)nc * h * w + (size_t)y * w + x] = v;
+}
+
+// affine_offsets backward: d(heads) from d(offset) [, d(mask) with the saved mask = sigmoid(logit)]
+__global__ __launch_bounds__(256) void affine_bwd_kernel(const float* __restrict__ doff, const float* __restrict__ dmask,
+                                                         const float* __restrict__ mask, float* __restrict__ dheads,
+                                                         int D, int hw, int head_c) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int g = blockIdx.y, bn = blockIdx.z;
+  const float* op = doff + ((size_t)bn * D * 18 + (size_t)g * 18) * hw + p;
+  float t00 = 0.f, t01 = 0.f, t10 = 0.f, t11 = 0.f, ty = 0.f, tx = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const float ry = (float)(k / 3 - 1), rx = (float)(k % 3 - 1);
+    const float gy = op[(size_t)(2 * k) * hw], gx = op[(size_t)(2 * k + 1) * hw];
+    t00 += gy * ry; t01 += gy * rx; t10 += gx * ry; t11 += gx * rx;
+    ty += gy; tx += gx;
+  }
+  float* hp = dheads + (size_t)bn * head_c * hw + p;
+  hp[(size_t)(g * 4 + 0) * hw] = t00;
+  hp[(size_t)(g * 4 + 1) * hw] = t01;
+  hp[(size_t)(g * 4 + 2) * hw] = t10;
+  hp[(size_t)(g * 4 + 3) * hw] = t11;
+  hp[(size_t)(4 * D + g * 2 + 0) * hw] = ty;
+  hp[(size_t)(4 * D + g * 2 + 1) * hw] = tx;
+  if (dmask != nullptr) {
+    const size_t mo = ((size_t)bn * D * 9 + (size_t)g * 9) * hw + p;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float s = mask[mo + (size_t)k * hw];
+      hp[(size_t)(6 * D + g * 9 + k) * hw] = dmask[mo + (size_t)k * hw] * s * (1.f - s);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int eavsr_act_bwd_f32(const float* dy, const float* y, float* g, int64_t count, int32_t act, float slope,
+                                 void* stream) {
+  EAVSR_REQUIRE(dy && y && g, -1, "act_bwd: NULL pointer");
+  EAVSR_REQUIRE(act == EAVSR_ACT_RELU || act == EAVSR_ACT_LRELU, -1, "act_bwd: act %d", act);
+  if (count <= 0) return 0;
+  long blocks = (count + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, eavsr::as_stream(stream), dy, y, g,
+                     (long)count, act == EAVSR_ACT_RELU ? 0.f : slope);
+  return eavsr::launch_status("act_bwd");
+}
+
+extern "C" int eavsr_plane_sum_f32(const float* a, const float* b, float* out, int32_t nc, int32_t hw, float scale,
+                                   void* stream) {
+  EAVSR_REQUIRE(a && out, -1, "plane_sum: NULL pointer");
+  EAVSR_REQUIRE(nc >= 0 && hw > 0, -1, "plane_sum: bad dims");
+  if (nc == 0) return 0;
+  hipLaunchKernelGGL(plane_sum_kernel, dim3(nc), dim3(256), 0, eavsr::as_stream(stream), a, b, out, hw, scale);
+  return eavsr::launch_status("plane_sum");
+}
+
+extern "C" int eavsr_scale_residual_bwd_f32(const float* d, const float* scale, const float* dmean, float* dr,
+                                            int32_t n, int32_t c, int32_t hw, void* stream) {
+  EAVSR_REQUIRE(d && scale && dr, -1, "scale_residual_bwd: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c >= 0 && hw > 0 && (long)n * c <= 65535, -1, "scale_residual_bwd: bad dims");
+  if (n * c == 0) return 0;
+  int bx = eavsr::cdiv(hw, 256);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(scale_bwd_kernel, dim3(bx, n * c), dim3(256), 0, eavsr::as_stream(stream), d, scale, dmean, dr, hw);
+  return eavsr::launch_status("scale_residual_bwd");
+}
+
+extern "C" int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const float* b1, const float* w2,
+                                    const float* b2, const float* dscale, float* dmean, float* dw1, float* db1,
+                                    float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, void* stream) {
+  EAVSR_REQUIRE(mean && w1 && b1 && w2 && b2 && dscale && dmean && dw1 && db1 && dw2 && db2, -1, "ca_mlp_bwd: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c > 0 && cr > 0 && c <= 1024 && cr <= 1024, -1, "ca_mlp_bwd: bad dims");
+  hipLaunchKernelGGL(ca_mlp_bwd_kernel, dim3(1), dim3(256), (size_t)(2 * c + 2 * cr) * sizeof(float),
+                     eavsr::as_stream(stream), mean, w1, b1, w2, b2, dscale, dmean, dw1, db1, dw2, db2, n, c, cr);
+  return eavsr::launch_status("ca_mlp_bwd");
+}
+
+extern "C" int eavsr_flow_warp_bwd_f32(const float* x, const float* flow, const float* flow2, const float* dout,
+                                       float* dx, float* dflow, int32_t n, int32_t c, int32_t h, int32_t w,
+                                       void* stream) {
+  EAVSR_REQUIRE(x && flow && dout, -1, "flow_warp_bwd: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c >= 0 && h > 0 && w > 0 && n <= 65535, -1, "flow_warp_bwd: bad dims");
+  if (n == 0 || c == 0) return 0;
+  dim3 grid(eavsr::cdiv(w, 64), eavsr::cdiv(h, 4), n), block(64, 4, 1);
+  hipLaunchKernelGGL(flow_warp_bwd_kernel, grid, block, 0, eavsr::as_stream(stream), x, flow, flow2, dout, dx, dflow, c,
+                     h, w);
+  return eavsr::launch_status("flow_warp_bwd");
+}
+
+extern "C" int eavsr_resize_bilinear_ac_bwd_f32(const float* dout, float* din, int32_t n, int32_t c, int32_t hin,
+                                                int32_t win, int32_t hout, int32_t wout, float scale, void* stream) {
+  EAVSR_REQUIRE(dout && din, -1, "resize_bilinear_ac_bwd: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c >= 0 && hin > 0 && win > 0 && hout > 0 && wout > 0 && (long)n * c <= 65535, -1,
+                "resize_bilinear_ac_bwd: bad dims");
+  if (n * c == 0) return 0;
+  const float rh = hout > 1 ? (float)(hin - 1) / (float)(hout - 1) : 0.f;
+  const float rw = wout > 1 ? (float)(win - 1) / (float)(wout - 1) : 0.f;
+  dim3 grid(eavsr::cdiv(wout, 64), eavsr::cdiv(hout, 4), n * c), block(64, 4, 1);
+  hipLaunchKernelGGL(resize_ac_bwd_kernel, grid, block, 0, eavsr::as_stream(stream), dout, din, hin, win, hout, wout,
+                     rh, rw, scale);
+  return eavsr::launch_status("resize_bilinear_ac_bwd");
+}
+
+extern "C" int eavsr_pyramid_bwd_f32(const float* ddown2, const float* ddown4, float* din, int32_t nc, int32_t h,
+                                     int32_t w, void* stream) {
+  EAVSR_REQUIRE(ddown2 && ddown4 && din, -1, "pyramid_bwd: NULL pointer");
+  EAVSR_REQUIRE(nc >= 0 && h > 0 && w > 0 && h % 4 == 0 && w % 4 == 0 && nc <= 65535, -1, "pyramid_bwd: bad dims");
+  if (nc == 0) return 0;
+  dim3 grid(eavsr::cdiv(w, 64), eavsr::cdiv(h, 4), nc), block(64, 4, 1);
+  hipLaunchKernelGGL(pyramid_bwd_kernel, grid, block, 0, eavsr::as_stream(stream), ddown2, ddown4, din, h, w);
+  return eavsr::launch_status("pyramid_bwd");
+}
+
+extern "C" int eavsr_affine_offsets_bwd_f32(const float* doffset, const float* dmask, const float* mask, float* dheads,
+                                            int32_t n, int32_t D, int32_t h, int32_t w, void* stream) {
+  EAVSR_REQUIRE(doffset && dheads, -1, "affine_offsets_bwd: NULL pointer");
+  EAVSR_REQUIRE((dmask == nullptr) == (mask == nullptr), -1, "affine_offsets_bwd: dmask and mask go together");
+  EAVSR_REQUIRE(n >= 0 && D > 0 && h > 0 && w > 0 && D <= 65535 && n <= 65535, -1, "affine_offsets_bwd: bad dims");
+  if (n == 0) return 0;
+  const int hw = h * w;
+  dim3 grid(eavsr::cdiv(hw, 256), D, n);
+  hipLaunchKernelGGL(affine_bwd_kernel, grid, dim3(256), 0, eavsr::as_stream(stream), doffset, dmask, mask, dheads, D,
+                     hw, dmask ? 15 * D : 6 * D);
+  return eavsr::launch_status("affine_offsets_bwd");
+}

@@ -1,0 +1,211 @@
+// Weight gradient of the dense stride-1 convolution (config 4, training):
+//   dW[co][ci][tap] = sum_{n,y,x} dY[n,co,y,x] * X[n,ci,y+ky-P,x+kx-P]
+// Reference: the cuDNN / MKLDNN conv backward-weights that autograd runs for every nn.Conv2d on the path
+// (loss.backward(), models/eavsrp_model.py:109-113).
+//
+// GEMM view: M = cout (64 per launch), N = (ci, tap) (64 input channels x k*k taps per launch),
+// K = pixels.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] = dY of output channel i at
+// pixel 2 kk + k and B[k][j = l & 31] = X of input channel j at that pixel shifted by the tap.  Each of the
+// 8 waves owns up to 5 of the 4 * k*k (M-tile, ci-tile, tap) output tiles of a pass and keeps them in
+// registers while the persistent workgroup walks its pixel tiles; partial sums go to a per-workgroup slab
+// that a second kernel adds up in a fixed order (deterministic, no atomics).
+// LDS operands are stored with ODD pitches so that the 32 lanes of a half-wave, which read 32 different
+// channels at the same pixel, hit 32 different banks.
+#include "common.h"
+
+#include <mutex>
+
+namespace {
+
+struct WgradArgs {
+  const float* dy;   // (n, cout_total, h, w), this launch uses channels co0 .. co0+63
+  const float* x;    // (n, cin_src, h, w),   this launch uses channels ci0 .. ci0+63
+  float* ws;         // [blocks][64][64][KK]
+  int n, h, w, cout_total, co0, co_valid, cin_src, ci0, ci_valid, tiles_x, tiles_y, num_tiles;
+};
+
+template <int KS>
+struct WgCfg {
+  static constexpr int KK = KS * KS, PAD = KS / 2;
+  static constexpr int TH = (KS <= 3) ? 8 : 4, TW = 32, PX = TH * TW;
+  static constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  static constexpr int PA = PX + 1;                       // odd pitch of the dY tile rows
+  static constexpr int PB = (IH * IW) | 1;                // odd pitch of the X patch planes
+  static constexpr int T = 4 * KK;                        // output tiles: 2 (co) x 2 (ci) x taps
+  static constexpr int TILES_PER_PASS = 40;               // 8 waves x 5
+  static constexpr int PASSES = (T + TILES_PER_PASS - 1) / TILES_PER_PASS;
+  static constexpr size_t LDS_BYTES = (size_t)(64 * PA + 64 * PB) * sizeof(float);
+};
+
+template <int KS>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
+  using Cfg = WgCfg<KS>;
+  constexpr int KK = Cfg::KK, PAD = Cfg::PAD, TH = Cfg::TH, TW = Cfg::TW, PX = Cfg::PX, IH = Cfg::IH, IW = Cfg::IW;
+  constexpr int PA = Cfg::PA, PB = Cfg::PB, T = Cfg::T, MAXT = 5;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;             // [64 co][PA]
+  float* sB = smem + 64 * PA;   // [64 ci][PB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+
+  for (int pass = 0; pass < Cfg::PASSES; ++pass) {
+    // this wave's output tiles of the pass: t = pass*40 + wave + 8*i ; (mt, ct, tap) = (t&1, (t>>1)&1, t>>2)
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    int aoff[MAXT], boff[MAXT];
+    bool tv[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = pass * Cfg::TILES_PER_PASS + wave + 8 * i;
+      tv[i] = t < T;
+      const int tt = tv[i] ? t : 0;
+      const int mt = tt & 1, ct = (tt >> 1) & 1, tap = tt >> 2;
+      const int ky = tap / KS, kx = tap - ky * KS;
+      aoff[i] = (mt * 32 + l31) * PA + half;
+      boff[i] = (ct * 32 + l31) * PB + ky * IW + kx;
+    }
+
+    for (int tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
+      int t = tile;
+      const int tx = t % a.tiles_x;
+      t /= a.tiles_x;
+      const int ty = t % a.tiles_y;
+      const int bn = t / a.tiles_y;
+      const int y0 = ty * TH, x0 = tx * TW;
+      __syncthreads();  // previous tile's MFMAs are done with the LDS tiles
+      // dY tile: 64 channels x PX pixels (zero beyond the image / beyond co_valid)
+      for (int e = tid; e < 64 * PX; e += 512) {
+        const int co = e / PX, p = e - co * PX;
+        const int gy = y0 + p / TW, gx = x0 + (p % TW);
+        float v = 0.f;
+        if (co < a.co_valid && gy < h && gx < w)
+          v = a.dy[((size_t)bn * a.cout_total + a.co0 + co) * plane + (size_t)gy * w + gx];
+        sA[co * PA + p] = v;
+      }
+      // X patch: 64 channels x IH x IW (zero padding)
+      for (int e = tid; e < 64 * IH * IW; e += 512) {
+        const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
+        const int r = rem / IW, c = rem - r * IW;
+        const int gy = y0 - PAD + r, gx = x0 - PAD + c;
+        float v = 0.f;
+        if (ci < a.ci_valid && gy >= 0 && gy < h && gx >= 0 && gx < w)
+          v = a.x[((size_t)bn * a.cin_src + a.ci0 + ci) * plane + (size_t)gy * w + gx];
+        sB[ci * PB + rem] = v;
+      }
+      __syncthreads();
+      // K loop over pixel pairs: pixel p = 2 kk + half -> (row p / 32, col p % 32)
+#pragma unroll 2
+      for (int kk = 0; kk < PX / 2; ++kk) {
+        const int p = 2 * kk;
+        const int prow = p / TW, pcol = (p % TW) + half;
+        const int bpix = prow * IW + pcol;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+          if (tv[i]) {  // wave-uniform
+            const float av = sA[aoff[i] + p];
+            const float bv = sB[boff[i] + bpix];
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // partial slab of this workgroup: ws[blk][co][ci][tap]
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      if (tv[i]) {
+        const int t = pass * Cfg::TILES_PER_PASS + wave + 8 * i;
+        const int mt = t & 1, ct = (t >> 1) & 1, tap = t >> 2;
+        const int ci = ct * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          a.ws[(((size_t)blockIdx.x * 64 + co) * 64 + ci) * KK + tap] = acc[i][r];
+        }
+      }
+    }
+  }
+}
+
+// dW[co0+co][ci_dst0+ci][tap] (+)= sum_blk ws[blk][co][ci][tap]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int blocks, int kk, int co0, int co_valid, int ci_dst0,
+                                                           int ci_valid, int cin_total, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int total = 64 * 64 * kk;
+  if (i >= total) return;
+  const int tap = i % kk;
+  const int ci = (i / kk) % 64;
+  const int co = i / (kk * 64);
+  if (co >= co_valid || ci >= ci_valid) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += ws[(size_t)b * total + i];
+  float* dst = dw + ((size_t)(co0 + co) * cin_total + ci_dst0 + ci) * kk + tap;
+  *dst = accumulate ? *dst + s : s;
+}
+
+template <int KS>
+int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
+  using Cfg = WgCfg<KS>;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  hipLaunchKernelGGL(conv_wgrad_kernel<KS>, dim3(blocks), dim3(512), Cfg::LDS_BYTES, st, a);
+  return eavsr::launch_status("conv_wgrad");
+}
+
+}  // namespace
+
+extern "C" int32_t eavsr_conv_wgrad_blocks(int32_t n, int32_t h, int32_t w, int32_t ksize) {
+  const int th = ksize <= 3 ? 8 : 4;
+  const long tiles = (long)n * eavsr::cdiv(h, th) * eavsr::cdiv(w, 32);
+  return (int32_t)(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
+}
+
+extern "C" int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float* workspace,
+                                    int32_t n, int32_t h, int32_t w, int32_t cout_total, int32_t co0,
+                                    int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,
+                                    int32_t accumulate, void* stream) {
+  EAVSR_REQUIRE(dy && x && dweight && workspace, -1, "conv_wgrad: NULL pointer");
+  EAVSR_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, -2, "conv_wgrad: kernel size %d unsupported (1, 3, 5)", ksize);
+  EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && cout_total > 0 && cin_src > 0 && cin_total > 0, -1, "conv_wgrad: bad dims");
+  EAVSR_REQUIRE(co0 >= 0 && co0 < cout_total && ci0 >= 0 && ci0 < cin_src && ci_dst0 >= 0 && ci_dst0 < cin_total, -1,
+                "conv_wgrad: channel offsets out of range");
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.ws = workspace;
+  a.n = n; a.h = h; a.w = w;
+  a.cout_total = cout_total; a.co0 = co0; a.co_valid = cout_total - co0 < 64 ? cout_total - co0 : 64;
+  a.cin_src = cin_src; a.ci0 = ci0; a.ci_valid = cin_src - ci0 < 64 ? cin_src - ci0 : 64;
+  EAVSR_REQUIRE(ci_dst0 + a.ci_valid <= cin_total, -1, "conv_wgrad: destination channel range exceeds cin_total");
+  const int th = ksize <= 3 ? 8 : 4;
+  a.tiles_x = eavsr::cdiv(w, 32);
+  a.tiles_y = eavsr::cdiv(h, th);
+  a.num_tiles = a.tiles_x * a.tiles_y * n;
+  const int blocks = eavsr_conv_wgrad_blocks(n, h, w, ksize);
+  hipStream_t st = eavsr::as_stream(stream);
+  int rc;
+  switch (ksize) {
+    case 1: rc = launch_wgrad<1>(a, blocks, st); break;
+    case 3: rc = launch_wgrad<3>(a, blocks, st); break;
+    default: rc = launch_wgrad<5>(a, blocks, st); break;
+  }
+  if (rc) return rc;
+  const int kk = ksize * ksize;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(eavsr::cdiv(64 * 64 * kk, 256)), dim3(256), 0, st, workspace, dweight,
+                     n == 0 ? 0 : blocks, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate);
+  return eavsr::launch_status("conv_wgrad_reduce");
+}

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import autograd as AG
 from . import networks as N
 from . import ops
 
@@ -31,7 +32,7 @@ def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_cor
     """Warp `x` (n,c,h,w) by `flow` (n,h,w,2): [...,0] = x displacement, [...,1] = y, in pixels."""
     if interpolation != "bilinear" or not align_corners:
         raise NotImplementedError("the reference path only uses bilinear, align_corners=True")
-    return ops.flow_warp(x, flow, padding_mode=padding_mode, flow_layout="nhwc")
+    return AG.flow_warp(x, flow, padding_mode=padding_mode, flow_layout="nhwc")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -207,14 +208,11 @@ class EAVSRP(nn.Module):
                                "the original repository with --gpu_ids -1")
         with torch.no_grad():
             flows_forward, flows_backward = self.compute_flow(lrs)
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training needs the backward kernels, which are not part of this round: "
-                                      "call .eval() / run under torch.no_grad()")
 
         # frame-major feature tensors so every per-frame slice is contiguous
         lr_tm = lrs.transpose(0, 1).reshape(t * n, c, h, w)
         f1 = self.encoder(lr_tm)                                   # :216
-        f2, f4 = ops.pyramid(f1)                                   # :218-220
+        f2, f4 = AG.pyramid(f1)                                    # :218-220
         feats: Dict[str, List[Tensor]] = {
             "spatial": [f1[i * n:(i + 1) * n] for i in range(t)],
             "spatial_d2": [f2[i * n:(i + 1) * n] for i in range(t)],
@@ -253,7 +251,7 @@ class EAVSRP(nn.Module):
                     feat_n2 = feats[module_name][-2]
                     nbr2 = [feats[k][mapping_idx[idx + 2 * step]] for k in _PYR]
                     flow_n2 = flows[:, flow_idx[i - 1]].contiguous()
-                    flow_n2 = ops.add(flow_n1, ops.flow_warp(flow_n2, flow_n1))          # :309-310
+                    flow_n2 = AG.add(flow_n1, AG.flow_warp(flow_n2, flow_n1))            # :309-310
                     cond_n2 = align(nbr2, cur, feat_n2, flow_n2)
                 else:
                     if zeros is None:
@@ -262,7 +260,7 @@ class EAVSRP(nn.Module):
                 feat_prop = fusion([cond_n1, cur[0], cond_n2])                          # :313-314
             others = [feats[k][idx] for k in feats if k not in _PYR and k != module_name]
             res = backbone([cur[0]] + others + [feat_prop])                             # :317-323
-            feat_prop = ops.add(feat_prop, res)
+            feat_prop = AG.add(feat_prop, res)
             feats[module_name].append(feat_prop)
         if backward:
             feats[module_name] = feats[module_name][::-1]

@@ -473,3 +473,183 @@ def scale_residual(r: Tensor, scale: Tensor, x: Tensor) -> Tensor:
     _launch("scale_residual", 2.0 * r.numel(), 12.0 * r.numel(), r,
             lambda: lib().eavsr_scale_residual_f32(_p(r), _p(scale), _p(x), _p(out), n, c, h * w, st), "scale_residual")
     return out
+
+
+# ==========================================================================================
+# backward kernels (training step; used by eavsr_amd/autograd.py)
+# ==========================================================================================
+def act_bwd(dy: Tensor, y: Tensor, act: str, slope: float = 0.0) -> Tensor:
+    dy, y = _chk(dy, "dy"), _chk(y, "y")
+    g = torch.empty_like(dy)
+    st = _stream(dy)
+    _launch("act_bwd", float(dy.numel()), 12.0 * dy.numel(), dy,
+            lambda: lib().eavsr_act_bwd_f32(_p(dy), _p(y), _p(g), dy.numel(), ACT[act], float(slope), st), "act_bwd")
+    return g
+
+
+def plane_sum(a: Tensor, b: Optional[Tensor] = None, scale: float = 1.0) -> Tensor:
+    """(n,c,h,w) -> (n,c): scale * sum_hw a (* b)"""
+    a = _chk(a, "a")
+    n, c, h, w = a.shape
+    if b is not None:
+        b = _chk(b, "b")
+    out = torch.empty((n, c), device=a.device, dtype=torch.float32)
+    st = _stream(a)
+    _launch("plane_sum", float(a.numel()), 4.0 * a.numel() * (2 if b is not None else 1), a,
+            lambda: lib().eavsr_plane_sum_f32(_p(a), _p(b), _p(out), n * c, h * w, float(scale), st), "plane_sum")
+    return out
+
+
+def scale_residual_bwd(d: Tensor, scale: Tensor, dmean: Optional[Tensor]) -> Tensor:
+    d, scale = _chk(d, "d"), _chk(scale, "scale")
+    n, c, h, w = d.shape
+    if dmean is not None:
+        dmean = _chk(dmean, "dmean")
+    dr = torch.empty_like(d)
+    st = _stream(d)
+    _launch("scale_residual_bwd", float(d.numel()), 8.0 * d.numel(), d,
+            lambda: lib().eavsr_scale_residual_bwd_f32(_p(d), _p(scale), _p(dmean), _p(dr), n, c, h * w, st),
+            "scale_residual_bwd")
+    return dr
+
+
+def ca_mlp_bwd(mean: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, dscale: Tensor):
+    mean, dscale = _chk(mean, "mean"), _chk(dscale, "dscale")
+    w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
+    n, c = mean.shape
+    cr = int(w1.shape[0])
+    dmean = torch.empty_like(mean)
+    dw1, db1, dw2, db2 = torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2)
+    st = _stream(mean)
+    _launch("ca_mlp_bwd", 0.0, 0.0, mean,
+            lambda: lib().eavsr_ca_mlp_bwd_f32(_p(mean), _p(w1), _p(b1), _p(w2), _p(b2), _p(dscale), _p(dmean), _p(dw1),
+                                               _p(db1), _p(dw2), _p(db2), n, c, cr, st), "ca_mlp_bwd")
+    return dmean, dw1, db1, dw2, db2
+
+
+def flow_warp_bwd(x: Tensor, flow: Tensor, flow2: Optional[Tensor], dout: Tensor, need_dx: bool, need_dflow: bool):
+    x, flow, dout = _chk(x, "x"), _chk(flow, "flow"), _chk(dout, "dout")
+    n, c, h, w = x.shape
+    if flow2 is not None:
+        flow2 = _chk(flow2, "flow2")
+    dx = torch.zeros_like(x) if need_dx else None
+    dflow = torch.empty_like(flow) if need_dflow else None
+    st = _stream(x)
+    _launch("flow_warp_bwd", 16.0 * x.numel(), 4.0 * x.numel() * 3, x,
+            lambda: lib().eavsr_flow_warp_bwd_f32(_p(x), _p(flow), _p(flow2), _p(dout), _p(dx), _p(dflow), n, c, h, w, st),
+            "flow_warp_bwd")
+    return dx, dflow
+
+
+def resize_bilinear_ac_bwd(dout: Tensor, in_shape, scale: float) -> Tensor:
+    dout = _chk(dout, "dout")
+    n, c, hin, win = in_shape
+    hout, wout = dout.shape[2:]
+    din = torch.zeros((n, c, hin, win), device=dout.device, dtype=torch.float32)
+    st = _stream(dout)
+    _launch("resize_bilinear_ac_bwd", 0.0, 4.0 * (dout.numel() + din.numel()), dout,
+            lambda: lib().eavsr_resize_bilinear_ac_bwd_f32(_p(dout), _p(din), n, c, hin, win, hout, wout, float(scale), st),
+            "resize_bilinear_ac_bwd")
+    return din
+
+
+def pyramid_bwd(dd2: Tensor, dd4: Tensor) -> Tensor:
+    dd2, dd4 = _chk(dd2, "dd2"), _chk(dd4, "dd4")
+    n, c, h2, w2 = dd2.shape
+    din = torch.empty((n, c, 2 * h2, 2 * w2), device=dd2.device, dtype=torch.float32)
+    st = _stream(dd2)
+    _launch("pyramid_bwd", 0.0, 4.0 * din.numel() * 1.3125, dd2,
+            lambda: lib().eavsr_pyramid_bwd_f32(_p(dd2), _p(dd4), _p(din), n * c, 2 * h2, 2 * w2, st), "pyramid_bwd")
+    return din
+
+
+def affine_offsets_bwd(doff: Tensor, dmask: Optional[Tensor], mask: Optional[Tensor], D: int) -> Tensor:
+    doff = _chk(doff, "doff")
+    n, _, h, w = doff.shape
+    with_mask = mask is not None
+    if with_mask:
+        mask = _chk(mask, "mask")
+        dmask = _chk(dmask, "dmask") if dmask is not None else torch.zeros_like(mask)
+    dheads = torch.empty((n, (15 if with_mask else 6) * D, h, w), device=doff.device, dtype=torch.float32)
+    st = _stream(doff)
+    _launch("affine_offsets_bwd", 0.0, 4.0 * (doff.numel() + dheads.numel()), doff,
+            lambda: lib().eavsr_affine_offsets_bwd_f32(_p(doff), _p(dmask) if with_mask else None,
+                                                       _p(mask) if with_mask else None, _p(dheads), n, D, h, w, st),
+            "affine_offsets_bwd")
+    return dheads
+
+
+def conv_wgrad(dy: Tensor, srcs: Sequence[Tensor], ksize: int) -> Tensor:
+    """Weight gradient (cout, cin_total, k, k) of a conv over the virtual concatenation of `srcs`."""
+    dy = _chk(dy, "dy")
+    srcs = [_chk(s, f"src{i}") for i, s in enumerate(srcs)]
+    n, cout, h, w = dy.shape
+    cin = sum(int(s.shape[1]) for s in srcs)
+    dw = torch.empty((cout, cin, ksize, ksize), device=dy.device, dtype=torch.float32)
+    blocks = lib().eavsr_conv_wgrad_blocks(n, h, w, ksize)
+    if blocks <= 0:
+        raise NotImplementedError(f"conv_wgrad: kernel size {ksize}")
+    ws = torch.empty(blocks * 64 * 64 * ksize * ksize, device=dy.device, dtype=torch.float32)
+    st = _stream(dy)
+    base = 0
+    for s in srcs:
+        cs = int(s.shape[1])
+        for ci0 in range(0, cs, 64):
+            for co0 in range(0, cout, 64):
+                _launch(f"conv_wgrad{ksize}x{ksize}", 2.0 * min(64, cout - co0) * min(64, cs - ci0) * ksize * ksize * n * h * w,
+                        4.0 * n * h * w * 128, dy,
+                        lambda s=s, cs=cs, ci0=ci0, co0=co0, base=base: lib().eavsr_conv_wgrad_f32(
+                            _p(dy), _p(s), _p(dw), _p(ws), n, h, w, cout, co0, cs, ci0, cin, base + ci0, ksize, 0, st),
+                        "conv_wgrad")
+        base += cs
+    return dw
+
+
+def dcnv2_im2col(x: Tensor, offset: Tensor, mask: Tensor, dg: int) -> Tensor:
+    x, offset, mask = _chk(x, "x"), _chk(offset, "offset"), _chk(mask, "mask")
+    n, c, h, w = x.shape
+    col = torch.empty((n, c * 9, h, w), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    _launch("dcnv2_im2col", 0.0, 4.0 * col.numel(), x,
+            lambda: lib().eavsr_dcnv2_im2col_f32(_p(x), _p(offset), _p(mask), _p(col), n, c, h, w, dg, st), "dcnv2_im2col")
+    return col
+
+
+def dcnv2_col2im(x: Tensor, offset: Tensor, mask: Tensor, dcol: Tensor, dg: int, need_dx: bool = True):
+    x, offset, mask, dcol = _chk(x, "x"), _chk(offset, "offset"), _chk(mask, "mask"), _chk(dcol, "dcol")
+    n, c, h, w = x.shape
+    dx = torch.zeros_like(x) if need_dx else None
+    doff, dmask = torch.empty_like(offset), torch.empty_like(mask)
+    st = _stream(x)
+    _launch("dcnv2_col2im", 0.0, 4.0 * dcol.numel(), x,
+            lambda: lib().eavsr_dcnv2_col2im_f32(_p(x), _p(offset), _p(mask), _p(dcol), _p(dx), _p(doff), _p(dmask), n, c,
+                                                 h, w, dg, st), "dcnv2_col2im")
+    return dx, doff, dmask
+
+
+def gconv3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], cpg: int, act: Optional[str] = None,
+             slope: float = 0.0) -> Tensor:
+    x, weight = _chk(x, "x"), _chk(weight.detach(), "weight")
+    n, cin, h, w = x.shape
+    cout = int(weight.shape[0])
+    if cin != cout * cpg or tuple(weight.shape) != (cout, cpg, 3, 3):
+        raise ValueError("gconv3x3: one output channel per group, cpg input channels per group")
+    b = None if bias is None else _chk(bias.detach(), "bias")
+    out = torch.empty((n, cout, h, w), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    _launch("gconv3x3", 18.0 * cpg * out.numel(), 4.0 * (x.numel() + out.numel()), x,
+            lambda: lib().eavsr_gconv3x3_fwd_f32(_p(x), _p(weight), _p(b), _p(out), n, cout, cpg, h, w, ACT[act],
+                                                 float(slope), st), "gconv3x3_fwd")
+    return out
+
+
+def gconv3x3_bwd(g: Tensor, x: Tensor, weight: Tensor, cpg: int):
+    g, x, weight = _chk(g, "g"), _chk(x, "x"), _chk(weight.detach(), "weight")
+    n, cout, h, w = g.shape
+    dx, dw = torch.empty_like(x), torch.empty_like(weight)
+    db = torch.empty(cout, device=g.device, dtype=torch.float32)
+    st = _stream(g)
+    _launch("gconv3x3_bwd", 36.0 * cpg * g.numel(), 4.0 * (2 * x.numel() + g.numel()), g,
+            lambda: lib().eavsr_gconv3x3_bwd_f32(_p(g), _p(x), _p(weight), _p(dx), _p(dw), _p(db), n, cout, cpg, h, w, st),
+            "gconv3x3_bwd")
+    return dx, dw, db

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 2
+#define EAVSR_ABI_VERSION 3
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -159,6 +159,69 @@ int eavsr_pyramid_f32(const float* in, float* down2, float* down4,
 /* out = a + b [+ c] elementwise (flow sums at networks.py:619, eavsrp_model.py:309,323) */
 int eavsr_add_f32(const float* a, const float* b, const float* c, float* out, int64_t count,
                   void* stream);
+
+/* ============================================================================================
+ * Backward entry points (training step).  They replace the ATen / cuDNN / mmcv
+ * backward kernels autograd runs for the same modules in the reference's loss.backward()
+ * (models/eavsrp_model.py:109-113).  Same boundary rules as above.
+ * ============================================================================================ */
+
+/* g = dy * act'(y) with y the activation OUTPUT (ReLU / LeakyReLU fused into eavsr_conv2d_f32) */
+int eavsr_act_bwd_f32(const float* dy, const float* y, float* g, int64_t count, int32_t act, float slope,
+                      void* stream);
+/* out[nc] = scale * sum_hw a[nc,hw] (* b[nc,hw] when b != NULL): bias gradients, channel means
+ * (CALayer avg_pool, networks.py:445) and d(scale) of the RCAB tail */
+int eavsr_plane_sum_f32(const float* a, const float* b, float* out, int32_t nc, int32_t hw, float scale,
+                        void* stream);
+/* backward of out = r * scale[n,c] + x w.r.t. r:  dr = d * scale[n,c] + dmean[n,c] (dmean nullable) */
+int eavsr_scale_residual_bwd_f32(const float* d, const float* scale, const float* dmean, float* dr,
+                                 int32_t n, int32_t c, int32_t hw, void* stream);
+/* backward of the channel-attention MLP scale = sigmoid(W2 relu(W1 mean + b1) + b2) (networks.py:436-447):
+ * writes dmean (n,c) and the four parameter gradients (overwritten, summed over n in a fixed order) */
+int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* dscale, float* dmean, float* dw1, float* db1, float* dw2, float* db2,
+                         int32_t n, int32_t c, int32_t cr, void* stream);
+/* backward of eavsr_flow_warp_f32 (zeros padding, NCHW flow): dx (pre-zeroed, accumulated with float
+ * atomics; NULL = skip) and dflow (n,2,h,w; NULL = skip).  flow2 as in the forward. */
+int eavsr_flow_warp_bwd_f32(const float* x, const float* flow, const float* flow2, const float* dout,
+                            float* dx, float* dflow, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+/* backward of eavsr_resize_bilinear_ac_f32 w.r.t. its input: din (pre-zeroed) += scale * scatter(dout) */
+int eavsr_resize_bilinear_ac_bwd_f32(const float* dout, float* din, int32_t n, int32_t c, int32_t hin,
+                                     int32_t win, int32_t hout, int32_t wout, float scale, void* stream);
+/* backward of eavsr_pyramid_f32 */
+int eavsr_pyramid_bwd_f32(const float* ddown2, const float* ddown4, float* din, int32_t nc, int32_t h,
+                          int32_t w, void* stream);
+/* backward of eavsr_affine_offsets_f32: d(heads) from d(offset) and, for blocks with a mask, d(mask) and the
+ * saved mask (= sigmoid(logits)) */
+int eavsr_affine_offsets_bwd_f32(const float* doffset, const float* dmask, const float* mask, float* dheads,
+                                 int32_t n, int32_t D, int32_t h, int32_t w, void* stream);
+
+/* conv weight gradient for a (<= 64 output channels) x (<= 64 input channels) block:
+ *   dweight[co0+co][ci_dst0+ci][tap] (+)= sum_{n,y,x} dy[n,co0+co,y,x] * x[n,ci0+ci,y+ky-P,x+kx-P]
+ * dweight is the full (cout_total, cin_total, k, k) gradient; x is one source of the virtual concatenation
+ * (cin_src channels) whose channel ci0 lands at input channel ci_dst0 of the weight.  ksize 1, 3 or 5.
+ * workspace: eavsr_conv_wgrad_blocks(n,h,w,ksize) * 64*64*ksize*ksize floats.  accumulate != 0 adds. */
+int32_t eavsr_conv_wgrad_blocks(int32_t n, int32_t h, int32_t w, int32_t ksize);
+int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float* workspace, int32_t n, int32_t h,
+                         int32_t w, int32_t cout_total, int32_t co0, int32_t cin_src, int32_t ci0,
+                         int32_t cin_total, int32_t ci_dst0, int32_t ksize, int32_t accumulate, void* stream);
+
+/* DCNv2 backward samplers (the two GEMMs run on eavsr_conv_wgrad_f32 / eavsr_conv2d_f32 with k = 1):
+ * columns (n, c*9, h, w) = im2col(x, offset, mask);  from dcolumns: dx (pre-zeroed, atomics; NULL = skip),
+ * doffset (n, dg*18, h, w), dmask (n, dg*9, h, w). */
+int eavsr_dcnv2_im2col_f32(const float* x, const float* offset, const float* mask, float* columns, int32_t n,
+                           int32_t c, int32_t h, int32_t w, int32_t deform_groups, void* stream);
+int eavsr_dcnv2_col2im_f32(const float* x, const float* offset, const float* mask, const float* dcolumns,
+                           float* dx, float* doffset, float* dmask, int32_t n, int32_t c, int32_t h, int32_t w,
+                           int32_t deform_groups, void* stream);
+
+/* un-fused training form of the predictor front end: grouped 3x3 conv with one output channel per group and
+ * cpg input channels per group (`concat`: cpg = 1, `concat2`: cpg = 2; networks.py:290-291,327-328),
+ * optional LeakyReLU; and its backward (g = gradient w.r.t. the pre-activation output). */
+int eavsr_gconv3x3_fwd_f32(const float* x, const float* weight, const float* bias, float* out, int32_t n,
+                           int32_t cout, int32_t cpg, int32_t h, int32_t w, int32_t act, float slope, void* stream);
+int eavsr_gconv3x3_bwd_f32(const float* g, const float* x, const float* weight, float* dx, float* dweight,
+                           float* dbias, int32_t n, int32_t cout, int32_t cpg, int32_t h, int32_t w, void* stream);
 
 #ifdef __cplusplus
 }

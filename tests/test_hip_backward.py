@@ -1,0 +1,260 @@
+"""GPU parity tests of the backward kernels (training step): gradients from the
+HIP backward kernels (through eavsr_amd.autograd) against CPU autograd through the oracle's restatement of
+the same functions.  `pytest -m gpu`."""
+from argparse import Namespace
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import eavsr_oracle as O
+from tests import helpers as H
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def AG(cuda):
+    from eavsr_amd import autograd as _ag, ops
+    ops.lib()
+    return _ag
+
+
+def leaf(t, dev=None):
+    t = t.clone().to(dev) if dev is not None else t.clone()
+    return t.requires_grad_(True)
+
+
+def grads(out, G, inputs):
+    return torch.autograd.grad((out * G).sum(), inputs, allow_unused=True)
+
+
+def check(gpu_grads, cpu_grads, tol, names):
+    for g, c, nme in zip(gpu_grads, cpu_grads, names):
+        assert (g is None) == (c is None), nme
+        if c is not None:
+            scale = max(1.0, c.abs().max().item())
+            assert H.maxabs(g.cpu(), c) <= tol * scale, (nme, H.maxabs(g.cpu(), c), scale)
+
+
+@pytest.mark.parametrize("k,chans,cout,act,res", [(3, [64], 64, "relu", False), (3, [64, 64, 64], 64, "lrelu", False),
+                                                  (3, [64], 64, None, True), (1, [64, 64, 64], 64, None, False),
+                                                  (5, [64], 120, None, False), (3, [18], 2, None, False),
+                                                  (3, [64], 6, None, False), (3, [64], 256, "lrelu", False),
+                                                  (3, [256], 64, None, False), (3, [3], 64, "relu", False)])
+def test_conv2d_backward(AG, cuda, k, chans, cout, act, res):
+    n, h, w = 2, 19, 37
+    cin = sum(chans)
+    srcs = [cases.randn(10 + i, n, c, h, w) for i, c in enumerate(chans)]
+    wt = cases.randn(20, cout, cin, k, k, scale=1.0 / (cin * k * k) ** 0.5)
+    b = cases.randn(21, cout, scale=0.1)
+    r = cases.randn(22, n, cout, h, w) if res else None
+    G = cases.randn(23, n, cout, h, w)
+    cs, cw, cb = [leaf(s) for s in srcs], leaf(wt), leaf(b)
+    cr = leaf(r) if res else None
+    y = F.conv2d(torch.cat(cs, 1), cw, cb, 1, k // 2)
+    y = F.relu(y) if act == "relu" else (F.leaky_relu(y, 0.1) if act == "lrelu" else y)
+    y = y + cr if res else y
+    ref = grads(y, G, cs + [cw, cb] + ([cr] if res else []))
+    gs, gw, gb = [leaf(s, cuda) for s in srcs], leaf(wt, cuda), leaf(b, cuda)
+    gr = leaf(r, cuda) if res else None
+    out = AG.conv2d(gs, gw, gb, act=act, slope=0.1, residual=gr)
+    got = grads(out, G.to(cuda), gs + [gw, gb] + ([gr] if res else []))
+    check(got, ref, 3e-5, [f"src{i}" for i in range(len(chans))] + ["weight", "bias", "residual"])
+
+
+def test_conv2d_multi_head_backward(AG, cuda):
+    x = cases.randn(1, 1, 64, 14, 18)
+    ws = [cases.randn(2 + i, co, 64, 3, 3, scale=0.05) for i, co in enumerate((4, 2))]
+    bs = [cases.randn(5 + i, co, scale=0.1) for i, co in enumerate((4, 2))]
+    G = cases.randn(9, 1, 6, 14, 18)
+    cx, cws, cbs = leaf(x), [leaf(w_) for w_ in ws], [leaf(b_) for b_ in bs]
+    ref = grads(F.conv2d(cx, torch.cat(cws), torch.cat(cbs), 1, 1), G, [cx] + cws + cbs)
+    gx, gws, gbs = leaf(x, cuda), [leaf(w_, cuda) for w_ in ws], [leaf(b_, cuda) for b_ in bs]
+    got = grads(AG.conv2d(gx, gws, gbs), G.to(cuda), [gx] + gws + gbs)
+    check(got, ref, 3e-5, ["x", "w0", "w1", "b0", "b1"])
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 24, 40), (1, 2, 13, 17), (1, 5, 9, 11)])
+def test_flow_warp_backward(AG, cuda, shape):
+    n, c, h, w = shape
+    x, f1, f2 = cases.randn(1, n, c, h, w), cases.randn(2, n, 2, h, w, scale=2.0), cases.randn(3, n, 2, h, w)
+    G = cases.randn(4, n, c, h, w)
+    cx, c1, c2 = leaf(x), leaf(f1), leaf(f2)
+    ref = grads(O.flow_warp(cx, c1 + c2), G, [cx, c1, c2])
+    gx, g1, g2 = leaf(x, cuda), leaf(f1, cuda), leaf(f2, cuda)
+    got = grads(AG.flow_warp(gx, g1, flow2=g2), G.to(cuda), [gx, g1, g2])
+    check(got, ref, 5e-5, ["x", "flow", "flow2"])
+
+
+@pytest.mark.parametrize("sigma", [0.5, 3.0])
+@pytest.mark.parametrize("shape", [(1, 64, 12, 20, 64, 8), (2, 16, 9, 12, 32, 2)])
+def test_dcnv2_backward(AG, cuda, shape, sigma):
+    n, c, h, w, cout, dg = shape
+    x = cases.randn(1, n, c, h, w)
+    off = cases.randn(2, n, dg * 18, h, w, scale=sigma)
+    mask = cases.rand(3, n, dg * 9, h, w)
+    wt = cases.randn(4, cout, c, 3, 3, scale=1.0 / (c * 9) ** 0.5)
+    b = cases.randn(5, cout, scale=0.1)
+    G = cases.randn(6, n, cout, h, w)
+    cl = [leaf(t) for t in (x, off, mask, wt, b)]
+    ref = grads(O.dcnv2(cl[0], cl[1], cl[2], cl[3], cl[4], 1, 1, 1, 1, dg), G, cl)
+    gl = [leaf(t, cuda) for t in (x, off, mask, wt, b)]
+    got = grads(AG.modulated_deform_conv2d(gl[0], gl[1], gl[2], gl[3], gl[4], 1, 1, 1, 1, dg), G.to(cuda), gl)
+    check(got, ref, 1e-4, ["x", "offset", "mask", "weight", "bias"])
+
+
+def test_adapt_frontend_and_affine_backward(AG, cuda):
+    sd = H.filled(H.adaptoffset_shapes("f."), "trained_like")
+    x, hh = cases.randn(1, 2, 64, 11, 14), cases.randn(2, 2, 64, 11, 14)
+    keys = ["f.concat.0.weight", "f.concat.0.bias", "f.concat2.0.weight", "f.concat2.0.bias"]
+    G = cases.randn(3, 2, 64, 11, 14)
+    cp = {k: leaf(sd[k]) for k in keys}
+    cx, ch = leaf(x), leaf(hh)
+    ref = grads(O.adapt_frontend({**sd, **cp}, "f.", cx, ch), G, [cx, ch] + [cp[k] for k in keys])
+    gp = {k: leaf(sd[k], cuda) for k in keys}
+    gx, gh = leaf(x, cuda), leaf(hh, cuda)
+    got = grads(AG.adapt_frontend(gx, gh, *[gp[k] for k in keys]), G.to(cuda), [gx, gh] + [gp[k] for k in keys])
+    check(got, ref, 3e-5, ["x", "h"] + keys)
+    # affine -> offsets (+ mask)
+    heads = cases.randn(4, 2, 120, 9, 13)
+    Go, Gm = cases.randn(5, 2, 144, 9, 13), cases.randn(6, 2, 72, 9, 13)
+    chd = leaf(heads)
+    ref = torch.autograd.grad((O.affine_offsets(chd[:, :32], chd[:, 32:48], 8) * Go).sum() +
+                              (torch.sigmoid(chd[:, 48:]) * Gm).sum(), [chd])
+    ghd = leaf(heads, cuda)
+    off, mask = AG.affine_offsets(ghd, 8, True)
+    got = torch.autograd.grad((off * Go.to(cuda)).sum() + (mask * Gm.to(cuda)).sum(), [ghd])
+    check(got, ref, 2e-5, ["heads"])
+
+
+def test_resampling_backward(AG, cuda):
+    x, pre = cases.randn(1, 2, 2, 8, 12), cases.randn(2, 2, 2, 8, 12)
+    post, G = cases.randn(3, 2, 2, 16, 24), cases.randn(4, 2, 2, 16, 24)
+    cl = [leaf(t) for t in (x, pre, post)]
+    ref = grads(F.interpolate(cl[0] + cl[1], size=(16, 24), mode="bilinear", align_corners=True) * 2.0 + cl[2], G, cl)
+    gl = [leaf(t, cuda) for t in (x, pre, post)]
+    got = grads(AG.resize_bilinear_ac(gl[0], (16, 24), 2.0, pre_add=gl[1], post_add=gl[2]), G.to(cuda), gl)
+    check(got, ref, 2e-5, ["x", "pre", "post"])
+    f = cases.randn(5, 3, 64, 12, 20)
+    G2, G4 = cases.randn(6, 3, 64, 6, 10), cases.randn(7, 3, 64, 3, 5)
+    cf = leaf(f)
+    d2, d4 = O.feature_pyramid(cf)
+    ref = torch.autograd.grad((d2 * G2).sum() + (d4 * G4).sum(), [cf])
+    gf = leaf(f, cuda)
+    e2, e4 = AG.pyramid(gf)
+    got = torch.autograd.grad((e2 * G2.to(cuda)).sum() + (e4 * G4.to(cuda)).sum(), [gf])
+    check(got, ref, 1e-6, ["x"])
+
+
+def test_rcab_tail_backward(AG, cuda):
+    sd = H.filled(H.rcab_shapes("b."), "trained_like")
+    keys = ["b.ca.conv_du.0.weight", "b.ca.conv_du.0.bias", "b.ca.conv_du.2.weight", "b.ca.conv_du.2.bias"]
+    r, x, G = cases.randn(1, 2, 64, 10, 14), cases.randn(2, 2, 64, 10, 14), cases.randn(3, 2, 64, 10, 14)
+    cp = {k: leaf(sd[k]) for k in keys}
+    cr, cx = leaf(r), leaf(x)
+    ref = grads(O.ca_layer({**sd, **cp}, "b.ca.", cr) + cx, G, [cr, cx] + [cp[k] for k in keys])
+    gp = {k: leaf(sd[k], cuda) for k in keys}
+    gr, gx = leaf(r, cuda), leaf(x, cuda)
+    got = grads(AG.rcab_tail(gr, gx, *[gp[k] for k in keys]), G.to(cuda), [gr, gx] + [gp[k] for k in keys])
+    check(got, ref, 2e-5, ["r", "x"] + keys)
+
+
+def _grads_of_module(mod, sd, prefix, loss_fn):
+    loss = loss_fn()
+    names = [k for k, p in mod.named_parameters() if p.requires_grad]
+    gs = torch.autograd.grad(loss, [p for _, p in mod.named_parameters() if p.requires_grad], allow_unused=True)
+    return dict(zip(names, gs))
+
+
+@pytest.mark.parametrize("preset", ["trained_like"])
+def test_multiadstn_backward_vs_oracle(AG, cuda, preset):
+    from eavsr_amd import networks as Nw
+    opt = Namespace(predict=False, n_frame=7, n_flow=5, scale=4)
+    sd = H.filled(H.multiadstn_shapes("a."), preset)
+    nbr, ref, fp, flow = cases.g5_inputs(h=16, w=24)
+    G = cases.randn(99, 1, 64, 16, 24)
+    # CPU oracle autograd
+    csd = {k: (leaf(v) if not k.endswith("regular_matrix") else v) for k, v in sd.items()}
+    cfp = leaf(fp)
+    out_c = O.multi_adstn(csd, "a.", nbr, ref, cfp, flow, 8)
+    pkeys = [k for k in csd if not k.endswith("regular_matrix")]
+    ref_g = torch.autograd.grad((out_c * G).sum(), [csd[k] for k in pkeys] + [cfp], allow_unused=True)
+    # HIP
+    m = Nw.MultiAdSTN(opt, 64, 64, deformable_groups=8)
+    m.load_state_dict({k[2:]: v for k, v in sd.items()}, strict=True)
+    m = m.to(cuda).train()
+    gfp = leaf(fp, cuda)
+    out_g = m([t.to(cuda) for t in nbr], [t.to(cuda) for t in ref], gfp, flow.to(cuda))
+    assert H.maxabs(out_g.detach().cpu(), out_c.detach()) <= 1e-4
+    params = dict(m.named_parameters())
+    got = torch.autograd.grad((out_g * G.to(cuda)).sum(), [params[k[2:]] for k in pkeys] + [gfp], allow_unused=True)
+    bad = []
+    for k, g, c in zip(pkeys + ["feat_prop"], got, ref_g):
+        if c is None:
+            assert g is None or g.abs().max().item() == 0, k
+            continue
+        scale = max(1e-3, c.abs().max().item())
+        if H.maxabs(g.cpu(), c) > 2e-3 * scale:
+            bad.append((k, H.maxabs(g.cpu(), c), scale))
+    assert not bad, bad
+
+
+def test_training_step_decreases_loss_and_matches_oracle_grads(AG, cuda):
+    """One EAVSRP x4 training step at 1 x 3 x 3 x 64 x 64: loss / a sample of parameter gradients against CPU
+    autograd through the oracle, then an Adam step lowers the L1 loss."""
+    from eavsr_amd.eavsrp_model import EAVSRP
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    opt = Namespace(predict=False, n_frame=7, n_flow=5, scale=4)
+    sd = H.filled(H.model_shapes("x4"), "trained_like")
+    net = EAVSRP(opt, None)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(cuda).train()
+    clip = synthetic_clip(1, 3, 64, 64, seed=11)
+    hr = synthetic_clip(1, 3, 256, 256, seed=12)
+    out = net(clip.to(cuda))
+    loss = (out - hr.to(cuda)).abs().mean()
+    loss.backward()
+    # oracle gradients for a few parameters spread over the path
+    watch = ["conv_last.weight", "backbone.forward_2.main.2.rg.3.res.0.weight", "fusion.backward_1.weight",
+             "deform_align.forward_1.weight", "deform_align.backward_2.adastn.mask_conv.bias",
+             "deform_align.forward_1.flow_l2.concat.0.weight", "encoder.tail.bias",
+             "backbone.backward_1.main.2.rg.7.ca.conv_du.0.weight"]
+    csd = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        with torch.no_grad():
+            flows = O.compute_flow(sd, clip)
+        out_c = _oracle_forward_with_grad(csd, clip, flows)
+        loss_c = (out_c - hr).abs().mean()
+    gs = torch.autograd.grad(loss_c, [csd[k] for k in watch])
+    assert abs(loss.item() - loss_c.item()) <= 1e-4
+    params = dict(net.named_parameters())
+    for k, gc in zip(watch, gs):
+        gg = params[k].grad
+        assert gg is not None, k
+        scale = max(1e-7, gc.abs().max().item())
+        assert H.maxabs(gg.cpu(), gc) <= 5e-3 * scale, (k, H.maxabs(gg.cpu(), gc), scale)
+    assert all(p.grad is None for p in net.spynet.parameters())
+    optim = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-4)
+    optim.step()
+    with torch.no_grad():
+        loss2 = (net(clip.to(cuda)) - hr.to(cuda)).abs().mean()
+    assert loss2.item() < loss.item()
+
+
+def _oracle_forward_with_grad(sd, lrs, flows):
+    """eavsrp_forward without its no_grad wrapper"""
+    n, t, c, h, w = lrs.shape
+    ff, fb = flows
+    f1 = O.encoder(sd, "encoder.", lrs.reshape(-1, c, h, w))
+    d2, d4 = O.feature_pyramid(f1)
+    f1, d2, d4 = f1.view(n, t, -1, h, w), d2.view(n, t, -1, h // 2, w // 2), d4.view(n, t, -1, h // 4, w // 4)
+    feats = {"spatial": [f1[:, i] for i in range(t)], "spatial_d2": [d2[:, i] for i in range(t)],
+             "spatial_d4": [d4[:, i] for i in range(t)]}
+    for it in (1, 2):
+        for direction in ("backward", "forward"):
+            module = f"{direction}_{it}"
+            feats[module] = []
+            feats = O.propagate(sd, feats, fb if direction == "backward" else ff, module, 8)
+    return O.upsample(sd, lrs, feats, 4)
