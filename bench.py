@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--preset", default="trained_like", choices=["default", "trained_like"])
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer: the BASELINE metric (default). train: BASELINE.json configs[3], a data-parallel "
+                         "training step (2 clips/GPU x 7 x 3 x 96 x 96, L1 loss, Adam, one RCCL all-reduce on the "
+                         "loss gradients); reported under its own metric name")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=[64, 96], help="h w of the CPU-baseline crop")
@@ -117,6 +121,51 @@ def cpu_baseline(preset, frames, crop_h, crop_w, full_h, full_w, timeout_s=240):
     }
 
 
+def train_bench(args, rank, world, device):
+    """BASELINE.json configs[3]: eavsrp x4 training step, 2 clips/GPU x 7 x 3 x 96 x 96, data parallel."""
+    from argparse import Namespace
+    from eavsr_amd import shard
+    from eavsr_amd.eavsrp_model import EAVSRPModel
+    from eavsr_amd.utils.synthetic import fill_state_dict, shapes_of, synthetic_clip
+    n, t = 2, 7
+    h = w = 96
+    opt = Namespace(predict=False, n_frame=7, n_flow=5, scale=4, isTrain=True, gpu_ids=[device.index], lr=1e-4,
+                    beta1=0.9, beta2=0.999, weight_decay=0.0, npost=350)
+    model = EAVSRPModel(opt)
+    sd0 = model.netEAVSRP.state_dict()
+    model.netEAVSRP.load_state_dict(fill_state_dict(shapes_of(sd0), args.preset, fixed=sd0), strict=True)
+    data = {"lr_seq": synthetic_clip(n, t, h, w, seed=rank), "hr_seq": synthetic_clip(n, t, 4 * h, 4 * w, seed=100 + rank),
+            "fname": "synthetic"}
+    model.set_input(data, epoch=0)
+    for _ in range(args.warmup):
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    on_dev = world > 1 and torch.distributed.get_backend() == "nccl"
+    elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training LR frames/sec, eavsrp x4 step (forward + backward + grad all-reduce + Adam)",
+            "value": world * n * t * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"eavsrp x4 training step, {n} clips/GPU x {t} x 3 x {h} x {w}, HR {4*h}x{4*w}, L1, "
+                                   "Adam (1e-4 / 1e-5), DP with one bucketed RCCL all-reduce on 49.1 MB of gradients "
+                                   "(BASELINE.json configs[3])"},
+            "loss": model.get_current_losses()}), flush=True)
+    if world > 1:
+        shard.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     from eavsr_amd import ops, shard
@@ -135,6 +184,8 @@ def main():
     ops.lib()  # fail loudly if the HIP extension is missing
 
     from eavsr_amd.utils.synthetic import synthetic_clip
+    if args.mode == "train":
+        return train_bench(args, rank, world, device)
     net, sd = build_model(device, args.preset)
     n, t, h, w = args.clips, args.frames, args.height, args.width
     clips = synthetic_clip(n, t, h, w, seed=rank).to(device)   # resident in HBM before the timed region

@@ -293,10 +293,12 @@ class EAVSRPx2(EAVSRP):
 # model wrapper (eavsrp_model.py:18-119), inference side
 # ---------------------------------------------------------------------------------------------
 class EAVSRPModel:
-    """Inference-side stand-in of EAVSRPModel / EAVSRPx2Model: set_input / test / forward /
-    get_current_visuals / load_networks / save_networks with the reference's checkpoint format
-    ({'state_dict': ...}, base_model.py:159-217).  Training (optimize_parameters) needs the
-    backward kernels, which are a later row of SURVEY.md section 8."""
+    """Stand-in of EAVSRPModel / EAVSRPx2Model (models/eavsrp_model.py:18-119): set_input / forward / test /
+    optimize_parameters / get_current_visuals / load_networks / save_networks with the reference's
+    checkpoint format ({'state_dict': ...}, base_model.py:159-217).  One process per GPU; with several
+    processes (torch.distributed initialised) the training step averages the loss gradients with one
+    bucketed RCCL all-reduce (eavsr_amd.shard.GradientAllReducer) instead of nn.DataParallel.
+    The reference's late-training PWC-Net mask (epoch >= opt.npost, eavsrp_model.py:85-97) is out of scope."""
 
     def __init__(self, opt):
         self.opt = opt
@@ -307,12 +309,31 @@ class EAVSRPModel:
             raise RuntimeError("eavsr_amd has no CPU path (--gpu_ids -1 is the reference's CPU mode)")
         self.device = torch.device("cuda", gpu_ids[0])
         self.visual_names = ["data_lr_seq", "data_hr_seq", "data_sr_seq"]
+        self.loss_names = ["EAVSRP_L1", "EAVSRP_Total"]
         self.model_names = ["EAVSRP"]
         self.netEAVSRP = N.init_net(EAVSRP(opt, getattr(opt, "spynet_pretrained", None)), gpu_ids=gpu_ids)
         self.time, self.isfirst, self.num = 0.0, True, 0
+        self.epoch = 0
+        if self.isTrain:
+            # two parameter groups: alignment modules at lr 1e-5, the rest at opt.lr (eavsrp_model.py:45-59)
+            align_ids = {id(p) for p in self.netEAVSRP.deform_align.parameters()}
+            trainable = [p for p in self.netEAVSRP.parameters() if p.requires_grad]
+            basic = [p for p in trainable if id(p) not in align_ids]
+            align = [p for p in trainable if id(p) in align_ids]
+            self.optimizer_EAVSRP = torch.optim.Adam(
+                [{"params": basic}, {"params": align, "lr": 1e-5}], lr=getattr(opt, "lr", 1e-4),
+                betas=(getattr(opt, "beta1", 0.9), getattr(opt, "beta2", 0.999)),
+                weight_decay=getattr(opt, "weight_decay", 0.0))
+            self.optimizers = [self.optimizer_EAVSRP]
+            from .shard import GradientAllReducer
+            self.grad_sync = GradientAllReducer(trainable)
+            self.netEAVSRP.train()
 
     def eval(self):
         self.netEAVSRP.eval()
+
+    def train(self):
+        self.netEAVSRP.train()
 
     def set_input(self, input, epoch=0):
         self.data_lr_seq = input["lr_seq"].to(self.device)
@@ -322,6 +343,13 @@ class EAVSRPModel:
         self.epoch = epoch
 
     def forward(self):
+        if self.isTrain and self.netEAVSRP.training:
+            if self.epoch >= getattr(self.opt, "npost", 350):
+                raise NotImplementedError("the PWC-Net validity mask of epochs >= npost (eavsrp_model.py:85-97) is "
+                                          "outside the hot path")
+            self.data_sr_seq = self.netEAVSRP(self.data_lr_seq)
+            self.data_sr = self.data_sr_seq[:, self.idx]
+            return
         start = time.time()
         self.data_sr_seq = self.netEAVSRP(self.data_lr_seq)
         self.data_sr = self.data_sr_seq[:, self.idx]
@@ -335,8 +363,21 @@ class EAVSRPModel:
         with torch.no_grad():
             self.forward()
 
+    def backward(self):
+        # criterionL1(hr, sr).mean()  (eavsrp_model.py:109-113)
+        self.loss_EAVSRP_L1 = (self.data_hr_seq - self.data_sr_seq).abs().mean()
+        self.loss_EAVSRP_Total = self.loss_EAVSRP_L1
+        self.loss_EAVSRP_Total.backward()
+        self.grad_sync.finish()      # one bucketed all-reduce over the loss gradients (no-op on 1 process)
+
     def optimize_parameters(self):
-        raise NotImplementedError("training needs the backward kernels (SURVEY.md 8: config 4, not in this round)")
+        self.forward()
+        self.optimizer_EAVSRP.zero_grad(set_to_none=True)
+        self.backward()
+        self.optimizer_EAVSRP.step()
+
+    def get_current_losses(self):
+        return {n: float(getattr(self, "loss_" + n)) for n in self.loss_names if hasattr(self, "loss_" + n)}
 
     def get_current_visuals(self):
         out = {}

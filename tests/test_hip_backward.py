@@ -258,3 +258,95 @@ def _oracle_forward_with_grad(sd, lrs, flows):
             feats[module] = []
             feats = O.propagate(sd, feats, fb if direction == "backward" else ff, module, 8)
     return O.upsample(sd, lrs, feats, 4)
+
+
+def test_model_wrapper_training_step(AG, cuda):
+    """EAVSRPModel.optimize_parameters: two Adam groups (alignment modules at lr 1e-5), L1 loss, parameters move."""
+    from eavsr_amd.eavsrp_model import EAVSRPModel
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    opt = Namespace(predict=False, n_frame=3, n_flow=5, scale=4, isTrain=True, gpu_ids=[0], lr=1e-4, beta1=0.9,
+                    beta2=0.999, weight_decay=0.0, npost=350)
+    model = EAVSRPModel(opt)
+    sd = H.filled(H.model_shapes("x4"), "trained_like")
+    model.netEAVSRP.load_state_dict(sd, strict=True)
+    groups = model.optimizer_EAVSRP.param_groups
+    assert groups[0]["lr"] == 1e-4 and groups[1]["lr"] == 1e-5
+    n_align = sum(p.numel() for p in model.netEAVSRP.deform_align.parameters())
+    assert sum(p.numel() for p in groups[1]["params"]) == n_align
+    assert sum(p.numel() for g_ in groups for p in g_["params"]) == 12277793   # SURVEY 2a: trainable parameters
+    data = {"lr_seq": synthetic_clip(1, 3, 64, 64, seed=1), "hr_seq": synthetic_clip(1, 3, 256, 256, seed=2), "fname": "x"}
+    before = model.netEAVSRP.conv_last.weight.detach().clone()
+    losses = []
+    for it in range(3):
+        model.set_input(data, epoch=0)
+        model.optimize_parameters()
+        losses.append(model.get_current_losses()["EAVSRP_L1"])
+    assert losses[-1] < losses[0]
+    assert not torch.equal(before, model.netEAVSRP.conv_last.weight.detach())
+    model.eval()
+    model.set_input(data)
+    model.test()
+    assert tuple(model.data_sr_seq.shape) == (1, 3, 3, 256, 256)
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    import sys
+    sys.path.insert(0, H.os.path.dirname(H.os.path.dirname(H.os.path.abspath(H.__file__))))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), EAVSR_DIST_BACKEND="gloo")
+    from eavsr_amd import shard
+    from eavsr_amd.eavsrp_model import EAVSRP
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    shard.init_process_group()
+    dev = torch.device("cuda:0")   # both ranks share the one GPU of the test box (gloo moves the buckets)
+    net = EAVSRP(Namespace(predict=False, n_frame=3, n_flow=5, scale=4), None)
+    net.load_state_dict(H.filled(H.model_shapes("x4"), "trained_like"), strict=True)
+    net = net.to(dev).train()
+    sync = shard.GradientAllReducer(net.parameters())
+    clips, hrs = synthetic_clip(world, 3, 64, 64, seed=21), synthetic_clip(world, 3, 256, 256, seed=22)
+    mine = shard.clip_indices(world, rank, world)
+    out = net(clips[mine].to(dev))
+    (out - hrs[mine].to(dev)).abs().mean().backward()
+    sync.finish()
+    names = ["conv_last.weight", "deform_align.backward_1.weight", "backbone.forward_1.main.0.bias"]
+    params = dict(net.named_parameters())
+    q.put((rank, {k: params[k].grad.cpu() for k in names}))
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_data_parallel_gradients_equal_the_mean_of_per_clip_gradients(AG, cuda):
+    """SURVEY 8e, training: clips sharded over ranks, ONE all-reduce on the loss gradients; the synchronised
+    gradient equals the mean of the single-clip gradients computed in this process."""
+    import socket
+    import torch.multiprocessing as mp
+    from eavsr_amd.eavsrp_model import EAVSRP
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    net = EAVSRP(Namespace(predict=False, n_frame=3, n_flow=5, scale=4), None)
+    net.load_state_dict(H.filled(H.model_shapes("x4"), "trained_like"), strict=True)
+    net = net.to(cuda).train()
+    clips, hrs = synthetic_clip(2, 3, 64, 64, seed=21), synthetic_clip(2, 3, 256, 256, seed=22)
+    acc = {}
+    params = dict(net.named_parameters())
+    for i in range(2):
+        net.zero_grad(set_to_none=True)
+        (net(clips[i:i + 1].to(cuda)) - hrs[i:i + 1].to(cuda)).abs().mean().backward()
+        for k in res[0]:
+            acc[k] = acc.get(k, 0) + params[k].grad.cpu() / 2
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
+        scale = max(1e-8, acc[k].abs().max().item())
+        assert H.maxabs(res[0][k], acc[k]) <= 2e-3 * scale, (k, H.maxabs(res[0][k], acc[k]), scale)

@@ -64,3 +64,61 @@ def test_clip_indices_partition_every_clip_once():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         clip_indices(4, 2, 2)
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from eavsr_amd import shard
+    shard.init_process_group("gloo")
+    torch.manual_seed(0)                       # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+    net[3].weight.requires_grad_(False)        # a frozen tensor, like SPyNet
+    sync = shard.GradientAllReducer(net.parameters(), bucket_bytes=1024)   # several small buckets
+    g = torch.Generator().manual_seed(100 + rank)                          # different data per rank
+    for step in range(2):
+        x = torch.randn(5, 16, generator=g)
+        net.zero_grad(set_to_none=True)
+        net(x).pow(2).mean().backward()        # hooks launch the bucket all-reduces during backward
+        sync.finish()
+    q.put((rank, [p.grad.clone() if p.grad is not None else None for p in net.parameters()], len(sync.buckets)))
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, nb0), (_, g1, nb1) = res
+    assert nb0 == nb1 and nb0 > 1
+    # every rank ends with the same (averaged) gradients ...
+    for a, b in zip(g0, g1):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    # ... equal to the mean of the per-rank gradients computed independently
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 4))
+    net[3].weight.requires_grad_(False)
+    per_rank = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        for step in range(2):
+            x = torch.randn(5, 16, generator=g)
+            net.zero_grad(set_to_none=True)
+            net(x).pow(2).mean().backward()
+        per_rank.append([p.grad.clone() if p.grad is not None else None for p in net.parameters()])
+    for a, p0, p1 in zip(g0, per_rank[0], per_rank[1]):
+        if a is None:
+            assert p0 is None
+        else:
+            assert torch.allclose(a, (p0 + p1) / 2, atol=1e-7)
