@@ -377,7 +377,7 @@ class EAVSRPModel:
         self.optimizer_EAVSRP.step()
 
     def get_current_losses(self):
-        return {n: float(getattr(self, "loss_" + n)) for n in self.loss_names if hasattr(self, "loss_" + n)}
+        return {n: float(getattr(self, "loss_" + n).detach()) for n in self.loss_names if hasattr(self, "loss_" + n)}
 
     def get_current_visuals(self):
         out = {}
