@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -78,6 +78,13 @@ SIGNATURES = {
     "eavsr_dcnv2_col2im_f32": (C.c_int, [vp] * 7 + [i32, i32, i32, i32, i32, vp]),
     "eavsr_gconv3x3_fwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_gconv3x3_bwd_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, i32, vp]),
+    # 16-bit backbone
+    "eavsr_conv_h16_tiles": (i32, [i32, i32]),
+    "eavsr_pack_conv3x3_c64_h16": (C.c_int, [vp, vp, i32, vp]),
+    "eavsr_conv3x3_c64_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "eavsr_nchw_f32_to_nhwc_h16": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_nhwc_h16_to_nchw_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_scale_residual_h16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
 }
 
 _lock = threading.Lock()

@@ -305,6 +305,17 @@ class RCABlock(nn.Module):
 # the 29 us scale_residual launch it removes, and leaves the step time unchanged -- so it is off by default.
 import os as _os
 FUSE_CA_INTO_CONV = _os.environ.get("EAVSR_FUSE_CA", "0") == "1"
+# Optional 16-bit residual backbone: None (exact fp32, the default and the BASELINE headline), "bf16" or "fp16"
+# (set_backbone_dtype / EAVSR_BACKBONE_DTYPE).  Only the RCAGroup internals change precision.
+BACKBONE_DTYPE = _os.environ.get("EAVSR_BACKBONE_DTYPE") or None
+
+
+def set_backbone_dtype(dtype):
+    """None -> fp32 everywhere; 'bf16' / 'fp16' -> 16-bit NHWC activations inside every RCAGroup."""
+    global BACKBONE_DTYPE
+    if dtype is not None:
+        ops.h16_code(dtype)
+    BACKBONE_DTYPE = dtype
 
 
 class RCAGroup(nn.Module):
@@ -319,8 +330,27 @@ class RCAGroup(nn.Module):
         RG.append(conv(out_channels, out_channels, mode="C"))
         self.rg = nn.Sequential(*RG)
 
+    def _forward_h16(self, x, dtype):
+        """16-bit backbone (BASELINE configs[2] / [4]): NHWC bf16 / fp16 activations through the whole group,
+        fp32 accumulation and fp32 channel-attention statistics; fp32 NCHW at the group's boundary."""
+        blocks, last = list(self.rg)[:-1], self.rg[-1]
+        hw = x.shape[2] * x.shape[3]
+        xs = ops.to_nhwc_h16(x, dtype)
+        for blk in blocks:
+            c1, c2 = blk.res[0], blk.res[2]
+            t = ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True)
+            r, partial = ops.conv3x3_c64_h16(t, c2.weight, c2.bias, chan_partial=True)
+            xs = ops.scale_residual_h16(r, blk.ca.scale_from_partial(partial, hw), xs)
+        y = ops.conv3x3_c64_h16(xs, last.weight, last.bias)
+        return ops.from_nhwc_h16(y, residual=x)
+
     def forward(self, x):
         blocks, last = list(self.rg)[:-1], self.rg[-1]
+        if BACKBONE_DTYPE is not None and not AG.needs_grad(x, list(self.parameters())) and x.shape[1] == 64 and \
+                all(isinstance(b, RCABlock) and len(b.res) == 3 and isinstance(b.res[1], _Act) and b.res[1].kind == "relu"
+                    and tuple(b.res[0].weight.shape) == (64, 64, 3, 3) for b in blocks) and \
+                tuple(last.weight.shape) == (64, 64, 3, 3):
+            return self._forward_h16(x, BACKBONE_DTYPE)
         fuse = FUSE_CA_INTO_CONV and not AG.needs_grad(x, list(self.parameters())) and ops.ca_fusable(x, last.weight.shape[0]) and len(blocks) > 0 and all(
             isinstance(b, RCABlock) and len(b.res) == 3 and isinstance(b.res[1], _Act) and b.res[1].kind == "relu"
             for b in blocks)

@@ -653,3 +653,110 @@ def gconv3x3_bwd(g: Tensor, x: Tensor, weight: Tensor, cpg: int):
             lambda: lib().eavsr_gconv3x3_bwd_f32(_p(g), _p(x), _p(weight), _p(dx), _p(dw), _p(db), n, cout, cpg, h, w, st),
             "gconv3x3_bwd")
     return dx, dw, db
+
+
+# ==========================================================================================
+# 16-bit residual backbone (NHWC bf16 / fp16 activations, fp32 accumulate)
+# ==========================================================================================
+_H16 = {torch.float16: 1, torch.bfloat16: 2, "fp16": 1, "f16": 1, "bf16": 2}
+_H16_TORCH = {1: torch.float16, 2: torch.bfloat16}
+
+
+def h16_code(dtype) -> int:
+    try:
+        return _H16[dtype]
+    except KeyError:
+        raise ValueError(f"16-bit dtype expected (torch.float16 / torch.bfloat16 / 'fp16' / 'bf16'), got {dtype!r}")
+
+
+def _chk_h16(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; eavsr_amd runs on the GPU only (no CPU path)")
+    if t.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError(f"{name}: dtype {t.dtype}, expected a 16-bit float")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def to_nhwc_h16(x: Tensor, dtype) -> Tensor:
+    """fp32 NCHW (n,c,h,w) -> 16-bit NHWC (n,h,w,c)"""
+    x = _chk(x, "x")
+    n, c, h, w = x.shape
+    code = h16_code(dtype)
+    out = torch.empty((n, h, w, c), device=x.device, dtype=_H16_TORCH[code])
+    st = _stream(x)
+    _launch("nchw_f32_to_nhwc_h16", 0.0, 6.0 * x.numel(), x,
+            lambda: lib().eavsr_nchw_f32_to_nhwc_h16(_p(x), _p(out), n, c, h * w, code, st), "nchw_f32_to_nhwc_h16")
+    return out
+
+
+def from_nhwc_h16(x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+    """16-bit NHWC (n,h,w,c) -> fp32 NCHW (n,c,h,w) (+ residual)"""
+    x = _chk_h16(x, "x")
+    n, h, w, c = x.shape
+    code = h16_code(x.dtype)
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _chk(residual, "residual")
+        if residual.shape != out.shape:
+            raise ValueError("residual shape mismatch")
+    st = _stream(x)
+    _launch("nhwc_h16_to_nchw_f32", 0.0, 6.0 * x.numel(), x,
+            lambda: lib().eavsr_nhwc_h16_to_nchw_f32(_p(x), _p(residual), _p(out), n, c, h * w, code, st),
+            "nhwc_h16_to_nchw_f32")
+    return out
+
+
+_h16_pack_cache = {}
+
+
+def _packed_h16(weight: Tensor, code: int) -> Tensor:
+    key = (id(weight), weight._version, code)
+    hit = _h16_pack_cache.get(key)
+    if hit is not None and hit[0]() is weight:
+        return hit[1]
+    w = _chk(weight.detach(), "weight")
+    if tuple(w.shape) != (64, 64, 3, 3):
+        raise NotImplementedError("the 16-bit backbone kernel is the 3x3 64->64 convolution")
+    packed = torch.empty(64 * 576, device=w.device, dtype=_H16_TORCH[code])
+    st = _stream(w)
+    with _DeviceOf(w):
+        N.check(lib().eavsr_pack_conv3x3_c64_h16(_p(w), _p(packed), code, st), "pack_conv3x3_c64_h16")
+    for k in [k for k in _h16_pack_cache if k[0] == id(weight)]:
+        _h16_pack_cache.pop(k, None)
+    _h16_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key: _h16_pack_cache.pop(k, None)), packed)
+    return packed
+
+
+def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool = False, chan_partial: bool = False):
+    """x: 16-bit NHWC (n,h,w,64); weight: the fp32 (64,64,3,3) parameter (packed + rounded once per version)"""
+    x = _chk_h16(x, "x")
+    n, h, w, c = x.shape
+    if c != 64:
+        raise NotImplementedError("the 16-bit backbone kernel needs 64 channels")
+    code = h16_code(x.dtype)
+    wp = _packed_h16(weight, code)
+    b = None if bias is None else _chk(bias.detach(), "bias")
+    out = torch.empty_like(x)
+    part = None
+    if chan_partial:
+        part = torch.empty((n, lib().eavsr_conv_h16_tiles(h, w), 64), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch("conv3x3_64to64_h16", 2.0 * 64 * 64 * 9 * px, 2.0 * px * 128, x,
+            lambda: lib().eavsr_conv3x3_c64_h16(_p(x), _p(wp), _p(b), _p(out), _p(part), n, h, w, 1 if relu else 0, code, st),
+            "conv3x3_c64_h16")
+    return (out, part) if chan_partial else out
+
+
+def scale_residual_h16(r: Tensor, scale: Tensor, x: Tensor) -> Tensor:
+    r, x, scale = _chk_h16(r, "r"), _chk_h16(x, "x"), _chk(scale, "scale")
+    n, h, w, c = r.shape
+    if x.shape != r.shape or x.dtype != r.dtype or tuple(scale.shape) != (n, c):
+        raise ValueError("scale_residual_h16: shape / dtype mismatch")
+    out = torch.empty_like(r)
+    code = h16_code(r.dtype)
+    st = _stream(r)
+    _launch("scale_residual_h16", 2.0 * r.numel(), 6.0 * r.numel(), r,
+            lambda: lib().eavsr_scale_residual_h16(_p(r), _p(scale), _p(x), _p(out), n, c, h * w, code, st),
+            "scale_residual_h16")
+    return out

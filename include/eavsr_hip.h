@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 3
+#define EAVSR_ABI_VERSION 4
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -222,6 +222,30 @@ int eavsr_gconv3x3_fwd_f32(const float* x, const float* weight, const float* bia
                            int32_t cout, int32_t cpg, int32_t h, int32_t w, int32_t act, float slope, void* stream);
 int eavsr_gconv3x3_bwd_f32(const float* g, const float* x, const float* weight, float* dx, float* dweight,
                            float* dbias, int32_t n, int32_t cout, int32_t cpg, int32_t h, int32_t w, void* stream);
+
+/* ============================================================================================
+ * 16-bit residual backbone (BASELINE.json configs[2] bf16 / configs[4] fp16; SURVEY.md 8a: a10, a11).
+ * dtype: 1 = fp16, 2 = bf16.  Activations are NHWC 16-bit (n, h, w, 64): one pixel = 128 contiguous bytes;
+ * accumulation, bias and the channel-attention statistics stay fp32.  Replaces the 3x3 64->64 convs of
+ * RCABlock / RCAGroup (models/networks.py:456-458,478) and the RCAB tail (:447,463-464) when the caller
+ * opts into a 16-bit backbone.  All pointers 16-byte aligned.
+ * ============================================================================================ */
+int32_t eavsr_conv_h16_tiles(int32_t h, int32_t w);
+/* weight (64,64,3,3) fp32 -> 64*576 16-bit values in MFMA fragment order */
+int eavsr_pack_conv3x3_c64_h16(const float* weight, void* packed, int32_t dtype, void* stream);
+/* out = [relu](conv3x3(x) + bias); chan_partial (nullable): fp32 (n, eavsr_conv_h16_tiles(h,w), 64) per-tile
+ * channel sums of the un-rounded output */
+int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float* bias, void* out,
+                          float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t relu, int32_t dtype,
+                          void* stream);
+/* fp32 NCHW -> 16-bit NHWC, and back with an optional fp32 NCHW residual added (RCAGroup's `+ x`) */
+int eavsr_nchw_f32_to_nhwc_h16(const float* in, void* out, int32_t n, int32_t c, int32_t hw, int32_t dtype,
+                               void* stream);
+int eavsr_nhwc_h16_to_nchw_f32(const void* in, const float* residual, float* out, int32_t n, int32_t c,
+                               int32_t hw, int32_t dtype, void* stream);
+/* NHWC 16-bit RCAB tail: out = r * scale[n,c] + x  (scale fp32) */
+int eavsr_scale_residual_h16(const void* r, const float* scale, const void* x, void* out, int32_t n,
+                             int32_t c, int32_t hw, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }
