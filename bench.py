@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--height", type=int, default=180)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--preset", default="trained_like", choices=["default", "trained_like"])
+    ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
+                    help="fp32 (default, the BASELINE headline: exact fp32 everywhere) or a 16-bit NHWC residual backbone "
+                         "(BASELINE.json configs[2] / [4]); the 16-bit runs are reported under their own metric name")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: the BASELINE metric (default). train: BASELINE.json configs[3], a data-parallel "
                          "training step (2 clips/GPU x 7 x 3 x 96 x 96, L1 loss, Adam, one RCCL all-reduce on the "
@@ -187,6 +190,9 @@ def main():
     if args.mode == "train":
         return train_bench(args, rank, world, device)
     net, sd = build_model(device, args.preset)
+    if args.backbone_dtype != "fp32":
+        from eavsr_amd import networks as _nw
+        _nw.set_backbone_dtype(args.backbone_dtype)
     n, t, h, w = args.clips, args.frames, args.height, args.width
     clips = synthetic_clip(n, t, h, w, seed=rank).to(device)   # resident in HBM before the timed region
 
@@ -209,7 +215,8 @@ def main():
     value = frames_total / elapsed
 
     line = {
-        "metric": "SR frames/sec at 4x 7-frame 180x320->720x1280",
+        "metric": "SR frames/sec at 4x 7-frame 180x320->720x1280" +
+                  ("" if args.backbone_dtype == "fp32" else f" [{args.backbone_dtype} residual backbone, not the fp32 headline]"),
         "value": value,
         "unit": "frames/s",
         "n_gpus": world,
@@ -219,7 +226,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.backbone_dtype == "fp32" else f"{args.backbone_dtype} backbone + f32",
         "data": "synthetic",
         "config": {"workload": f"eavsrp x4 inference, {n} clips/GPU x {t} frames x 3 x {h} x {w} fp32 "
                                f"(BASELINE.json configs[1]), weights: seeded '{args.preset}' init",
@@ -249,6 +256,10 @@ def main():
                     "share_of_step": v["ms"] / total_ms}
 
         dom = entry("conv3x3_64to64", "mfma")
+        if args.backbone_dtype != "fp32":
+            e16 = entry("conv3x3_64to64_h16", "hbm")
+            if e16:
+                line.setdefault("kernels_16bit", []).append(e16)
         if dom is not None:
             line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
             line["roofline"]["kernel"] = "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)"
