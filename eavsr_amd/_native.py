@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -56,6 +56,7 @@ SIGNATURES = {
     "eavsr_conv2d_tiles": (i32, [i32, i32]),
     "eavsr_packed_weight_elems": (i64, [i32, i32, i32]),
     "eavsr_pack_conv_weight_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "eavsr_conv3x3_smallco_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_ca_scale_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_scale_residual_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_adapt_frontend_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

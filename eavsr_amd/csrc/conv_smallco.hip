@@ -1,0 +1,165 @@
+// 3x3 convolution with a handful of output channels (2, 3, 4 or 6) on the vector ALUs
+// (a3 heads 64 -> 4+2, a4 TransOffsetworelu 18 -> 2; 8f: conv_last 64 -> 3 at 4x resolution).
+//
+// Reference: nn.Conv2d at models/networks.py:330-331 (transform_matrix_conv + translation_conv),
+// :568 (TransOffsetworelu), models/eavsrp_model.py:156 (conv_last).
+//
+// These layers have 2-6 output channels: an MFMA tile (32 output channels) would idle > 80 % of the matrix
+// pipe and the kernel is bound by streaming the input anyway (64 input channels per output pixel).  Here a
+// workgroup stages an 8-channel slab of the (8 + 2) x (64 + 2) input patch in LDS (coalesced loads), every
+// thread owns 2 vertically adjacent pixels and keeps COUT x 2 accumulators; the slab's weights sit in LDS too
+// and are read back as 16-byte broadcasts, so the inner loop is one ds_read_b32 per input value (4 rows x 3
+// columns shared by the 2 pixels), one or two ds_read_b128 per tap and COUT FMAs per pixel and tap.
+#include "common.h"
+
+namespace {
+
+constexpr int ST_H = 8, ST_W = 64;              // output tile per workgroup (256 threads, 2 pixels each)
+constexpr int SP_H = ST_H + 2, SP_W = ST_W + 2; // patch
+constexpr int SCK = 8;                          // channels per LDS slab
+
+struct SmallArgs {
+  const float* x;
+  const float* wt;    // (cout, cin, 3, 3), original layout
+  const float* bias;
+  const float* residual;
+  float* out;
+  int n, cin, h, w, tiles_x, tiles_y, act;
+  float slope;
+};
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_smallco_kernel(SmallArgs a) {
+  __shared__ float s_in[SCK][SP_H][SP_W + 1];
+  constexpr int CP = COUT <= 4 ? 4 : 8;                      // weights of one (channel, tap): CP floats, 16-byte rows
+  __shared__ __attribute__((aligned(16))) float s_wt[SCK][9][CP];
+  const int tid = threadIdx.x;
+  const int lx = tid & 63, ly = tid >> 6;  // thread -> column lx, rows 2*ly and 2*ly + 1
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int bn = bid / a.tiles_y;
+  const int y0 = ty * ST_H, x0 = tx * ST_W;
+  const int h = a.h, w = a.w, cin = a.cin;
+  const size_t plane = (size_t)h * w;
+
+  float acc[COUT][2];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co][0] = acc[co][1] = 0.f;
+
+  for (int c0 = 0; c0 < cin; c0 += SCK) {
+    // stage the slab: issue every global load first (straight-line, always-valid addresses, select afterwards),
+    // then write LDS -- a load / wait / write loop serialises ~20 HBM latencies per slab
+    constexpr int IN_N = SCK * SP_H * SP_W, IN_IT = (IN_N + 255) / 256;
+    constexpr int W_N = SCK * 9 * CP, W_IT = (W_N + 255) / 256;
+    float tin[IN_IT], tw[W_IT];
+    const float* xb = a.x + ((size_t)bn * cin + c0) * plane;
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int e = tid + i * 256;
+      const int ci = e / (SP_H * SP_W), rem = e - ci * (SP_H * SP_W);
+      const int r = rem / SP_W, c = rem - r * SP_W;
+      const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+      const bool ok = e < IN_N && c0 + ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w;
+      const int cci = min(ci, cin - c0 - 1), cgy = min(max(gy, 0), h - 1), cgx = min(max(gx, 0), w - 1);
+      const float v = xb[(size_t)cci * plane + (size_t)cgy * w + cgx];
+      tin[i] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int e = min(tid + i * 256, W_N - 1);
+      const int co = e % CP, tap = (e / CP) % 9, ci = e / (CP * 9);
+      const bool ok = co < COUT && c0 + ci < cin;
+      const float v = a.wt[((size_t)min(co, COUT - 1) * cin + min(c0 + ci, cin - 1)) * 9 + tap];
+      tw[i] = ok ? v : 0.f;
+    }
+    __syncthreads();  // the previous slab has been consumed
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int e = tid + i * 256;
+      if (i < IN_IT - 1 || e < IN_N) {
+        const int ci = e / (SP_H * SP_W), rem = e - ci * (SP_H * SP_W);
+        s_in[ci][rem / SP_W][rem % SP_W] = tin[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int e = tid + i * 256;
+      if (i < W_IT - 1 || e < W_N) (&s_wt[0][0][0])[e] = tw[i];
+    }
+    __syncthreads();
+    const int nci = min(SCK, cin - c0);
+    for (int ci = 0; ci < nci; ++ci) {   // uniform trip count
+      // 4 input rows x 3 columns around the two pixels (rows 2ly .. 2ly+3 of the patch)
+      float v[4][3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[r][c] = s_in[ci][2 * ly + r][lx + c];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          float wv[CP];
+#pragma unroll
+          for (int q = 0; q < CP / 4; ++q) {
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(&s_wt[ci][ky * 3 + kx][4 * q]);
+            wv[4 * q] = t4[0]; wv[4 * q + 1] = t4[1]; wv[4 * q + 2] = t4[2]; wv[4 * q + 3] = t4[3];
+          }
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) {
+            acc[co][0] += wv[co] * v[ky][kx];
+            acc[co][1] += wv[co] * v[ky + 1][kx];
+          }
+        }
+    }
+  }
+  const int gx = x0 + lx;
+  if (gx < w) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int gy = y0 + 2 * ly + p;
+      if (gy < h) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          float v = acc[co][p] + (a.bias ? a.bias[co] : 0.f);
+          if (a.act == EAVSR_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (a.act == EAVSR_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+          const size_t o = ((size_t)bn * COUT + co) * plane + (size_t)gy * w + gx;
+          if (a.residual) v += a.residual[o];
+          a.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, const float* bias,
+                                         const float* residual, float* out, int32_t n, int32_t cin, int32_t h,
+                                         int32_t w, int32_t cout, int32_t act, float slope, void* stream) {
+  EAVSR_REQUIRE(x && weight && out, -1, "conv3x3_smallco: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && cin > 0 && h > 0 && w > 0, -1, "conv3x3_smallco: bad dims");
+  EAVSR_REQUIRE(cout == 2 || cout == 3 || cout == 4 || cout == 6, -2,
+                "conv3x3_smallco: %d output channels unsupported (2, 3, 4, 6); use eavsr_conv2d_f32", cout);
+  EAVSR_REQUIRE(act >= 0 && act <= 2, -1, "conv3x3_smallco: act %d", act);
+  if (n == 0) return 0;
+  SmallArgs a;
+  a.x = x; a.wt = weight; a.bias = bias; a.residual = residual; a.out = out;
+  a.n = n; a.cin = cin; a.h = h; a.w = w; a.act = act; a.slope = slope;
+  a.tiles_x = eavsr::cdiv(w, ST_W);
+  a.tiles_y = eavsr::cdiv(h, ST_H);
+  const long blocks = (long)a.tiles_x * a.tiles_y * n;
+  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_smallco: too many tiles");
+  hipStream_t st = eavsr::as_stream(stream);
+  dim3 grid((unsigned)blocks), block(256);
+  switch (cout) {
+    case 2: hipLaunchKernelGGL(conv3x3_smallco_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(conv3x3_smallco_kernel<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(conv3x3_smallco_kernel<4>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(conv3x3_smallco_kernel<6>, grid, block, 0, st, a); break;
+  }
+  return eavsr::launch_status("conv3x3_smallco");
+}

@@ -36,17 +36,29 @@ __global__ __launch_bounds__(256) void adapt_frontend_kernel(
   const int y0 = ty * FT_H, x0 = tx * FT_W;
   const size_t plane = (size_t)h * w;
 
-  for (int e = tid; e < 2 * FP_H * FP_W; e += 256) {
-    const int ch = e / (FP_H * FP_W);
+  // issue every load of the patch first, then write LDS (a load / wait / write loop would serialise ~11 HBM
+  // latencies per workgroup)
+  constexpr int P_N = 2 * FP_H * FP_W, P_IT = (P_N + 255) / 256;
+  float tin[P_IT];
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) {
+    const int e = tid + i * 256;
+    const int ch = min(e / (FP_H * FP_W), 1);
     const int rem = e - ch * (FP_H * FP_W);
     const int r = rem / FP_W, cc = rem - r * FP_W;
     const int gy = y0 - 2 + r, gx = x0 - 2 + cc;
     const int cat_c = 2 * o + ch;
     const float* src = cat_c < c ? x : hh;
     const int sc = cat_c < c ? cat_c : cat_c - c;
-    float v = 0.f;
-    if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = src[((size_t)bn * c + sc) * plane + (size_t)gy * w + gx];
-    s_in[ch][r][cc] = v;
+    const bool ok = e < P_N && gy >= 0 && gy < h && gx >= 0 && gx < w;
+    const int cgy = min(max(gy, 0), h - 1), cgx = min(max(gx, 0), w - 1);
+    const float v = src[((size_t)bn * c + sc) * plane + (size_t)cgy * w + cgx];
+    tin[i] = ok ? v : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) {
+    const int e = tid + i * 256;
+    if (i < P_IT - 1 || e < P_N) (&s_in[0][0][0])[e] = tin[i];
   }
   __syncthreads();
   for (int e = tid; e < 2 * FM_H * FM_W; e += 256) {

@@ -227,6 +227,44 @@ def _bias_of(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
     return cat
 
 
+_wcat_cache = {}
+
+
+def _cat_weights(weights: Sequence[Tensor]) -> Tensor:
+    """cat(weights, 0) in the original layout, cached per (object, version) like the packed weights"""
+    if len(weights) == 1:
+        return _chk(weights[0].detach(), "weight")
+    key = tuple((id(w), w._version) for w in weights)
+    hit = _wcat_cache.get(key)
+    if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
+        return hit[1]
+    cat = _chk(torch.cat([w.detach() for w in weights], 0), "weight")
+    ids = {id(w) for w in weights}
+    for k_ in [k_ for k_ in _wcat_cache if any(i in ids for i, _ in k_)]:
+        _wcat_cache.pop(k_, None)
+    refs = tuple(weakref.ref(w, lambda _r, k_=key: _wcat_cache.pop(k_, None)) for w in weights)
+    _wcat_cache[key] = (refs, cat)
+    return cat
+
+
+def _conv3x3_smallco(x: Tensor, weights, biases, act, slope, residual):
+    n, cin, h, w = x.shape
+    wt = _cat_weights(weights)
+    cout = int(wt.shape[0])
+    b = _bias_of(biases)
+    out = torch.empty((n, cout, h, w), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _chk(residual, "residual")
+        if residual.shape != out.shape:
+            raise ValueError("residual shape mismatch")
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch(f"conv3x3_{cin}to{cout}", 2.0 * cin * cout * 9 * px, 4.0 * px * (cin + cout + (cout if residual is not None else 0)), x,
+            lambda: lib().eavsr_conv3x3_smallco_f32(_p(x), _p(wt), _p(b), _p(residual), _p(out), n, cin, h, w, cout,
+                                                    ACT[act], float(slope), st), "conv3x3_smallco")
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # dense conv  (nn.Conv2d, stride 1, "same" padding)
 # ------------------------------------------------------------------------------------------
@@ -262,6 +300,8 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     k = int(weights[0].shape[-1])
     if any(int(x.shape[1]) != cin for x in weights):
         raise ValueError(f"weight expects {[int(x.shape[1]) for x in weights]} input channels, sources give {cin}")
+    if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None:
+        return _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
     ck = lib().eavsr_conv2d_ck(k)
     if any(int(s.shape[1]) % ck for s in srcs[:-1]):
         srcs = [torch.cat(srcs, 1)]  # ragged middle source: materialise (tiny SPyNet inputs only)

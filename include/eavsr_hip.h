@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 4
+#define EAVSR_ABI_VERSION 5
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -120,6 +120,13 @@ int64_t eavsr_packed_weight_elems(int32_t cout, int32_t cin, int32_t ksize);
 /* weight (cout,cin,k,k) -> packed [cout_tile][cin_pad][k*k][co_in_tile], zero padded */
 int eavsr_pack_conv_weight_f32(const float* weight, float* packed, int32_t cout, int32_t cin,
                                int32_t ksize, void* stream);
+
+/* 3x3 convolutions with 2, 3, 4 or 6 output channels (predictor heads networks.py:330-331, TransOffsetworelu :568,
+ * conv_last eavsrp_model.py:156) on the vector ALUs: an MFMA tile would idle > 80 % of the matrix pipe.  weight is
+ * the ORIGINAL (cout, cin, 3, 3) layout.  out = act(conv + bias) + residual.  Other cout: returns -2. */
+int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, const float* bias, const float* residual,
+                              float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t act,
+                              float slope, void* stream);
 
 /* ---- a11: channel attention -----------------------------------------------------------------
  * CALayer (models/networks.py:432-447): scale[n,c] = sigmoid(W2 . relu(W1 . mean_hw(r) + b1) + b2)
