@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 4) void dcnv2_kernel(DcnArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// LDS-patch variant (w % 4 == 0, 16-byte aligned input): the (4 + 12) x (32 + 16) input window of the
+// LDS-patch variant, the one the hot path runs (w % 4 == 0, 16-byte aligned input): the (4 + 12) x (32 + 16) input window of the
 // 4 channels of a chunk is brought into LDS once by 16-byte LDS-DMA (two stages: the window of chunk
 // c+1 lands behind the sampling + contraction of chunk c) and the 9 taps gather from LDS (ds_read2_b32,
 // 128 B/clk) instead of from L1 (the gathers through the texture path were the bottleneck of the
@@ -199,6 +199,10 @@ __global__ __launch_bounds__(256, 4) void dcnv2_kernel(DcnArgs a) {
 // The window is zero outside the image, which is exactly the corner-wise zero padding of the sampler.
 // Offsets / masks of chunk c+1 are prefetched into registers during chunk c.
 // ---------------------------------------------------------------------------------------------------
+// window pieces outside the image read these zeros: every lane of every DMA is then always issued, which
+// keeps the number of outstanding vector-memory operations per wave a compile-time constant (counted vmcnt)
+__device__ __attribute__((aligned(16))) float g_dcn_zero[4];
+
 constexpr int PH = 16, PW = 48;           // window rows y0-6 .. y0+9, columns x0-8 .. x0+39
 constexpr int PY0 = 6, PX0 = 8;
 constexpr int PATCH_F = DCK * PH * PW;    // 3072 floats = 12 KiB = 12 one-KiB DMA pieces
@@ -267,10 +271,10 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
   auto issue_patch = [&](int c0, int stage) {
     const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin + c0) * plane);
 #pragma unroll
-    for (int i = 0; i < PATCH_IT; ++i)
-      if (voff[i] != 0xFFFFFFFFu)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xb + voff[i]),
-                                         (lptr_t)(s_patch + stage * PATCH_F + (i * 4 + wave) * 256), 16, 0, 0);
+    for (int i = 0; i < PATCH_IT; ++i) {
+      const char* src = voff[i] != 0xFFFFFFFFu ? xb + voff[i] : reinterpret_cast<const char*>(g_dcn_zero);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_patch + stage * PATCH_F + (i * 4 + wave) * 256), 16, 0, 0);
+    }
   };
   float oy[TAPS_PER_THREAD], ox[TAPS_PER_THREAD], mk[TAPS_PER_THREAD];
   float oyn[TAPS_PER_THREAD], oxn[TAPS_PER_THREAD], mkn[TAPS_PER_THREAD];
@@ -299,19 +303,19 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
     __syncthreads();
     {
       const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)c0) * (DKK * CO));
+      // exactly W_IT pieces per wave (a surplus piece rewrites the last slab piece with the same bytes)
 #pragma unroll
       for (int i = 0; i < (W_SEGS + 3) / 4; ++i) {
-        const int seg = i * 4 + wave;
-        if (seg < W_SEGS) {
-          const unsigned e4 = (unsigned)min(seg * 64 + lane, W4 - 1);
-          __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(s_w + seg * 256), 16, 0, 0);
-        }
+        const int seg = min(i * 4 + wave, W_SEGS - 1);
+        const unsigned e4 = (unsigned)min(seg * 64 + lane, W4 - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(s_w + seg * 256), 16, 0, 0);
       }
     }
     const bool more = c0 + DCK < a.cin;
     if (more) {
+      // issued AFTER the weights: the wait before the contraction leaves exactly these in flight
       issue_patch(c0 + DCK, stage ^ 1);
-      load_offsets(c0 + DCK, oyn, oxn, mkn);  // first used after the next vmcnt(0): never waited for early
+      load_offsets(c0 + DCK, oyn, oxn, mkn);
     }
     const float* pst = s_patch + stage * PATCH_F;
     const float* xp = a.x + ((size_t)bn * a.cin + c0) * plane;
@@ -369,8 +373,12 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
         for (int c = 0; c < DCK; ++c) s_col[(c * DKK + tap) * DT_PX + p] = vals[c];
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights(c0), window(c0+4), offsets(c0+4) have landed
-    __syncthreads();
+    // Only the weight slab is needed now.  vmcnt counts in issue order: leaving the PATCH_IT window pieces and the
+    // 3 * TAPS_PER_THREAD offset / mask loads of the NEXT chunk in flight lets their HBM latency run under the
+    // contraction instead of stalling every chunk; they are drained at the top of the next iteration.
+    if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PATCH_IT + 3 * TAPS_PER_THREAD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int tap = 0; tap < DKK; ++tap) {
 #pragma unroll
@@ -410,7 +418,282 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// Register-fed variant (the one the hot path runs): no column tile at all.
+// Wave-specialised variant (EAVSR_DCN_VARIANT=w; an experiment kept for A-B runs, 410 us vs 270 us for the
+// LDS-window kernel, so NOT the default): measured on the LDS-window kernel above, the matrix
+// pipe is busy 38 % of the time because every wave alternates sample -> barrier -> contract and the phases of
+// co-resident workgroups do not interleave (contraction alone 143 us, sampler 77 us, DMA + barriers 110 us
+// of a 289 us launch).  Here the two jobs run on DIFFERENT waves of one 512-thread workgroup:
+//   waves 4-7 (producers): issue the LDS-DMA of weight slabs and input windows, prefetch offsets / masks,
+//                          sample chunk c+1 into col stage (c+1)&1
+//   waves 0-3 (consumers): contract chunk c from col stage c&1 on the MFMA pipe, nothing else
+// with ONE workgroup barrier per 4-channel chunk.  Producer VALU / LDS work and consumer MFMAs issue from
+// different waves of the same SIMD, so they overlap by construction; the chunk period is
+// max(sampling, 2 consumer waves x 36 MFMAs) on each SIMD (two workgroups per CU).
+// ---------------------------------------------------------------------------------------------------
+template <int MT>
+struct WsCfg {
+  static constexpr int CO = 32 * MT;
+  static constexpr int COL_F = DCK * DKK * DT_PX;                 // 4608 floats per col stage
+  static constexpr int W_SEGS = (DCK * DKK * CO + 255) / 256;     // weight slab pieces (1 KiB each)
+  static constexpr int W_F = W_SEGS * 256;
+  static constexpr int LDS_FLOATS = 2 * COL_F + 2 * W_F + 2 * PATCH_F;
+  static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+};
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void dcnv2_ws_kernel(DcnArgs a) {
+  using Cfg = WsCfg<MT>;
+  constexpr int CO = Cfg::CO, COL_F = Cfg::COL_F, W_SEGS = Cfg::W_SEGS, W_F = Cfg::W_F;
+  constexpr int W4 = DCK * DKK * CO / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_col = smem;                    // [2][COL_F]
+  float* s_w = smem + 2 * COL_F;          // [2][W_F]
+  float* s_patch = s_w + 2 * W_F;         // [2][PATCH_F]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int pw = wave & 3;                // index within the role
+  const int l31 = lane & 31, half = lane >> 5;
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int bn = bid / a.tiles_y;
+  const int cot = blockIdx.y;
+  const int y0 = ty * DT_H, x0 = tx * DT_W;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+  const unsigned uplane = (unsigned)plane;
+  const int nchunks = a.cin / DCK;
+
+  {  // zero both window stages once: pieces outside the image are never moved and stay zero
+    f32x4* z = reinterpret_cast<f32x4*>(s_patch);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < 2 * PATCH_F / 4; e += 512) z[e] = zero;
+  }
+
+  // ---- producer state ---------------------------------------------------------------------------------
+  const int ptid = tid & 255;
+  const int p = ptid & (DT_PX - 1);
+  const int tap0 = ptid >> 7;
+  const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
+  const bool pix_ok = gy < h && gx < w;
+  const unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
+  unsigned voff[PATCH_IT];
+#pragma unroll
+  for (int i = 0; i < PATCH_IT; ++i) {
+    const int e4 = (i * 4 + pw) * 64 + lane;
+    const int ci = e4 / (PH * (PW / 4));
+    const int rem = e4 - ci * (PH * (PW / 4));
+    const int r = rem / (PW / 4), c4 = rem - r * (PW / 4);
+    const int yy = y0 - PY0 + r, xx = x0 - PX0 + 4 * c4;
+    const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+    voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)yy * w + xx) * 4) : 0xFFFFFFFFu;
+  }
+  auto issue_window = [&](int chunk, int stage) {
+    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin + chunk * DCK) * plane);
+#pragma unroll
+    for (int i = 0; i < PATCH_IT; ++i)
+      if (voff[i] != 0xFFFFFFFFu)
+        __builtin_amdgcn_global_load_lds((gptr_t)(xb + voff[i]),
+                                         (lptr_t)(s_patch + stage * PATCH_F + (i * 4 + pw) * 256), 16, 0, 0);
+  };
+  auto issue_weights = [&](int chunk, int stage) {
+    const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)chunk * DCK) * (DKK * CO));
+#pragma unroll
+    for (int i = 0; i < (W_SEGS + 3) / 4; ++i) {
+      const int seg = i * 4 + pw;
+      if (seg < W_SEGS) {
+        const unsigned e4 = (unsigned)min(seg * 64 + lane, W4 - 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(s_w + stage * W_F + seg * 256), 16, 0, 0);
+      }
+    }
+  };
+  float oy[TAPS_PER_THREAD], ox[TAPS_PER_THREAD], mk[TAPS_PER_THREAD];
+  float oyn[TAPS_PER_THREAD], oxn[TAPS_PER_THREAD], mkn[TAPS_PER_THREAD];
+#pragma unroll
+  for (int j = 0; j < TAPS_PER_THREAD; ++j) oyn[j] = oxn[j] = mkn[j] = 0.f;
+  auto load_offsets = [&](int chunk, float* fy, float* fx, float* fm) {
+    const int g = chunk * DCK / a.cpg;
+    const float* offb = a.offset + ((size_t)bn * a.dg + g) * 18 * plane;
+    const float* mkb = a.mask + ((size_t)bn * a.dg + g) * 9 * plane;
+#pragma unroll
+    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
+      const unsigned tap = (unsigned)min(tap0 + 2 * j, DKK - 1);
+      fy[j] = ld_b(offb, (2u * tap * uplane + pix) * 4u);
+      fx[j] = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
+      fm[j] = ld_b(mkb, (tap * uplane + pix) * 4u);
+    }
+  };
+  // sample chunk `chunk` (offsets in fy/fx/fm) from window stage `wst` into col stage `cst`
+  auto sample = [&](int chunk, int wst, int cst, const float* fy, const float* fx, const float* fm) {
+    const float* pst = s_patch + wst * PATCH_F;
+    float* col = s_col + cst * COL_F;
+    const float* xp = a.x + ((size_t)bn * a.cin + chunk * DCK) * plane;
+#pragma unroll
+    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
+      const int tap = tap0 + 2 * j;
+      const int ti = tap / 3, tj = tap - 3 * ti;
+      const float py = (float)(gy - 1 + ti) + fy[j];
+      const float px = (float)(gx - 1 + tj) + fx[j];
+      const bool in = pix_ok && tap < DKK && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+      const float fy0 = floorf(py), fx0 = floorf(px);
+      const float lh = py - fy0, lw = px - fx0;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
+      const float m = in ? fm[j] : 0.f;
+      float vals[DCK];
+      const int ry = hl - (y0 - PY0), rx = wl - (x0 - PX0);
+      const bool in_win = ry >= 0 && ry <= PH - 2 && rx >= 0 && rx <= PW - 2;
+      if (in_win || !in) {
+        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+        const float* q = pst + (in ? ry * PW + rx : 0);
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) {
+          float v = w1 * q[c * (PH * PW)];
+          v += w2 * q[c * (PH * PW) + 1];
+          v += w3 * q[c * (PH * PW) + PW];
+          v += w4 * q[c * (PH * PW) + PW + 1];
+          vals[c] = v * m;
+        }
+      } else {
+        const int hh_i = hl + 1, wh_i = wl + 1;
+        const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
+        const float w1 = (t_ok & l_ok) ? hh * hw : 0.f;
+        const float w2 = (t_ok & r_ok) ? hh * lw : 0.f;
+        const float w3 = (b_ok & l_ok) ? lh * hw : 0.f;
+        const float w4 = (b_ok & r_ok) ? lh * lw : 0.f;
+        const int cy0 = min(max(hl, 0), h - 1), cy1 = min(max(hh_i, 0), h - 1);
+        const int cx0 = min(max(wl, 0), w - 1), cx1 = min(max(wh_i, 0), w - 1);
+        const unsigned i1 = (unsigned)(cy0 * w + cx0) * 4u, i2 = (unsigned)(cy0 * w + cx1) * 4u;
+        const unsigned i3 = (unsigned)(cy1 * w + cx0) * 4u, i4 = (unsigned)(cy1 * w + cx1) * 4u;
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) {
+          const float* q = xp + (size_t)c * plane;
+          float v = w1 * ld_b(q, i1);
+          v += w2 * ld_b(q, i2);
+          v += w3 * ld_b(q, i3);
+          v += w4 * ld_b(q, i4);
+          vals[c] = v * m;
+        }
+      }
+      if (tap < DKK) {
+#pragma unroll
+        for (int c = 0; c < DCK; ++c) col[(c * DKK + tap) * DT_PX + p] = vals[c];
+      }
+    }
+  };
+
+  // After an explicit vmcnt(0) the prefetched offsets ARE in their registers, but hipcc still attributes them to
+  // the loads and, with an LDS-DMA in flight, waits vmcnt(0) again at their first use -- which then also waits
+  // for everything issued since (a full HBM latency per chunk).  Passing the registers through an empty asm
+  // makes the asm their definition.
+  auto launder = [&](float* fy, float* fx, float* fm) {
+#pragma unroll
+    for (int j = 0; j < TAPS_PER_THREAD; ++j) asm volatile("" : "+v"(fy[j]), "+v"(fx[j]), "+v"(fm[j]));
+  };
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  __syncthreads();  // zero fill complete before any DMA may land
+  if (producer) {
+    issue_window(0, 0);
+    issue_weights(0, 0);
+    load_offsets(0, oy, ox, mk);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    launder(oy, ox, mk);
+  }
+  __syncthreads();  // window(0) visible to every producer wave
+  if (producer) {
+    if (nchunks > 1) {
+      issue_window(1, 1);
+      load_offsets(1, oyn, oxn, mkn);
+    }
+    sample(0, 0, 0, oy, ox, mk);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    launder(oyn, oxn, mkn);
+  }
+  __syncthreads();  // col(0), weights(0), window(1) ready
+
+  for (int c = 0; c < nchunks; ++c) {
+    if (producer) {
+      if (c + 1 < nchunks) {
+        // offsets(c+1) are in (oyn, oxn, mkn): rotate them BEFORE anything is issued in this iteration -- hipcc
+        // waits vmcnt(0) at the first use of an ordinary load's result while an LDS-DMA is in flight, and right
+        // here nothing is (the previous iteration drained the queue), so the wait is free
+#pragma unroll
+        for (int j = 0; j < TAPS_PER_THREAD; ++j) { oy[j] = oyn[j]; ox[j] = oxn[j]; mk[j] = mkn[j]; }
+        asm volatile("" ::: "memory");
+        issue_weights(c + 1, (c + 1) & 1);
+        if (c + 2 < nchunks) {
+          issue_window(c + 2, c & 1);               // stage c&1 was sampled during iteration c-1: free
+          load_offsets(c + 2, oyn, oxn, mkn);
+        }
+        sample(c + 1, (c + 1) & 1, (c + 1) & 1, oy, ox, mk);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        launder(oyn, oxn, mkn);
+      }
+    } else {
+      const float* bcol = s_col + (c & 1) * COL_F + half * (DKK * DT_PX) + pw * 32 + l31;
+      const float* acol = s_w + (c & 1) * W_F + half * (DKK * CO) + l31;
+#pragma unroll
+      for (int tap = 0; tap < DKK; ++tap) {
+#pragma unroll
+        for (int cp = 0; cp < DCK / 2; ++cp) {
+          const float b = bcol[(cp * 2 * DKK + tap) * DT_PX];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float av = acol[(cp * 2 * DKK + tap) * CO + m * 32];
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[m], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (!producer) {
+    const int oy_ = y0 + pw, ox_ = x0 + l31;
+    if (oy_ < h && ox_ < w) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (co < a.cout) {
+            const float b = a.bias ? a.bias[co] : 0.f;
+            a.out[((size_t)bn * a.cout + co) * plane + (size_t)oy_ * w + ox_] = acc[m][r] + b;
+          }
+        }
+    }
+  }
+}
+
+template <int MT>
+int launch_ws(const DcnArgs& a, dim3 grid, hipStream_t st) {
+  using Cfg = WsCfg<MT>;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnv2_ws_kernel<MT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("dcnv2: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  hipLaunchKernelGGL(dcnv2_ws_kernel<MT>, grid, dim3(512), Cfg::LDS_BYTES, st, a);
+  return eavsr::launch_status("dcnv2");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Register-fed variant (EAVSR_DCN_VARIANT=r, 308 us; A-B only): no column tile at all.
 // v_mfma_f32_32x32x2_f32 wants B[k = lane >> 5][j = lane & 31]: lane (half, j) therefore samples ITS OWN
 // pixel j of channel 2 cp + half and hands the value to the MFMA straight from a VGPR -- the sampler's
 // output never touches LDS, and the only barrier is the one per 8-channel group that publishes the next
@@ -716,10 +999,10 @@ extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float*
   const bool patch = (w % 4) == 0 && (((uintptr_t)x) & 15) == 0;
   hipStream_t st = eavsr::as_stream(stream);
   static const int variant = [] {
-    // A-B switch: "reg" = register-fed B operand (experimental, currently slower: 308 us vs 271 us at
-    // 4x64x180x320), "global" = no LDS window; default = LDS-window kernel
+    // A-B switch: default = LDS-window kernel; "w" = wave-specialised producers / consumers, "r" = register-fed
+    // B operand, "g" = global gathers without an LDS window (the measured ranking is in DESIGN.md)
     const char* e = getenv("EAVSR_DCN_VARIANT");
-    return e == nullptr ? 1 : (e[0] == 'r' ? 0 : (e[0] == 'g' ? 2 : 1));
+    return e == nullptr ? 1 : (e[0] == 'r' ? 0 : (e[0] == 'g' ? 2 : (e[0] == 'w' ? 3 : 1)));
   }();
   static const int rows = [] {
     const char* e = getenv("EAVSR_DCN_ROWS");  // A-B: 8, 12 or 16 rows (waves) per workgroup
@@ -734,6 +1017,7 @@ extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float*
     if (R == 16) return CO == 32 ? launch_reg<1, 16, false>(a, rgrid, st) : launch_reg<2, 16, false>(a, rgrid, st);
     return CO == 32 ? launch_reg<1, 12, true>(a, rgrid, st) : launch_reg<2, 12, true>(a, rgrid, st);
   }
+  if (patch && variant == 3) return CO == 32 ? launch_ws<1>(a, grid, st) : launch_ws<2>(a, grid, st);
   if (patch && variant == 1) {
     if (CO == 32) hipLaunchKernelGGL(dcnv2_patch_kernel<1>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dcnv2_patch_kernel<2>, grid, dim3(256), 0, st, a);
