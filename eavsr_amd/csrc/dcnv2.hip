@@ -18,7 +18,6 @@
 // same lines).  The per-(pixel, tap) corner indices / weights are computed once per 4-channel chunk.
 #include "common.h"
 
-#include <mutex>
 #include <stdlib.h>
 
 namespace {
@@ -190,14 +189,13 @@ __global__ __launch_bounds__(256, 4) void dcnv2_kernel(DcnArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// LDS-patch variant, the one the hot path runs (w % 4 == 0, 16-byte aligned input): the (4 + 12) x (32 + 16) input window of the
-// 4 channels of a chunk is brought into LDS once by 16-byte LDS-DMA (two stages: the window of chunk
-// c+1 lands behind the sampling + contraction of chunk c) and the 9 taps gather from LDS (ds_read2_b32,
-// 128 B/clk) instead of from L1 (the gathers through the texture path were the bottleneck of the
-// global-gather kernel: ~27 clk per wave-instruction).  Taps that leave the window -- offsets beyond
-// ~+-6 px, rare after the flow pre-warp of MultiAdSTN -- fall back to a global gather, lane by lane.
-// The window is zero outside the image, which is exactly the corner-wise zero padding of the sampler.
-// Offsets / masks of chunk c+1 are prefetched into registers during chunk c.
+// LDS-window kernel, the one the hot path runs (w % 4 == 0, 16-byte aligned input): the (4 + 12) x (32 + 16)
+// input window of the 4 channels of a chunk is brought into LDS once by 16-byte LDS-DMA (two stages: the window
+// of chunk c+1 lands behind the sampling + contraction of chunk c) and the 9 taps gather from LDS (ds_read2_b32)
+// instead of from L1 (the gathers through the texture path were the bottleneck of the global-gather kernel:
+// ~27 clk per wave-instruction).  Taps that leave the window -- offsets beyond ~+-6 px, rare after the flow
+// pre-warp of MultiAdSTN -- are redone from global memory.  The window is zero outside the image, which is
+// exactly the corner-wise zero padding of the sampler.
 // ---------------------------------------------------------------------------------------------------
 // window pieces outside the image read these zeros: every lane of every DMA is then always issued, which
 // keeps the number of outstanding vector-memory operations per wave a compile-time constant (counted vmcnt)
@@ -209,20 +207,54 @@ constexpr int PATCH_F = DCK * PH * PW;    // 3072 floats = 12 KiB = 12 one-KiB D
 constexpr int PATCH_SEGS = PATCH_F / 256;
 constexpr int PATCH_IT = PATCH_SEGS / 4;  // pieces per wave
 
+// What bounds it.  v_mfma_f32_32x32x2_f32 runs at exactly the packed-fp32 vector rate and, measured with
+// in-kernel cycle stamps on four differently structured kernels (tools/gpu_dcn_stamps.py; the software-
+// pipelined, wave-specialised and ping-pong variants are described in DESIGN.md), a wave's vector instructions
+// do not issue while another wave of its SIMD streams fp32 MFMAs: matrix time and vector time ADD per SIMD
+// instead of overlapping.  The lever is therefore the vector instruction count of the sampler, not the overlap
+// structure (409 -> 172 vector instructions per wave and chunk against 36 MFMAs):
+//   * sampling positions, bilinear weights (mask folded in) and the LDS corner address are computed once per
+//     deformable group (8 channels = 2 chunks) and kept in registers for the second chunk; offsets / masks are
+//     loaded once per group, straight into the registers the previous group no longer needs
+//   * the main sampling path is branch-free (taps that leave the LDS window are flagged and redone from global
+//     memory in a wave-uniform fix-up branch); waves 0-1 own the 5 even taps, waves 2-3 the 4 odd taps (no
+//     dummy slot)
+//   * the blend uses packed fp32: (w1, w2) * (a, b) + (w3, w4) * (c, d) then one add -- 3 instructions per
+//     column value
+//   * column tile, weight slab and window are three distinct LDS objects, so the compiler may move gathers
+//     across column stores; 52 KB LDS and <= 168 VGPRs keep three workgroups per CU
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef EAVSR_DCN_STAMPS
+// diagnostic build only (tools/build_dcn_diag.sh): cycles of wave 0 / wave 2 of every workgroup per phase
+__device__ unsigned long long g_dcn_stamps[16];
+#define DCN_STAMP(i)                                                  \
+  do {                                                                \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+    st_acc[i] += t_ - st_last;                                        \
+    st_last = t_;                                                     \
+  } while (0)
+#else
+#define DCN_STAMP(i) do { } while (0)
+#endif
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+template <int V> struct IntTag { static constexpr int value = V; };
+
 template <int MT>
-__global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
+__global__ __launch_bounds__(256, 3) void dcnv2_grp_kernel(DcnArgs a) {
   constexpr int CO = 32 * MT;
   constexpr int W4 = DCK * DKK * CO / 4;
   constexpr int W_SEGS = (DCK * DKK * CO + 255) / 256;
-  // one LDS array: [col tile][weight slab][window stage 0][window stage 1]
-  __shared__ __attribute__((aligned(16))) float smem[DCK * DKK * DT_PX + W_SEGS * 256 + 2 * PATCH_F];
-  float* s_col = smem;
-  float* s_w = smem + DCK * DKK * DT_PX;
-  float* s_patch = s_w + W_SEGS * 256;
+  constexpr int W_IT = (W_SEGS + 3) / 4;
+  // three distinct LDS objects: the compiler may then move window gathers across column-tile stores
+  __shared__ float s_col[DCK * DKK * DT_PX];
+  __shared__ __attribute__((aligned(16))) float s_w[W_SEGS * 256];
+  __shared__ __attribute__((aligned(16))) float s_patch[2 * PATCH_F];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool even_taps = wave < 2;
   const int l31 = lane & 31, half = lane >> 5;
   int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;
@@ -234,6 +266,7 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
   const int h = a.h, w = a.w;
   const size_t plane = (size_t)h * w;
   const unsigned uplane = (unsigned)plane;
+  const int nchunks = a.cin / DCK;
 
   f32x16 acc[MT];
 #pragma unroll
@@ -250,13 +283,11 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
   const bool pix_ok = gy < h && gx < w;
   const unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
 
-  // zero both window stages once; pieces that lie outside the image are never moved and stay zero
   {
     f32x4* z = reinterpret_cast<f32x4*>(s_patch);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int e = tid; e < 2 * PATCH_F / 4; e += 256) z[e] = zero;
   }
-  // per-lane byte offsets of this wave's window pieces within a 4-channel slab (0xFFFFFFFF: outside)
   unsigned voff[PATCH_IT];
 #pragma unroll
   for (int i = 0; i < PATCH_IT; ++i) {
@@ -268,86 +299,99 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
     const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
     voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)yy * w + xx) * 4) : 0xFFFFFFFFu;
   }
-  auto issue_patch = [&](int c0, int stage) {
-    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin + c0) * plane);
+  auto issue_window = [&](int chunk, int stage) __attribute__((always_inline)) {
+    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin + chunk * DCK) * plane);
 #pragma unroll
     for (int i = 0; i < PATCH_IT; ++i) {
       const char* src = voff[i] != 0xFFFFFFFFu ? xb + voff[i] : reinterpret_cast<const char*>(g_dcn_zero);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_patch + stage * PATCH_F + (i * 4 + wave) * 256), 16, 0, 0);
     }
   };
-  float oy[TAPS_PER_THREAD], ox[TAPS_PER_THREAD], mk[TAPS_PER_THREAD];
-  float oyn[TAPS_PER_THREAD], oxn[TAPS_PER_THREAD], mkn[TAPS_PER_THREAD];
-  auto load_offsets = [&](int c0, float* fy, float* fx, float* fm) {
-    const int g = c0 / a.cpg;
+  auto issue_weights = [&](int chunk) __attribute__((always_inline)) {
+    const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)chunk * DCK) * (DKK * CO));
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int seg = min(i * 4 + wave, W_SEGS - 1);
+      const unsigned e4 = (unsigned)min(seg * 64 + lane, W4 - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(s_w + seg * 256), 16, 0, 0);
+    }
+  };
+  constexpr int MAXS = 5;
+  // offsets / masks of the NEXT deformable group (dead once setup() has turned them into weights and addresses,
+  // so the following group's values are loaded straight into them during the group's second chunk)
+  float oy[MAXS], ox[MAXS], mk[MAXS];
+#pragma unroll
+  for (int j = 0; j < MAXS; ++j) oy[j] = ox[j] = mk[j] = 0.f;
+  auto load_offsets = [&](int chunk, float* fy, float* fx, float* fm, auto ns_tag) __attribute__((always_inline)) {
+    constexpr int NS = decltype(ns_tag)::value;
+    const int g = chunk * DCK / a.cpg;
     const float* offb = a.offset + ((size_t)bn * a.dg + g) * 18 * plane;
     const float* mkb = a.mask + ((size_t)bn * a.dg + g) * 9 * plane;
 #pragma unroll
-    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
-      const unsigned tap = (unsigned)min(tap0 + 2 * j, DKK - 1);
+    for (int j = 0; j < NS; ++j) {
+      const unsigned tap = (unsigned)(tap0 + 2 * j);
       fy[j] = ld_b(offb, (2u * tap * uplane + pix) * 4u);
       fx[j] = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
       fm[j] = ld_b(mkb, (tap * uplane + pix) * 4u);
     }
   };
-
-  __syncthreads();  // zero fill done before the first DMA may land
-  issue_patch(0, 0);
-  load_offsets(0, oy, ox, mk);
-
-  int stage = 0;
-  for (int c0 = 0; c0 < a.cin; c0 += DCK, stage ^= 1) {
-    // window(c0) has landed (vmcnt + barrier of the previous iteration, or here for the first chunk) and
-    // the previous contraction is done with s_col / s_w
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
-      const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)c0) * (DKK * CO));
-      // exactly W_IT pieces per wave (a surplus piece rewrites the last slab piece with the same bytes)
+  // per-slot sampling state of the current deformable group (positions are shared by its 8 channels)
+  f32x2 sw[MAXS][2];      // (w1, w2), (w3, w4): bilinear corner weights x mask (0 when outside the image)
+  int sq[MAXS];           // float offset of the top-left corner in a window stage
+  unsigned slow = 0;      // slots whose corners left the LDS window: redone by fixup()
+  auto setup = [&](int j) __attribute__((always_inline)) {
+    const int tap = tap0 + 2 * j;
+    const int ti = tap / 3, tj = tap - 3 * ti;
+    const float py = (float)(gy - 1 + ti) + oy[j];
+    const float px = (float)(gx - 1 + tj) + ox[j];
+    const bool in = pix_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+    const float fy0 = floorf(py), fx0 = floorf(px);
+    const float lh = py - fy0, lw = px - fx0;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
+    const float m = in ? mk[j] : 0.f;
+    const int ry = hl - (y0 - PY0), rx = wl - (x0 - PX0);
+    const bool in_win = ry >= 0 && ry <= PH - 2 && rx >= 0 && rx <= PW - 2;
+    const float hm = hh * m, lm = lh * m;
+    sw[j][0] = f32x2{hm * hw, hm * lw};
+    sw[j][1] = f32x2{lm * hw, lm * lw};
+    sq[j] = (in && in_win) ? ry * PW + rx : 0;
+    slow = (in && !in_win) ? (slow | (1u << j)) : (slow & ~(1u << j));
+  };
+  auto sample_slot = [&](int j, const float* pst) __attribute__((always_inline)) {
+    const float* q = pst + sq[j];
+    float vals[DCK];
 #pragma unroll
-      for (int i = 0; i < (W_SEGS + 3) / 4; ++i) {
-        const int seg = min(i * 4 + wave, W_SEGS - 1);
-        const unsigned e4 = (unsigned)min(seg * 64 + lane, W4 - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(s_w + seg * 256), 16, 0, 0);
-      }
+    for (int c = 0; c < DCK; ++c) {
+      const f32x2 top = {q[c * (PH * PW)], q[c * (PH * PW) + 1]};
+      const f32x2 bot = {q[c * (PH * PW) + PW], q[c * (PH * PW) + PW + 1]};
+      const f32x2 r = sw[j][0] * top + sw[j][1] * bot;
+      vals[c] = r.x + r.y;
     }
-    const bool more = c0 + DCK < a.cin;
-    if (more) {
-      // issued AFTER the weights: the wait before the contraction leaves exactly these in flight
-      issue_patch(c0 + DCK, stage ^ 1);
-      load_offsets(c0 + DCK, oyn, oxn, mkn);
-    }
-    const float* pst = s_patch + stage * PATCH_F;
-    const float* xp = a.x + ((size_t)bn * a.cin + c0) * plane;
 #pragma unroll
-    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
-      const int tap = tap0 + 2 * j;
-      const int ti = tap / 3, tj = tap - 3 * ti;
-      const float py = (float)(gy - 1 + ti) + oy[j];
-      const float px = (float)(gx - 1 + tj) + ox[j];
-      const bool in = pix_ok && tap < DKK && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
-      const float fy0 = floorf(py), fx0 = floorf(px);
-      const float lh = py - fy0, lw = px - fx0;
-      const float hh = 1.f - lh, hw = 1.f - lw;
-      const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
-      const float m = in ? mk[j] : 0.f;
-      float vals[DCK];
-      // window coordinates of the top-left corner
-      const int ry = hl - (y0 - PY0), rx = wl - (x0 - PX0);
-      const bool in_win = ry >= 0 && ry <= PH - 2 && rx >= 0 && rx <= PW - 2;
-      if (in_win || !in) {
-        // fast path: the window holds zeros outside the image == corner-wise zero padding
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        const float* q = pst + (in ? ry * PW + rx : 0);
+    for (int c = 0; c < DCK; ++c) s_col[(c * DKK + tap0 + 2 * j) * DT_PX + p] = vals[c];
+  };
+  auto fixup = [&](int chunk, auto ns_tag) __attribute__((always_inline)) {
+    constexpr int NS = decltype(ns_tag)::value;
+    const float* xp = a.x + ((size_t)bn * a.cin + chunk * DCK) * plane;
+    const int g = chunk * DCK / a.cpg;
+    const float* offb = a.offset + ((size_t)bn * a.dg + g) * 18 * plane;
+    const float* mkb = a.mask + ((size_t)bn * a.dg + g) * 9 * plane;
 #pragma unroll
-        for (int c = 0; c < DCK; ++c) {
-          float v = w1 * q[c * (PH * PW)];
-          v += w2 * q[c * (PH * PW) + 1];
-          v += w3 * q[c * (PH * PW) + PW];
-          v += w4 * q[c * (PH * PW) + PW + 1];
-          vals[c] = v * m;
-        }
-      } else {
+    for (int j = 0; j < NS; ++j) {
+      if (slow & (1u << j)) {
+        const int tap = tap0 + 2 * j;
+        const int ti = tap / 3, tj = tap - 3 * ti;
+        // rare path: the offsets are read again (the prefetch registers already hold the next group's)
+        const float fy = ld_b(offb, (2u * (unsigned)tap * uplane + pix) * 4u);
+        const float fx = ld_b(offb, ((2u * (unsigned)tap + 1u) * uplane + pix) * 4u);
+        const float fm = ld_b(mkb, ((unsigned)tap * uplane + pix) * 4u);
+        const float py = (float)(gy - 1 + ti) + fy;
+        const float px = (float)(gx - 1 + tj) + fx;
+        const float fy0 = floorf(py), fx0 = floorf(px);
+        const float lh = py - fy0, lw = px - fx0;
+        const float hh = 1.f - lh, hw = 1.f - lw;
+        const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
         const int hh_i = hl + 1, wh_i = wl + 1;
         const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
         const float w1 = (t_ok & l_ok) ? hh * hw : 0.f;
@@ -365,20 +409,54 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
           v += w2 * ld_b(q, i2);
           v += w3 * ld_b(q, i3);
           v += w4 * ld_b(q, i4);
-          vals[c] = v * m;
+          s_col[(c * DKK + tap) * DT_PX + p] = v * fm;
         }
       }
-      if (tap < DKK) {
-#pragma unroll
-        for (int c = 0; c < DCK; ++c) s_col[(c * DKK + tap) * DT_PX + p] = vals[c];
-      }
     }
-    // Only the weight slab is needed now.  vmcnt counts in issue order: leaving the PATCH_IT window pieces and the
-    // 3 * TAPS_PER_THREAD offset / mask loads of the NEXT chunk in flight lets their HBM latency run under the
-    // contraction instead of stalling every chunk; they are drained at the top of the next iteration.
-    if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PATCH_IT + 3 * TAPS_PER_THREAD) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  };
+#ifdef EAVSR_DCN_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+  constexpr int WAIT_VM0 = 0x0F70;
+  auto wait_vm_lgkm0 = [](auto n_tag) __attribute__((always_inline)) {
+    constexpr int N = decltype(n_tag)::value;
+    __builtin_amdgcn_s_waitcnt(0x0070 | (N & 15) | ((N >> 4) << 14));
+  };
+
+  // one chunk: FIRST opens a deformable group (positions set up); otherwise the next group's offsets are loaded
+  auto chunk_step = [&](int c, auto first_tag, auto ns_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int NS = decltype(ns_tag)::value;
+    const int stage = c & 1;
+    DCN_STAMP(0);
+    // window(c) has landed and is visible; the previous contraction is done with s_col / s_w
+    __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+    __syncthreads();
+    DCN_STAMP(1);
+    issue_weights(c);
+    const bool more = c + 1 < nchunks;
+    if (more) {
+      issue_window(c + 1, stage ^ 1);
+      if (!FIRST) load_offsets(c + 1, oy, ox, mk, ns_tag);
+    }
+    DCN_STAMP(2);
+    const float* pst = s_patch + stage * PATCH_F;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      if (FIRST) setup(j);
+      sample_slot(j, pst);
+      // bound the gathers in flight (2 slots x 16 dwords): the scheduler would hoist all of them and spill
+      if (j & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    DCN_STAMP(3);
+    if (__builtin_amdgcn_ballot_w64(slow != 0) != 0) fixup(c, ns_tag);
+    DCN_STAMP(4);
+    // only the weight slab is needed now: the window pieces (and offset loads) of the next chunk stay in flight
+    if (more) wait_vm_lgkm0(IntTag<PATCH_IT + (FIRST ? 0 : 3 * NS)>{});
+    else wait_vm_lgkm0(IntTag<0>{});
     __builtin_amdgcn_s_barrier();
+    DCN_STAMP(5);
 #pragma unroll
     for (int tap = 0; tap < DKK; ++tap) {
 #pragma unroll
@@ -391,16 +469,30 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
         }
       }
     }
-    if (more) {
-#pragma unroll
-      for (int j = 0; j < TAPS_PER_THREAD; ++j) {
-        oy[j] = oyn[j];
-        ox[j] = oxn[j];
-        mk[j] = mkn[j];
-      }
+  };
+
+  __syncthreads();  // zero fill done before the first DMA may land
+  issue_window(0, 0);
+  if (even_taps) {
+    load_offsets(0, oy, ox, mk, IntTag<5>{});
+    for (int c = 0; c < nchunks; c += 2) {
+      chunk_step(c, BoolTag<true>{}, IntTag<5>{});
+      if (c + 1 < nchunks) chunk_step(c + 1, BoolTag<false>{}, IntTag<5>{});
+    }
+  } else {
+    load_offsets(0, oy, ox, mk, IntTag<4>{});
+    for (int c = 0; c < nchunks; c += 2) {
+      chunk_step(c, BoolTag<true>{}, IntTag<4>{});
+      if (c + 1 < nchunks) chunk_step(c + 1, BoolTag<false>{}, IntTag<4>{});
     }
   }
 
+#ifdef EAVSR_DCN_STAMPS
+  DCN_STAMP(0);
+  if (lane == 0 && (wave == 0 || wave == 2)) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_dcn_stamps[(wave == 2 ? 8 : 0) + i], st_acc[i]);
+  }
+#endif
   const int oy_ = y0 + wave, ox_ = x0 + l31;
   if (oy_ < h && ox_ < w) {
 #pragma unroll
@@ -416,560 +508,19 @@ __global__ __launch_bounds__(256, 3) void dcnv2_patch_kernel(DcnArgs a) {
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------------
-// Wave-specialised variant (EAVSR_DCN_VARIANT=w; an experiment kept for A-B runs, 410 us vs 270 us for the
-// LDS-window kernel, so NOT the default): measured on the LDS-window kernel above, the matrix
-// pipe is busy 38 % of the time because every wave alternates sample -> barrier -> contract and the phases of
-// co-resident workgroups do not interleave (contraction alone 143 us, sampler 77 us, DMA + barriers 110 us
-// of a 289 us launch).  Here the two jobs run on DIFFERENT waves of one 512-thread workgroup:
-//   waves 4-7 (producers): issue the LDS-DMA of weight slabs and input windows, prefetch offsets / masks,
-//                          sample chunk c+1 into col stage (c+1)&1
-//   waves 0-3 (consumers): contract chunk c from col stage c&1 on the MFMA pipe, nothing else
-// with ONE workgroup barrier per 4-channel chunk.  Producer VALU / LDS work and consumer MFMAs issue from
-// different waves of the same SIMD, so they overlap by construction; the chunk period is
-// max(sampling, 2 consumer waves x 36 MFMAs) on each SIMD (two workgroups per CU).
-// ---------------------------------------------------------------------------------------------------
-template <int MT>
-struct WsCfg {
-  static constexpr int CO = 32 * MT;
-  static constexpr int COL_F = DCK * DKK * DT_PX;                 // 4608 floats per col stage
-  static constexpr int W_SEGS = (DCK * DKK * CO + 255) / 256;     // weight slab pieces (1 KiB each)
-  static constexpr int W_F = W_SEGS * 256;
-  static constexpr int LDS_FLOATS = 2 * COL_F + 2 * W_F + 2 * PATCH_F;
-  static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-};
-
-template <int MT>
-__global__ __launch_bounds__(512, 2) void dcnv2_ws_kernel(DcnArgs a) {
-  using Cfg = WsCfg<MT>;
-  constexpr int CO = Cfg::CO, COL_F = Cfg::COL_F, W_SEGS = Cfg::W_SEGS, W_F = Cfg::W_F;
-  constexpr int W4 = DCK * DKK * CO / 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_col = smem;                    // [2][COL_F]
-  float* s_w = smem + 2 * COL_F;          // [2][W_F]
-  float* s_patch = s_w + 2 * W_F;         // [2][PATCH_F]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool producer = wave >= 4;
-  const int pw = wave & 3;                // index within the role
-  const int l31 = lane & 31, half = lane >> 5;
-  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int bn = bid / a.tiles_y;
-  const int cot = blockIdx.y;
-  const int y0 = ty * DT_H, x0 = tx * DT_W;
-  const int h = a.h, w = a.w;
-  const size_t plane = (size_t)h * w;
-  const unsigned uplane = (unsigned)plane;
-  const int nchunks = a.cin / DCK;
-
-  {  // zero both window stages once: pieces outside the image are never moved and stay zero
-    f32x4* z = reinterpret_cast<f32x4*>(s_patch);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < 2 * PATCH_F / 4; e += 512) z[e] = zero;
-  }
-
-  // ---- producer state ---------------------------------------------------------------------------------
-  const int ptid = tid & 255;
-  const int p = ptid & (DT_PX - 1);
-  const int tap0 = ptid >> 7;
-  const int gy = y0 + (p >> 5), gx = x0 + (p & 31);
-  const bool pix_ok = gy < h && gx < w;
-  const unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
-  unsigned voff[PATCH_IT];
-#pragma unroll
-  for (int i = 0; i < PATCH_IT; ++i) {
-    const int e4 = (i * 4 + pw) * 64 + lane;
-    const int ci = e4 / (PH * (PW / 4));
-    const int rem = e4 - ci * (PH * (PW / 4));
-    const int r = rem / (PW / 4), c4 = rem - r * (PW / 4);
-    const int yy = y0 - PY0 + r, xx = x0 - PX0 + 4 * c4;
-    const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
-    voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)yy * w + xx) * 4) : 0xFFFFFFFFu;
-  }
-  auto issue_window = [&](int chunk, int stage) {
-    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin + chunk * DCK) * plane);
-#pragma unroll
-    for (int i = 0; i < PATCH_IT; ++i)
-      if (voff[i] != 0xFFFFFFFFu)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xb + voff[i]),
-                                         (lptr_t)(s_patch + stage * PATCH_F + (i * 4 + pw) * 256), 16, 0, 0);
-  };
-  auto issue_weights = [&](int chunk, int stage) {
-    const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)chunk * DCK) * (DKK * CO));
-#pragma unroll
-    for (int i = 0; i < (W_SEGS + 3) / 4; ++i) {
-      const int seg = i * 4 + pw;
-      if (seg < W_SEGS) {
-        const unsigned e4 = (unsigned)min(seg * 64 + lane, W4 - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(s_w + stage * W_F + seg * 256), 16, 0, 0);
-      }
-    }
-  };
-  float oy[TAPS_PER_THREAD], ox[TAPS_PER_THREAD], mk[TAPS_PER_THREAD];
-  float oyn[TAPS_PER_THREAD], oxn[TAPS_PER_THREAD], mkn[TAPS_PER_THREAD];
-#pragma unroll
-  for (int j = 0; j < TAPS_PER_THREAD; ++j) oyn[j] = oxn[j] = mkn[j] = 0.f;
-  auto load_offsets = [&](int chunk, float* fy, float* fx, float* fm) {
-    const int g = chunk * DCK / a.cpg;
-    const float* offb = a.offset + ((size_t)bn * a.dg + g) * 18 * plane;
-    const float* mkb = a.mask + ((size_t)bn * a.dg + g) * 9 * plane;
-#pragma unroll
-    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
-      const unsigned tap = (unsigned)min(tap0 + 2 * j, DKK - 1);
-      fy[j] = ld_b(offb, (2u * tap * uplane + pix) * 4u);
-      fx[j] = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
-      fm[j] = ld_b(mkb, (tap * uplane + pix) * 4u);
-    }
-  };
-  // sample chunk `chunk` (offsets in fy/fx/fm) from window stage `wst` into col stage `cst`
-  auto sample = [&](int chunk, int wst, int cst, const float* fy, const float* fx, const float* fm) {
-    const float* pst = s_patch + wst * PATCH_F;
-    float* col = s_col + cst * COL_F;
-    const float* xp = a.x + ((size_t)bn * a.cin + chunk * DCK) * plane;
-#pragma unroll
-    for (int j = 0; j < TAPS_PER_THREAD; ++j) {
-      const int tap = tap0 + 2 * j;
-      const int ti = tap / 3, tj = tap - 3 * ti;
-      const float py = (float)(gy - 1 + ti) + fy[j];
-      const float px = (float)(gx - 1 + tj) + fx[j];
-      const bool in = pix_ok && tap < DKK && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
-      const float fy0 = floorf(py), fx0 = floorf(px);
-      const float lh = py - fy0, lw = px - fx0;
-      const float hh = 1.f - lh, hw = 1.f - lw;
-      const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
-      const float m = in ? fm[j] : 0.f;
-      float vals[DCK];
-      const int ry = hl - (y0 - PY0), rx = wl - (x0 - PX0);
-      const bool in_win = ry >= 0 && ry <= PH - 2 && rx >= 0 && rx <= PW - 2;
-      if (in_win || !in) {
-        const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-        const float* q = pst + (in ? ry * PW + rx : 0);
-#pragma unroll
-        for (int c = 0; c < DCK; ++c) {
-          float v = w1 * q[c * (PH * PW)];
-          v += w2 * q[c * (PH * PW) + 1];
-          v += w3 * q[c * (PH * PW) + PW];
-          v += w4 * q[c * (PH * PW) + PW + 1];
-          vals[c] = v * m;
-        }
-      } else {
-        const int hh_i = hl + 1, wh_i = wl + 1;
-        const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
-        const float w1 = (t_ok & l_ok) ? hh * hw : 0.f;
-        const float w2 = (t_ok & r_ok) ? hh * lw : 0.f;
-        const float w3 = (b_ok & l_ok) ? lh * hw : 0.f;
-        const float w4 = (b_ok & r_ok) ? lh * lw : 0.f;
-        const int cy0 = min(max(hl, 0), h - 1), cy1 = min(max(hh_i, 0), h - 1);
-        const int cx0 = min(max(wl, 0), w - 1), cx1 = min(max(wh_i, 0), w - 1);
-        const unsigned i1 = (unsigned)(cy0 * w + cx0) * 4u, i2 = (unsigned)(cy0 * w + cx1) * 4u;
-        const unsigned i3 = (unsigned)(cy1 * w + cx0) * 4u, i4 = (unsigned)(cy1 * w + cx1) * 4u;
-#pragma unroll
-        for (int c = 0; c < DCK; ++c) {
-          const float* q = xp + (size_t)c * plane;
-          float v = w1 * ld_b(q, i1);
-          v += w2 * ld_b(q, i2);
-          v += w3 * ld_b(q, i3);
-          v += w4 * ld_b(q, i4);
-          vals[c] = v * m;
-        }
-      }
-      if (tap < DKK) {
-#pragma unroll
-        for (int c = 0; c < DCK; ++c) col[(c * DKK + tap) * DT_PX + p] = vals[c];
-      }
-    }
-  };
-
-  // After an explicit vmcnt(0) the prefetched offsets ARE in their registers, but hipcc still attributes them to
-  // the loads and, with an LDS-DMA in flight, waits vmcnt(0) again at their first use -- which then also waits
-  // for everything issued since (a full HBM latency per chunk).  Passing the registers through an empty asm
-  // makes the asm their definition.
-  auto launder = [&](float* fy, float* fx, float* fm) {
-#pragma unroll
-    for (int j = 0; j < TAPS_PER_THREAD; ++j) asm volatile("" : "+v"(fy[j]), "+v"(fx[j]), "+v"(fm[j]));
-  };
-
-  f32x16 acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-  __syncthreads();  // zero fill complete before any DMA may land
-  if (producer) {
-    issue_window(0, 0);
-    issue_weights(0, 0);
-    load_offsets(0, oy, ox, mk);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    launder(oy, ox, mk);
-  }
-  __syncthreads();  // window(0) visible to every producer wave
-  if (producer) {
-    if (nchunks > 1) {
-      issue_window(1, 1);
-      load_offsets(1, oyn, oxn, mkn);
-    }
-    sample(0, 0, 0, oy, ox, mk);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    launder(oyn, oxn, mkn);
-  }
-  __syncthreads();  // col(0), weights(0), window(1) ready
-
-  for (int c = 0; c < nchunks; ++c) {
-    if (producer) {
-      if (c + 1 < nchunks) {
-        // offsets(c+1) are in (oyn, oxn, mkn): rotate them BEFORE anything is issued in this iteration -- hipcc
-        // waits vmcnt(0) at the first use of an ordinary load's result while an LDS-DMA is in flight, and right
-        // here nothing is (the previous iteration drained the queue), so the wait is free
-#pragma unroll
-        for (int j = 0; j < TAPS_PER_THREAD; ++j) { oy[j] = oyn[j]; ox[j] = oxn[j]; mk[j] = mkn[j]; }
-        asm volatile("" ::: "memory");
-        issue_weights(c + 1, (c + 1) & 1);
-        if (c + 2 < nchunks) {
-          issue_window(c + 2, c & 1);               // stage c&1 was sampled during iteration c-1: free
-          load_offsets(c + 2, oyn, oxn, mkn);
-        }
-        sample(c + 1, (c + 1) & 1, (c + 1) & 1, oy, ox, mk);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        launder(oyn, oxn, mkn);
-      }
-    } else {
-      const float* bcol = s_col + (c & 1) * COL_F + half * (DKK * DT_PX) + pw * 32 + l31;
-      const float* acol = s_w + (c & 1) * W_F + half * (DKK * CO) + l31;
-#pragma unroll
-      for (int tap = 0; tap < DKK; ++tap) {
-#pragma unroll
-        for (int cp = 0; cp < DCK / 2; ++cp) {
-          const float b = bcol[(cp * 2 * DKK + tap) * DT_PX];
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const float av = acol[(cp * 2 * DKK + tap) * CO + m * 32];
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[m], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  if (!producer) {
-    const int oy_ = y0 + pw, ox_ = x0 + l31;
-    if (oy_ < h && ox_ < w) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (co < a.cout) {
-            const float b = a.bias ? a.bias[co] : 0.f;
-            a.out[((size_t)bn * a.cout + co) * plane + (size_t)oy_ * w + ox_] = acc[m][r] + b;
-          }
-        }
-    }
-  }
-}
-
-template <int MT>
-int launch_ws(const DcnArgs& a, dim3 grid, hipStream_t st) {
-  using Cfg = WsCfg<MT>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnv2_ws_kernel<MT>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-  });
-  if (attr_err != hipSuccess) {
-    eavsr::set_error("dcnv2: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    return (int)attr_err;
-  }
-  hipLaunchKernelGGL(dcnv2_ws_kernel<MT>, grid, dim3(512), Cfg::LDS_BYTES, st, a);
-  return eavsr::launch_status("dcnv2");
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Register-fed variant (EAVSR_DCN_VARIANT=r, 308 us; A-B only): no column tile at all.
-// v_mfma_f32_32x32x2_f32 wants B[k = lane >> 5][j = lane & 31]: lane (half, j) therefore samples ITS OWN
-// pixel j of channel 2 cp + half and hands the value to the MFMA straight from a VGPR -- the sampler's
-// output never touches LDS, and the only barrier is the one per 8-channel group that publishes the next
-// LDS window / weight slab (both moved by 16-byte LDS-DMA while the current group computes).
-// Workgroup = 512 threads = 8 waves = 8 rows x 32 pixels; per tap a lane computes the sampling position
-// once (shared by the 4 channels it owns in the group), gathers 4 x 4 corners from the LDS window
-// (ds_read2_b32) and issues 4 x MT MFMAs whose 64-cycle shadows hide the next tap's arithmetic.
-// ---------------------------------------------------------------------------------------------------
-constexpr int RCK = 8;                        // channels per chunk
-constexpr int WW = 48;                        // window columns x0-8 .. x0+39
-
-// R = rows (= waves) per workgroup: R/4 waves per SIMD.  More waves per SIMD hide the sampler's LDS /
-// VALU latency under the other waves' MFMAs; the VGPR budget shrinks accordingly (512 / (R/4)).
-template <int MT, int R>
-struct RegCfg {
-  static constexpr int CO = 32 * MT;
-  static constexpr int WH = R + 12;                         // window rows y0-6 .. y0+R+5
-  static constexpr int WIN_F = RCK * WH * WW;
-  static constexpr int WIN_SEGS = (WIN_F + 255) / 256;
-  static constexpr int WIN_IT = (WIN_SEGS + R - 1) / R;
-  static constexpr int W_F = RCK * DKK * CO;               // weight slab floats
-  static constexpr int W_SEGS = (W_F + 255) / 256;
-  static constexpr int W_IT = (W_SEGS + R - 1) / R;
-  static constexpr int STAGE = WIN_SEGS * 256 + W_SEGS * 256;
-  static constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(float);
-};
-
-template <int MT, int R, bool PREFETCH>
-__global__ __launch_bounds__(64 * R, R / 4) void dcnv2_reg_kernel(DcnArgs a) {
-  using Cfg = RegCfg<MT, R>;
-  constexpr int CO = Cfg::CO, W_F = Cfg::W_F, W_SEGS = Cfg::W_SEGS, W_IT = Cfg::W_IT, STAGE = Cfg::STAGE;
-  constexpr int WH = Cfg::WH, WIN_F = Cfg::WIN_SEGS * 256, WIN_SEGS = Cfg::WIN_SEGS, WIN_IT = Cfg::WIN_IT;
-  constexpr int RT_H = R, NTHR = 64 * R;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [stage][window | weights]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int bn = bid / a.tiles_y;
-  const int cot = blockIdx.y;
-  const int y0 = ty * RT_H, x0 = tx * DT_W;
-  const int h = a.h, w = a.w;
-  const size_t plane = (size_t)h * w;
-  const unsigned uplane = (unsigned)plane;
-
-  f32x16 acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-  const int gy = y0 + wave, gx = x0 + l31;
-  const bool pix_ok = gy < h && gx < w;
-  const unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
-
-  {  // zero both stages once: window pieces outside the image are never moved and stay zero
-    f32x4* z = reinterpret_cast<f32x4*>(smem);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < 2 * STAGE / 4; e += NTHR) z[e] = zero;
-  }
-  unsigned voff[WIN_IT];
-#pragma unroll
-  for (int i = 0; i < WIN_IT; ++i) {
-    const int seg = i * R + wave;
-    const int e4 = seg * 64 + lane;
-    const int ci = e4 / (WH * (WW / 4));
-    const int rem = e4 - ci * (WH * (WW / 4));
-    const int r = rem / (WW / 4), c4 = rem - r * (WW / 4);
-    const int yy = y0 - 6 + r, xx = x0 - 8 + 4 * c4;
-    const bool ok = seg < WIN_SEGS && e4 < RCK * WH * WW / 4 && yy >= 0 && yy < h && xx >= 0 && xx < w;
-    voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)yy * w + xx) * 4) : 0xFFFFFFFFu;
-  }
-  auto issue_stage = [&](int c0, int stage) {
-    float* win = smem + stage * STAGE;
-    float* sw = win + WIN_F;
-    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin + c0) * plane);
-#pragma unroll
-    for (int i = 0; i < WIN_IT; ++i)
-      if (voff[i] != 0xFFFFFFFFu)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xb + voff[i]), (lptr_t)(win + (i * R + wave) * 256), 16, 0, 0);
-    const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)c0) * (DKK * CO));
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int seg = i * R + wave;
-      if (seg < W_SEGS) {
-        const unsigned e4 = (unsigned)min(seg * 64 + lane, W_F / 4 - 1);
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + e4 * 16u), (lptr_t)(sw + seg * 256), 16, 0, 0);
-      }
-    }
-  };
-  float oy[DKK], ox[DKK], mk[DKK], oyn[PREFETCH ? DKK : 1], oxn[PREFETCH ? DKK : 1], mkn[PREFETCH ? DKK : 1];
-  auto load_offsets = [&](int c0, float* fy, float* fx, float* fm) {
-    const int g = c0 / a.cpg;
-    const float* offb = a.offset + ((size_t)bn * a.dg + g) * 18 * plane;
-    const float* mkb = a.mask + ((size_t)bn * a.dg + g) * 9 * plane;
-#pragma unroll
-    for (int t = 0; t < DKK; ++t) {
-      fy[t] = ld_b(offb, (2u * t * uplane + pix) * 4u);
-      fx[t] = ld_b(offb, ((2u * t + 1u) * uplane + pix) * 4u);
-      fm[t] = ld_b(mkb, ((unsigned)t * uplane + pix) * 4u);
-    }
-  };
-
-  __syncthreads();  // zero fill complete before the first DMA may land
-  issue_stage(0, 0);
-  if (PREFETCH) load_offsets(0, oy, ox, mk);
-
-  int stage = 0;
-  for (int c0 = 0; c0 < a.cin; c0 += RCK, stage ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage data + this chunk's offsets have landed
-    __syncthreads();                                   // ... for every wave; the other stage is free
-    const bool more = c0 + RCK < a.cin;
-    if (!PREFETCH) load_offsets(c0, oy, ox, mk);  // issued BEFORE the DMAs: waited for by a counted vmcnt
-    if (more) {
-      issue_stage(c0 + RCK, stage ^ 1);
-      if (PREFETCH) load_offsets(c0 + RCK, oyn, oxn, mkn);  // first used after the next vmcnt(0)
-    }
-    const float* win = smem + stage * STAGE;
-    const float* awt = win + WIN_F + half * (DKK * CO) + l31;
-    const float* xg = a.x + ((size_t)bn * a.cin + c0) * plane;
-    // Does any lane of this wave have a valid tap whose 2x2 footprint leaves the LDS window?  (rare)
-    bool need_fb = false;
-#pragma unroll
-    for (int tap = 0; tap < DKK; ++tap) {
-      const float py = (float)(gy - 1 + tap / 3) + oy[tap];
-      const float px = (float)(gx - 1 + tap % 3) + ox[tap];
-      const bool in = pix_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
-      // window rows y0-6 .. y0+WH-7: floor(py) in [y0-6, y0+WH-8]  <=>  py in [y0-6, y0+WH-7)
-      const bool in_win = py >= (float)(y0 - 6) && py < (float)(y0 - 6 + WH - 1) &&
-                          px >= (float)(x0 - 8) && px < (float)(x0 - 8 + WW - 1);
-      need_fb |= in && !in_win;
-    }
-    if (!__any(need_fb)) {
-      // ---- straight-line fast path: no branch inside, so the scheduler can slide the next tap's address
-      // arithmetic and LDS gathers under the current tap's MFMAs
-#pragma unroll
-      for (int tap = 0; tap < DKK; ++tap) {
-        const int ti = tap / 3, tj = tap - 3 * ti;
-        const float py = (float)(gy - 1 + ti) + oy[tap];
-        const float px = (float)(gx - 1 + tj) + ox[tap];
-        const bool in = pix_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
-        const float fy0 = floorf(py), fx0 = floorf(px);
-        const float lh = py - fy0, lw = px - fx0;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const float m = in ? mk[tap] : 0.f;
-        // clamped window coordinates (every lane that is `in` is inside the window here)
-        const int ry = (int)fminf(fmaxf(fy0 - (float)(y0 - 6), 0.f), (float)(WH - 2));
-        const int rx = (int)fminf(fmaxf(fx0 - (float)(x0 - 8), 0.f), (float)(WW - 2));
-        const float w1 = hh * hw * m, w2 = hh * lw * m, w3 = lh * hw * m, w4 = lh * lw * m;
-        const float* q = win + half * (WH * WW) + ry * WW + rx;
-        float bval[RCK / 2];
-#pragma unroll
-        for (int cp = 0; cp < RCK / 2; ++cp) {
-          const float* qc = q + cp * 2 * (WH * WW);
-          float v = w1 * qc[0];
-          v += w2 * qc[1];
-          v += w3 * qc[WW];
-          v += w4 * qc[WW + 1];
-          bval[cp] = v;
-        }
-#pragma unroll
-        for (int cp = 0; cp < RCK / 2; ++cp) {
-#pragma unroll
-          for (int mm = 0; mm < MT; ++mm) {
-            const float av = awt[(cp * 2 * DKK + tap) * CO + mm * 32];
-            acc[mm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bval[cp], acc[mm], 0, 0, 0);
-          }
-        }
-      }
-    } else {
-  #pragma unroll
-      for (int tap = 0; tap < DKK; ++tap) {
-        const int ti = tap / 3, tj = tap - 3 * ti;
-        const float py = (float)(gy - 1 + ti) + oy[tap];
-        const float px = (float)(gx - 1 + tj) + ox[tap];
-        const bool in = pix_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
-        const float fy0 = floorf(py), fx0 = floorf(px);
-        const float lh = py - fy0, lw = px - fx0;
-        const float hh = 1.f - lh, hw = 1.f - lw;
-        const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
-        const float m = in ? mk[tap] : 0.f;
-        const int ry = hl - (y0 - 6), rx = wl - (x0 - 8);
-        const bool in_win = ry >= 0 && ry <= WH - 2 && rx >= 0 && rx <= WW - 2;
-        float bval[RCK / 2];
-        if (in_win || !in) {
-          // the window holds zeros outside the image == the sampler's corner-wise zero padding
-          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-          const float* q = win + half * (WH * WW) + (in ? ry * WW + rx : 0);
-  #pragma unroll
-          for (int cp = 0; cp < RCK / 2; ++cp) {
-            const float* qc = q + cp * 2 * (WH * WW);
-            float v = w1 * qc[0];
-            v += w2 * qc[1];
-            v += w3 * qc[WW];
-            v += w4 * qc[WW + 1];
-            bval[cp] = v * m;
-          }
-        } else {
-          const int hh_i = hl + 1, wh_i = wl + 1;
-          const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
-          const float w1 = (t_ok & l_ok) ? hh * hw : 0.f;
-          const float w2 = (t_ok & r_ok) ? hh * lw : 0.f;
-          const float w3 = (b_ok & l_ok) ? lh * hw : 0.f;
-          const float w4 = (b_ok & r_ok) ? lh * lw : 0.f;
-          const int cy0 = min(max(hl, 0), h - 1), cy1 = min(max(hh_i, 0), h - 1);
-          const int cx0 = min(max(wl, 0), w - 1), cx1 = min(max(wh_i, 0), w - 1);
-          const unsigned i1 = (unsigned)(cy0 * w + cx0) * 4u, i2 = (unsigned)(cy0 * w + cx1) * 4u;
-          const unsigned i3 = (unsigned)(cy1 * w + cx0) * 4u, i4 = (unsigned)(cy1 * w + cx1) * 4u;
-          const unsigned hoff = (unsigned)half * uplane * 4u;
-  #pragma unroll
-          for (int cp = 0; cp < RCK / 2; ++cp) {
-            const float* qc = xg + (size_t)(2 * cp) * plane;  // uniform; + half * plane via the lane offset
-            float v = w1 * ld_b(qc, i1 + hoff);
-            v += w2 * ld_b(qc, i2 + hoff);
-            v += w3 * ld_b(qc, i3 + hoff);
-            v += w4 * ld_b(qc, i4 + hoff);
-            bval[cp] = v * m;
-          }
-        }
-  #pragma unroll
-        for (int cp = 0; cp < RCK / 2; ++cp) {
-  #pragma unroll
-          for (int mm = 0; mm < MT; ++mm) {
-            const float av = awt[(cp * 2 * DKK + tap) * CO + mm * 32];
-            acc[mm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bval[cp], acc[mm], 0, 0, 0);
-          }
-        }
-      }
-    }
-    if (PREFETCH && more) {
-#pragma unroll
-      for (int t = 0; t < DKK; ++t) {
-        oy[t] = oyn[t];
-        ox[t] = oxn[t];
-        mk[t] = mkn[t];
-      }
-    }
-  }
-
-  if (pix_ok) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co < a.cout) {
-          const float b = a.bias ? a.bias[co] : 0.f;
-          a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = acc[m][r] + b;
-        }
-      }
-  }
-}
-
-template <int MT, int R, bool PREFETCH>
-int launch_reg(const DcnArgs& a, dim3 grid, hipStream_t st) {
-  using Cfg = RegCfg<MT, R>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnv2_reg_kernel<MT, R, PREFETCH>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-  });
-  if (attr_err != hipSuccess) {
-    eavsr::set_error("dcnv2: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
-    return (int)attr_err;
-  }
-  hipLaunchKernelGGL((dcnv2_reg_kernel<MT, R, PREFETCH>), grid, dim3(64 * R), Cfg::LDS_BYTES, st, a);
-  return eavsr::launch_status("dcnv2");
-}
-
 }  // namespace
+
+#ifdef EAVSR_DCN_STAMPS
+extern "C" int eavsr_debug_dcn_stamps(unsigned long long* host_out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dcn_stamps), sizeof(g_dcn_stamps));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_dcn_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float* mask,
                                const float* weight_packed, const float* bias, float* out, int32_t n,
@@ -998,29 +549,13 @@ extern "C" int eavsr_dcnv2_f32(const float* x, const float* offset, const float*
   // LDS-window path: whole 16-byte pieces are inside or outside the image, and aligned
   const bool patch = (w % 4) == 0 && (((uintptr_t)x) & 15) == 0;
   hipStream_t st = eavsr::as_stream(stream);
-  static const int variant = [] {
-    // A-B switch: default = LDS-window kernel; "w" = wave-specialised producers / consumers, "r" = register-fed
-    // B operand, "g" = global gathers without an LDS window (the measured ranking is in DESIGN.md)
-    const char* e = getenv("EAVSR_DCN_VARIANT");
-    return e == nullptr ? 1 : (e[0] == 'r' ? 0 : (e[0] == 'g' ? 2 : (e[0] == 'w' ? 3 : 1)));
+  static const bool force_global = [] {
+    const char* e = getenv("EAVSR_DCN_VARIANT");  // A-B switch: "g" = global gathers without an LDS window
+    return e != nullptr && e[0] == 'g';
   }();
-  static const int rows = [] {
-    const char* e = getenv("EAVSR_DCN_ROWS");  // A-B: 8, 12 or 16 rows (waves) per workgroup
-    return e == nullptr ? 8 : atoi(e);
-  }();
-  if (patch && variant == 0) {
-    const int R = rows == 8 ? 8 : rows == 16 ? 16 : 12;
-    a.tiles_y = eavsr::cdiv(h, R);
-    const long rblocks = (long)a.tiles_x * a.tiles_y * n;
-    dim3 rgrid((unsigned)rblocks, eavsr::cdiv(cout, CO));
-    if (R == 8) return CO == 32 ? launch_reg<1, 8, true>(a, rgrid, st) : launch_reg<2, 8, true>(a, rgrid, st);
-    if (R == 16) return CO == 32 ? launch_reg<1, 16, false>(a, rgrid, st) : launch_reg<2, 16, false>(a, rgrid, st);
-    return CO == 32 ? launch_reg<1, 12, true>(a, rgrid, st) : launch_reg<2, 12, true>(a, rgrid, st);
-  }
-  if (patch && variant == 3) return CO == 32 ? launch_ws<1>(a, grid, st) : launch_ws<2>(a, grid, st);
-  if (patch && variant == 1) {
-    if (CO == 32) hipLaunchKernelGGL(dcnv2_patch_kernel<1>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(dcnv2_patch_kernel<2>, grid, dim3(256), 0, st, a);
+  if (patch && !force_global) {
+    if (CO == 32) hipLaunchKernelGGL(dcnv2_grp_kernel<1>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dcnv2_grp_kernel<2>, grid, dim3(256), 0, st, a);
   } else {
     if (CO == 32) hipLaunchKernelGGL(dcnv2_kernel<1>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dcnv2_kernel<2>, grid, dim3(256), 0, st, a);

@@ -22,7 +22,7 @@ if "convhr" in which:
     for _ in range(2):
         ops.conv2d(hr, w33, b, act="relu")
 if "dcn" in which:
-    off = r(n, 144, h, w) * 1.5
+    off = r(n, 144, h, w) * float(os.environ.get("SIGMA", 1.5))
     mask = torch.rand(n, 72, h, w, device=dev)
     for _ in range(reps):
         ops.modulated_deform_conv2d(x64, off, mask, w33, b, 1, 1, 1, 1, 8)
