@@ -11,6 +11,7 @@ One process drives one GPU (no nn.DataParallel: networks.init_net here does not 
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Dict, List
 
@@ -387,10 +388,70 @@ class EAVSRPModel:
                 out[name] = torch.clamp(v.detach() * 255.0, 0, 255).round()
         return out
 
-    def save_networks(self, path):
-        torch.save({"state_dict": {k: v.cpu() for k, v in self.netEAVSRP.state_dict().items()}}, path)
+    # ---- checkpoint and optimizer files (base_model.py:159-270) ---------------------------------
+    @property
+    def optimizer_names(self):
+        return ["EAVSRP_optimizer_%s" % getattr(self.opt, "optimizer", "Adam")]   # eavsrp_model.py:31
 
-    def load_networks(self, path):
+    def _save_dir(self):
+        d = getattr(self, "save_dir", None) or os.path.join(getattr(self.opt, "checkpoints_dir", "./ckpt"),
+                                                             getattr(self.opt, "name", "eavsr"))
+        os.makedirs(d, exist_ok=True)
+        return d
+
+    def _network_path(self, epoch_or_path):
+        """An int is the reference's epoch (`<save_dir>/<name>_model_<epoch>.pth`, base_model.py:161-162); opt.load_path
+        overrides it on load (base_model.py:182-183); a string is taken as the file itself."""
+        if isinstance(epoch_or_path, int):
+            return os.path.join(self._save_dir(), "%s_model_%d.pth" % (self.model_names[0], epoch_or_path))
+        return epoch_or_path
+
+    def save_networks(self, epoch_or_path):
+        """{'state_dict': cpu tensors} (base_model.py:165-170); with an epoch number the optimizer files are written
+        beside it as the reference does (base_model.py:172)."""
+        path = self._network_path(epoch_or_path)
+        torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.netEAVSRP.state_dict().items()}}, path)
+        if isinstance(epoch_or_path, int) and self.isTrain:
+            self.save_optimizers(epoch_or_path)
+        return path
+
+    def load_networks(self, epoch_or_path):
+        """Every key of the file must exist in the network with the same shape and every parameter of the network
+        must be in the file: the reference `exit()`s on either mismatch (base_model.py:193-213); here it raises."""
+        path = self._network_path(epoch_or_path)
+        if isinstance(epoch_or_path, int) and getattr(self.opt, "load_path", ""):
+            path = self.opt.load_path
         sd = torch.load(path, map_location="cpu")
         sd = sd.get("state_dict", sd)
+        own = self.netEAVSRP.state_dict()
+        unknown = [k for k in sd if k not in own]
+        missing = [k for k in own if k not in sd]
+        if unknown:
+            raise RuntimeError("Saved parameter named [%s] is not in the network (%d such keys)" % (unknown[0], len(unknown)))
+        if missing:
+            raise RuntimeError("Parameter named [%s] is not in %s (%d such keys)" % (missing[0], path, len(missing)))
+        for k, v in sd.items():
+            if tuple(own[k].shape) != tuple(v.shape):
+                raise RuntimeError("While copying the parameter named [%s], whose dimensions in the model are %s and "
+                                   "whose dimensions in the checkpoint are %s." % (k, list(own[k].shape), list(v.shape)))
         self.netEAVSRP.load_state_dict(sd, strict=True)
+        if isinstance(epoch_or_path, int):
+            self.start_epoch = epoch_or_path
+        return path
+
+    def save_optimizers(self, epoch):
+        """One file per optimizer: {'name', 'epoch', 'state_dict'} at <save_dir>/<optimizer name>.pth (base_model.py:251-260)."""
+        assert len(self.optimizers) == len(self.optimizer_names)
+        for name, optimizer in zip(self.optimizer_names, self.optimizers):
+            torch.save({"name": name, "epoch": epoch, "state_dict": optimizer.state_dict()},
+                       os.path.join(self._save_dir(), name + ".pth"))
+
+    def load_optimizers(self, epoch):
+        """base_model.py:262-270: name and epoch recorded in the file must match."""
+        assert len(self.optimizers) == len(self.optimizer_names)
+        for name, optimizer in zip(self.optimizer_names, self.optimizers):
+            state = torch.load(os.path.join(self._save_dir(), name + ".pth"), map_location=self.device)
+            if state["name"] != name or state["epoch"] != epoch:
+                raise RuntimeError("optimizer file %s.pth holds (%s, epoch %s), expected (%s, epoch %s)"
+                                   % (name, state["name"], state["epoch"], name, epoch))
+            optimizer.load_state_dict(state["state_dict"])

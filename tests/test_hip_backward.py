@@ -289,6 +289,63 @@ def test_model_wrapper_training_step(AG, cuda):
     assert tuple(model.data_sr_seq.shape) == (1, 3, 3, 256, 256)
 
 
+def test_checkpoint_optimizer_files_and_eval_harness(AG, cuda, tmp_path):
+    """`<name>_model_<epoch>.pth` = {'state_dict'}, `<optimizer name>.pth` = {'name','epoch',
+    'state_dict'} (base_model.py:159-270), strict loading, resume reproduces the next step; the test
+    loop of test_basic.py on synthetic items."""
+    from eavsr_amd.eavsrp_model import EAVSRPModel
+    from eavsr_amd import harness
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    mk = lambda: Namespace(predict=False, n_frame=3, n_flow=5, scale=4, isTrain=True, gpu_ids=[0], lr=1e-4, beta1=0.9,
+                           beta2=0.999, weight_decay=0.0, npost=350, checkpoints_dir=str(tmp_path), name="run",
+                           optimizer="Adam", load_path="")
+    data = {"lr_seq": synthetic_clip(1, 3, 64, 64, seed=1), "hr_seq": synthetic_clip(1, 3, 256, 256, seed=2), "fname": "x"}
+    model = EAVSRPModel(mk())
+    model.netEAVSRP.load_state_dict(H.filled(H.model_shapes("x4"), "trained_like"), strict=True)
+    for _ in range(2):
+        model.set_input(data, epoch=0)
+        model.optimize_parameters()
+    path = model.save_networks(7)
+    assert path.endswith("run/EAVSRP_model_7.pth") and H.os.path.exists(H.os.path.join(str(tmp_path), "run", "EAVSRP_optimizer_Adam.pth"))
+    blob = torch.load(path, map_location="cpu")
+    assert set(blob) == {"state_dict"} and set(blob["state_dict"]) == set(model.netEAVSRP.state_dict())
+    ob = torch.load(H.os.path.join(str(tmp_path), "run", "EAVSRP_optimizer_Adam.pth"), map_location="cpu")
+    assert ob["name"] == "EAVSRP_optimizer_Adam" and ob["epoch"] == 7 and len(ob["state_dict"]["param_groups"]) == 2
+    model.set_input(data, epoch=0)
+    model.optimize_parameters()          # step 3 of the original run
+    want = {k: v.detach().clone() for k, v in model.netEAVSRP.state_dict().items()}
+
+    resumed = EAVSRPModel(mk())
+    resumed.load_networks(7)
+    resumed.load_optimizers(7)
+    assert resumed.start_epoch == 7
+    resumed.set_input(data, epoch=0)
+    resumed.optimize_parameters()
+    got = resumed.netEAVSRP.state_dict()
+    worst = max((got[k].float() - want[k].float()).abs().max().item() for k in want)
+    assert worst < 1e-6, worst           # restored Adam moments: the same step (float atomics in the backward scatter
+                                         # kernels make it reproducible to rounding, not bit for bit)
+    with pytest.raises(RuntimeError):
+        resumed.load_optimizers(8)       # epoch recorded in the file must match
+    bad = dict(blob["state_dict"])
+    bad.pop("conv_last.bias")
+    torch.save({"state_dict": bad}, H.os.path.join(str(tmp_path), "bad.pth"))
+    with pytest.raises(RuntimeError):
+        resumed.load_networks(H.os.path.join(str(tmp_path), "bad.pth"))
+    bad["conv_last.bias"] = blob["state_dict"]["conv_last.bias"]
+    bad["stray.weight"] = torch.zeros(1)
+    torch.save({"state_dict": bad}, H.os.path.join(str(tmp_path), "bad2.pth"))
+    with pytest.raises(RuntimeError):
+        resumed.load_networks(H.os.path.join(str(tmp_path), "bad2.pth"))
+
+    items = [dict(data), dict(data)]
+    rep = harness.evaluate(resumed, items)
+    assert rep["frames"] == 6 and len(rep["psnr"]) == 2 and rep["psnr"][0] == rep["psnr"][1]
+    vis = resumed.get_current_visuals()
+    assert abs(rep["psnr"][0] - harness.calc_psnr(vis["data_sr_seq"], vis["data_hr_seq"])) < 1e-6
+    assert rep["frames_per_s"] > 0 and resumed.num == 1    # the wrapper skips its first timed call (eavsrp_model.py:104-107)
+
+
 def _dp_worker(rank, world, port, q):
     import os
     import sys

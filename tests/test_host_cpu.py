@@ -92,3 +92,25 @@ def test_synthetic_fill_is_order_independent_and_deterministic():
     assert torch.equal(synthetic_clip(1, 2, 64, 64, 3), synthetic_clip(1, 2, 64, 64, 3))
     c = synthetic_clip(2, 3, 64, 96, 1)
     assert c.shape == (2, 3, 3, 64, 96) and 0 <= c.min() and c.max() < 1
+
+
+# ---- harness (f4): window index maps and PSNR -----------------------------------------
+def test_harness_window_maps_and_psnr():
+    import numpy as np
+    from eavsr_amd import harness as H
+    # test items: scenes of 14 frames cut into two windows of 7 (mvsr4x_dataset.py:130-136)
+    assert H.test_window_starts(42, 14, 7) == [0, 7, 14, 21, 28, 35]
+    with pytest.raises(ValueError):
+        H.test_window_starts(30, 10, 7)
+    # interior key frame: contiguous window
+    assert H.train_window(idx=103, frame=3, n_frame=7, n_seq=50) == [100, 101, 102, 103, 104, 105, 106]
+    # scene start: mirrored about the key frame, never below the first frame of the scene (image 100)
+    assert H.train_window(idx=100, frame=0, n_frame=7, n_seq=50) == [103, 102, 101, 100, 101, 102, 103]
+    assert H.train_window(idx=101, frame=1, n_frame=7, n_seq=50) == [104, 103, 100, 101, 102, 103, 104]
+    # scene end (last frame is image 149): mirrored, never above it
+    w = H.train_window(idx=149, frame=49, n_frame=7, n_seq=50)
+    assert w[:4] == [146, 147, 148, 149] and max(w) == 149 and w[4:] == [148, 147, 146]
+    # PSNR formula (util/util.py:302-320): uniform error of 1 grey level -> 20 log10(255)
+    a = torch.zeros(1, 2, 3, 8, 8)
+    assert abs(H.calc_psnr(a + 1.0, a) - 20 * np.log10(255.0)) < 1e-4
+    assert H.crop_center(torch.arange(36.0).view(1, 6, 6), 2).flatten().tolist() == [14.0, 15.0, 20.0, 21.0]
