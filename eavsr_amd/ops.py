@@ -8,6 +8,7 @@ fp32 CUDA(HIP) tensors; there is no CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -387,7 +388,6 @@ def modulated_deform_conv2d(input: Tensor, offset: Tensor, mask: Tensor, weight:
         raise ValueError(f"offset shape {tuple(offset.shape)} != {(n, deform_groups * 18, h, w)}")
     if tuple(mask.shape) != (n, deform_groups * 9, h, w):
         raise ValueError(f"mask shape {tuple(mask.shape)} != {(n, deform_groups * 9, h, w)}")
-    wp = pack_cache.get([weight])
     b = None if bias is None else _chk(bias.detach(), "bias")
     out = torch.empty((n, cout, h, w), device=x.device, dtype=torch.float32)
     if (cin // deform_groups) % 8 != 0:
@@ -395,10 +395,53 @@ def modulated_deform_conv2d(input: Tensor, offset: Tensor, mask: Tensor, weight:
                                   "unsupported (must be a multiple of 8; the reference uses 64 channels / 8 groups)")
     st = _stream(x)
     px = float(n) * h * w
-    _launch("dcnv2", 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * deform_groups + cout), x,
+    flops, nbytes = 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * deform_groups + cout)
+    if DCN_MODE == "bf16x9" and w % 4 == 0 and x.data_ptr() % 16 == 0:
+        wx = _packed_dcn_x9(weight)
+        _launch("dcnv2_x9", flops, nbytes, x,
+                lambda: lib().eavsr_dcnv2_f32x9(_p(x), _p(offset), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout,
+                                                deform_groups, st), "dcnv2_f32x9")
+        return out
+    wp = pack_cache.get([weight])
+    _launch("dcnv2", flops, nbytes, x,
             lambda: lib().eavsr_dcnv2_f32(_p(x), _p(offset), _p(mask), _p(wp), _p(b), _p(out), n, cin, h, w, cout,
                                           deform_groups, st), "dcnv2")
     return out
+
+
+# How the fp32 contraction of the DCNv2 kernel is carried: "native" = v_mfma_f32_32x32x2_f32 (an fp32 fma chain, the
+# default), "bf16x9" = exact three-way bf16 split of both operands, nine bf16 MFMA partial products accumulated in
+# fp32 (eavsr_dcnv2_f32x9: no operand is rounded, only the accumulation order differs).  Opt-in.
+DCN_MODE = os.environ.get("EAVSR_DCN_MODE", "native")
+
+
+def set_dcn_mode(mode: str) -> None:
+    global DCN_MODE
+    if mode not in ("native", "bf16x9"):
+        raise ValueError(f"dcn mode {mode!r}: 'native' or 'bf16x9'")
+    DCN_MODE = mode
+
+
+_x9_pack_cache = {}
+
+
+def _packed_dcn_x9(weight: Tensor) -> Tensor:
+    key = (id(weight), weight._version)
+    hit = _x9_pack_cache.get(key)
+    if hit is not None and hit[0]() is weight:
+        return hit[1]
+    w = _chk(weight.detach(), "weight")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    nbytes = lib().eavsr_dcn_weight_x9_bytes(cout, cin)
+    if nbytes <= 0:
+        raise NotImplementedError(f"bf16x9 DCN weight shape {tuple(w.shape)} unsupported")
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.int32)
+    with _DeviceOf(w):
+        N.check(lib().eavsr_pack_dcn_weight_x9(_p(w), _p(packed), cout, cin, _stream(w)), "pack_dcn_weight_x9")
+    for k in [k for k in _x9_pack_cache if k[0] == id(weight)]:
+        _x9_pack_cache.pop(k, None)
+    _x9_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key: _x9_pack_cache.pop(k, None)), packed)
+    return packed
 
 
 # ------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 5
+#define EAVSR_ABI_VERSION 6
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -75,6 +75,19 @@ int eavsr_dcnv2_f32(const float* x, const float* offset, const float* mask,
                     const float* weight_packed, const float* bias, float* out,
                     int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
                     int32_t deform_groups, void* stream);
+
+/* Same operation with the 576-deep fp32 contraction carried by the bf16 matrix pipe ("bf16x9"): every fp32 operand
+ * is split EXACTLY into three bf16 terms (hi + mid + lo reproduces all 24 significant bits) and all nine partial
+ * products are accumulated in fp32 -- no operand is rounded; only the accumulation order differs from the fma
+ * chain of eavsr_dcnv2_f32.  weight_x9: eavsr_dcn_weight_x9_bytes(cout, cin) bytes written by
+ * eavsr_pack_dcn_weight_x9 from weight(cout,cin,3,3).  Additionally requires w % 4 == 0 and a 16-byte aligned x
+ * (returns -2 otherwise: call eavsr_dcnv2_f32).  Opt-in; the reference-facing wrappers default to eavsr_dcnv2_f32. */
+int64_t eavsr_dcn_weight_x9_bytes(int32_t cout, int32_t cin);
+int eavsr_pack_dcn_weight_x9(const float* weight, void* weight_x9, int32_t cout, int32_t cin, void* stream);
+int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask,
+                      const void* weight_x9, const float* bias, float* out,
+                      int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                      int32_t deform_groups, void* stream);
 
 /* ---- dense convolution (a9, a10, a11 convs; predictor heads a3/a4/a6; callers f1/f2) ----------
  * replaces torch.nn.Conv2d forward (stride 1, padding k/2, dilation 1, groups 1) as used at

@@ -200,6 +200,56 @@ def test_dcnv2_unsupported_configs_raise(ops, cuda):
                                     None, 2, 1, 1, 1, 8)
 
 
+# ---- a7, bf16x9 contraction (opt-in): exact three-way bf16 split of both operands, nine partial products --------
+@pytest.fixture()
+def dcn_x9(ops):
+    ops.set_dcn_mode("bf16x9")
+    yield ops
+    ops.set_dcn_mode("native")
+
+
+@pytest.mark.parametrize("sigma", [0.0, 0.5, 2.0, 8.0])
+@pytest.mark.parametrize("shape", [(1, 64, 24, 40, 64, 8), (2, 64, 13, 36, 64, 8), (1, 64, 10, 12, 64, 1),
+                                   (1, 16, 9, 32, 32, 2), (1, 64, 7, 8, 40, 8), (1, 64, 21, 68, 96, 4)])
+def test_dcnv2_x9_vs_oracle(dcn_x9, cuda, shape, sigma):
+    n, c, h, w, cout, dg = shape
+    x, off, mask, wt, b = _dcn_inputs(n, c, h, w, cout, dg, sigma)
+    ref = O.dcnv2(x, off, mask, wt, b, 1, 1, 1, 1, dg)
+    with dcn_x9.profile() as prof:
+        out = dcn_x9.modulated_deform_conv2d(g(x, cuda), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), 1, 1, 1, 1, dg)
+    assert list(prof.summary()) == ["dcnv2_x9"]                # the bf16x9 kernel ran, not the native one
+    assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_dcnv2_x9_falls_back_to_native_kernel_on_unaligned_width(dcn_x9, cuda):
+    x, off, mask, wt, b = _dcn_inputs(1, 64, 9, 37, 64, 8, 1.0)   # w % 4 != 0: no LDS window, native kernel
+    ref = O.dcnv2(x, off, mask, wt, b, 1, 1, 1, 1, 8)
+    with dcn_x9.profile() as prof:
+        out = dcn_x9.modulated_deform_conv2d(g(x, cuda), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), 1, 1, 1, 1, 8)
+    assert list(prof.summary()) == ["dcnv2"]
+    assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_dcnv2_x9_error_against_fp64_is_that_of_the_fp32_kernel(ops, cuda):
+    """The split is exact and all nine partial products are kept, so against an fp64 evaluation of the same sums
+    the bf16x9 kernel must be as accurate as the native fp32-MFMA kernel (both only round in the accumulation) --
+    and far inside what rounding the operands to bf16 would give (~4e-3 relative)."""
+    x, off, mask, wt, b = _dcn_inputs(2, 64, 32, 64, 64, 8, 1.5, seed=10)
+    x = x * 3.0 + 0.5                                          # non-zero mean: the running sums are large
+    ref64 = O.dcnv2(x.double(), off.double(), mask.double(), wt.double(), b.double(), 1, 1, 1, 1, 8)
+    scale = ref64.abs().max().item()
+    args = (g(x, cuda), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), 1, 1, 1, 1, 8)
+    ops.set_dcn_mode("native")
+    e_native = (ops.modulated_deform_conv2d(*args).cpu().double() - ref64).abs().max().item() / scale
+    ops.set_dcn_mode("bf16x9")
+    try:
+        e_x9 = (ops.modulated_deform_conv2d(*args).cpu().double() - ref64).abs().max().item() / scale
+    finally:
+        ops.set_dcn_mode("native")
+    assert e_native < 5e-6 and e_x9 < 5e-6, (e_native, e_x9)      # measured: 2.1e-6 and 2.2e-6 (sampler rounding dominates)
+    assert e_x9 <= 1.5 * e_native + 1e-7, (e_native, e_x9)
+
+
 # ------------------------------------------------------------------------------------------ a3/a6 pieces
 @pytest.mark.parametrize("shape", [(1, 64, 12, 16), (2, 64, 45, 80), (1, 64, 33, 130)])
 def test_adapt_frontend_vs_oracle(ops, cuda, shape):

@@ -61,6 +61,12 @@ T("dcnv2 sigma1.5", lambda: ops.modulated_deform_conv2d(x64, off, mask, w33, b, 
 off0 = off * 0
 T("dcnv2 sigma0", lambda: ops.modulated_deform_conv2d(x64, off0, mask, w33, b, 1, 1, 1, 1, 8),
   flops=2 * 64 * 64 * 9 * px, nbytes=4 * px * 344)
+ops.set_dcn_mode("bf16x9")
+T("dcnv2 bf16x9 sigma1.5", lambda: ops.modulated_deform_conv2d(x64, off, mask, w33, b, 1, 1, 1, 1, 8),
+  flops=2 * 64 * 64 * 9 * px, nbytes=4 * px * 344)
+T("dcnv2 bf16x9 sigma0", lambda: ops.modulated_deform_conv2d(x64, off0, mask, w33, b, 1, 1, 1, 1, 8),
+  flops=2 * 64 * 64 * 9 * px, nbytes=4 * px * 344)
+ops.set_dcn_mode(os.environ.get("EAVSR_DCN_MODE", "native"))
 wa, ba, wb, bb = r(128, 1, 3, 3), r(128), r(64, 2, 3, 3), r(64)
 T("adapt_frontend", lambda: ops.adapt_frontend(x64, x64, wa, ba, wb, bb), nbytes=4 * px * 192)
 heads = r(n, 120, h, w)

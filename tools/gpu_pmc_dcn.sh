@@ -2,8 +2,8 @@ R=$PWD
 rm -rf $R/gpurun_out/prof2; mkdir -p $R/gpurun_out/prof2
 cd /tmp && export TMPDIR=/tmp
 export WHICH=dcn REPS=3
-for v in ${VARIANTS:-i patch}; do
-  export EAVSR_DCN_VARIANT=$v
+for v in ${MODES:-native bf16x9}; do
+  export EAVSR_DCN_MODE=$v
   timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --kernel-trace --output-format csv -d $R/gpurun_out/prof2/${v}_a -- python3 $R/tools/bench_kernels.py > /dev/null 2>&1
   timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/prof2/${v}_b -- python3 $R/tools/bench_kernels.py > /dev/null 2>&1
 done
