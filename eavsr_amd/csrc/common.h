@@ -44,7 +44,6 @@ __device__ __forceinline__ int eavsr_xcd_remap(int bid, int nblk) {
 }
 #endif
 
-// spatial tile of the implicit-GEMM conv kernels: 32 rows x 32 columns per 512-thread workgroup,
-// wave w owns rows 4w..4w+3, one 32-pixel MFMA N-tile per row.
-#define EAVSR_CONV_TH 32
+// spatial tile of the implicit-GEMM conv kernels: (32, 16 or 8) rows x 32 columns per 512-thread workgroup,
+// wave w owns NT = 4, 2 or 1 consecutive rows, one 32-pixel MFMA N-tile per row.
 #define EAVSR_CONV_TW 32

@@ -59,12 +59,15 @@ template <int KS> struct ChunkOf { static constexpr int value = (KS == 1) ? 16 :
 // FUSE = true: channel-attention prologue (RCABlock tail, networks.py:447,463-464, fused into the next conv):
 //              two input patches (r, x) per stage and B = r * scale + x formed on the way to the MFMA;
 //              chunks of 4 channels so that two stages still fit the 160 KiB of LDS.
-template <int KS, int MT, bool VEC, bool FUSE = false>
+// NT_  : rows per wave (4, 2 or 1): the tile is 8 NT_ rows x 32 columns.  Small images launch too few 32-row
+//        tiles to occupy 256 CUs (a training crop of 2 x 96 x 96 has 18), so the host picks the tile height that
+//        minimises rounds x (rows + fixed cost) -- eavsr_conv2d_tile_rows().
+template <int KS, int MT, bool VEC, bool FUSE = false, int NT_ = 4>
 struct ConvCfg {
   static constexpr int CK = FUSE ? 4 : ChunkOf<KS>::value;
   static constexpr int NIN = FUSE ? 2 : 1;                 // input patches per stage
-  static constexpr int NT = 4;
-  static constexpr int TH = EAVSR_CONV_TH, TW = EAVSR_CONV_TW;
+  static constexpr int NT = NT_;
+  static constexpr int TH = 8 * NT_, TW = EAVSR_CONV_TW;
   static constexpr int PAD = KS / 2, KK = KS * KS;
   static constexpr int MARG = VEC ? (PAD ? 4 : 0) : PAD;  // columns staged left/right of the tile
   static constexpr int IH = TH + KS - 1, IW = TW + 2 * MARG;
@@ -73,7 +76,7 @@ struct ConvCfg {
   static constexpr int PIECE = VEC ? 256 : 64;            // floats moved by one wave-level DMA
   static constexpr int IN_SEGS = (IN_ELEMS + PIECE - 1) / PIECE;
   static constexpr int IN_PAD = IN_SEGS * PIECE;
-  static constexpr int NW = EAVSR_CONV_TH / NT;            // waves per workgroup (one 4-row strip each)
+  static constexpr int NW = 8;                             // waves per workgroup (one NT-row strip each)
   static constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;    // pieces per wave
   static constexpr int W_ELEMS = CK * KK * CO;
   static constexpr int W_SEGS = (W_ELEMS + 255) / 256;     // one wave-level dwordx4 DMA = 256 floats
@@ -87,9 +90,9 @@ struct ConvCfg {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int KS, int MT, bool VEC, bool FUSE>
+template <int KS, int MT, bool VEC, bool FUSE, int NT_>
 __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
-  using Cfg = ConvCfg<KS, MT, VEC, FUSE>;
+  using Cfg = ConvCfg<KS, MT, VEC, FUSE, NT_>;
   static_assert(!FUSE || VEC, "the fused channel-attention prologue exists for the 16-byte DMA path only");
   constexpr int CK = Cfg::CK, NT = Cfg::NT, TH = Cfg::TH, TW = Cfg::TW, PAD = Cfg::PAD, KK = Cfg::KK;
   constexpr int MARG = Cfg::MARG, IH = Cfg::IH, IW = Cfg::IW, CO = Cfg::CO;
@@ -347,35 +350,61 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 inline int chunk_of(int ks) { return ks == 1 ? 16 : ks == 3 ? 8 : ks == 5 ? 4 : 2; }
 inline int co_tile_of(int cout) { return cout <= 32 ? 32 : 64; }
 
-template <int KS, int MT, bool VEC, bool FUSE = false>
+template <int KS, int MT, bool VEC, bool FUSE = false, int NT_ = 4>
 int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  using Cfg = ConvCfg<KS, MT, VEC, FUSE>;
+  using Cfg = ConvCfg<KS, MT, VEC, FUSE, NT_>;
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<KS, MT, VEC, FUSE>),
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<KS, MT, VEC, FUSE, NT_>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv2d: hipFuncSetAttribute(%zu B of LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, MT, VEC, FUSE>), grid, dim3(64 * Cfg::NW), Cfg::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv2d_mfma_kernel<KS, MT, VEC, FUSE, NT_>), grid, dim3(64 * Cfg::NW), Cfg::LDS_BYTES, st, a);
   return eavsr::launch_status("conv2d");
 }
 
-template <int KS>
+template <int KS, int NT_>
 int launch_ks(const ConvArgs& a, dim3 grid, int CO, bool vec, hipStream_t st) {
-  if (vec) return CO == 32 ? launch_one<KS, 1, true>(a, grid, st) : launch_one<KS, 2, true>(a, grid, st);
-  return CO == 32 ? launch_one<KS, 1, false>(a, grid, st) : launch_one<KS, 2, false>(a, grid, st);
+  if (vec) return CO == 32 ? launch_one<KS, 1, true, false, NT_>(a, grid, st) : launch_one<KS, 2, true, false, NT_>(a, grid, st);
+  return CO == 32 ? launch_one<KS, 1, false, false, NT_>(a, grid, st) : launch_one<KS, 2, false, false, NT_>(a, grid, st);
+}
+
+// rows per wave for an (n, h, w) problem: minimise rounds over the 256 CUs x (rows per tile + fixed per-tile cost).
+// 7x7 (SPyNet only) keeps the 32-row tile.
+inline int tile_rows_of(int n, int h, int w, int ksize) {
+  if (ksize == 7) return 4;
+  int best = 4;
+  long best_cost = -1;
+  for (int nt = 4; nt >= 1; nt >>= 1) {
+    const long tiles = (long)n * eavsr::cdiv(h, 8 * nt) * eavsr::cdiv(w, EAVSR_CONV_TW);
+    const long rounds = (tiles + 255) / 256;
+    const long cost = rounds * (2 * nt + 1);   // fixed cost = half a row-unit
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = nt; }
+  }
+  return best;
+}
+
+template <int KS>
+int launch_nt(const ConvArgs& a, dim3 grid, int CO, bool vec, int nt, hipStream_t st) {
+  if (nt == 1) return launch_ks<KS, 1>(a, grid, CO, vec, st);
+  if (nt == 2) return launch_ks<KS, 2>(a, grid, CO, vec, st);
+  return launch_ks<KS, 4>(a, grid, CO, vec, st);
 }
 
 }  // namespace
 
 extern "C" int32_t eavsr_conv2d_ck(int32_t ksize) { return chunk_of(ksize); }
 
-extern "C" int32_t eavsr_conv2d_tiles(int32_t h, int32_t w) {
-  return eavsr::cdiv(h, EAVSR_CONV_TH) * eavsr::cdiv(w, EAVSR_CONV_TW);
+extern "C" int32_t eavsr_conv2d_tile_rows(int32_t n, int32_t h, int32_t w, int32_t ksize) {
+  return 8 * tile_rows_of(n > 0 ? n : 1, h, w, ksize);
+}
+
+extern "C" int32_t eavsr_conv2d_tiles(int32_t n, int32_t h, int32_t w, int32_t ksize) {
+  return eavsr::cdiv(h, eavsr_conv2d_tile_rows(n, h, w, ksize)) * eavsr::cdiv(w, EAVSR_CONV_TW);
 }
 
 extern "C" int64_t eavsr_packed_weight_elems(int32_t cout, int32_t cin, int32_t ksize) {
@@ -433,8 +462,9 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
   a.ca_out = d->ca_out;
   a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
   a.cin_pad = eavsr::cdiv(d->cin, ck) * ck;
+  const int nt = tile_rows_of(d->n, d->h, d->w, d->ksize);
   a.tiles_x = eavsr::cdiv(d->w, EAVSR_CONV_TW);
-  a.tiles_y = eavsr::cdiv(d->h, EAVSR_CONV_TH);
+  a.tiles_y = eavsr::cdiv(d->h, 8 * nt);
   a.act = d->act;
   a.slope = d->slope;
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
@@ -453,13 +483,15 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
                   -2, "conv2d: the fused channel-attention prologue needs a single 16-byte aligned source, k = 3, "
                       "w %% 4 == 0, cin %% 4 == 0, cin <= 256 and 33..64 output channels; use eavsr_scale_residual_f32 + "
                       "a plain conv otherwise");
+    EAVSR_REQUIRE(nt == 4, -2, "conv2d: the fused channel-attention prologue exists for the 32-row tile only "
+                               "(this problem size runs %d-row tiles)", 8 * nt);
     return launch_one<3, 2, true, true>(a, grid, st);
   }
   EAVSR_REQUIRE(d->ca_x == nullptr && d->ca_out == nullptr, -1, "conv2d: ca_x / ca_out without ca_scale");
   switch (d->ksize) {
-    case 1: return launch_ks<1>(a, grid, CO, vec, st);
-    case 3: return launch_ks<3>(a, grid, CO, vec, st);
-    case 5: return launch_ks<5>(a, grid, CO, vec, st);
-    default: return launch_ks<7>(a, grid, CO, vec, st);
+    case 1: return launch_nt<1>(a, grid, CO, vec, nt, st);
+    case 3: return launch_nt<3>(a, grid, CO, vec, nt, st);
+    case 5: return launch_nt<5>(a, grid, CO, vec, nt, st);
+    default: return launch_ks<7, 4>(a, grid, CO, vec, st);
   }
 }

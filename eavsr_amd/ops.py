@@ -272,7 +272,8 @@ def _conv3x3_smallco(x: Tensor, weights, biases, act, slope, residual):
 def ca_fusable(x: Tensor, cout: int = 64) -> bool:
     """Can the channel-attention tail `r * scale + x` be folded into the next 3x3 conv (16-byte DMA path)?"""
     return (x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[1] % 4 == 0 and x.shape[1] <= 256 and 32 < cout <= 64
-            and x.is_contiguous() and x.data_ptr() % 16 == 0)
+            and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and lib().eavsr_conv2d_tile_rows(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), 3) == 32)
 
 
 def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence[Tensor]],
@@ -311,7 +312,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
     part = None
     if chan_partial:
-        tiles = lib().eavsr_conv2d_tiles(h, w)
+        tiles = lib().eavsr_conv2d_tiles(n, h, w, k)
         part = torch.empty((n, tiles, cout), device=out.device, dtype=torch.float32)
     if residual is not None:
         residual = _chk(residual, "residual")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 6
+#define EAVSR_ABI_VERSION 7
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -108,7 +108,7 @@ typedef struct eavsr_conv2d_desc {
   const float* residual;      /* (n,cout,h,w) or NULL, added after the activation */
   float* out;                 /* (n,cout,h,w) */
   /* optional: per-tile channel sums of `out` for the channel attention (networks.py:444-445):
-   * chan_partial[(n * tiles + tile) * cout + co], tiles = eavsr_conv2d_tiles(h,w); NULL = off */
+   * chan_partial[(n * tiles + tile) * cout + co], tiles = eavsr_conv2d_tiles(n,h,w,ksize); NULL = off */
   float* chan_partial;
   int32_t n, h, w, cin, cout;
   int32_t act;
@@ -126,8 +126,11 @@ typedef struct eavsr_conv2d_desc {
 int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);
 /* input-channel chunk the kernel for this kernel size works in (sources must be multiples of it) */
 int32_t eavsr_conv2d_ck(int32_t ksize);
-/* number of spatial tiles per image (rows of chan_partial per sample) */
-int32_t eavsr_conv2d_tiles(int32_t h, int32_t w);
+/* rows of the spatial tile (32, 16 or 8; 32 columns) the kernel runs an (n, h, w) problem in: small images get
+ * shorter tiles so that the launch still covers the 256 CUs; and the number of tiles per image (= rows of
+ * chan_partial per sample).  The fused channel-attention prologue exists for 32-row tiles only (-2 otherwise). */
+int32_t eavsr_conv2d_tile_rows(int32_t n, int32_t h, int32_t w, int32_t ksize);
+int32_t eavsr_conv2d_tiles(int32_t n, int32_t h, int32_t w, int32_t ksize);
 /* number of floats of the packed weight buffer for (cout, cin, ksize) */
 int64_t eavsr_packed_weight_elems(int32_t cout, int32_t cin, int32_t ksize);
 /* weight (cout,cin,k,k) -> packed [cout_tile][cin_pad][k*k][co_in_tile], zero padded */

@@ -98,12 +98,21 @@ CONV_CASES = [
     (7, [32], 64, 1, 24, 40, "relu", False, False),
     (7, [64], 32, 1, 6, 10, "relu", False, False),
     (7, [16], 2, 1, 48, 80, None, False, False),
+    # the host picks the tile height from the tile count (eavsr_conv2d_tile_rows): everything above runs 8-row
+    # tiles; these run 16-row (4 x 9 x 5 tiles) and 32-row (10 x 5 x 5 tiles) tiles
+    (3, [64], 64, 4, 133, 156, "relu", True, True),
+    (3, [64, 64], 64, 10, 133, 156, "lrelu", True, True),
+    (5, [64], 120, 4, 133, 156, None, False, False),
+    (1, [64, 64, 64], 64, 10, 133, 156, None, False, False),
+    (3, [18], 2, 10, 130, 155, None, False, False),
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"k{c[0]}_c{'+'.join(map(str, c[1]))}_o{c[2]}_{c[4]}x{c[5]}")
 def test_conv2d_vs_torch_cpu(ops, cuda, case):
     k, chans, cout, n, h, w, act, use_res, use_part = case
+    if h > 100:   # the large cases exist to cover the taller tiles
+        assert ops.lib().eavsr_conv2d_tile_rows(n, h, w, k) == (16 if n == 4 else 32)
     cin = sum(chans)
     srcs = [cases.randn(10 + i, n, c, h, w) for i, c in enumerate(chans)]
     wt = cases.randn(20, cout, cin, k, k, scale=1.0 / (cin * k * k) ** 0.5)
@@ -316,8 +325,10 @@ def test_channel_attention_pieces(ops, cuda):
 
 
 def test_conv2d_fused_channel_attention_prologue(ops, cuda):
-    """conv(r * scale + x) with the side output of the effective input == scale_residual followed by conv"""
-    n, c, h, w = 2, 64, 37, 44
+    """conv(r * scale + x) with the side output of the effective input == scale_residual followed by conv
+    (the fused prologue exists for the 32-row tile, which the host picks when it fills the CUs: 10 x 5 x 5 tiles here)"""
+    n, c, h, w = 10, 64, 133, 156
+    assert ops.ca_fusable(torch.zeros(n, c, h, w, device=cuda))
     r, x = cases.randn(1, n, c, h, w), cases.randn(2, n, c, h, w)
     scale = cases.rand(3, n, c)
     wt = cases.randn(4, 64, c, 3, 3, scale=0.05)

@@ -27,7 +27,10 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.eavsr_version()
     # pure host helpers (no device work)
     assert lib.eavsr_conv2d_ck(3) == 8 and lib.eavsr_conv2d_ck(7) == 2 and lib.eavsr_conv2d_ck(5) == 4 and lib.eavsr_conv2d_ck(1) == 16
-    assert lib.eavsr_conv2d_tiles(180, 320) == 6 * 10
+    assert lib.eavsr_conv2d_tile_rows(4, 180, 320, 3) == 32 and lib.eavsr_conv2d_tiles(4, 180, 320, 3) == 6 * 10
+    # a training crop launches too few 32-row tiles for 256 CUs: 8-row tiles
+    assert lib.eavsr_conv2d_tile_rows(2, 96, 96, 3) == 8 and lib.eavsr_conv2d_tiles(2, 96, 96, 3) == 12 * 3
+    assert lib.eavsr_conv2d_tile_rows(2, 96, 96, 7) == 32
     assert lib.eavsr_packed_weight_elems(64, 64, 3) == 64 * 64 * 9
     assert lib.eavsr_packed_weight_elems(120, 64, 5) == 2 * 64 * 25 * 64
     assert lib.eavsr_packed_weight_elems(2, 18, 3) == 24 * 9 * 32
