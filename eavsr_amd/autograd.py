@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple, Union
 
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -32,6 +34,28 @@ def _needs_grad(*ts) -> bool:
 
 
 # ------------------------------------------------------------------------------------------ conv
+# dgrad operand of a conv: the weight with its taps flipped and (cout, cin) transposed, for the source channels
+# c0 .. c0+cs.  A weight is used once per frame and branch, so within a step the same operand is asked for 7-28
+# times: it is built once per weight version (and, being the same tensor object, its packed form is then also a
+# hit in ops.pack_cache).
+_dgrad_cache = {}
+
+
+def _dgrad_weight(ws, c0: int, cs: int) -> Tensor:
+    key = tuple((id(w), w._version) for w in ws) + (c0, cs)
+    hit = _dgrad_cache.get(key)
+    if hit is not None and all(r() is w for r, w in zip(hit[0], ws)):
+        return hit[1]
+    W = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
+    wt = W.detach()[:, c0:c0 + cs].flip(2, 3).transpose(0, 1).contiguous()   # (cs, cout, k, k)
+    ids = {id(w) for w in ws}
+    for k_ in [k_ for k_ in _dgrad_cache if k_[-2:] == (c0, cs) and any(i in ids for i, _ in k_[:-2])]:
+        _dgrad_cache.pop(k_, None)
+    refs = tuple(weakref.ref(w, lambda _r, k_=key: _dgrad_cache.pop(k_, None)) for w in ws)
+    _dgrad_cache[key] = (refs, wt)
+    return wt
+
+
 class _ConvFn(Function):
     @staticmethod
     def forward(ctx, act, slope, n_w, has_bias, has_res, n_src, *ts):
@@ -62,7 +86,6 @@ class _ConvFn(Function):
         need_res = need[o] if has_res else False
         o += 1 if has_res else 0
         need_src = need[o:o + n_src]
-        W = ws[0] if n_w == 1 else torch.cat(ws, 0)
         dws: List[Optional[Tensor]] = [None] * n_w
         if any(need_w):
             dW = ops.conv_wgrad(g, srcs, k)
@@ -82,8 +105,7 @@ class _ConvFn(Function):
         for i, s in enumerate(srcs):
             cs = int(s.shape[1])
             if need_src[i]:
-                wt = W[:, c0:c0 + cs].flip(2, 3).transpose(0, 1).contiguous()   # (cs, cout, k, k)
-                dsrcs.append(ops.conv2d(g, wt, None))
+                dsrcs.append(ops.conv2d(g, _dgrad_weight(ws, c0, cs), None))
             else:
                 dsrcs.append(None)
             c0 += cs
