@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="fp32 (default, the BASELINE headline: exact fp32 everywhere) or a 16-bit NHWC residual backbone "
                          "(BASELINE.json configs[2] / [4]); the 16-bit runs are reported under their own metric name")
+    ap.add_argument("--f32-mode", default="native", choices=["native", "bf16x9"],
+                    help="how the fp32 contractions of the 3x3 convolutions and of DCNv2 are carried: native = fp32 MFMA "
+                         "(default, the headline); bf16x9 = both operands split EXACTLY into three bf16 terms, all nine "
+                         "partial products accumulated in fp32 on the bf16 matrix pipe (no operand is rounded; reported "
+                         "under its own metric name)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: the BASELINE metric (default). train: BASELINE.json configs[3], a data-parallel "
                          "training step (2 clips/GPU x 7 x 3 x 96 x 96, L1 loss, Adam, one RCCL all-reduce on the "
@@ -193,6 +198,9 @@ def main():
     if args.backbone_dtype != "fp32":
         from eavsr_amd import networks as _nw
         _nw.set_backbone_dtype(args.backbone_dtype)
+    if args.f32_mode != "native":
+        ops.set_conv_mode(args.f32_mode)
+        ops.set_dcn_mode(args.f32_mode)
     n, t, h, w = args.clips, args.frames, args.height, args.width
     clips = synthetic_clip(n, t, h, w, seed=rank).to(device)   # resident in HBM before the timed region
 
@@ -216,7 +224,8 @@ def main():
 
     line = {
         "metric": "SR frames/sec at 4x 7-frame 180x320->720x1280" +
-                  ("" if args.backbone_dtype == "fp32" else f" [{args.backbone_dtype} residual backbone, not the fp32 headline]"),
+                  ("" if args.backbone_dtype == "fp32" else f" [{args.backbone_dtype} residual backbone, not the fp32 headline]") +
+                  ("" if args.f32_mode == "native" else " [fp32 via exact bf16x9 split products, opt-in mode]"),
         "value": value,
         "unit": "frames/s",
         "n_gpus": world,
@@ -226,7 +235,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.backbone_dtype == "fp32" else f"{args.backbone_dtype} backbone + f32",
+        "dtype": ("f32" if args.backbone_dtype == "fp32" else f"{args.backbone_dtype} backbone + f32") +
+                 ("" if args.f32_mode == "native" else " (3x3 conv / DCNv2 contractions: exact 3 x bf16 operand split, 9 products, f32 accumulate)"),
         "data": "synthetic",
         "config": {"workload": f"eavsrp x4 inference, {n} clips/GPU x {t} frames x 3 x {h} x {w} fp32 "
                                f"(BASELINE.json configs[1]), weights: seeded '{args.preset}' init",
@@ -255,17 +265,18 @@ def main():
                     "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
                     "share_of_step": v["ms"] / total_ms}
 
-        dom = entry("conv3x3_64to64", "mfma")
+        dom = entry("conv3x3_64to64" if args.f32_mode == "native" else "conv3x3_64to64_x9", "mfma")
         if args.backbone_dtype != "fp32":
             e16 = entry("conv3x3_64to64_h16", "hbm")
             if e16:
                 line.setdefault("kernels_16bit", []).append(e16)
         if dom is not None:
             line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-            line["roofline"]["kernel"] = "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)"
+            line["roofline"]["kernel"] = ("conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)" if args.f32_mode == "native"
+                                          else "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)")
             line["roofline"]["avg_ms"] = dom["avg_ms"]
             line["roofline"]["share_of_step"] = dom["share_of_step"]
-        line["kernels"] = [e for e in (entry("dcnv2", "hbm"), entry("flow_warp", "hbm"),
+        line["kernels"] = [e for e in (entry("dcnv2" if args.f32_mode == "native" else "dcnv2_x9", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120", "mfma")) if e]
         line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
@@ -276,7 +287,7 @@ def main():
         if os.path.exists(pmc):
             try:
                 tr = json.load(open(pmc))
-                if "roofline" in line:
+                if "roofline" in line and args.f32_mode == "native":
                     line["roofline"]["traffic"] = tr.get("conv3x3_64to64")
                 for e in line["kernels"]:
                     e["traffic"] = tr.get(e["kernel"])

@@ -348,6 +348,14 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError("ca_out needs ca")
     st = _stream(out)
     px = float(n) * h * w
+    if (CONV_MODE == "bf16x9" and k == 3 and ca is None and w % 4 == 0
+            and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs)
+            and lib().eavsr_conv2d_tile_rows(n, h, w, 3) == 32):
+        wx = _packed_x9(weights)
+        _launch(f"conv3x3_{cin}to{cout}_x9", 2.0 * cin * cout * 9 * px,
+                4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+                lambda: lib().eavsr_conv3x3_f32x9(C.byref(d), _p(wx), st), "conv3x3_f32x9")
+        return out if not chan_partial else (out, part)
     _launch(f"conv{k}x{k}_{cin}to{cout}" + ("_ca" if ca is not None else ""), 2.0 * cin * cout * k * k * px,
             4.0 * px * (cin * (1 if ca is None else (3 if ca_out else 2)) + cout + (cout if residual is not None else 0)), out,
             lambda: lib().eavsr_conv2d_f32(C.byref(d), st), "conv2d")
@@ -426,23 +434,46 @@ def set_dcn_mode(mode: str) -> None:
 _x9_pack_cache = {}
 
 
-def _packed_dcn_x9(weight: Tensor) -> Tensor:
-    key = (id(weight), weight._version)
+def _packed_x9(weights: Sequence[Tensor]) -> Tensor:
+    """Pre-split (3 x bf16) weight slab of a 3x3 weight -- or of several stacked along cout -- for the bf16x9 kernels;
+    cached per weight objects and versions, verified by identity (as pack_cache)."""
+    key = tuple((id(w), w._version) for w in weights)
     hit = _x9_pack_cache.get(key)
-    if hit is not None and hit[0]() is weight:
+    if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
         return hit[1]
-    w = _chk(weight.detach(), "weight")
+    w = weights[0] if len(weights) == 1 else torch.cat([x.detach() for x in weights], 0)
+    w = _chk(w.detach(), "weight")
     cout, cin = int(w.shape[0]), int(w.shape[1])
+    if tuple(w.shape[2:]) != (3, 3):
+        raise NotImplementedError("bf16x9 kernels are 3x3")
     nbytes = lib().eavsr_dcn_weight_x9_bytes(cout, cin)
     if nbytes <= 0:
-        raise NotImplementedError(f"bf16x9 DCN weight shape {tuple(w.shape)} unsupported")
+        raise NotImplementedError(f"bf16x9 weight shape {tuple(w.shape)} unsupported")
     packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.int32)
     with _DeviceOf(w):
         N.check(lib().eavsr_pack_dcn_weight_x9(_p(w), _p(packed), cout, cin, _stream(w)), "pack_dcn_weight_x9")
-    for k in [k for k in _x9_pack_cache if k[0] == id(weight)]:
+    ids = {id(x) for x in weights}
+    for k in [k for k in _x9_pack_cache if any(i in ids for i, _ in k)]:
         _x9_pack_cache.pop(k, None)
-    _x9_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key: _x9_pack_cache.pop(k, None)), packed)
+    refs = tuple(weakref.ref(x, lambda _r, k=key: _x9_pack_cache.pop(k, None)) for x in weights)
+    _x9_pack_cache[key] = (refs, packed)
     return packed
+
+
+def _packed_dcn_x9(weight: Tensor) -> Tensor:
+    return _packed_x9([weight])
+
+
+# How the fp32 contraction of the 3x3 convolutions is carried: "native" = v_mfma_f32_32x32x2_f32 (default), "bf16x9" =
+# exact three-way bf16 split of both operands, nine partial products in fp32 (eavsr_conv3x3_f32x9).  Opt-in.
+CONV_MODE = os.environ.get("EAVSR_CONV_MODE", "native")
+
+
+def set_conv_mode(mode: str) -> None:
+    global CONV_MODE
+    if mode not in ("native", "bf16x9"):
+        raise ValueError(f"conv mode {mode!r}: 'native' or 'bf16x9'")
+    CONV_MODE = mode
 
 
 # ------------------------------------------------------------------------------------------

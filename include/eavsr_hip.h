@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 7
+#define EAVSR_ABI_VERSION 8
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -124,6 +124,13 @@ typedef struct eavsr_conv2d_desc {
 } eavsr_conv2d_desc;
 
 int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);
+/* Opt-in "bf16x9" form of the 3x3 convolution (same descriptor, same tensors, same epilogue): both fp32 operands
+ * are split EXACTLY into three bf16 terms and all nine partial products are accumulated in fp32 on
+ * v_mfma_f32_32x32x16_bf16 (see eavsr_dcnv2_f32x9).  weight_x9 comes from eavsr_pack_dcn_weight_x9 on the
+ * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  Requires ksize 3, w % 4 == 0, 16-byte aligned sources
+ * with channels % 8 == 0, no fused channel-attention prologue, and a problem size that runs 32-row tiles
+ * (eavsr_conv2d_tile_rows); returns -2 otherwise and the caller uses eavsr_conv2d_f32.                          */
+int eavsr_conv3x3_f32x9(const eavsr_conv2d_desc* desc, const void* weight_x9, void* stream);
 /* input-channel chunk the kernel for this kernel size works in (sources must be multiples of it) */
 int32_t eavsr_conv2d_ck(int32_t ksize);
 /* rows of the spatial tile (32, 16 or 8; 32 columns) the kernel runs an (n, h, w) problem in: small images get

@@ -155,6 +155,31 @@ def test_batch_of_clips_equals_single_clips(nets, cuda):
     assert H.maxabs(both.cpu(), one.cpu()) <= 1e-5
 
 
+def test_forward_with_bf16x9_contractions_equals_the_native_forward(nets, cuda):
+    """The opt-in bf16x9 kernels (exact three-way operand split, nine partial products) only change the
+    accumulation order: at the BASELINE size, where they engage, the whole forward must agree with the native
+    fp32 forward far inside the 1e-3 parity tolerance -- and must really have run them."""
+    from eavsr_amd import ops
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    net, _ = _model(nets, cuda, "x4", "trained_like")
+    clips = synthetic_clip(4, 3, 180, 320, seed=7).to(cuda)
+    with torch.no_grad():
+        ref = net(clips)
+        ops.set_conv_mode("bf16x9")
+        ops.set_dcn_mode("bf16x9")
+        try:
+            with ops.profile() as prof:
+                got = net(clips)
+            names = set(prof.summary())
+        finally:
+            ops.set_conv_mode("native")
+            ops.set_dcn_mode("native")
+    assert "conv3x3_64to64_x9" in names and "dcnv2_x9" in names and "conv3x3_64to64" not in names
+    diff = H.maxabs(got.cpu(), ref.cpu())
+    assert diff <= 2e-5, diff
+    assert O.psnr_255(got.cpu(), ref.cpu()) > 100.0
+
+
 def test_model_rejects_cpu_and_small_inputs(nets, cuda):
     net, _ = _model(nets, cuda, "x4", "default")
     with pytest.raises(AssertionError):

@@ -14,5 +14,14 @@ cd $R
 find gpurun_out/prof/bench -name "*kernel_trace.csv" -size +30M -delete
 python3 tools/summarize_prof.py gpurun_out/prof > gpurun_out/prof/summary.txt 2>&1
 cat gpurun_out/prof/summary.txt | head -60
+# bench.py reads profiles/traffic.json (bench kernel names -> bytes per launch): regenerate it from this visit's PMC passes
+python3 - <<'PY'
+import json
+r = json.load(open('gpurun_out/prof/traffic.json'))
+out = {'conv3x3_64to64': r['conv2d_mfma_kernel']['total_bytes'], 'dcnv2': r['dcnv2']['total_bytes'], 'flow_warp': r['flow_warp_kernel']['total_bytes'],
+       'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950; bytes per launch at 4x64x180x320'}
+json.dump(out, open('profiles/traffic.json', 'w'), indent=1)
+json.dump(out, open('gpurun_out/prof/traffic_bench.json', 'w'), indent=1)
+PY
 timeout 600 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.err
 tail -c 1200 gpurun_out/bench_${TAG}.json
