@@ -80,25 +80,61 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
       const int ty = t % a.tiles_y;
       const int bn = t / a.tiles_y;
       const int y0 = ty * TH, x0 = tx * TW;
+      // Stage the tiles in batches of 16 loads per thread, every load of a batch issued before its first LDS
+      // write: a load / wait / write loop serialises ~75 HBM latencies per tile (this kernel is latency-bound at
+      // training-crop sizes).  Loads go through a wave-uniform base + 32-bit byte offset.
+      constexpr int A_N = 64 * PX, B_N = 64 * IH * IW;
+      constexpr int BATCH = 16;
+      const char* dyb = reinterpret_cast<const char*>(a.dy + ((size_t)bn * a.cout_total + a.co0) * plane);
+      const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin_src + a.ci0) * plane);
       __syncthreads();  // previous tile's MFMAs are done with the LDS tiles
       // dY tile: 64 channels x PX pixels (zero beyond the image / beyond co_valid)
-      for (int e = tid; e < 64 * PX; e += 512) {
-        const int co = e / PX, p = e - co * PX;
-        const int gy = y0 + p / TW, gx = x0 + (p % TW);
-        float v = 0.f;
-        if (co < a.co_valid && gy < h && gx < w)
-          v = a.dy[((size_t)bn * a.cout_total + a.co0 + co) * plane + (size_t)gy * w + gx];
-        sA[co * PA + p] = v;
+#pragma unroll 1
+      for (int e0 = 0; e0 < A_N; e0 += BATCH * 512) {
+        float tv_[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+          const int e = min(e0 + tid + i * 512, A_N - 1);
+          const int co = e / PX, p = e - co * PX;
+          const int gy = y0 + p / TW, gx = x0 + (p % TW);
+          const bool ok = co < a.co_valid && gy < h && gx < w;
+          const unsigned off = ((unsigned)min(co, a.co_valid - 1) * (unsigned)plane + (unsigned)(min(gy, h - 1) * w + min(gx, w - 1))) * 4u;
+          const float v = *reinterpret_cast<const float*>(dyb + off);
+          tv_[i] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+          const int e = e0 + tid + i * 512;
+          if (e < A_N) {
+            const int co = e / PX, p = e - co * PX;
+            sA[co * PA + p] = tv_[i];
+          }
+        }
       }
       // X patch: 64 channels x IH x IW (zero padding)
-      for (int e = tid; e < 64 * IH * IW; e += 512) {
-        const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
-        const int r = rem / IW, c = rem - r * IW;
-        const int gy = y0 - PAD + r, gx = x0 - PAD + c;
-        float v = 0.f;
-        if (ci < a.ci_valid && gy >= 0 && gy < h && gx >= 0 && gx < w)
-          v = a.x[((size_t)bn * a.cin_src + a.ci0 + ci) * plane + (size_t)gy * w + gx];
-        sB[ci * PB + rem] = v;
+#pragma unroll 1
+      for (int e0 = 0; e0 < B_N; e0 += BATCH * 512) {
+        float tv_[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+          const int e = min(e0 + tid + i * 512, B_N - 1);
+          const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
+          const int r = rem / IW, c = rem - r * IW;
+          const int gy = y0 - PAD + r, gx = x0 - PAD + c;
+          const bool ok = ci < a.ci_valid && gy >= 0 && gy < h && gx >= 0 && gx < w;
+          const unsigned off = ((unsigned)min(ci, a.ci_valid - 1) * (unsigned)plane +
+                                (unsigned)(min(max(gy, 0), h - 1) * w + min(max(gx, 0), w - 1))) * 4u;
+          const float v = *reinterpret_cast<const float*>(xb + off);
+          tv_[i] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+          const int e = e0 + tid + i * 512;
+          if (e < B_N) {
+            const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
+            sB[ci * PB + rem] = tv_[i];
+          }
+        }
       }
       __syncthreads();
       // K loop over pixel pairs: pixel p = 2 kk + half -> (row p / 32, col p % 32)
