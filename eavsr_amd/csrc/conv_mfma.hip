@@ -294,7 +294,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
         float v = acc[m][t][r] + b;
         if (a.act == EAVSR_ACT_RELU) v = fmaxf(v, 0.f);
         else if (a.act == EAVSR_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+#ifdef EAVSR_CONV_EXP_NOSTORE   // timing ablation only (tools/gpu_conv_ablate.py)
+        if (cok && xok && gy < h && v == 12345.678f) {
+#else
         if (cok && xok && gy < h) {
+#endif
           const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
           sum += v;
           if (a.residual) v += a.residual[o];

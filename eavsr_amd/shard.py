@@ -53,13 +53,20 @@ def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
         if backend is None:
             # RCCL ("nccl") on GPUs; EAVSR_DIST_BACKEND=gloo lets several ranks share one GPU in tests
             backend = os.environ.get("EAVSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            # one process per GPU: bind this process to its device BEFORE the communicator exists, so that RCCL's
+            # collectives (and barrier) never have to guess the device from the rank
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device=None) -> float:

@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+export EAVSR_DIST_BACKEND=gloo
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 --clips 2 --no-cpu-baseline 2>&1 | tail -2 | cut -c1-300
