@@ -145,12 +145,14 @@ class _FlowWarpFn(Function):
         return dx, (dflow if ctx.needs_input_grad[1] else None), (dflow if flow2 is not None and ctx.needs_input_grad[2] else None)
 
 
-def flow_warp(x, flow, padding_mode="zeros", flow2=None, flow_layout="nchw"):
+def flow_warp(x, flow, padding_mode="zeros", flow2=None, flow_layout="nchw", interpolation="bilinear",
+              align_corners=True):
     if not _needs_grad(x, flow, flow2):
-        return ops.flow_warp(x, flow, padding_mode=padding_mode, flow2=flow2, flow_layout=flow_layout)
-    if padding_mode != "zeros":
-        raise NotImplementedError("flow_warp backward exists for padding_mode='zeros' (border is only used inside the "
-                                  "frozen SPyNet)")
+        return ops.flow_warp(x, flow, padding_mode=padding_mode, flow2=flow2, flow_layout=flow_layout,
+                             interpolation=interpolation, align_corners=align_corners)
+    if padding_mode != "zeros" or interpolation != "bilinear" or not align_corners:
+        raise NotImplementedError("flow_warp backward exists for the configuration the trainable path uses (bilinear, "
+                                  "padding_mode='zeros', align_corners=True; border is only used inside the frozen SPyNet)")
     if flow_layout == "nhwc":
         flow = flow.permute(0, 3, 1, 2)
         flow2 = None if flow2 is None else flow2.permute(0, 3, 1, 2)

@@ -85,6 +85,88 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(
   }
 }
 
+// The other grid_sample modes the reference's signature admits (interpolation='nearest', padding_mode=
+// 'reflection', align_corners=False; networks.py:699-739 passes them straight to F.grid_sample).  Off the hot path:
+// one kernel with run-time switches, same thread mapping, coordinate arithmetic as aten's grid_sampler.
+__device__ __forceinline__ float reflect_coord(float in, int twice_low, int twice_high) {
+  if (twice_low == twice_high) return 0.f;
+  const float mn = (float)twice_low / 2.f;
+  const float span = (float)(twice_high - twice_low) / 2.f;
+  in = fabsf(in - mn);
+  const float extra = fmodf(in, span);
+  const int flips = (int)floorf(in / span);
+  return (flips % 2 == 0) ? extra + mn : span - extra + mn;
+}
+
+__global__ __launch_bounds__(256) void flow_warp_generic_kernel(
+    const float* __restrict__ x, const float* __restrict__ flow, const float* __restrict__ flow2,
+    float* __restrict__ out, int n, int c, int h, int w, long fs_n, long fs_c, long fs_y, long fs_x,
+    int c_chunks, int tiles_x, int tiles_y, int padmode, int nearest, int align) {
+  int lid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = lid % tiles_x;
+  lid /= tiles_x;
+  const int ty = lid % tiles_y;
+  lid /= tiles_y;
+  const int c0 = (lid % c_chunks) * kChanPerThread;
+  const int bn = lid / c_chunks;
+  const int px = tx * 64 + threadIdx.x;
+  const int py = ty * 4 + threadIdx.y;
+  if (px >= w || py >= h) return;
+  const long fo = (long)bn * fs_n + (long)py * fs_y + (long)px * fs_x;
+  float fx = flow[fo], fy = flow[fo + fs_c];
+  if (flow2 != nullptr) {
+    fx += flow2[fo];
+    fy += flow2[fo + fs_c];
+  }
+  const float nx = 2.0f * ((float)px + fx) / (float)max(w - 1, 1) - 1.0f;
+  const float ny = 2.0f * ((float)py + fy) / (float)max(h - 1, 1) - 1.0f;
+  float ix = align ? ((nx + 1.0f) / 2.0f) * (float)(w - 1) : ((nx + 1.0f) * (float)w - 1.0f) / 2.0f;
+  float iy = align ? ((ny + 1.0f) / 2.0f) * (float)(h - 1) : ((ny + 1.0f) * (float)h - 1.0f) / 2.0f;
+  if (padmode == EAVSR_PAD_REFLECTION) {
+    ix = align ? reflect_coord(ix, 0, 2 * (w - 1)) : reflect_coord(ix, -1, 2 * w - 1);
+    iy = align ? reflect_coord(iy, 0, 2 * (h - 1)) : reflect_coord(iy, -1, 2 * h - 1);
+  }
+  if (padmode != EAVSR_PAD_ZEROS) {
+    ix = fminf((float)(w - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(h - 1), fmaxf(iy, 0.0f));
+  }
+  ix = fminf(fmaxf(ix, -4.0f), (float)w + 4.0f);
+  iy = fminf(fmaxf(iy, -4.0f), (float)h + 4.0f);
+  const size_t plane = (size_t)h * w;
+  const float* xp = x + ((size_t)bn * c + c0) * plane;
+  float* op = out + ((size_t)bn * c + c0) * plane + (size_t)py * w + px;
+  const int cend = min(kChanPerThread, c - c0);
+  if (nearest) {
+    const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);   // round half to even, as aten
+    const bool ok = xn >= 0 && xn < w && yn >= 0 && yn < h;
+    const int idx = min(max(yn, 0), h - 1) * w + min(max(xn, 0), w - 1);
+    for (int cc = 0; cc < cend; ++cc) op[(size_t)cc * plane] = ok ? xp[(size_t)cc * plane + idx] : 0.f;
+    return;
+  }
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const int x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx0, wy1 = iy - fy0;
+  const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+  const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x1 >= 0) & (x1 < w);
+  const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y1 >= 0) & (y1 < h);
+  const float w_nw = (vx0 & vy0) ? wx0 * wy0 : 0.0f;
+  const float w_ne = (vx1 & vy0) ? wx1 * wy0 : 0.0f;
+  const float w_sw = (vx0 & vy1) ? wx0 * wy1 : 0.0f;
+  const float w_se = (vx1 & vy1) ? wx1 * wy1 : 0.0f;
+  const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+  const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+  const int i_nw = cy0 * w + cx0, i_ne = cy0 * w + cx1, i_sw = cy1 * w + cx0, i_se = cy1 * w + cx1;
+  for (int cc = 0; cc < cend; ++cc) {
+    const float* p = xp + (size_t)cc * plane;
+    float v = p[i_nw] * w_nw;
+    v += p[i_ne] * w_ne;
+    v += p[i_sw] * w_sw;
+    v += p[i_se] * w_se;
+    op[(size_t)cc * plane] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int eavsr_flow_warp_f32(const float* x, const float* flow, const float* flow2, float* out,
@@ -94,8 +176,10 @@ extern "C" int eavsr_flow_warp_f32(const float* x, const float* flow, const floa
   EAVSR_REQUIRE(n >= 0 && c >= 0 && h >= 0 && w >= 0, -1, "flow_warp: negative dimension");
   EAVSR_REQUIRE(flow_layout == EAVSR_FLOW_NCHW || flow_layout == EAVSR_FLOW_NHWC, -1,
                 "flow_warp: flow_layout %d", flow_layout);
-  EAVSR_REQUIRE(padding_mode == EAVSR_PAD_ZEROS || padding_mode == EAVSR_PAD_BORDER, -2,
-                "flow_warp: padding_mode %d unsupported (the reference uses zeros and border)", padding_mode);
+  const int padmode = padding_mode & 3;
+  const int nearest = (padding_mode & EAVSR_WARP_NEAREST) != 0, align = (padding_mode & EAVSR_WARP_NO_ALIGN_CORNERS) == 0;
+  EAVSR_REQUIRE(padmode <= EAVSR_PAD_REFLECTION && (padding_mode & ~(3 | EAVSR_WARP_NEAREST | EAVSR_WARP_NO_ALIGN_CORNERS)) == 0, -2,
+                "flow_warp: padding_mode / flags 0x%x unsupported", padding_mode);
   EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "flow_warp: plane too large");
   if (n == 0 || c == 0 || h == 0 || w == 0) return 0;
   long fs_n, fs_c, fs_y, fs_x;
@@ -109,7 +193,10 @@ extern "C" int eavsr_flow_warp_f32(const float* x, const float* flow, const floa
   const long nblk = (long)tiles_x * tiles_y * c_chunks * n;
   EAVSR_REQUIRE(nblk < (1L << 31), -1, "flow_warp: too many tiles");
   dim3 grid((unsigned)nblk), block(64, 4, 1);
-  if (padding_mode == EAVSR_PAD_ZEROS)
+  if (nearest || !align || padmode == EAVSR_PAD_REFLECTION)
+    hipLaunchKernelGGL(flow_warp_generic_kernel, grid, block, 0, eavsr::as_stream(stream), x, flow, flow2, out, n, c, h, w,
+                       fs_n, fs_c, fs_y, fs_x, c_chunks, tiles_x, tiles_y, padmode, nearest, align);
+  else if (padmode == EAVSR_PAD_ZEROS)
     hipLaunchKernelGGL(flow_warp_kernel<EAVSR_PAD_ZEROS>, grid, block, 0, eavsr::as_stream(stream), x, flow,
                        flow2, out, n, c, h, w, fs_n, fs_c, fs_y, fs_x, c_chunks, tiles_x, tiles_y);
   else

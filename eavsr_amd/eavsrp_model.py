@@ -31,9 +31,8 @@ Tensor = torch.Tensor
 # ---------------------------------------------------------------------------------------------
 def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_corners=True):
     """Warp `x` (n,c,h,w) by `flow` (n,h,w,2): [...,0] = x displacement, [...,1] = y, in pixels."""
-    if interpolation != "bilinear" or not align_corners:
-        raise NotImplementedError("the reference path only uses bilinear, align_corners=True")
-    return AG.flow_warp(x, flow, padding_mode=padding_mode, flow_layout="nhwc")
+    return AG.flow_warp(x, flow, padding_mode=padding_mode, flow_layout="nhwc", interpolation=interpolation,
+                        align_corners=align_corners)
 
 
 # ---------------------------------------------------------------------------------------------

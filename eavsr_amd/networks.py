@@ -100,9 +100,8 @@ def _run_fused(seq_mod: nn.Sequential, x: TensorOrList, residual=None, chan_part
 # --------------------------------------------------------------------------------------------
 def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_corners=True):
     """Warp `x` (n,c,h,w) by `flow` (n,2,h,w; channel 0 = x displacement, 1 = y, in pixels)."""
-    if interpolation != "bilinear" or not align_corners:
-        raise NotImplementedError("the reference path only uses bilinear, align_corners=True")
-    return AG.flow_warp(x, flow, padding_mode=padding_mode, flow_layout="nchw")
+    return AG.flow_warp(x, flow, padding_mode=padding_mode, flow_layout="nchw", interpolation=interpolation,
+                        align_corners=align_corners)
 
 
 # --------------------------------------------------------------------------------------------

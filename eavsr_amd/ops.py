@@ -126,7 +126,7 @@ def selftest_mfma(device="cuda:0") -> int:
 # flow_warp  (networks.py:699-739, eavsrp_model.py:587-626)
 # ------------------------------------------------------------------------------------------
 def flow_warp(x: Tensor, flow: Tensor, padding_mode: str = "zeros", flow2: Optional[Tensor] = None,
-              flow_layout: str = "nchw") -> Tensor:
+              flow_layout: str = "nchw", interpolation: str = "bilinear", align_corners: bool = True) -> Tensor:
     x = _chk(x, "x")
     n, c, h, w = x.shape
     if flow_layout == "nchw":
@@ -144,9 +144,12 @@ def flow_warp(x: Tensor, flow: Tensor, padding_mode: str = "zeros", flow2: Optio
             layout = 1
     else:
         raise ValueError(flow_layout)
-    pm = {"zeros": 0, "border": 1}.get(padding_mode)
+    pm = {"zeros": 0, "border": 1, "reflection": 2}.get(padding_mode)
     if pm is None:
-        raise NotImplementedError(f"padding_mode={padding_mode!r}: the reference path uses 'zeros' and 'border'")
+        raise ValueError(f"padding_mode={padding_mode!r}: 'zeros', 'border' or 'reflection'")
+    if interpolation not in ("bilinear", "nearest"):
+        raise ValueError(f"interpolation={interpolation!r}: 'bilinear' or 'nearest'")
+    pm |= (0x10 if interpolation == "nearest" else 0) | (0 if align_corners else 0x20)
     flow = _chk(flow, "flow")
     if flow2 is not None:
         flow2 = _chk(flow2, "flow2")

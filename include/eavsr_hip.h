@@ -36,6 +36,11 @@ extern "C" {
 /* padding modes of eavsr_flow_warp_f32 (torch grid_sample padding_mode) */
 #define EAVSR_PAD_ZEROS 0
 #define EAVSR_PAD_BORDER 1
+#define EAVSR_PAD_REFLECTION 2
+/* or-ed into padding_mode for the grid_sample variants off the reference's path (networks.py:699-739 forwards
+ * `interpolation` and `align_corners` to F.grid_sample): nearest-neighbour sampling, align_corners=False */
+#define EAVSR_WARP_NEAREST 0x10
+#define EAVSR_WARP_NO_ALIGN_CORNERS 0x20
 
 /* flow layouts of eavsr_flow_warp_f32 */
 #define EAVSR_FLOW_NCHW 0 /* networks.py:699-739      (n,2,h,w): ch0 = x disp, ch1 = y disp */
@@ -58,7 +63,8 @@ int eavsr_selftest_mfma_f32(float* scratch, void* stream);
  * (models/eavsrp_model.py:587-626): bilinear grid_sample, align_corners=True, of x by a pixel-unit
  * flow.  out[n,c,y,x] = bilinear(x[n,c], y + fy, x + fx), corner-wise zero padding (ZEROS) or
  * coordinate clamping (BORDER).  flow2 (nullable, same layout) is added to flow first
- * (networks.py:610,615 warp by a sum of two flows).                                            */
+ * (networks.py:610,615 warp by a sum of two flows).  The modes the reference never uses on the path
+ * (REFLECTION, EAVSR_WARP_NEAREST, EAVSR_WARP_NO_ALIGN_CORNERS) run a generic kernel; forward only.      */
 int eavsr_flow_warp_f32(const float* x, const float* flow, const float* flow2, float* out,
                         int32_t n, int32_t c, int32_t h, int32_t w,
                         int32_t flow_layout, int32_t padding_mode, void* stream);

@@ -47,9 +47,11 @@ BRANCHES = ("backward_1", "forward_1", "backward_2", "forward_2")  # eavsrp_mode
 # --------------------------------------------------------------------------------------
 # a1 / a2  flow_warp
 # --------------------------------------------------------------------------------------
-def flow_warp_nhwc(x: Tensor, flow: Tensor, padding_mode: str = "zeros") -> Tensor:
+def flow_warp_nhwc(x: Tensor, flow: Tensor, padding_mode: str = "zeros", interpolation: str = "bilinear",
+                   align_corners: bool = True) -> Tensor:
     """eavsrp_model.py:587-626.  flow is (n,h,w,2), [...,0]=x displacement, [...,1]=y
-    displacement, in pixels.  Bilinear, align_corners=True."""
+    displacement, in pixels.  The path uses bilinear, align_corners=True; the other two arguments are forwarded to
+    grid_sample exactly as the reference does (eavsrp_model.py:620-625)."""
     n, c, h, w = x.shape
     if tuple(flow.shape[1:3]) != (h, w):
         raise ValueError("The spatial sizes of input and flow are not the same.")
@@ -58,13 +60,14 @@ def flow_warp_nhwc(x: Tensor, flow: Tensor, padding_mode: str = "zeros") -> Tens
     gf = grid + flow
     gfx = 2.0 * gf[..., 0] / max(w - 1, 1) - 1.0
     gfy = 2.0 * gf[..., 1] / max(h - 1, 1) - 1.0
-    return F.grid_sample(x, torch.stack((gfx, gfy), dim=3), mode="bilinear",
-                         padding_mode=padding_mode, align_corners=True)
+    return F.grid_sample(x, torch.stack((gfx, gfy), dim=3), mode=interpolation,
+                         padding_mode=padding_mode, align_corners=align_corners)
 
 
-def flow_warp(x: Tensor, flow: Tensor, padding_mode: str = "zeros") -> Tensor:
+def flow_warp(x: Tensor, flow: Tensor, padding_mode: str = "zeros", interpolation: str = "bilinear",
+              align_corners: bool = True) -> Tensor:
     """networks.py:699-739.  flow is NCHW (n,2,h,w): channel 0 = x, 1 = y displacement."""
-    return flow_warp_nhwc(x, flow.permute(0, 2, 3, 1), padding_mode)
+    return flow_warp_nhwc(x, flow.permute(0, 2, 3, 1), padding_mode, interpolation, align_corners)
 
 
 def flow_warp_direct(x: Tensor, flow: Tensor, padding_mode: str = "zeros") -> Tensor:

@@ -73,8 +73,10 @@ def test_flow_warp_rejects_bad_inputs(ops, cuda):
     x = torch.zeros(1, 2, 8, 8, device=cuda)
     with pytest.raises(ValueError):
         ops.flow_warp(x, torch.zeros(1, 2, 8, 9, device=cuda))
-    with pytest.raises(NotImplementedError):
-        ops.flow_warp(x, torch.zeros(1, 2, 8, 8, device=cuda), padding_mode="reflection")
+    with pytest.raises(ValueError):
+        ops.flow_warp(x, torch.zeros(1, 2, 8, 8, device=cuda), padding_mode="mirror")
+    with pytest.raises(ValueError):
+        ops.flow_warp(x, torch.zeros(1, 2, 8, 8, device=cuda), interpolation="bicubic")
     with pytest.raises(RuntimeError):
         ops.flow_warp(torch.zeros(1, 2, 8, 8), torch.zeros(1, 2, 8, 8))  # CPU tensor: no CPU path
 
@@ -152,6 +154,25 @@ def test_conv2d_weight_cache_tracks_inplace_updates(ops, cuda):
         w_.mul_(2.0)
     b = ops.conv2d(x, w_, None).cpu()
     assert H.maxabs(b, 2 * a) <= 1e-5
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("interp", ["bilinear", "nearest"])
+@pytest.mark.parametrize("pad", ["zeros", "border", "reflection"])
+def test_flow_warp_all_grid_sample_modes(ops, cuda, pad, interp, align):
+    """networks.flow_warp forwards interpolation / padding_mode / align_corners to grid_sample (networks.py:733-738);
+    the path uses (bilinear, zeros|border, True), the drop-in accepts the rest of the signature too."""
+    from eavsr_amd import networks, eavsrp_model
+    x = cases.randn(1, 2, 5, 19, 27)
+    flow = cases.randn(2, 2, 2, 19, 27, scale=4.0)
+    flow[:, :, :3] += 30.0                      # far outside: padding really matters
+    # positions within 1e-3 of a rounding / cell boundary may legitimately flip under fp32 coordinate rounding
+    ref = O.flow_warp(x, flow, pad, interp, align)
+    got = networks.flow_warp(g(x, cuda), g(flow, cuda), interp, pad, align).cpu()
+    got2 = eavsrp_model.flow_warp(g(x, cuda), g(flow.permute(0, 2, 3, 1).contiguous(), cuda), interp, pad, align).cpu()
+    assert torch.equal(got, got2)
+    bad = ((got - ref).abs() > 1e-4).float().mean().item()
+    assert bad <= (0.002 if interp == "nearest" else 0.0), bad
 
 
 # ------------------------------------------------------------------------------------------ a7
