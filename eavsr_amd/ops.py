@@ -382,29 +382,43 @@ def _one(v):
 def modulated_deform_conv2d(input: Tensor, offset: Tensor, mask: Tensor, weight: Tensor,
                             bias: Optional[Tensor] = None, stride=1, padding=0, dilation=1, groups=1,
                             deform_groups=1) -> Tensor:
-    """Same signature as mmcv.ops.modulated_deform_conv2d.  Supported configuration: 3x3 kernel,
-    stride 1, padding 1, dilation 1, groups 1, (cin / deform_groups) % 8 == 0 (the reference uses
-    64 channels, 8 groups).  Anything else raises NotImplementedError -- there is no fallback."""
+    """Same signature as mmcv.ops.modulated_deform_conv2d.  The reference's configuration (3x3, stride 1, padding 1,
+    dilation 1, groups 1, channels per deformable group a multiple of 8: networks.py:577-583 + eavsrp_model.py:143) runs
+    the fused LDS-window MFMA kernel; every other configuration of the signature runs eavsr_dcnv2_generic_f32 (a plain
+    kernel, forward only).  There is no CPU path."""
     x = _chk(input, "input")
-    cout, cin_g, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or _one(stride) != 1 or _one(padding) != 1 or _one(dilation) != 1 or groups != 1:
-        raise NotImplementedError(
-            f"modulated_deform_conv2d: kernel {(kh, kw)}, stride {stride}, padding {padding}, dilation {dilation}, "
-            f"groups {groups} unsupported (reference configuration: 3x3, 1, 1, 1, 1)")
+    cout, cin_g, kh, kw = (int(v) for v in weight.shape)
     n, cin, h, w = x.shape
-    if cin_g != cin:
+    two = lambda v: (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+    (sh, sw), (ph, pw), (dh, dw) = two(stride), two(padding), two(dilation)
+    if cin_g * groups != cin:
         raise ValueError("weight / input channel mismatch")
+    if cin % deform_groups or cout % groups:
+        raise ValueError("channels not divisible by groups / deform_groups")
+    ho = (h + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    wo = (w + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
     offset = _chk(offset, "offset")
     mask = _chk(mask, "mask")
-    if tuple(offset.shape) != (n, deform_groups * 18, h, w):
-        raise ValueError(f"offset shape {tuple(offset.shape)} != {(n, deform_groups * 18, h, w)}")
-    if tuple(mask.shape) != (n, deform_groups * 9, h, w):
-        raise ValueError(f"mask shape {tuple(mask.shape)} != {(n, deform_groups * 9, h, w)}")
+    if tuple(offset.shape) != (n, deform_groups * 2 * kh * kw, ho, wo):
+        raise ValueError(f"offset shape {tuple(offset.shape)} != {(n, deform_groups * 2 * kh * kw, ho, wo)}")
+    if tuple(mask.shape) != (n, deform_groups * kh * kw, ho, wo):
+        raise ValueError(f"mask shape {tuple(mask.shape)} != {(n, deform_groups * kh * kw, ho, wo)}")
     b = None if bias is None else _chk(bias.detach(), "bias")
-    out = torch.empty((n, cout, h, w), device=x.device, dtype=torch.float32)
-    if (cin // deform_groups) % 8 != 0:
-        raise NotImplementedError(f"modulated_deform_conv2d: {cin // deform_groups} channels per deformable group "
-                                  "unsupported (must be a multiple of 8; the reference uses 64 channels / 8 groups)")
+    out = torch.empty((n, cout, ho, wo), device=x.device, dtype=torch.float32)
+    on_path = ((kh, kw) == (3, 3) and (sh, sw, ph, pw, dh, dw) == (1, 1, 1, 1, 1, 1) and groups == 1
+               and (cin // deform_groups) % 8 == 0)
+    if not on_path:
+        if groups > 1 and (cout // groups) % 8:
+            raise NotImplementedError("modulated_deform_conv2d: with conv groups > 1 the output channels per group must be "
+                                      "a multiple of 8")
+        wt = _chk(weight.detach(), "weight")
+        st = _stream(x)
+        _launch("dcnv2_generic", 2.0 * cin_g * kh * kw * cout * n * ho * wo,
+                4.0 * n * (cin * h * w + (3 * deform_groups * kh * kw + cout) * ho * wo), x,
+                lambda: lib().eavsr_dcnv2_generic_f32(_p(x), _p(offset), _p(mask), _p(wt), _p(b), _p(out), n, cin, h, w, cout,
+                                                      kh, kw, sh, sw, ph, pw, dh, dw, groups, deform_groups, st),
+                "dcnv2_generic")
+        return out
     st = _stream(x)
     px = float(n) * h * w
     flops, nbytes = 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * deform_groups + cout)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 8
+#define EAVSR_ABI_VERSION 9
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -94,6 +94,16 @@ int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask,
                       const void* weight_x9, const float* bias, float* out,
                       int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
                       int32_t deform_groups, void* stream);
+
+/* The rest of mmcv.ops.modulated_deform_conv2d's signature (any kernel size, stride, padding, dilation, conv groups,
+ * deformable groups; networks.py:575-583 declares them, the reference never uses them): a plain one-thread-per-pixel
+ * kernel on the ORIGINAL weight layout (cout, cin/groups, kh, kw).  offset (n, dg*2*kh*kw, ho, wo), mask
+ * (n, dg*kh*kw, ho, wo), out (n, cout, ho, wo).  Forward only.                                                    */
+int eavsr_dcnv2_generic_f32(const float* x, const float* offset, const float* mask, const float* weight,
+                            const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w,
+                            int32_t cout, int32_t kh, int32_t kw, int32_t stride_h, int32_t stride_w,
+                            int32_t pad_h, int32_t pad_w, int32_t dil_h, int32_t dil_w, int32_t groups,
+                            int32_t deform_groups, void* stream);
 
 /* ---- dense convolution (a9, a10, a11 convs; predictor heads a3/a4/a6; callers f1/f2) ----------
  * replaces torch.nn.Conv2d forward (stride 1, padding k/2, dilation 1, groups 1) as used at

@@ -219,15 +219,52 @@ def test_dcnv2_integer_offsets_shift_the_taps(ops, cuda):
     assert H.maxabs(out, ref) <= 2e-5
 
 
-def test_dcnv2_unsupported_configs_raise(ops, cuda):
-    x = torch.zeros(1, 12, 8, 8, device=cuda)
-    with pytest.raises(NotImplementedError):  # 12/3 = 4 channels per group
-        ops.modulated_deform_conv2d(x, torch.zeros(1, 54, 8, 8, device=cuda), torch.zeros(1, 27, 8, 8, device=cuda),
-                                    torch.zeros(8, 12, 3, 3, device=cuda), None, 1, 1, 1, 1, 3)
-    with pytest.raises(NotImplementedError):  # stride 2
-        ops.modulated_deform_conv2d(torch.zeros(1, 64, 8, 8, device=cuda), torch.zeros(1, 144, 8, 8, device=cuda),
-                                    torch.zeros(1, 72, 8, 8, device=cuda), torch.zeros(64, 64, 3, 3, device=cuda),
-                                    None, 2, 1, 1, 1, 8)
+@pytest.mark.parametrize("cfg", [
+    # cin, cout, kh, kw, stride, pad, dil, groups, dg, h, w
+    (12, 8, 3, 3, 1, 1, 1, 1, 3, 9, 11),        # 4 channels per deformable group (MultiAdSTN's default dg = 64 has 1)
+    (64, 64, 3, 3, 1, 1, 1, 1, 64, 8, 10),      # deformable_groups = 64 (networks.py:576 default)
+    (16, 24, 3, 3, 2, 1, 1, 1, 2, 13, 17),      # stride 2
+    (8, 16, 5, 3, 1, 2, 1, 1, 1, 10, 12),       # 5 x 3 kernel, asymmetric output size
+    (8, 8, 3, 3, 1, 2, 2, 1, 2, 11, 9),         # dilation 2
+    (16, 16, 3, 3, 1, 1, 1, 2, 4, 7, 9),        # conv groups 2
+], ids=lambda c: "c%d_o%d_k%dx%d_s%d_p%d_d%d_g%d_dg%d" % c[:9])
+def test_dcnv2_rest_of_the_mmcv_signature(ops, cuda, cfg):
+    """Configurations the reference never runs go through the generic kernel (forward only) and match the oracle."""
+    cin, cout, kh, kw, st, pd, dl, groups, dg, h, w = cfg
+    K = kh * kw
+    ho = (h + 2 * pd - (dl * (kh - 1) + 1)) // st + 1
+    wo = (w + 2 * pd - (dl * (kw - 1) + 1)) // st + 1
+    x = cases.randn(1, 2, cin, h, w)
+    off = cases.randn(2, 2, dg * 2 * K, ho, wo, scale=1.5)
+    mask = cases.rand(3, 2, dg * K, ho, wo)
+    wt = cases.randn(4, cout, cin // groups, kh, kw, scale=0.2)
+    b = cases.randn(5, cout, scale=0.1)
+    if groups == 1:
+        ref = O.dcnv2(x, off, mask, wt, b, st, pd, dl, 1, dg)
+    else:   # conv groups: each group of output channels sees its slice of the (already deformably sampled) input
+        cig, cog, dgg = cin // groups, cout // groups, dg // groups
+        parts = []
+        for gi in range(groups):
+            parts.append(O.dcnv2(x[:, gi * cig:(gi + 1) * cig], off[:, gi * dgg * 2 * K:(gi + 1) * dgg * 2 * K],
+                                 mask[:, gi * dgg * K:(gi + 1) * dgg * K], wt[gi * cog:(gi + 1) * cog],
+                                 b[gi * cog:(gi + 1) * cog], st, pd, dl, 1, dgg))
+        ref = torch.cat(parts, 1)
+    with ops.profile() as prof:
+        out = ops.modulated_deform_conv2d(g(x, cuda), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), st, pd, dl,
+                                          groups, dg)
+    assert list(prof.summary()) == ["dcnv2_generic"]
+    assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_dcnv2_bad_arguments_raise(ops, cuda):
+    z = lambda *s_: torch.zeros(*s_, device=cuda)
+    with pytest.raises(ValueError):      # offset for the wrong number of deformable groups
+        ops.modulated_deform_conv2d(z(1, 64, 8, 8), z(1, 18, 8, 8), z(1, 72, 8, 8), z(64, 64, 3, 3), None, 1, 1, 1, 1, 8)
+    with pytest.raises(ValueError):      # weight / input channel mismatch
+        ops.modulated_deform_conv2d(z(1, 64, 8, 8), z(1, 144, 8, 8), z(1, 72, 8, 8), z(64, 32, 3, 3), None, 1, 1, 1, 1, 8)
+    with pytest.raises(RuntimeError):    # no CPU path
+        ops.modulated_deform_conv2d(torch.zeros(1, 64, 8, 8), torch.zeros(1, 144, 8, 8), torch.zeros(1, 72, 8, 8),
+                                    torch.zeros(64, 64, 3, 3), None, 1, 1, 1, 1, 8)
 
 
 # ---- 3x3 conv, bf16x9 contraction (opt-in): same descriptor / tensors / epilogue as the native kernel -------------
