@@ -227,7 +227,11 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
     __syncthreads();
     if (it + 1 < total_chunks) {
       advance();
+#ifndef EAVSR_CONV_EXP_NODMA   // timing ablation only (tools/gpu_conv_ablate.py): 173 -> 162 us without the DMA,
+                               // 167 us without the output stores.  Handing the pieces out from inside the tap loop
+                               // (2 per tap) instead of here changes nothing: the cost is per piece, not the burst.
       issue_chunk((it + 1) & 1);  // in flight behind the MFMA loop below
+#endif
     }
     const float* bin = smem + (it & 1) * BUF + half * (IH * IW) + (wave * NT) * IW + (MARG - PAD) + l31;
     const float* ain = smem + (it & 1) * BUF + NIN * IN_PAD + half * (KK * CO) + l31;
