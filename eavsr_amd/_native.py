@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -57,6 +57,10 @@ SIGNATURES = {
     "eavsr_dcnv2_f32x9": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "eavsr_conv3x3_f32x9": (C.c_int, [vp, vp, vp]),
+    "eavsr_wino_weight_elems": (C.c_int64, [i32, i32]),
+    "eavsr_pack_conv_weight_wino": (C.c_int, [vp, vp, i32, i32, vp]),
+    "eavsr_conv3x3_wino_tiles": (i32, [i32, i32]),
+    "eavsr_conv3x3_wino_f32": (C.c_int, [vp, vp, vp]),
     "eavsr_conv2d_ck": (i32, [i32]),
     "eavsr_conv2d_tile_rows": (i32, [i32, i32, i32, i32]),
     "eavsr_conv2d_tiles": (i32, [i32, i32, i32, i32]),

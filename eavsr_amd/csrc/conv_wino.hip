@@ -1,0 +1,378 @@
+// 3x3 stride-1 convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores.
+// Same operands / epilogue / tensors as conv2d_mfma_kernel<3, 2, true> (conv_mfma.hip) for the residual backbone
+// (networks.py:456-458,478; eavsrp_model.py:381), 2.25x fewer multiplications:
+//
+//   Y(2x2) = A^T [ (G g G^T) .* (B^T d B) ] A        per 4x4 input tile d, 3x3 filter g   (Lavin & Gray 2016)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]    G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]    A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// i.e. 16 independent GEMMs (one per transform-domain position xi): M_xi[co, t] = sum_ci U_xi[co, ci] V_xi[ci, t], all
+// fp32 (v_mfma_f32_32x32x2_f32); the transforms are additions and multiplications by 1/2.  This is what cuDNN / MIOpen
+// run for an fp32 3x3 convolution by default -- fp32 arithmetic throughout, different rounding than the direct sum
+// (tests/test_hip_ops.py compares both against fp64).
+//
+// Per workgroup (512 threads = 8 waves, one per CU): 16 x 16 output pixels = 64 Winograd tiles, 64 output channels.
+//   wave w owns the transform positions xi = 2w, 2w+1: accumulators M[2][64 co][64 tiles] = 128 registers per lane.
+//   per chunk of 8 input channels (two LDS stages for the DMA'd data, one for V):
+//     LDS-DMA: the (8 x 18 x 24) fp32 input patch (zero padding = never-written zero-initialised LDS) and the
+//              pre-transformed weight slab U[16][8][64] (eavsr_pack_conv_weight_wino)          (HBM / L2 -> LDS)
+//     input transform: thread (c, tile) reads its 4 x 4 patch, 32 additions, writes V[16][8][64]   (LDS -> LDS)
+//     GEMM: per owned xi and channel pair: 2 + 2 ds_read_b32, 4 MFMAs                             (LDS -> MFMA)
+//   epilogue: the 16 M_xi of a (co, tile) live in 8 different waves: exchanged through LDS in two passes of 32 output
+//   channels, output transform (24 additions), + bias, activation, + residual, float2 row stores, optional per-tile
+//   channel sums (deterministic).
+#include "common.h"
+
+#include <mutex>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WnArgs {
+  const float* src[5];
+  int src_c[5];
+  int n_src;
+  const float* wu;        // [cot][cin / 8][16][8][64]
+  const float* bias;
+  const float* residual;
+  float* out;
+  float* chan_partial;
+  int n, h, w, cin, cout, tiles_x, tiles_y;
+  int act;
+  float slope;
+};
+
+constexpr int CK = 8, NW = 8;
+constexpr int TO = 16;                                // output tile edge (8 x 8 Winograd tiles)
+constexpr int MARG = 4;                               // patch starts 4 columns left of the tile: 16-byte DMA pieces
+constexpr int IH = TO + 2, IW = TO + 2 * MARG;        // 18 x 24
+constexpr int IN_ELEMS = CK * IH * IW;                // 3456 floats
+constexpr int IN_SEGS = (IN_ELEMS + 255) / 256;       // 14 one-KiB pieces (the last one half)
+constexpr int IN_PAD = IN_SEGS * 256;
+constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;        // 2
+constexpr int UV = 16 * CK * 64;                      // floats of one U (or V) chunk: 8192 = 32 KB
+constexpr int W_SEGS = UV / 256;                      // 32 pieces
+constexpr int W_IT = W_SEGS / NW;                     // 4
+constexpr int STAGE = IN_PAD + UV;                    // DMA'd floats per pipeline stage
+constexpr int M_HALF = 16 * 32 * 64;                  // epilogue exchange buffer: 32 output channels of M
+constexpr int LDS_MAIN = 2 * STAGE + UV;              // two DMA stages + V
+constexpr int LDS_FLOATS = (LDS_MAIN > M_HALF ? LDS_MAIN : M_HALF) + 64;
+constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_v = smem + 2 * STAGE;
+  float* s_red = smem + (LDS_MAIN > M_HALF ? LDS_MAIN : M_HALF);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int bn = bid / a.tiles_y;
+  const int cot = blockIdx.y;
+  const int y0 = ty * TO, x0 = tx * TO;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+
+  // acc[comp][mt][nt]: M of transform position 2 wave + comp, output channels 32 mt .., tiles 32 nt ..
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][m][t][r] = 0.f;
+
+  int cs = 0, cc0 = 0, cbase = 0;
+  int total_chunks = 0;
+  for (int s = 0; s < a.n_src; ++s) total_chunks += a.src_c[s] / CK;
+
+  unsigned voff[IN_IT];
+  {
+    f32x4* z = reinterpret_cast<f32x4*>(smem);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < (2 * STAGE) / 4; e += 64 * NW) z[e] = zero;
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int seg = i * NW + wave;
+      const int e4 = seg * 64 + lane;
+      const int ci = e4 / (IH * (IW / 4));
+      const int rem = e4 - ci * (IH * (IW / 4));
+      const int r = rem / (IW / 4);
+      const int c4 = rem - r * (IW / 4);
+      const int gy = y0 - 1 + r, gx = x0 - MARG + 4 * c4;
+      const bool ok = seg < IN_SEGS && e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
+      voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+  }
+
+  auto issue_chunk = [&](int stage) {
+    float* s_in = smem + stage * STAGE;
+    float* s_u = s_in + IN_PAD;
+    const int sc = a.src_c[cs];
+    const float* sp = a.src[cs] + ((size_t)bn * sc + cc0) * plane;
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int seg = i * NW + wave;
+      if (voff[i] != 0xFFFFFFFFu)
+        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(sp) + voff[i]), (lptr_t)(s_in + seg * 256), 16, 0, 0);
+    }
+    const char* usrc = reinterpret_cast<const char*>(a.wu + ((size_t)cot * (a.cin / CK) + (size_t)(cbase + cc0) / CK) * UV);
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int seg = i * NW + wave;
+      __builtin_amdgcn_global_load_lds((gptr_t)(usrc + (unsigned)(seg * 64 + lane) * 16u), (lptr_t)(s_u + seg * 256), 16, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    cc0 += CK;
+    if (cc0 >= a.src_c[cs]) {
+      cbase += a.src_c[cs];
+      ++cs;
+      cc0 = 0;
+    }
+  };
+
+  // input-transform job of this thread: channel tc of the chunk, Winograd tile tt = 8 tty + ttx
+  const int tc = tid >> 6, tt = tid & 63;
+  const int tty = tt >> 3, ttx = tt & 7;
+  const int poff = tc * (IH * IW) + (2 * tty) * IW + (MARG - 1) + 2 * ttx;   // top-left of its 4 x 4 patch
+  float* vdst = s_v + tc * 64 + tt;                                          // + xi * (CK * 64)
+
+  issue_chunk(0);
+  for (int it = 0; it < total_chunks; ++it) {
+    // chunk `it` has landed; every wave is done with the GEMM of chunk it-1 (V and the other DMA stage are free)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 1 < total_chunks) {
+      advance();
+      issue_chunk((it + 1) & 1);
+    }
+    // ---- input transform V = B^T d B of this thread's (channel, tile) ----------------------------
+    {
+      const float* pp = smem + (it & 1) * STAGE + poff;
+      float d[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[r][q] = pp[r * IW + q];
+      float t[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {      // B^T d: rows
+        t[0][q] = d[0][q] - d[2][q];
+        t[1][q] = d[1][q] + d[2][q];
+        t[2][q] = d[2][q] - d[1][q];
+        t[3][q] = d[1][q] - d[3][q];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {      // (.) B: columns
+        vdst[(r * 4 + 0) * (CK * 64)] = t[r][0] - t[r][2];
+        vdst[(r * 4 + 1) * (CK * 64)] = t[r][1] + t[r][2];
+        vdst[(r * 4 + 2) * (CK * 64)] = t[r][2] - t[r][1];
+        vdst[(r * 4 + 3) * (CK * 64)] = t[r][1] - t[r][3];
+      }
+    }
+    __syncthreads();
+    // ---- 2 of the 16 GEMMs: M_xi[co, t] += sum over the chunk's 8 channels U_xi[co, c] V_xi[c, t] --------
+    const float* su = smem + (it & 1) * STAGE + IN_PAD;
+#pragma unroll
+    for (int comp = 0; comp < 2; ++comp) {
+      const int xi = 2 * wave + comp;
+      const float* ua = su + (xi * CK + half) * 64 + l31;
+      const float* vb = s_v + (xi * CK + half) * 64 + l31;
+#pragma unroll
+      for (int kp = 0; kp < CK / 2; ++kp) {
+        float av[2], bv[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) av[m] = ua[(2 * kp) * 64 + m * 32];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bv[t] = vb[(2 * kp) * 64 + t * 32];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[comp][m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[comp][m][t], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: exchange M through LDS (32 output channels per pass), output transform, stores ----
+  float* s_m = smem;   // [16 xi][32 co][64 tiles]
+  const int tile_lin = ty * a.tiles_x + tx;
+#pragma unroll 1
+  for (int mt = 0; mt < 2; ++mt) {
+    __syncthreads();   // main loop / previous pass done with this LDS
+#pragma unroll
+    for (int comp = 0; comp < 2; ++comp) {
+      const int xi = 2 * wave + comp;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int col = (r & 3) + 8 * (r >> 2) + 4 * half;   // output channel within the pass
+          s_m[(xi * 32 + col) * 64 + t * 32 + l31] = (mt == 0) ? acc[comp][0][t][r] : acc[comp][1][t][r];
+        }
+    }
+    __syncthreads();
+    // thread -> (output channel col = wave + 8 j, tile tt2 = lane): all 64 lanes of a wave share the channel
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wave + 8 * j;
+      const int co = cot * 64 + mt * 32 + col;
+      const int t2 = lane, t2y = t2 >> 3, t2x = t2 & 7;
+      float m[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[r][q] = s_m[((r * 4 + q) * 32 + col) * 64 + t2];
+      float s0[4], s1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {      // A^T m: rows
+        s0[q] = m[0][q] + m[1][q] + m[2][q];
+        s1[q] = m[1][q] - m[2][q] - m[3][q];
+      }
+      float y[2][2];
+      y[0][0] = s0[0] + s0[1] + s0[2];
+      y[0][1] = s0[1] - s0[2] - s0[3];
+      y[1][0] = s1[0] + s1[1] + s1[2];
+      y[1][1] = s1[1] - s1[2] - s1[3];
+      const bool cok = co < a.cout;
+      const float b = (cok && a.bias) ? a.bias[co] : 0.f;
+      const int gx = x0 + 2 * t2x;
+      float sum = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int gy = y0 + 2 * t2y + dy;
+        float v0 = y[dy][0] + b, v1 = y[dy][1] + b;
+        if (a.act == EAVSR_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        else if (a.act == EAVSR_ACT_LRELU) { v0 = v0 > 0.f ? v0 : v0 * a.slope; v1 = v1 > 0.f ? v1 : v1 * a.slope; }
+        if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
+          const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
+          sum += v0 + v1;
+          if (a.residual) {
+            const f32x2 rr = *reinterpret_cast<const f32x2*>(a.residual + o);
+            v0 += rr.x; v1 += rr.y;
+          }
+          *reinterpret_cast<f32x2*>(a.out + o) = f32x2{v0, v1};
+        }
+      }
+      if (a.chan_partial) {
+        sum += __shfl_xor(sum, 32);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 8);
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 1);
+        if (lane == 0 && cok)
+          a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + tile_lin) * a.cout + co] = sum;
+      }
+    }
+  }
+  (void)s_red;
+}
+
+// weight (cout, cin, 3, 3) -> U = G g G^T laid out [cot][cin / 8][xi][c][co] (zero for co >= cout)
+__global__ void pack_wino_kernel(const float* __restrict__ wt, float* __restrict__ out, int cout, int cin, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int col = (int)(e & 63);
+  long u = e >> 6;
+  const int c = (int)(u % CK); u /= CK;
+  const int xi = (int)(u % 16); u /= 16;
+  const int nchunks = cin / CK;
+  const int chunk = (int)(u % nchunks);
+  const int cot = (int)(u / nchunks);
+  const int co = cot * 64 + col, ci = chunk * CK + c;
+  float v = 0.f;
+  if (co < cout) {
+    const float* g = wt + ((size_t)co * cin + ci) * 9;
+    const int r = xi >> 2, q = xi & 3;
+    // row r of G g (a 3-vector), then column q of (.) G^T
+    float gr[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float g0 = g[0 * 3 + j], g1 = g[1 * 3 + j], g2 = g[2 * 3 + j];
+      gr[j] = r == 0 ? g0 : (r == 1 ? 0.5f * (g0 + g1 + g2) : (r == 2 ? 0.5f * (g0 - g1 + g2) : g2));
+    }
+    v = q == 0 ? gr[0] : (q == 1 ? 0.5f * (gr[0] + gr[1] + gr[2]) : (q == 2 ? 0.5f * (gr[0] - gr[1] + gr[2]) : gr[2]));
+  }
+  out[e] = v;
+}
+
+}  // namespace
+
+extern "C" int64_t eavsr_wino_weight_elems(int32_t cout, int32_t cin) {
+  if (cout <= 0 || cin <= 0 || cin % CK != 0) return 0;
+  return (int64_t)eavsr::cdiv(cout, 64) * (cin / CK) * UV;
+}
+
+extern "C" int eavsr_pack_conv_weight_wino(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight_wino: NULL pointer");
+  EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % CK == 0, -1, "pack_conv_weight_wino: cin %d must be a multiple of 8", cin);
+  const long total = eavsr_wino_weight_elems(cout, cin);
+  hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight, packed,
+                     cout, cin, total);
+  return eavsr::launch_status("pack_conv_weight_wino");
+}
+
+extern "C" int32_t eavsr_conv3x3_wino_tiles(int32_t h, int32_t w) { return eavsr::cdiv(h, TO) * eavsr::cdiv(w, TO); }
+
+extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* weight_wino, void* stream) {
+  EAVSR_REQUIRE(d != nullptr && weight_wino != nullptr, -1, "conv3x3_wino: NULL descriptor / weights");
+  EAVSR_REQUIRE(d->n_src >= 1 && d->n_src <= 5, -1, "conv3x3_wino: n_src %d not in 1..5", d->n_src);
+  EAVSR_REQUIRE(d->ksize == 3, -2, "conv3x3_wino: kernel size %d (3 only)", d->ksize);
+  EAVSR_REQUIRE(d->out, -1, "conv3x3_wino: NULL out");
+  EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv3x3_wino: bad dims");
+  EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv3x3_wino: act %d", d->act);
+  EAVSR_REQUIRE(d->ca_scale == nullptr && d->ca_x == nullptr && d->ca_out == nullptr, -2,
+                "conv3x3_wino: no fused channel-attention prologue");
+  EAVSR_REQUIRE(d->w % 4 == 0, -2, "conv3x3_wino: w %% 4 != 0 (use eavsr_conv2d_f32)");
+  EAVSR_REQUIRE((((uintptr_t)d->out) & 7) == 0 && (d->residual == nullptr || (((uintptr_t)d->residual) & 7) == 0), -2,
+                "conv3x3_wino: out / residual must be 8-byte aligned");
+  WnArgs a;
+  int csum = 0;
+  for (int s = 0; s < 5; ++s) {
+    a.src[s] = s < d->n_src ? d->src[s] : nullptr;
+    a.src_c[s] = s < d->n_src ? d->src_c[s] : 0;
+    if (s < d->n_src) {
+      EAVSR_REQUIRE(d->src[s] != nullptr && d->src_c[s] > 0 && d->src_c[s] % CK == 0 && (((uintptr_t)d->src[s]) & 15) == 0, -2,
+                    "conv3x3_wino: source %d must be 16-byte aligned with a multiple of 8 channels", s);
+      csum += d->src_c[s];
+    }
+  }
+  EAVSR_REQUIRE(csum == d->cin, -1, "conv3x3_wino: sources sum to %d channels, cin = %d", csum, d->cin);
+  if (d->n == 0) return 0;
+  a.n_src = d->n_src;
+  a.wu = weight_wino;
+  a.bias = d->bias; a.residual = d->residual; a.out = d->out; a.chan_partial = d->chan_partial;
+  a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
+  a.tiles_x = eavsr::cdiv(d->w, TO);
+  a.tiles_y = eavsr::cdiv(d->h, TO);
+  a.act = d->act; a.slope = d->slope;
+  const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
+  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_wino: too many tiles");
+  EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv3x3_wino: image plane too large for 32-bit tile offsets");
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("conv3x3_wino: hipFuncSetAttribute(%zu B of LDS): %s", LDS_BYTES, hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  dim3 grid((unsigned)blocks, eavsr::cdiv(d->cout, 64));
+  hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(64 * NW), LDS_BYTES, eavsr::as_stream(stream), a);
+  return eavsr::launch_status("conv3x3_wino");
+}

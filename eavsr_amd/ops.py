@@ -313,9 +313,12 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     wp = pack_cache.get(weights)
     b = _bias_of(biases)
     out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
+    x9_ok = (k == 3 and ca is None and w % 4 == 0
+             and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs))
+    use_wino = CONV_MODE == "winograd" and x9_ok and n * lib().eavsr_conv3x3_wino_tiles(h, w) >= WINO_MIN_TILES
     part = None
     if chan_partial:
-        tiles = lib().eavsr_conv2d_tiles(n, h, w, k)
+        tiles = lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino else lib().eavsr_conv2d_tiles(n, h, w, k)
         part = torch.empty((n, tiles, cout), device=out.device, dtype=torch.float32)
     if residual is not None:
         residual = _chk(residual, "residual")
@@ -351,9 +354,13 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError("ca_out needs ca")
     st = _stream(out)
     px = float(n) * h * w
-    if (CONV_MODE == "bf16x9" and k == 3 and ca is None and w % 4 == 0
-            and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs)
-            and lib().eavsr_conv2d_tile_rows(n, h, w, 3) == 32):
+    if use_wino:
+        wu = _packed_wino(weights)
+        _launch(f"conv3x3_{cin}to{cout}_wino", 2.0 * cin * cout * 9 * px,
+                4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+                lambda: lib().eavsr_conv3x3_wino_f32(C.byref(d), _p(wu), st), "conv3x3_wino")
+        return out if not chan_partial else (out, part)
+    if CONV_MODE == "bf16x9" and x9_ok and lib().eavsr_conv2d_tile_rows(n, h, w, 3) == 32:
         wx = _packed_x9(weights)
         _launch(f"conv3x3_{cin}to{cout}_x9", 2.0 * cin * cout * 9 * px,
                 4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
@@ -481,16 +488,44 @@ def _packed_dcn_x9(weight: Tensor) -> Tensor:
     return _packed_x9([weight])
 
 
-# How the fp32 contraction of the 3x3 convolutions is carried: "native" = v_mfma_f32_32x32x2_f32 (default), "bf16x9" =
-# exact three-way bf16 split of both operands, nine partial products in fp32 (eavsr_conv3x3_f32x9).  Opt-in.
+# How the 3x3 convolutions are computed: "native" = direct sum on v_mfma_f32_32x32x2_f32 (default); "winograd" =
+# Winograd F(2x2, 3x3) on the same fp32 MFMA (2.25x fewer multiplications, eavsr_conv3x3_wino_f32); "bf16x9" = direct
+# sum with an exact three-way bf16 split of both operands, nine partial products in fp32 (eavsr_conv3x3_f32x9).
 CONV_MODE = os.environ.get("EAVSR_CONV_MODE", "native")
+WINO_MIN_TILES = 192      # 16 x 16-pixel tiles per launch below which the direct kernel (8-row tiles) is used
 
 
 def set_conv_mode(mode: str) -> None:
     global CONV_MODE
-    if mode not in ("native", "bf16x9"):
-        raise ValueError(f"conv mode {mode!r}: 'native' or 'bf16x9'")
+    if mode not in ("native", "winograd", "bf16x9"):
+        raise ValueError(f"conv mode {mode!r}: 'native', 'winograd' or 'bf16x9'")
     CONV_MODE = mode
+
+
+_wino_pack_cache = {}
+
+
+def _packed_wino(weights: Sequence[Tensor]) -> Tensor:
+    """G g G^T of a 3x3 weight (or of several stacked along cout); cached per weight objects and versions."""
+    key = tuple((id(w), w._version) for w in weights)
+    hit = _wino_pack_cache.get(key)
+    if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
+        return hit[1]
+    w = weights[0] if len(weights) == 1 else torch.cat([x.detach() for x in weights], 0)
+    w = _chk(w.detach(), "weight")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    elems = lib().eavsr_wino_weight_elems(cout, cin)
+    if elems <= 0 or tuple(w.shape[2:]) != (3, 3):
+        raise NotImplementedError(f"winograd weight shape {tuple(w.shape)} unsupported")
+    packed = torch.empty(elems, device=w.device, dtype=torch.float32)
+    with _DeviceOf(w):
+        N.check(lib().eavsr_pack_conv_weight_wino(_p(w), _p(packed), cout, cin, _stream(w)), "pack_conv_weight_wino")
+    ids = {id(x) for x in weights}
+    for k in [k for k in _wino_pack_cache if any(i in ids for i, _ in k)]:
+        _wino_pack_cache.pop(k, None)
+    refs = tuple(weakref.ref(x, lambda _r, k=key: _wino_pack_cache.pop(k, None)) for x in weights)
+    _wino_pack_cache[key] = (refs, packed)
+    return packed
 
 
 # ------------------------------------------------------------------------------------------

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 9
+#define EAVSR_ABI_VERSION 10
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -147,6 +147,16 @@ int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);
  * with channels % 8 == 0, no fused channel-attention prologue, and a problem size that runs 32-row tiles
  * (eavsr_conv2d_tile_rows); returns -2 otherwise and the caller uses eavsr_conv2d_f32.                          */
 int eavsr_conv3x3_f32x9(const eavsr_conv2d_desc* desc, const void* weight_x9, void* stream);
+/* The 3x3 convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores (same descriptor, tensors and epilogue;
+ * 2.25x fewer multiplications; fp32 arithmetic throughout, as cuDNN / MIOpen run fp32 3x3 convolutions by default).
+ * weight_wino: eavsr_wino_weight_elems(cout, cin) floats written by eavsr_pack_conv_weight_wino from the
+ * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  16 x 16-pixel tiles: chan_partial has
+ * eavsr_conv3x3_wino_tiles(h, w) rows per sample.  Requires ksize 3, w % 4 == 0, 16-byte aligned sources with
+ * channels % 8 == 0 and no fused channel-attention prologue; returns -2 otherwise (call eavsr_conv2d_f32).   */
+int64_t eavsr_wino_weight_elems(int32_t cout, int32_t cin);
+int eavsr_pack_conv_weight_wino(const float* weight, float* weight_wino, int32_t cout, int32_t cin, void* stream);
+int32_t eavsr_conv3x3_wino_tiles(int32_t h, int32_t w);
+int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* desc, const float* weight_wino, void* stream);
 /* input-channel chunk the kernel for this kernel size works in (sources must be multiples of it) */
 int32_t eavsr_conv2d_ck(int32_t ksize);
 /* rows of the spatial tile (32, 16 or 8; 32 columns) the kernel runs an (n, h, w) problem in: small images get

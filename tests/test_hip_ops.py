@@ -267,6 +267,68 @@ def test_dcnv2_bad_arguments_raise(ops, cuda):
                                     torch.zeros(64, 64, 3, 3), None, 1, 1, 1, 1, 8)
 
 
+# ---- 3x3 conv by Winograd F(2x2, 3x3) on the fp32 MFMA: same descriptor / tensors / epilogue as the direct kernel ---
+@pytest.fixture()
+def conv_wino(ops):
+    ops.set_conv_mode("winograd")
+    yield ops
+    ops.set_conv_mode("native")
+
+
+@pytest.mark.parametrize("case", [([64], 64, "relu", True, True, 10, 133, 156), ([64, 64], 64, "lrelu", True, False, 10, 133, 156),
+                                  ([64], 256, None, False, False, 4, 100, 128), ([64, 64, 64, 64, 64], 64, "lrelu", False, False, 3, 180, 320),
+                                  ([8], 40, None, False, True, 13, 65, 68), ([128], 64, "relu", False, True, 1, 400, 320)],
+                         ids=lambda c: f"c{'+'.join(map(str, c[0]))}_o{c[1]}_{c[5]}x{c[6]}x{c[7]}")
+def test_conv3x3_winograd_vs_torch_cpu(conv_wino, cuda, case):
+    chans, cout, act, use_res, use_part, n, h, w = case
+    cin = sum(chans)
+    srcs = [cases.randn(10 + i, n, c, h, w) for i, c in enumerate(chans)]
+    wt = cases.randn(20, cout, cin, 3, 3, scale=1.0 / (cin * 9) ** 0.5)
+    b = cases.randn(21, cout, scale=0.1)
+    res = cases.randn(22, n, cout, h, w) if use_res else None
+    ref = F.conv2d(torch.cat(srcs, 1), wt, b, 1, 1)
+    ref = F.relu(ref) if act == "relu" else (F.leaky_relu(ref, 0.1) if act == "lrelu" else ref)
+    pre = ref
+    if use_res:
+        ref = ref + res
+    with conv_wino.profile() as prof:
+        out = conv_wino.conv2d([g(s_, cuda) for s_ in srcs], g(wt, cuda), g(b, cuda), act=act, slope=0.1,
+                               residual=None if res is None else g(res, cuda), chan_partial=use_part)
+    assert list(prof.summary()) == [f"conv3x3_{cin}to{cout}_wino"]
+    if use_part:
+        out, part = out
+        sums = pre.sum(dim=(2, 3))
+        assert H.maxabs(part.sum(dim=1).cpu(), sums) <= 2e-6 * sums.abs().max().item() + 2e-3
+    assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_winograd_small_problems_run_the_direct_kernel(conv_wino, cuda):
+    x, wt = cases.randn(1, 1, 64, 20, 32), cases.randn(2, 64, 64, 3, 3, scale=0.05)
+    with conv_wino.profile() as prof:
+        out = conv_wino.conv2d(g(x, cuda), g(wt, cuda), None)
+    assert list(prof.summary()) == ["conv3x3_64to64"]
+    assert H.maxabs(out.cpu(), F.conv2d(x, wt, None, 1, 1)) <= 2e-5
+
+
+def test_conv3x3_winograd_error_against_fp64(ops, cuda):
+    """F(2x2, 3x3) rounds differently from the direct sum (transform additions before and after the products); in fp32
+    its error stays within a small factor of the direct kernel's."""
+    n, h, w = 10, 133, 156
+    x = cases.randn(1, n, 64, h, w) * 2.0 + 0.7
+    wt = cases.randn(2, 64, 64, 3, 3, scale=0.05)
+    ref64 = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    scale = ref64.abs().max().item()
+    ops.set_conv_mode("native")
+    e_native = (ops.conv2d(g(x, cuda), g(wt, cuda), None).cpu().double() - ref64).abs().max().item() / scale
+    ops.set_conv_mode("winograd")
+    try:
+        e_wino = (ops.conv2d(g(x, cuda), g(wt, cuda), None).cpu().double() - ref64).abs().max().item() / scale
+    finally:
+        ops.set_conv_mode("native")
+    print("relative max error vs fp64: direct", e_native, "winograd", e_wino)
+    assert e_native < 3e-6 and e_wino < 6e-6, (e_native, e_wino)
+
+
 # ---- 3x3 conv, bf16x9 contraction (opt-in): same descriptor / tensors / epilogue as the native kernel -------------
 @pytest.fixture()
 def conv_x9(ops):

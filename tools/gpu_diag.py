@@ -61,6 +61,9 @@ T("dcnv2 sigma1.5", lambda: ops.modulated_deform_conv2d(x64, off, mask, w33, b, 
 off0 = off * 0
 T("dcnv2 sigma0", lambda: ops.modulated_deform_conv2d(x64, off0, mask, w33, b, 1, 1, 1, 1, 8),
   flops=2 * 64 * 64 * 9 * px, nbytes=4 * px * 344)
+ops.set_conv_mode("winograd")
+T("conv3x3 64->64 relu  winograd", lambda: ops.conv2d(x64, w33, b, act="relu"), flops=2 * 64 * 64 * 9 * px)
+T("conv3x3 64->64 +partial winograd", lambda: ops.conv2d(x64, w33, b, chan_partial=True), flops=2 * 64 * 64 * 9 * px)
 ops.set_conv_mode("bf16x9")
 T("conv3x3 64->64 relu  bf16x9", lambda: ops.conv2d(x64, w33, b, act="relu"), flops=2 * 64 * 64 * 9 * px)
 T("conv3x3 64->64 +partial bf16x9", lambda: ops.conv2d(x64, w33, b, chan_partial=True), flops=2 * 64 * 64 * 9 * px)
