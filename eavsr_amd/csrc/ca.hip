@@ -9,14 +9,17 @@
 
 namespace {
 
-// one workgroup per sample; 256 threads = Q groups of c threads, group q sums tiles q, q+Q, ... of its
-// channel (coalesced over channels), fixed-order LDS reduction over the groups, then the tiny MLP.
-__global__ __launch_bounds__(256) void ca_scale_kernel(const float* __restrict__ partial, int tiles, float inv_hw,
+// one workgroup per sample; 1024 threads = Q groups of c threads, group q sums tiles q, q+Q, ... of its
+// channel (coalesced over channels; four independent partial sums so that the loads of a thread are in flight
+// together -- the launch is pure latency: 60..240 tiles of 64 floats per sample), fixed-order LDS reduction over
+// the groups, then the tiny MLP.
+constexpr int CA_THREADS = 1024;
+__global__ __launch_bounds__(CA_THREADS) void ca_scale_kernel(const float* __restrict__ partial, int tiles, float inv_hw,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        float* __restrict__ scale, int c, int cr) {
   extern __shared__ float sm[];  // part[Q*c] then mean[c] then hidden[cr]
-  const int Q = 256 / c;
+  const int Q = CA_THREADS / c;
   float* part = sm;
   float* mean = sm + Q * c;
   float* hid = mean + c;
@@ -25,9 +28,15 @@ __global__ __launch_bounds__(256) void ca_scale_kernel(const float* __restrict__
   const int q = tid / c, ch = tid - q * c;
   if (q < Q) {
     const float* p = partial + (size_t)bn * tiles * c + ch;
-    float s = 0.f;
-    for (int t = q; t < tiles; t += Q) s += p[(size_t)t * c];
-    part[q * c + ch] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = q;
+    for (; t + 3 * Q < tiles; t += 4 * Q) {
+      const float v0 = p[(size_t)t * c], v1 = p[(size_t)(t + Q) * c], v2 = p[(size_t)(t + 2 * Q) * c],
+                  v3 = p[(size_t)(t + 3 * Q) * c];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; t < tiles; t += Q) s0 += p[(size_t)t * c];
+    part[q * c + ch] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   if (tid < c) {
@@ -84,8 +93,8 @@ extern "C" int eavsr_ca_scale_f32(const float* chan_partial, int32_t tiles, int3
   EAVSR_REQUIRE(n >= 0 && c > 0 && cr > 0 && tiles > 0 && hw > 0, -1, "ca_scale: bad dims");
   EAVSR_REQUIRE(c <= 256 && cr <= 256, -2, "ca_scale: c=%d / cr=%d unsupported (<= 256)", c, cr);
   if (n == 0) return 0;
-  const int Q = 256 / c;
-  hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(256), (size_t)(Q * c + c + cr) * sizeof(float), eavsr::as_stream(stream),
+  const int Q = CA_THREADS / c;
+  hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(CA_THREADS), (size_t)(Q * c + c + cr) * sizeof(float), eavsr::as_stream(stream),
                      chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, scale, c, cr);
   return eavsr::launch_status("ca_scale");
 }

@@ -10,16 +10,20 @@
 // run for an fp32 3x3 convolution by default -- fp32 arithmetic throughout, different rounding than the direct sum
 // (tests/test_hip_ops.py compares both against fp64).
 //
-// Per workgroup (512 threads = 8 waves, one per CU): 16 x 16 output pixels = 64 Winograd tiles, 64 output channels.
-//   wave w owns the transform positions xi = 2w, 2w+1: accumulators M[2][64 co][64 tiles] = 128 registers per lane.
+// Per workgroup (512 threads = 8 waves, one per CU): 8 x 32 output pixels = 4 x 16 Winograd tiles, 64 output channels.
+//   The GEMMs run on v_mfma_f32_16x16x4_f32 (same FLOP rate as 32x32x2) so that ONE wave can hold all 16 transform
+//   positions of a (16 output channels x 16 tiles) block in 64 registers: wave w owns output channels 16 (w >> 1) ..
+//   and the tile rows 2 (w & 1), 2 (w & 1) + 1 (16 tiles each) -- 128 accumulator registers -- and the output transform needs no
+//   exchange between waves (a first version with 32x32x2 tiles, two positions per wave, spent 22 % of its time
+//   moving M through LDS).
 //   per chunk of 8 input channels (two LDS stages for the DMA'd data, one for V):
-//     LDS-DMA: the (8 x 18 x 24) fp32 input patch (zero padding = never-written zero-initialised LDS) and the
+//     LDS-DMA: the (8 x 10 x 40) fp32 input patch (zero padding = never-written zero-initialised LDS) and the
 //              pre-transformed weight slab U[16][8][64] (eavsr_pack_conv_weight_wino)          (HBM / L2 -> LDS)
 //     input transform: thread (c, tile) reads its 4 x 4 patch, 32 additions, writes V[16][8][64]   (LDS -> LDS)
-//     GEMM: per owned xi and channel pair: 2 + 2 ds_read_b32, 4 MFMAs                             (LDS -> MFMA)
-//   epilogue: the 16 M_xi of a (co, tile) live in 8 different waves: exchanged through LDS in two passes of 32 output
-//   channels, output transform (24 additions), + bias, activation, + residual, float2 row stores, optional per-tile
-//   channel sums (deterministic).
+//     GEMM: per position and 4-channel k-step: 1 + 2 ds_read_b32, 2 MFMAs; U and V rows carry an XOR swizzle
+//           (column ^ 16 (c & 1)) so that the four k-rows a wave reads at once fall on different banks
+//   epilogue in registers: output transform (24 additions per (co, tile)), + bias, activation, + residual, float2
+//   row stores, optional per-tile channel sums (deterministic).
 #include "common.h"
 
 #include <mutex>
@@ -45,31 +49,29 @@ struct WnArgs {
 };
 
 constexpr int CK = 8, NW = 8;
-constexpr int TO = 16;                                // output tile edge (8 x 8 Winograd tiles)
+constexpr int TOH = 8, TOW = 32;                      // output tile: 4 x 16 Winograd tiles; a row is 32 px = one 128-byte line
 constexpr int MARG = 4;                               // patch starts 4 columns left of the tile: 16-byte DMA pieces
-constexpr int IH = TO + 2, IW = TO + 2 * MARG;        // 18 x 24
-constexpr int IN_ELEMS = CK * IH * IW;                // 3456 floats
-constexpr int IN_SEGS = (IN_ELEMS + 255) / 256;       // 14 one-KiB pieces (the last one half)
+constexpr int IH = TOH + 2, IW = TOW + 2 * MARG;      // 10 x 40
+constexpr int IN_ELEMS = CK * IH * IW;                // 3200 floats
+constexpr int IN_SEGS = (IN_ELEMS + 255) / 256;       // 13 one-KiB pieces (the last one half)
 constexpr int IN_PAD = IN_SEGS * 256;
 constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;        // 2
 constexpr int UV = 16 * CK * 64;                      // floats of one U (or V) chunk: 8192 = 32 KB
 constexpr int W_SEGS = UV / 256;                      // 32 pieces
 constexpr int W_IT = W_SEGS / NW;                     // 4
 constexpr int STAGE = IN_PAD + UV;                    // DMA'd floats per pipeline stage
-constexpr int M_HALF = 16 * 32 * 64;                  // epilogue exchange buffer: 32 output channels of M
 constexpr int LDS_MAIN = 2 * STAGE + UV;              // two DMA stages + V
-constexpr int LDS_FLOATS = (LDS_MAIN > M_HALF ? LDS_MAIN : M_HALF) + 64;
+constexpr int LDS_FLOATS = LDS_MAIN + 128;
 constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_v = smem + 2 * STAGE;
-  float* s_red = smem + (LDS_MAIN > M_HALF ? LDS_MAIN : M_HALF);
+  float* s_red = smem + LDS_MAIN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
 
   int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;
@@ -77,20 +79,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   const int ty = bid % a.tiles_y;
   const int bn = bid / a.tiles_y;
   const int cot = blockIdx.y;
-  const int y0 = ty * TO, x0 = tx * TO;
+  const int y0 = ty * TOH, x0 = tx * TOW;
   const int h = a.h, w = a.w;
   const size_t plane = (size_t)h * w;
 
-  // acc[comp][mt][nt]: M of transform position 2 wave + comp, output channels 32 mt .., tiles 32 nt ..
-  f32x16 acc[2][2][2];
+  // acc[b][xi]: M_xi of output channels 16 cb + 4 (lane >> 4) + r, tile 16 (tb0 + b) + (lane & 15)
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int cb = wave >> 1, tb0 = 2 * (wave & 1);
+  f32x4 acc[2][16];
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][m][t][r] = 0.f;
+    for (int x = 0; x < 16; ++x) acc[b][x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int cs = 0, cc0 = 0, cbase = 0;
   int total_chunks = 0;
@@ -143,11 +143,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
     }
   };
 
-  // input-transform job of this thread: channel tc of the chunk, Winograd tile tt = 8 tty + ttx
+  // input-transform job of this thread: channel tc of the chunk, Winograd tile tt = 16 tty + ttx
   const int tc = tid >> 6, tt = tid & 63;
-  const int tty = tt >> 3, ttx = tt & 7;
+  const int tty = tt >> 4, ttx = tt & 15;
   const int poff = tc * (IH * IW) + (2 * tty) * IW + (MARG - 1) + 2 * ttx;   // top-left of its 4 x 4 patch
-  float* vdst = s_v + tc * 64 + tt;                                          // + xi * (CK * 64)
+  float* vdst = s_v + tc * 64 + (tt ^ ((tc & 1) << 4));                      // + xi * (CK * 64); swizzled column
 
   issue_chunk(0);
   for (int it = 0; it < total_chunks; ++it) {
@@ -156,8 +156,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
     __syncthreads();
     if (it + 1 < total_chunks) {
       advance();
+#ifndef EAVSR_WINO_EXP_NODMA     // timing ablations only (tools/gpu_wino_ablate.py): results are wrong
       issue_chunk((it + 1) & 1);
+#endif
     }
+#ifndef EAVSR_WINO_EXP_NOTRANSFORM
     // ---- input transform V = B^T d B of this thread's (channel, tile) ----------------------------
     {
       const float* pp = smem + (it & 1) * STAGE + poff;
@@ -182,103 +185,101 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
         vdst[(r * 4 + 3) * (CK * 64)] = t[r][1] - t[r][3];
       }
     }
+#endif
     __syncthreads();
-    // ---- 2 of the 16 GEMMs: M_xi[co, t] += sum over the chunk's 8 channels U_xi[co, c] V_xi[c, t] --------
+    // ---- the 16 GEMMs of this wave's two blocks: M_xi[co, t] += sum over the chunk's 8 channels U_xi[co, c] V_xi[c, t]
     const float* su = smem + (it & 1) * STAGE + IN_PAD;
+    const int sw = (kq & 1) << 4;                       // swizzle of the row this lane reads (c = 4 ks + kq)
+    const float* ua = su + kq * 64 + ((cb * 16 + l15) ^ sw);
+    const float* vb0 = s_v + kq * 64 + ((tb0 * 16 + l15) ^ sw);
+    const float* vb1 = s_v + kq * 64 + ((tb0 * 16 + 16 + l15) ^ sw);
+    // operands run three steps ahead of the MFMAs (32 steps = 16 positions x 2 k-steps): an LDS read takes longer than
+    // the 64 cycles of a step's two MFMAs
+    constexpr int NSTEP = 16 * (CK / 4), AHEAD = 3;
+    auto row_of = [](int i) { return ((i / (CK / 4)) * CK + 4 * (i % (CK / 4))) * 64; };
+    float av[AHEAD + 1], b0[AHEAD + 1], b1[AHEAD + 1];
 #pragma unroll
-    for (int comp = 0; comp < 2; ++comp) {
-      const int xi = 2 * wave + comp;
-      const float* ua = su + (xi * CK + half) * 64 + l31;
-      const float* vb = s_v + (xi * CK + half) * 64 + l31;
+    for (int i = 0; i < AHEAD; ++i) { av[i] = ua[row_of(i)]; b0[i] = vb0[row_of(i)]; b1[i] = vb1[row_of(i)]; }
 #pragma unroll
-      for (int kp = 0; kp < CK / 2; ++kp) {
-        float av[2], bv[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) av[m] = ua[(2 * kp) * 64 + m * 32];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) bv[t] = vb[(2 * kp) * 64 + t * 32];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            acc[comp][m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[t], acc[comp][m][t], 0, 0, 0);
+    for (int i = 0; i < NSTEP; ++i) {
+      if (i + AHEAD < NSTEP) {
+        av[(i + AHEAD) % (AHEAD + 1)] = ua[row_of(i + AHEAD)];
+        b0[(i + AHEAD) % (AHEAD + 1)] = vb0[row_of(i + AHEAD)];
+        b1[(i + AHEAD) % (AHEAD + 1)] = vb1[row_of(i + AHEAD)];
       }
+      const int xi = i / (CK / 4), cur = i % (AHEAD + 1);
+      acc[0][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur], b0[cur], acc[0][xi], 0, 0, 0);
+      acc[1][xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur], b1[cur], acc[1][xi], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the 3 reads of step i + AHEAD
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // the 2 MFMAs of step i
     }
   }
 
-  // ---- epilogue: exchange M through LDS (32 output channels per pass), output transform, stores ----
-  float* s_m = smem;   // [16 xi][32 co][64 tiles]
-  const int tile_lin = ty * a.tiles_x + tx;
-#pragma unroll 1
-  for (int mt = 0; mt < 2; ++mt) {
-    __syncthreads();   // main loop / previous pass done with this LDS
+  // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile] for every xi ----------
+#ifdef EAVSR_WINO_EXP_NOEPI
+  if (acc[0][0][0] == 12345.678f)
+#endif
+  {
+    const int tile_lin = ty * a.tiles_x + tx;
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int comp = 0; comp < 2; ++comp) {
-      const int xi = 2 * wave + comp;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int col = (r & 3) + 8 * (r >> 2) + 4 * half;   // output channel within the pass
-          s_m[(xi * 32 + col) * 64 + t * 32 + l31] = (mt == 0) ? acc[comp][0][t][r] : acc[comp][1][t][r];
-        }
-    }
-    __syncthreads();
-    // thread -> (output channel col = wave + 8 j, tile tt2 = lane): all 64 lanes of a wave share the channel
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = wave + 8 * j;
-      const int co = cot * 64 + mt * 32 + col;
-      const int t2 = lane, t2y = t2 >> 3, t2x = t2 & 7;
-      float m[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) m[r][q] = s_m[((r * 4 + q) * 32 + col) * 64 + t2];
-      float s0[4], s1[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {      // A^T m: rows
-        s0[q] = m[0][q] + m[1][q] + m[2][q];
-        s1[q] = m[1][q] - m[2][q] - m[3][q];
-      }
-      float y[2][2];
-      y[0][0] = s0[0] + s0[1] + s0[2];
-      y[0][1] = s0[1] - s0[2] - s0[3];
-      y[1][0] = s1[0] + s1[1] + s1[2];
-      y[1][1] = s1[1] - s1[2] - s1[3];
-      const bool cok = co < a.cout;
-      const float b = (cok && a.bias) ? a.bias[co] : 0.f;
+    for (int b = 0; b < 2; ++b) {
+      const int t2y = tb0 + b, t2x = l15;   // tile block = one row of 16 tiles: 16 lanes x float2 = one 128-byte line
       const int gx = x0 + 2 * t2x;
-      float sum = 0.f;
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const int gy = y0 + 2 * t2y + dy;
-        float v0 = y[dy][0] + b, v1 = y[dy][1] + b;
-        if (a.act == EAVSR_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-        else if (a.act == EAVSR_ACT_LRELU) { v0 = v0 > 0.f ? v0 : v0 * a.slope; v1 = v1 > 0.f ? v1 : v1 * a.slope; }
-        if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
-          const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
-          sum += v0 + v1;
-          if (a.residual) {
-            const f32x2 rr = *reinterpret_cast<const f32x2*>(a.residual + o);
-            v0 += rr.x; v1 += rr.y;
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * 64 + cb * 16 + 4 * kq + r;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {      // A^T m: rows
+          s0[q] = acc[b][0 + q][r] + acc[b][4 + q][r] + acc[b][8 + q][r];
+          s1[q] = acc[b][4 + q][r] - acc[b][8 + q][r] - acc[b][12 + q][r];
+        }
+        float y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2];
+        y[0][1] = s0[1] - s0[2] - s0[3];
+        y[1][0] = s1[0] + s1[1] + s1[2];
+        y[1][1] = s1[1] - s1[2] - s1[3];
+        const bool cok = co < a.cout;
+        const float bb = (cok && a.bias) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int gy = y0 + 2 * t2y + dy;
+          float v0 = y[dy][0] + bb, v1 = y[dy][1] + bb;
+          if (a.act == EAVSR_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          else if (a.act == EAVSR_ACT_LRELU) { v0 = v0 > 0.f ? v0 : v0 * a.slope; v1 = v1 > 0.f ? v1 : v1 * a.slope; }
+          if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
+            const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
+            csum[r] += v0 + v1;
+            if (a.residual) {
+              const f32x2 rr = *reinterpret_cast<const f32x2*>(a.residual + o);
+              v0 += rr.x; v1 += rr.y;
+            }
+            *reinterpret_cast<f32x2*>(a.out + o) = f32x2{v0, v1};
           }
-          *reinterpret_cast<f32x2*>(a.out + o) = f32x2{v0, v1};
         }
       }
-      if (a.chan_partial) {
-        sum += __shfl_xor(sum, 32);
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 8);
-        sum += __shfl_xor(sum, 4);
-        sum += __shfl_xor(sum, 2);
-        sum += __shfl_xor(sum, 1);
-        if (lane == 0 && cok)
-          a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + tile_lin) * a.cout + co] = sum;
+    }
+    if (a.chan_partial) {
+      // per output channel: 16 lanes (tiles) x 2 blocks here, and the same again in wave ^ 1 (fixed order)
+      __syncthreads();   // the main loop is done with the LDS
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = csum[r];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if (l15 == 0) s_red[(wave & 1) * 64 + cb * 16 + 4 * kq + r] = v;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int co = cot * 64 + tid;
+        if (co < a.cout)
+          a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + tile_lin) * a.cout + co] = s_red[tid] + s_red[64 + tid];
       }
     }
   }
-  (void)s_red;
 }
 
 // weight (cout, cin, 3, 3) -> U = G g G^T laid out [cot][cin / 8][xi][c][co] (zero for co >= cout)
@@ -306,7 +307,8 @@ __global__ void pack_wino_kernel(const float* __restrict__ wt, float* __restrict
     }
     v = q == 0 ? gr[0] : (q == 1 ? 0.5f * (gr[0] + gr[1] + gr[2]) : (q == 2 ? 0.5f * (gr[0] - gr[1] + gr[2]) : gr[2]));
   }
-  out[e] = v;
+  // XOR swizzle of the column (see the GEMM loop): element (xi, c, co) lives at column co ^ 16 (c & 1)
+  out[e - col + (col ^ ((c & 1) << 4))] = v;
 }
 
 }  // namespace
@@ -325,7 +327,7 @@ extern "C" int eavsr_pack_conv_weight_wino(const float* weight, float* packed, i
   return eavsr::launch_status("pack_conv_weight_wino");
 }
 
-extern "C" int32_t eavsr_conv3x3_wino_tiles(int32_t h, int32_t w) { return eavsr::cdiv(h, TO) * eavsr::cdiv(w, TO); }
+extern "C" int32_t eavsr_conv3x3_wino_tiles(int32_t h, int32_t w) { return eavsr::cdiv(h, TOH) * eavsr::cdiv(w, TOW); }
 
 extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* weight_wino, void* stream) {
   EAVSR_REQUIRE(d != nullptr && weight_wino != nullptr, -1, "conv3x3_wino: NULL descriptor / weights");
@@ -356,8 +358,8 @@ extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* w
   a.wu = weight_wino;
   a.bias = d->bias; a.residual = d->residual; a.out = d->out; a.chan_partial = d->chan_partial;
   a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
-  a.tiles_x = eavsr::cdiv(d->w, TO);
-  a.tiles_y = eavsr::cdiv(d->h, TO);
+  a.tiles_x = eavsr::cdiv(d->w, TOW);
+  a.tiles_y = eavsr::cdiv(d->h, TOH);
   a.act = d->act; a.slope = d->slope;
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_wino: too many tiles");

@@ -492,7 +492,7 @@ def _packed_dcn_x9(weight: Tensor) -> Tensor:
 # Winograd F(2x2, 3x3) on the same fp32 MFMA (2.25x fewer multiplications, eavsr_conv3x3_wino_f32); "bf16x9" = direct
 # sum with an exact three-way bf16 split of both operands, nine partial products in fp32 (eavsr_conv3x3_f32x9).
 CONV_MODE = os.environ.get("EAVSR_CONV_MODE", "native")
-WINO_MIN_TILES = 192      # 16 x 16-pixel tiles per launch below which the direct kernel (8-row tiles) is used
+WINO_MIN_TILES = 192      # 8 x 32-pixel tiles per launch below which the direct kernel (8-row tiles) is used
 
 
 def set_conv_mode(mode: str) -> None:

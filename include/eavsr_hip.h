@@ -150,7 +150,7 @@ int eavsr_conv3x3_f32x9(const eavsr_conv2d_desc* desc, const void* weight_x9, vo
 /* The 3x3 convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores (same descriptor, tensors and epilogue;
  * 2.25x fewer multiplications; fp32 arithmetic throughout, as cuDNN / MIOpen run fp32 3x3 convolutions by default).
  * weight_wino: eavsr_wino_weight_elems(cout, cin) floats written by eavsr_pack_conv_weight_wino from the
- * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  16 x 16-pixel tiles: chan_partial has
+ * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  8 x 32-pixel tiles: chan_partial has
  * eavsr_conv3x3_wino_tiles(h, w) rows per sample.  Requires ksize 3, w % 4 == 0, 16-byte aligned sources with
  * channels % 8 == 0 and no fused channel-attention prologue; returns -2 otherwise (call eavsr_conv2d_f32).   */
 int64_t eavsr_wino_weight_elems(int32_t cout, int32_t cin);
