@@ -45,11 +45,12 @@ def parse():
     ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="fp32 (default, the BASELINE headline: exact fp32 everywhere) or a 16-bit NHWC residual backbone "
                          "(BASELINE.json configs[2] / [4]); the 16-bit runs are reported under their own metric name")
-    ap.add_argument("--f32-mode", default="native", choices=["native", "bf16x9"],
-                    help="how the fp32 contractions of the 3x3 convolutions and of DCNv2 are carried: native = fp32 MFMA "
-                         "(default, the headline); bf16x9 = both operands split EXACTLY into three bf16 terms, all nine "
-                         "partial products accumulated in fp32 on the bf16 matrix pipe (no operand is rounded; reported "
-                         "under its own metric name)")
+    ap.add_argument("--conv-mode", default="winograd", choices=["winograd", "direct", "bf16x9"],
+                    help="large 3x3 convolutions (all fp32 in / out / accumulate): winograd = F(2x2,3x3) on the fp32 MFMA "
+                         "(default); direct = direct sum on the fp32 MFMA; bf16x9 = direct sum, both operands split exactly "
+                         "into three bf16 terms, nine partial products on the bf16 MFMA")
+    ap.add_argument("--dcn-mode", default="native", choices=["native", "bf16x9"],
+                    help="DCNv2 contraction: native fp32 MFMA (default) or the exact bf16x9 split")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: the BASELINE metric (default). train: BASELINE.json configs[3], a data-parallel "
                          "training step (2 clips/GPU x 7 x 3 x 96 x 96, L1 loss, Adam, one RCCL all-reduce on the "
@@ -198,9 +199,8 @@ def main():
     if args.backbone_dtype != "fp32":
         from eavsr_amd import networks as _nw
         _nw.set_backbone_dtype(args.backbone_dtype)
-    if args.f32_mode != "native":
-        ops.set_conv_mode(args.f32_mode)
-        ops.set_dcn_mode(args.f32_mode)
+    ops.set_conv_mode(args.conv_mode)
+    ops.set_dcn_mode(args.dcn_mode)
     n, t, h, w = args.clips, args.frames, args.height, args.width
     clips = synthetic_clip(n, t, h, w, seed=rank).to(device)   # resident in HBM before the timed region
 
@@ -225,7 +225,7 @@ def main():
     line = {
         "metric": "SR frames/sec at 4x 7-frame 180x320->720x1280" +
                   ("" if args.backbone_dtype == "fp32" else f" [{args.backbone_dtype} residual backbone, not the fp32 headline]") +
-                  ("" if args.f32_mode == "native" else " [fp32 via exact bf16x9 split products, opt-in mode]"),
+                  ("" if args.conv_mode != "bf16x9" and args.dcn_mode == "native" else " [fp32 via exact bf16x9 split products, opt-in mode]"),
         "value": value,
         "unit": "frames/s",
         "n_gpus": world,
@@ -236,11 +236,15 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": ("f32" if args.backbone_dtype == "fp32" else f"{args.backbone_dtype} backbone + f32") +
-                 ("" if args.f32_mode == "native" else " (3x3 conv / DCNv2 contractions: exact 3 x bf16 operand split, 9 products, f32 accumulate)"),
+                 ("" if args.conv_mode != "bf16x9" and args.dcn_mode == "native"
+                  else " (contractions in bf16x9 mode: exact 3 x bf16 operand split, 9 products, f32 accumulate)"),
         "data": "synthetic",
         "config": {"workload": f"eavsrp x4 inference, {n} clips/GPU x {t} frames x 3 x {h} x {w} fp32 "
                                f"(BASELINE.json configs[1]), weights: seeded '{args.preset}' init",
-                   "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "scale": 4, "sharding": "clips across ranks, no collective"},
+                   "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "scale": 4, "sharding": "clips across ranks, no collective",
+                   "conv3x3": {"winograd": "Winograd F(2x2,3x3), fp32 MFMA (direct fp32 kernel for the shapes it does not cover)",
+                               "direct": "direct sum, fp32 MFMA", "bf16x9": "direct sum, exact bf16x9 split"}[args.conv_mode],
+                   "dcnv2": args.dcn_mode},
     }
 
     if rank == 0 and not args.no_kernel_profile:
@@ -265,18 +269,22 @@ def main():
                     "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
                     "share_of_step": v["ms"] / total_ms}
 
-        dom = entry("conv3x3_64to64" if args.f32_mode == "native" else "conv3x3_64to64_x9", "mfma")
+        dom_name = {"winograd": "conv3x3_64to64_wino", "direct": "conv3x3_64to64", "bf16x9": "conv3x3_64to64_x9"}[args.conv_mode]
+        dom = entry(dom_name, "mfma")
         if args.backbone_dtype != "fp32":
             e16 = entry("conv3x3_64to64_h16", "hbm")
             if e16:
                 line.setdefault("kernels_16bit", []).append(e16)
         if dom is not None:
             line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-            line["roofline"]["kernel"] = ("conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)" if args.f32_mode == "native"
-                                          else "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)")
+            line["roofline"]["kernel"] = {
+                "winograd": "conv3x3_wino_kernel (3x3 64->64, the residual backbone); `achieved` counts the ALGORITHMIC "
+                            "2*cin*cout*9 FLOP per pixel (SURVEY 8d) -- the kernel performs 2.25x fewer multiplications",
+                "direct": "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)",
+                "bf16x9": "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)"}[args.conv_mode]
             line["roofline"]["avg_ms"] = dom["avg_ms"]
             line["roofline"]["share_of_step"] = dom["share_of_step"]
-        line["kernels"] = [e for e in (entry("dcnv2" if args.f32_mode == "native" else "dcnv2_x9", "hbm"), entry("flow_warp", "hbm"),
+        line["kernels"] = [e for e in (entry("dcnv2" if args.dcn_mode == "native" else "dcnv2_x9", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120", "mfma")) if e]
         line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
@@ -287,8 +295,8 @@ def main():
         if os.path.exists(pmc):
             try:
                 tr = json.load(open(pmc))
-                if "roofline" in line and args.f32_mode == "native":
-                    line["roofline"]["traffic"] = tr.get("conv3x3_64to64")
+                if "roofline" in line:
+                    line["roofline"]["traffic"] = tr.get(dom_name)
                 for e in line["kernels"]:
                     e["traffic"] = tr.get(e["kernel"])
             except Exception:

@@ -488,18 +488,28 @@ def _packed_dcn_x9(weight: Tensor) -> Tensor:
     return _packed_x9([weight])
 
 
-# How the 3x3 convolutions are computed: "native" = direct sum on v_mfma_f32_32x32x2_f32 (default); "winograd" =
-# Winograd F(2x2, 3x3) on the same fp32 MFMA (2.25x fewer multiplications, eavsr_conv3x3_wino_f32); "bf16x9" = direct
-# sum with an exact three-way bf16 split of both operands, nine partial products in fp32 (eavsr_conv3x3_f32x9).
-CONV_MODE = os.environ.get("EAVSR_CONV_MODE", "native")
+# How the large 3x3 convolutions are computed (all fp32 in, fp32 out, fp32 accumulation):
+#   "winograd" (default) = Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32 (eavsr_conv3x3_wino_f32): 2.25x fewer
+#                multiplications, what cuDNN / MIOpen run for fp32 3x3 convolutions; measured closer to fp64 than the
+#                direct sum (tests/test_hip_ops.py)
+#   "direct"   = direct sum on v_mfma_f32_32x32x2_f32 (eavsr_conv2d_f32) -- also what every shape the Winograd kernel
+#                does not cover runs (small images, widths not a multiple of 4, channels not a multiple of 8, 1x1/5x5/7x7)
+#   "bf16x9"   = direct sum with an exact three-way bf16 split of both operands, nine partial products in fp32
+#                (eavsr_conv3x3_f32x9), opt-in
+def _norm_conv_mode(mode: str) -> str:
+    mode = {"native": "direct"}.get(mode, mode)
+    if mode not in ("direct", "winograd", "bf16x9"):
+        raise ValueError(f"conv mode {mode!r}: 'winograd', 'direct' or 'bf16x9'")
+    return mode
+
+
+CONV_MODE = _norm_conv_mode(os.environ.get("EAVSR_CONV_MODE", "winograd"))
 WINO_MIN_TILES = 192      # 8 x 32-pixel tiles per launch below which the direct kernel (8-row tiles) is used
 
 
 def set_conv_mode(mode: str) -> None:
     global CONV_MODE
-    if mode not in ("native", "winograd", "bf16x9"):
-        raise ValueError(f"conv mode {mode!r}: 'native', 'winograd' or 'bf16x9'")
-    CONV_MODE = mode
+    CONV_MODE = _norm_conv_mode(mode)
 
 
 _wino_pack_cache = {}

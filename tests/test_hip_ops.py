@@ -10,6 +10,8 @@ from tests.golden import cases
 
 pytestmark = pytest.mark.gpu
 
+DEFAULT_CONV_MODE = "winograd"   # eavsr_amd.ops.CONV_MODE's default; tests that switch modes restore it
+
 
 @pytest.fixture(scope="module")
 def ops(cuda):
@@ -110,8 +112,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture()
+def direct_conv(ops):
+    """The direct fp32-MFMA convolution kernel (the default mode sends large 3x3 problems to the Winograd kernel)."""
+    ops.set_conv_mode("direct")
+    yield ops
+    ops.set_conv_mode(DEFAULT_CONV_MODE)
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"k{c[0]}_c{'+'.join(map(str, c[1]))}_o{c[2]}_{c[4]}x{c[5]}")
-def test_conv2d_vs_torch_cpu(ops, cuda, case):
+def test_conv2d_vs_torch_cpu(ops, cuda, case, direct_conv):
     k, chans, cout, n, h, w, act, use_res, use_part = case
     if h > 100:   # the large cases exist to cover the taller tiles
         assert ops.lib().eavsr_conv2d_tile_rows(n, h, w, k) == (16 if n == 4 else 32)
@@ -272,7 +282,7 @@ def test_dcnv2_bad_arguments_raise(ops, cuda):
 def conv_wino(ops):
     ops.set_conv_mode("winograd")
     yield ops
-    ops.set_conv_mode("native")
+    ops.set_conv_mode(DEFAULT_CONV_MODE)
 
 
 @pytest.mark.parametrize("case", [([64], 64, "relu", True, True, 10, 133, 156), ([64, 64], 64, "lrelu", True, False, 10, 133, 156),
@@ -318,13 +328,13 @@ def test_conv3x3_winograd_error_against_fp64(ops, cuda):
     wt = cases.randn(2, 64, 64, 3, 3, scale=0.05)
     ref64 = F.conv2d(x.double(), wt.double(), None, 1, 1)
     scale = ref64.abs().max().item()
-    ops.set_conv_mode("native")
+    ops.set_conv_mode("direct")
     e_native = (ops.conv2d(g(x, cuda), g(wt, cuda), None).cpu().double() - ref64).abs().max().item() / scale
     ops.set_conv_mode("winograd")
     try:
         e_wino = (ops.conv2d(g(x, cuda), g(wt, cuda), None).cpu().double() - ref64).abs().max().item() / scale
     finally:
-        ops.set_conv_mode("native")
+        ops.set_conv_mode(DEFAULT_CONV_MODE)
     print("relative max error vs fp64: direct", e_native, "winograd", e_wino)
     assert e_native < 3e-6 and e_wino < 6e-6, (e_native, e_wino)
 
@@ -334,7 +344,7 @@ def test_conv3x3_winograd_error_against_fp64(ops, cuda):
 def conv_x9(ops):
     ops.set_conv_mode("bf16x9")
     yield ops
-    ops.set_conv_mode("native")
+    ops.set_conv_mode(DEFAULT_CONV_MODE)
 
 
 @pytest.mark.parametrize("case", [([64], 64, "relu", True, True), ([64, 64], 64, "lrelu", True, False),
@@ -378,13 +388,13 @@ def test_conv3x3_x9_error_against_fp64_is_that_of_the_fp32_kernel(ops, cuda):
     wt = cases.randn(2, 64, 64, 3, 3, scale=0.05)
     ref64 = F.conv2d(x.double(), wt.double(), None, 1, 1)
     scale = ref64.abs().max().item()
-    ops.set_conv_mode("native")
+    ops.set_conv_mode("direct")
     e_native = (ops.conv2d(g(x, cuda), g(wt, cuda), None).cpu().double() - ref64).abs().max().item() / scale
     ops.set_conv_mode("bf16x9")
     try:
         e_x9 = (ops.conv2d(g(x, cuda), g(wt, cuda), None).cpu().double() - ref64).abs().max().item() / scale
     finally:
-        ops.set_conv_mode("native")
+        ops.set_conv_mode(DEFAULT_CONV_MODE)
     assert e_native < 3e-6 and e_x9 < 3e-6, (e_native, e_x9)       # measured: 1.3e-6 native, 0.94e-6 bf16x9
     assert e_x9 <= 1.5 * e_native + 2e-8, (e_native, e_x9)
 

@@ -82,7 +82,9 @@ def _grad_worker(rank, world, port, q):
         net.zero_grad(set_to_none=True)
         net(x).pow(2).mean().backward()        # hooks launch the bucket all-reduces during backward
         sync.finish()
-    q.put((rank, [p.grad.clone() if p.grad is not None else None for p in net.parameters()], len(sync.buckets)))
+    # plain nested lists, not tensors: a tensor travels through the queue as a shared-memory handle that dies with
+    # this process (a race with the parent's q.get)
+    q.put((rank, [p.grad.tolist() if p.grad is not None else None for p in net.parameters()], len(sync.buckets)))
     shard.barrier()
     torch.distributed.destroy_process_group()
 
@@ -99,6 +101,8 @@ def test_gradient_allreduce_averages_over_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, g0, nb0), (_, g1, nb1) = res
+    g0 = [None if a is None else torch.tensor(a) for a in g0]
+    g1 = [None if a is None else torch.tensor(a) for a in g1]
     assert nb0 == nb1 and nb0 > 1
     # every rank ends with the same (averaged) gradients ...
     for a, b in zip(g0, g1):

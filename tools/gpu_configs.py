@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run the other BASELINE.json configs once (shape / memory robustness and timing):
-configs[2] x2 model 8 x 7 x 3 x 256 x 256 (fp32 and bf16 backbone), configs[4] x4 1 x 15 x 3 x 540 x 960 (fp32 and fp16 backbone)."""
+configs[2] x2 model 8 x 7 x 3 x 256 x 256 (fp32 and bf16 backbone), configs[4] x4 1 x 15 x 3 x 540 x 960 (fp32 and fp16 backbone);
+fp32 = the default mode (Winograd 3x3 convolutions), then the direct-convolution and bf16x9 modes."""
 import math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,15 +34,16 @@ for name, scale, (n, t, h, w), mode in [("configs[2] x2 8x7x256x256", 2, (8, 7, 
         print(f"{name} backbone={m or 'fp32'}: {dt*1e3:.0f} ms -> {n*t/dt:.1f} frames/s, out {tuple(y.shape)}, "
               f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, finite={bool(torch.isfinite(y).all())}", flush=True)
     print(f"   {mode} vs fp32: max abs {float((res[mode]-res[None]).abs().max()):.2e}, PSNR {psnr(res[mode], res[None]):.1f} dB", flush=True)
-    # the exact-split (bf16x9) contractions on the fp32 path
+    # the other fp32 modes: direct convolutions, and the exact-split (bf16x9) contractions
     Nw.set_backbone_dtype(None)
     from eavsr_amd import ops
-    ops.set_conv_mode("bf16x9"); ops.set_dcn_mode("bf16x9")
-    with torch.no_grad():
-        y = net(clips); torch.cuda.synchronize()
-        t0 = time.perf_counter(); y = net(clips); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    ops.set_conv_mode("native"); ops.set_dcn_mode("native")
-    print(f"{name} fp32 via bf16x9: {dt*1e3:.0f} ms -> {n*t/dt:.1f} frames/s, max abs vs native {float((y-res[None]).abs().max()):.2e}", flush=True)
+    for cm, dm in (("direct", "native"), ("bf16x9", "bf16x9")):
+        ops.set_conv_mode(cm); ops.set_dcn_mode(dm)
+        with torch.no_grad():
+            y = net(clips); torch.cuda.synchronize()
+            t0 = time.perf_counter(); y = net(clips); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"{name} fp32, conv {cm} / dcn {dm}: {dt*1e3:.0f} ms -> {n*t/dt:.1f} frames/s, max abs vs default {float((y-res[None]).abs().max()):.2e}", flush=True)
+    ops.set_conv_mode("winograd"); ops.set_dcn_mode("native")
     Nw.set_backbone_dtype(None)
     del net, clips, res, y
     torch.cuda.empty_cache()

@@ -41,6 +41,7 @@ print("device", torch.cuda.get_device_name(0), "n", n, flush=True)
 T("flow_warp c64", lambda: ops.flow_warp(x64, flow), nbytes=4 * px * 130)
 w33 = r(64, 64, 3, 3) * 0.05
 b = r(64) * 0.1
+ops.set_conv_mode("direct")
 T("conv3x3 64->64 relu", lambda: ops.conv2d(x64, w33, b, act="relu"), flops=2 * 64 * 64 * 9 * px)
 T("conv3x3 64->64 +partial", lambda: ops.conv2d(x64, w33, b, chan_partial=True), flops=2 * 64 * 64 * 9 * px)
 w5 = r(120, 64, 5, 5) * 0.02
@@ -67,7 +68,7 @@ T("conv3x3 64->64 +partial winograd", lambda: ops.conv2d(x64, w33, b, chan_parti
 ops.set_conv_mode("bf16x9")
 T("conv3x3 64->64 relu  bf16x9", lambda: ops.conv2d(x64, w33, b, act="relu"), flops=2 * 64 * 64 * 9 * px)
 T("conv3x3 64->64 +partial bf16x9", lambda: ops.conv2d(x64, w33, b, chan_partial=True), flops=2 * 64 * 64 * 9 * px)
-ops.set_conv_mode(os.environ.get("EAVSR_CONV_MODE", "native"))
+ops.set_conv_mode(os.environ.get("EAVSR_CONV_MODE", "winograd"))
 ops.set_dcn_mode("bf16x9")
 T("dcnv2 bf16x9 sigma1.5", lambda: ops.modulated_deform_conv2d(x64, off, mask, w33, b, 1, 1, 1, 1, 8),
   flops=2 * 64 * 64 * 9 * px, nbytes=4 * px * 344)
