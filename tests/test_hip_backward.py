@@ -368,7 +368,7 @@ def _dp_worker(rank, world, port, q):
     sync.finish()
     names = ["conv_last.weight", "deform_align.backward_1.weight", "backbone.forward_1.main.0.bias"]
     params = dict(net.named_parameters())
-    q.put((rank, {k: params[k].grad.cpu() for k in names}))
+    q.put((rank, {k: params[k].grad.cpu().numpy() for k in names}))   # arrays travel by value (no shared-memory handle)
     shard.barrier()
     torch.distributed.destroy_process_group()
 
@@ -388,7 +388,7 @@ def test_two_rank_data_parallel_gradients_equal_the_mean_of_per_clip_gradients(A
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(2))
+    res = {r_: {k: torch.from_numpy(v) for k, v in d_.items()} for r_, d_ in (q.get(timeout=600) for _ in range(2))}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
