@@ -16,7 +16,7 @@
 //   and the tile rows 2 (w & 1), 2 (w & 1) + 1 (16 tiles each) -- 128 accumulator registers -- and the output transform needs no
 //   exchange between waves (a first version with 32x32x2 tiles, two positions per wave, spent 22 % of its time
 //   moving M through LDS).
-//   per chunk of 8 input channels (two LDS stages for the DMA'd data, one for V):
+//   per chunk of 8 input channels (two LDS stages each for the patch, U and V; one barrier per chunk):
 //     LDS-DMA: the (8 x 10 x 40) fp32 input patch (zero padding = never-written zero-initialised LDS) and the
 //              pre-transformed weight slab U[16][8][64] (eavsr_pack_conv_weight_wino)          (HBM / L2 -> LDS)
 //     input transform: thread (c, tile) reads its 4 x 4 patch, 32 additions, writes V[16][8][64]   (LDS -> LDS)
@@ -59,14 +59,15 @@ constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;        // 2
 constexpr int UV = 16 * CK * 64;                      // floats of one U (or V) chunk: 8192 = 32 KB
 constexpr int W_SEGS = UV / 256;                      // 32 pieces
 constexpr int W_IT = W_SEGS / NW;                     // 4
-constexpr int STAGE = IN_PAD + UV;                    // DMA'd floats per pipeline stage
-constexpr int LDS_MAIN = 2 * STAGE + UV;              // two DMA stages + V
+constexpr int OFF_U = 2 * IN_PAD;                     // LDS map: [patch 0][patch 1][U 0][U 1][V 0][V 1][channel sums]
+constexpr int OFF_V = OFF_U + 2 * UV;
+constexpr int LDS_MAIN = OFF_V + 2 * UV;              // 154.6 KB
 constexpr int LDS_FLOATS = LDS_MAIN + 128;
 constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_v = smem + 2 * STAGE;
+  float* s_v = smem + OFF_V;
   float* s_red = smem + LDS_MAIN;
 
   const int tid = threadIdx.x;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
 #pragma unroll
     for (int x = 0; x < 16; ++x) acc[b][x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int cs = 0, cc0 = 0, cbase = 0;
+  int cs = 0, cc0 = 0;
   int total_chunks = 0;
   for (int s = 0; s < a.n_src; ++s) total_chunks += a.src_c[s] / CK;
 
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   {
     f32x4* z = reinterpret_cast<f32x4*>(smem);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < (2 * STAGE) / 4; e += 64 * NW) z[e] = zero;
+    for (int e = tid; e < (2 * IN_PAD) / 4; e += 64 * NW) z[e] = zero;
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int seg = i * NW + wave;
@@ -116,9 +117,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
     __syncthreads();
   }
 
-  auto issue_chunk = [&](int stage) {
-    float* s_in = smem + stage * STAGE;
-    float* s_u = s_in + IN_PAD;
+  // the patch of the NEXT chunk of the source cursor -> patch stage; the weight slab of chunk g -> U stage
+  auto issue_patch = [&](int stage) {
+    float* s_in = smem + stage * IN_PAD;
     const int sc = a.src_c[cs];
     const float* sp = a.src[cs] + ((size_t)bn * sc + cc0) * plane;
 #pragma unroll
@@ -127,19 +128,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
       if (voff[i] != 0xFFFFFFFFu)
         __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(sp) + voff[i]), (lptr_t)(s_in + seg * 256), 16, 0, 0);
     }
-    const char* usrc = reinterpret_cast<const char*>(a.wu + ((size_t)cot * (a.cin / CK) + (size_t)(cbase + cc0) / CK) * UV);
+    cc0 += CK;   // advance the cursor over the virtual concatenation of the sources
+    if (cc0 >= a.src_c[cs]) {
+      ++cs;
+      cc0 = 0;
+    }
+  };
+  auto issue_u = [&](int g, int stage) {
+    float* s_u = smem + OFF_U + stage * UV;
+    const char* usrc = reinterpret_cast<const char*>(a.wu + ((size_t)cot * (a.cin / CK) + (size_t)g) * UV);
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
       const int seg = i * NW + wave;
       __builtin_amdgcn_global_load_lds((gptr_t)(usrc + (unsigned)(seg * 64 + lane) * 16u), (lptr_t)(s_u + seg * 256), 16, 0, 0);
-    }
-  };
-  auto advance = [&]() {
-    cc0 += CK;
-    if (cc0 >= a.src_c[cs]) {
-      cbase += a.src_c[cs];
-      ++cs;
-      cc0 = 0;
     }
   };
 
@@ -149,50 +150,58 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   const int poff = tc * (IH * IW) + (2 * tty) * IW + (MARG - 1) + 2 * ttx;   // top-left of its 4 x 4 patch
   float* vdst = s_v + tc * 64 + (tt ^ ((tc & 1) << 4));                      // + xi * (CK * 64); swizzled column
 
-  issue_chunk(0);
+  // input transform V = B^T d B of this thread's (channel, tile): patch stage ps -> V stage vs
+  auto transform = [&](int ps, int vs) __attribute__((always_inline)) {
+#ifndef EAVSR_WINO_EXP_NOTRANSFORM   // timing ablations only (tools/gpu_wino_ablate.py): results are wrong
+    const float* pp = smem + ps * IN_PAD + poff;
+    float* vd = vdst + vs * UV;
+    float d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[r][q] = pp[r * IW + q];
+    float t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // B^T d: rows
+      t[0][q] = d[0][q] - d[2][q];
+      t[1][q] = d[1][q] + d[2][q];
+      t[2][q] = d[2][q] - d[1][q];
+      t[3][q] = d[1][q] - d[3][q];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {      // (.) B: columns
+      vd[(r * 4 + 0) * (CK * 64)] = t[r][0] - t[r][2];
+      vd[(r * 4 + 1) * (CK * 64)] = t[r][1] + t[r][2];
+      vd[(r * 4 + 2) * (CK * 64)] = t[r][2] - t[r][1];
+      vd[(r * 4 + 3) * (CK * 64)] = t[r][1] - t[r][3];
+    }
+#endif
+  };
+
+  // Pipeline (one barrier per chunk): iteration c multiplies chunk c (V[c&1], U[c&1]) right after transforming chunk
+  // c+1 (patch[(c+1)&1] -> V[(c+1)&1]); the weight slab runs one chunk ahead of its GEMM, the input patch two.
+  issue_patch(0);
+  issue_u(0, 0);
+  if (total_chunks > 1) issue_patch(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  transform(0, 0);
   for (int it = 0; it < total_chunks; ++it) {
-    // chunk `it` has landed; every wave is done with the GEMM of chunk it-1 (V and the other DMA stage are free)
+    // U(it) and patch(it+1) have landed; V[it&1] is complete; every wave is done with the GEMM of chunk it-1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (it + 1 < total_chunks) {
-      advance();
-#ifndef EAVSR_WINO_EXP_NODMA     // timing ablations only (tools/gpu_wino_ablate.py): results are wrong
-      issue_chunk((it + 1) & 1);
+#ifndef EAVSR_WINO_EXP_NODMA
+    if (it + 1 < total_chunks) issue_u(it + 1, (it + 1) & 1);
+    if (it + 2 < total_chunks) issue_patch(it & 1);
 #endif
-    }
-#ifndef EAVSR_WINO_EXP_NOTRANSFORM
-    // ---- input transform V = B^T d B of this thread's (channel, tile) ----------------------------
-    {
-      const float* pp = smem + (it & 1) * STAGE + poff;
-      float d[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) d[r][q] = pp[r * IW + q];
-      float t[4][4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {      // B^T d: rows
-        t[0][q] = d[0][q] - d[2][q];
-        t[1][q] = d[1][q] + d[2][q];
-        t[2][q] = d[2][q] - d[1][q];
-        t[3][q] = d[1][q] - d[3][q];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {      // (.) B: columns
-        vdst[(r * 4 + 0) * (CK * 64)] = t[r][0] - t[r][2];
-        vdst[(r * 4 + 1) * (CK * 64)] = t[r][1] + t[r][2];
-        vdst[(r * 4 + 2) * (CK * 64)] = t[r][2] - t[r][1];
-        vdst[(r * 4 + 3) * (CK * 64)] = t[r][1] - t[r][3];
-      }
-    }
-#endif
-    __syncthreads();
+    if (it + 1 < total_chunks) transform((it + 1) & 1, (it + 1) & 1);
     // ---- the 16 GEMMs of this wave's two blocks: M_xi[co, t] += sum over the chunk's 8 channels U_xi[co, c] V_xi[c, t]
-    const float* su = smem + (it & 1) * STAGE + IN_PAD;
+    const float* su = smem + OFF_U + (it & 1) * UV;
     const int sw = (kq & 1) << 4;                       // swizzle of the row this lane reads (c = 4 ks + kq)
     const float* ua = su + kq * 64 + ((cb * 16 + l15) ^ sw);
-    const float* vb0 = s_v + kq * 64 + ((tb0 * 16 + l15) ^ sw);
-    const float* vb1 = s_v + kq * 64 + ((tb0 * 16 + 16 + l15) ^ sw);
+    const float* sv = s_v + (it & 1) * UV;
+    const float* vb0 = sv + kq * 64 + ((tb0 * 16 + l15) ^ sw);
+    const float* vb1 = sv + kq * 64 + ((tb0 * 16 + 16 + l15) ^ sw);
     // operands run three steps ahead of the MFMAs (32 steps = 16 positions x 2 k-steps): an LDS read takes longer than
     // the 64 cycles of a step's two MFMAs
     constexpr int NSTEP = 16 * (CK / 4), AHEAD = 3;
