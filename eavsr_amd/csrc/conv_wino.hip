@@ -43,6 +43,9 @@ struct WnArgs {
   const float* residual;
   float* out;
   float* chan_partial;
+  const float* ca_scale;  // FUSE: effective input = src[0] * ca_scale[n, c] + ca_x
+  const float* ca_x;
+  float* ca_out;          // FUSE: optional copy of the effective input (the next residual stream)
   int n, h, w, cin, cout, tiles_x, tiles_y;
   int act;
   float slope;
@@ -64,11 +67,20 @@ constexpr int OFF_V = OFF_U + 2 * UV;
 constexpr int LDS_MAIN = OFF_V + 2 * UV;              // 154.6 KB
 constexpr int LDS_FLOATS = LDS_MAIN + 128;
 constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+// FUSE (channel-attention prologue, RCABlock tail folded into the next conv): two patches (r, x) per stage, ONE V stage
+// (two barriers per chunk): [r 0][r 1][x 0][x 1][U 0][U 1][V][scale (<= 256 channels)][channel sums]
+constexpr int F_OFF_X = 2 * IN_PAD, F_OFF_U = 4 * IN_PAD, F_OFF_V = F_OFF_U + 2 * UV, F_OFF_Y = F_OFF_V + UV;
+constexpr int F_MAXC = 256;
+constexpr int F_LDS_FLOATS = F_OFF_Y + F_MAXC + 128;
+constexpr size_t F_LDS_BYTES = (size_t)F_LDS_FLOATS * sizeof(float);
 
+template <bool FUSE>
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_v = smem + OFF_V;
-  float* s_red = smem + LDS_MAIN;
+  constexpr int O_U = FUSE ? F_OFF_U : OFF_U;
+  float* s_v = smem + (FUSE ? F_OFF_V : OFF_V);
+  float* s_y = smem + F_OFF_Y;                       // FUSE only
+  float* s_red = smem + (FUSE ? F_OFF_Y + F_MAXC : LDS_MAIN);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -101,7 +113,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   {
     f32x4* z = reinterpret_cast<f32x4*>(smem);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < (2 * IN_PAD) / 4; e += 64 * NW) z[e] = zero;
+    for (int e = tid; e < ((FUSE ? 4 : 2) * IN_PAD) / 4; e += 64 * NW) z[e] = zero;
+    if (FUSE)
+      for (int c = tid; c < a.cin; c += 64 * NW) s_y[c] = a.ca_scale[(size_t)bn * a.cin + c];
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int seg = i * NW + wave;
@@ -125,8 +139,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int seg = i * NW + wave;
-      if (voff[i] != 0xFFFFFFFFu)
+      if (voff[i] != 0xFFFFFFFFu) {
         __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(sp) + voff[i]), (lptr_t)(s_in + seg * 256), 16, 0, 0);
+        if (FUSE) {
+          const float* xp = a.ca_x + ((size_t)bn * sc + cc0) * plane;
+          __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(xp) + voff[i]),
+                                           (lptr_t)(s_in + F_OFF_X + seg * 256), 16, 0, 0);
+        }
+      }
     }
     cc0 += CK;   // advance the cursor over the virtual concatenation of the sources
     if (cc0 >= a.src_c[cs]) {
@@ -135,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
     }
   };
   auto issue_u = [&](int g, int stage) {
-    float* s_u = smem + OFF_U + stage * UV;
+    float* s_u = smem + O_U + stage * UV;
     const char* usrc = reinterpret_cast<const char*>(a.wu + ((size_t)cot * (a.cin / CK) + (size_t)g) * UV);
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   float* vdst = s_v + tc * 64 + (tt ^ ((tc & 1) << 4));                      // + xi * (CK * 64); swizzled column
 
   // input transform V = B^T d B of this thread's (channel, tile): patch stage ps -> V stage vs
-  auto transform = [&](int ps, int vs) __attribute__((always_inline)) {
+  auto transform = [&](int ps, int vs, int chunk) __attribute__((always_inline)) {
 #ifndef EAVSR_WINO_EXP_NOTRANSFORM   // timing ablations only (tools/gpu_wino_ablate.py): results are wrong
     const float* pp = smem + ps * IN_PAD + poff;
     float* vd = vdst + vs * UV;
@@ -160,6 +180,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int q = 0; q < 4; ++q) d[r][q] = pp[r * IW + q];
+    if (FUSE) {
+      // effective input r * scale[n, c] + x (RCABlock tail, networks.py:447,463-464); its interior 2 x 2 pixels are
+      // this tile's share of the side output (the next block's residual stream)
+      const float sc_ = s_y[chunk * CK + tc];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[r][q] = fmaf(d[r][q], sc_, pp[F_OFF_X + r * IW + q]);
+      if (a.ca_out != nullptr && cot == 0) {
+        const int gx = x0 + 2 * ttx;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int gy = y0 + 2 * tty + dy;
+          if (gy < h && gx < w)
+            *reinterpret_cast<f32x2*>(a.ca_out + ((size_t)bn * a.cin + chunk * CK + tc) * plane + (size_t)gy * w + gx) =
+                f32x2{d[1 + dy][1], d[1 + dy][2]};
+        }
+      }
+    }
     float t[4][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {      // B^T d: rows
@@ -180,26 +219,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
 
   // Pipeline (one barrier per chunk): iteration c multiplies chunk c (V[c&1], U[c&1]) right after transforming chunk
   // c+1 (patch[(c+1)&1] -> V[(c+1)&1]); the weight slab runs one chunk ahead of its GEMM, the input patch two.
+  // FUSE (one V stage): iteration c transforms chunk c, barrier, multiplies it; everything runs one chunk ahead.
   issue_patch(0);
   issue_u(0, 0);
-  if (total_chunks > 1) issue_patch(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  transform(0, 0);
+  if (!FUSE) {
+    if (total_chunks > 1) issue_patch(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    transform(0, 0, 0);
+  }
   for (int it = 0; it < total_chunks; ++it) {
-    // U(it) and patch(it+1) have landed; V[it&1] is complete; every wave is done with the GEMM of chunk it-1
+    // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of chunk it-1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifndef EAVSR_WINO_EXP_NODMA
     if (it + 1 < total_chunks) issue_u(it + 1, (it + 1) & 1);
-    if (it + 2 < total_chunks) issue_patch(it & 1);
+    if (FUSE) {
+      if (it + 1 < total_chunks) issue_patch((it + 1) & 1);
+    } else {
+      if (it + 2 < total_chunks) issue_patch(it & 1);
+    }
 #endif
-    if (it + 1 < total_chunks) transform((it + 1) & 1, (it + 1) & 1);
+    if (FUSE) {
+      transform(it & 1, 0, it);
+      __syncthreads();
+    } else if (it + 1 < total_chunks) {
+      transform((it + 1) & 1, (it + 1) & 1, it + 1);
+    }
     // ---- the 16 GEMMs of this wave's two blocks: M_xi[co, t] += sum over the chunk's 8 channels U_xi[co, c] V_xi[c, t]
-    const float* su = smem + OFF_U + (it & 1) * UV;
+    const float* su = smem + O_U + (it & 1) * UV;
     const int sw = (kq & 1) << 4;                       // swizzle of the row this lane reads (c = 4 ks + kq)
     const float* ua = su + kq * 64 + ((cb * 16 + l15) ^ sw);
-    const float* sv = s_v + (it & 1) * UV;
+    const float* sv = s_v + (FUSE ? 0 : (it & 1) * UV);
     const float* vb0 = sv + kq * 64 + ((tb0 * 16 + l15) ^ sw);
     const float* vb1 = sv + kq * 64 + ((tb0 * 16 + 16 + l15) ^ sw);
     // operands run three steps ahead of the MFMAs (32 steps = 16 positions x 2 k-steps): an LDS read takes longer than
@@ -345,8 +396,16 @@ extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* w
   EAVSR_REQUIRE(d->out, -1, "conv3x3_wino: NULL out");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv3x3_wino: bad dims");
   EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv3x3_wino: act %d", d->act);
-  EAVSR_REQUIRE(d->ca_scale == nullptr && d->ca_x == nullptr && d->ca_out == nullptr, -2,
-                "conv3x3_wino: no fused channel-attention prologue");
+  const bool fuse = d->ca_scale != nullptr;
+  if (fuse) {
+    EAVSR_REQUIRE(d->ca_x != nullptr, -1, "conv3x3_wino: ca_scale without ca_x");
+    EAVSR_REQUIRE(d->n_src == 1 && d->cin <= F_MAXC && (((uintptr_t)d->ca_x) & 15) == 0 &&
+                      (d->ca_out == nullptr || (((uintptr_t)d->ca_out) & 7) == 0), -2,
+                  "conv3x3_wino: the fused channel-attention prologue needs a single source, cin <= %d and aligned ca_x / "
+                  "ca_out", F_MAXC);
+  } else {
+    EAVSR_REQUIRE(d->ca_x == nullptr && d->ca_out == nullptr, -1, "conv3x3_wino: ca_x / ca_out without ca_scale");
+  }
   EAVSR_REQUIRE(d->w % 4 == 0, -2, "conv3x3_wino: w %% 4 != 0 (use eavsr_conv2d_f32)");
   EAVSR_REQUIRE((((uintptr_t)d->out) & 7) == 0 && (d->residual == nullptr || (((uintptr_t)d->residual) & 7) == 0), -2,
                 "conv3x3_wino: out / residual must be 8-byte aligned");
@@ -366,6 +425,7 @@ extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* w
   a.n_src = d->n_src;
   a.wu = weight_wino;
   a.bias = d->bias; a.residual = d->residual; a.out = d->out; a.chan_partial = d->chan_partial;
+  a.ca_scale = d->ca_scale; a.ca_x = d->ca_x; a.ca_out = d->ca_out;
   a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
   a.tiles_x = eavsr::cdiv(d->w, TOW);
   a.tiles_y = eavsr::cdiv(d->h, TOH);
@@ -376,14 +436,18 @@ extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* w
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)LDS_BYTES);
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (attr_err == hipSuccess)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)F_LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv3x3_wino: hipFuncSetAttribute(%zu B of LDS): %s", LDS_BYTES, hipGetErrorString(attr_err));
     return (int)attr_err;
   }
   dim3 grid((unsigned)blocks, eavsr::cdiv(d->cout, 64));
-  hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(64 * NW), LDS_BYTES, eavsr::as_stream(stream), a);
+  if (fuse) hipLaunchKernelGGL(conv3x3_wino_kernel<true>, grid, dim3(64 * NW), F_LDS_BYTES, eavsr::as_stream(stream), a);
+  else hipLaunchKernelGGL(conv3x3_wino_kernel<false>, grid, dim3(64 * NW), LDS_BYTES, eavsr::as_stream(stream), a);
   return eavsr::launch_status("conv3x3_wino");
 }

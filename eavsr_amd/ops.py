@@ -272,8 +272,17 @@ def _conv3x3_smallco(x: Tensor, weights, biases, act, slope, residual):
 # ------------------------------------------------------------------------------------------
 # dense conv  (nn.Conv2d, stride 1, "same" padding)
 # ------------------------------------------------------------------------------------------
+def _wino_fusable(x: Tensor) -> bool:
+    return (CONV_MODE == "winograd" and x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[1] % 8 == 0 and x.shape[1] <= 256
+            and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and int(x.shape[0]) * lib().eavsr_conv3x3_wino_tiles(int(x.shape[2]), int(x.shape[3])) >= WINO_MIN_TILES)
+
+
 def ca_fusable(x: Tensor, cout: int = 64) -> bool:
-    """Can the channel-attention tail `r * scale + x` be folded into the next 3x3 conv (16-byte DMA path)?"""
+    """Can the channel-attention tail `r * scale + x` be folded into the next 3x3 conv?  Yes where the Winograd kernel
+    runs (its input transform applies it), or on the direct kernel's 32-row, 16-byte-DMA path."""
+    if _wino_fusable(x):
+        return True
     return (x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[1] % 4 == 0 and x.shape[1] <= 256 and 32 < cout <= 64
             and x.is_contiguous() and x.data_ptr() % 16 == 0
             and lib().eavsr_conv2d_tile_rows(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), 3) == 32)
@@ -313,9 +322,10 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     wp = pack_cache.get(weights)
     b = _bias_of(biases)
     out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
-    x9_ok = (k == 3 and ca is None and w % 4 == 0
-             and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs))
-    use_wino = CONV_MODE == "winograd" and x9_ok and n * lib().eavsr_conv3x3_wino_tiles(h, w) >= WINO_MIN_TILES
+    base_ok = (k == 3 and w % 4 == 0 and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs))
+    x9_ok = base_ok and ca is None
+    use_wino = (CONV_MODE == "winograd" and base_ok and n * lib().eavsr_conv3x3_wino_tiles(h, w) >= WINO_MIN_TILES
+                and (ca is None or (len(srcs) == 1 and cin <= 256 and ca[1].data_ptr() % 16 == 0)))
     part = None
     if chan_partial:
         tiles = lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino else lib().eavsr_conv2d_tiles(n, h, w, k)
@@ -343,7 +353,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         scale, cx = _chk(ca[0], "ca scale"), _chk(ca[1], "ca x")
         if len(srcs) != 1 or cx.shape != srcs[0].shape or tuple(scale.shape) != (n, cin):
             raise ValueError("ca=(scale, x): one source, x of the same shape, scale (n, cin)")
-        if k != 3 or not ca_fusable(srcs[0], cout) or cx.data_ptr() % 16:
+        if not use_wino and (k != 3 or not ca_fusable(srcs[0], cout) or cx.data_ptr() % 16):
             raise NotImplementedError("fused channel-attention prologue unavailable for this shape; use "
                                       "scale_residual + conv2d (see ops.ca_fusable)")
         d.ca_scale, d.ca_x = _p(scale), _p(cx)
@@ -356,10 +366,11 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     px = float(n) * h * w
     if use_wino:
         wu = _packed_wino(weights)
-        _launch(f"conv3x3_{cin}to{cout}_wino", 2.0 * cin * cout * 9 * px,
-                4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+        _launch(f"conv3x3_{cin}to{cout}_wino" + ("_ca" if ca is not None else ""), 2.0 * cin * cout * 9 * px,
+                4.0 * px * (cin * (1 if ca is None else (3 if ca_out else 2)) + cout + (cout if residual is not None else 0)), out,
                 lambda: lib().eavsr_conv3x3_wino_f32(C.byref(d), _p(wu), st), "conv3x3_wino")
-        return out if not chan_partial else (out, part)
+        res = [out] + ([part] if chan_partial else []) + ([xs] if xs is not None else [])
+        return res[0] if len(res) == 1 else tuple(res)
     if CONV_MODE == "bf16x9" and x9_ok and lib().eavsr_conv2d_tile_rows(n, h, w, 3) == 32:
         wx = _packed_x9(weights)
         _launch(f"conv3x3_{cin}to{cout}_x9", 2.0 * cin * cout * 9 * px,
@@ -504,7 +515,7 @@ def _norm_conv_mode(mode: str) -> str:
 
 
 CONV_MODE = _norm_conv_mode(os.environ.get("EAVSR_CONV_MODE", "winograd"))
-WINO_MIN_TILES = 192      # 8 x 32-pixel tiles per launch below which the direct kernel (8-row tiles) is used
+WINO_MIN_TILES = int(os.environ.get("EAVSR_WINO_MIN_TILES", "192"))   # 8 x 32-px tiles per launch below which the direct kernel runs
 
 
 def set_conv_mode(mode: str) -> None:

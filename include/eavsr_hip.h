@@ -152,7 +152,8 @@ int eavsr_conv3x3_f32x9(const eavsr_conv2d_desc* desc, const void* weight_x9, vo
  * weight_wino: eavsr_wino_weight_elems(cout, cin) floats written by eavsr_pack_conv_weight_wino from the
  * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  8 x 32-pixel tiles: chan_partial has
  * eavsr_conv3x3_wino_tiles(h, w) rows per sample.  Requires ksize 3, w % 4 == 0, 16-byte aligned sources with
- * channels % 8 == 0 and no fused channel-attention prologue; returns -2 otherwise (call eavsr_conv2d_f32).   */
+ * channels % 8 == 0; the fused channel-attention prologue (ca_scale / ca_x / ca_out of the descriptor) is applied in
+ * the input transform and needs a single source with cin <= 256.  Returns -2 otherwise (call eavsr_conv2d_f32).  */
 int64_t eavsr_wino_weight_elems(int32_t cout, int32_t cin);
 int eavsr_pack_conv_weight_wino(const float* weight, float* weight_wino, int32_t cout, int32_t cin, void* stream);
 int32_t eavsr_conv3x3_wino_tiles(int32_t h, int32_t w);

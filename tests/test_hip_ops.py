@@ -312,6 +312,29 @@ def test_conv3x3_winograd_vs_torch_cpu(conv_wino, cuda, case):
     assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_conv3x3_winograd_fused_channel_attention_prologue(conv_wino, cuda):
+    """conv(r * scale + x) with the side output of the effective input, applied in the Winograd input transform"""
+    n, c, h, w = 10, 64, 133, 156
+    r, x = cases.randn(1, n, c, h, w), cases.randn(2, n, c, h, w)
+    scale = cases.rand(3, n, c)
+    wt = cases.randn(4, 64, c, 3, 3, scale=0.05)
+    b = cases.randn(5, 64, scale=0.1)
+    res = cases.randn(6, n, 64, h, w)
+    eff = r * scale.view(n, c, 1, 1) + x
+    ref = F.relu(F.conv2d(eff, wt, b, 1, 1))
+    assert conv_wino.ca_fusable(torch.zeros(n, c, h, w, device=cuda))
+    with conv_wino.profile() as prof:
+        out, part, xs = conv_wino.conv2d(g(r, cuda), g(wt, cuda), g(b, cuda), act="relu", ca=(g(scale, cuda), g(x, cuda)),
+                                         ca_out=True, chan_partial=True)
+    assert list(prof.summary()) == ["conv3x3_64to64_wino_ca"]
+    assert H.maxabs(xs.cpu(), eff) <= 1e-6
+    assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+    sums = ref.sum(dim=(2, 3))
+    assert H.maxabs(part.sum(dim=1).cpu(), sums) <= 2e-6 * sums.abs().max().item() + 2e-3
+    out2 = conv_wino.conv2d(g(r, cuda), g(wt, cuda), g(b, cuda), residual=g(res, cuda), ca=(g(scale, cuda), g(x, cuda)))
+    assert H.maxabs(out2.cpu(), F.conv2d(eff, wt, b, 1, 1) + res) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_conv3x3_winograd_small_problems_run_the_direct_kernel(conv_wino, cuda):
     x, wt = cases.randn(1, 1, 64, 20, 32), cases.randn(2, 64, 64, 3, 3, scale=0.05)
     with conv_wino.profile() as prof:
