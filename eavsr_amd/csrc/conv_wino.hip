@@ -34,6 +34,8 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+__device__ __attribute__((aligned(16))) float g_wino_zero[4];   // source of the zero-padding DMA lanes
+
 struct WnArgs {
   const float* src[5];
   int src_c[5];
@@ -86,15 +88,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int bn = bid / a.tiles_y;
+  // Persistent workgroups: workgroup b walks the tiles b, b + gridDim.x, ... (XCD-contiguous order) as ONE flattened
+  // sequence of (tile, chunk) iterations, so the LDS-DMA stream never drains at a tile boundary and the epilogue of
+  // a tile runs while the first chunks of the next one are already in flight (the per-tile fixed cost was 23 % of
+  // the kernel).
   const int cot = blockIdx.y;
-  const int y0 = ty * TOH, x0 = tx * TOW;
   const int h = a.h, w = a.w;
   const size_t plane = (size_t)h * w;
+  const int total_tiles = a.tiles_x * a.tiles_y * a.n;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto tile_coords = [&](int k, int& bn_, int& y0_, int& x0_, int& lin_) __attribute__((always_inline)) {
+    int t = eavsr_xcd_remap((int)blockIdx.x + k * (int)gridDim.x, total_tiles);
+    const int tx_ = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty_ = t % a.tiles_y;
+    bn_ = t / a.tiles_y;
+    y0_ = ty_ * TOH;
+    x0_ = tx_ * TOW;
+    lin_ = ty_ * a.tiles_x + tx_;
+  };
 
   // acc[b][xi]: M_xi of output channels 16 cb + 4 (lane >> 4) + r, tile 16 (tb0 + b) + (lane & 15)
   const int l15 = lane & 15, kq = lane >> 4;
@@ -105,17 +117,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
 #pragma unroll
     for (int x = 0; x < 16; ++x) acc[b][x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int cs = 0, cc0 = 0;
   int total_chunks = 0;
   for (int s = 0; s < a.n_src; ++s) total_chunks += a.src_c[s] / CK;
+  const int total_iters = my_tiles * total_chunks;
 
-  unsigned voff[IN_IT];
-  {
-    f32x4* z = reinterpret_cast<f32x4*>(smem);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < ((FUSE ? 4 : 2) * IN_PAD) / 4; e += 64 * NW) z[e] = zero;
-    if (FUSE)
-      for (int c = tid; c < a.cin; c += 64 * NW) s_y[c] = a.ca_scale[(size_t)bn * a.cin + c];
+  // ---- prefetch stream (runs up to two chunks ahead of the compute stream, across tile boundaries) -------------
+  int p_k = 0, p_cs = 0, p_cc0 = 0, p_bn = 0, p_y0 = 0, p_x0 = 0, p_lin = 0;
+  unsigned voff[IN_IT];   // per-lane byte offsets of this wave's patch pieces; 0xFFFFFFFF: zero padding
+  auto p_setup_tile = [&]() __attribute__((always_inline)) {
+    tile_coords(p_k, p_bn, p_y0, p_x0, p_lin);
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int seg = i * NW + wave;
@@ -124,34 +134,46 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
       const int rem = e4 - ci * (IH * (IW / 4));
       const int r = rem / (IW / 4);
       const int c4 = rem - r * (IW / 4);
-      const int gy = y0 - 1 + r, gx = x0 - MARG + 4 * c4;
-      const bool ok = seg < IN_SEGS && e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
+      const int gy = p_y0 - 1 + r, gx = p_x0 - MARG + 4 * c4;
+      const bool ok = e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
       voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
     }
-    __syncthreads();
+  };
+  p_setup_tile();
+  // ---- compute stream -----------------------------------------------------------------------------------------
+  int bn = 0, y0 = 0, x0 = 0, tile_lin = 0;
+  tile_coords(0, bn, y0, x0, tile_lin);
+  if (FUSE) {
+    for (int c = tid; c < a.cin; c += 64 * NW) s_y[c] = a.ca_scale[(size_t)bn * a.cin + c];
   }
 
-  // the patch of the NEXT chunk of the source cursor -> patch stage; the weight slab of chunk g -> U stage
+  // the patch of the NEXT chunk of the prefetch stream -> patch stage.  Every piece is always issued -- lanes outside
+  // the image copy 16 zero bytes -- so a stage never keeps data of the previous tile.
   auto issue_patch = [&](int stage) {
     float* s_in = smem + stage * IN_PAD;
-    const int sc = a.src_c[cs];
-    const float* sp = a.src[cs] + ((size_t)bn * sc + cc0) * plane;
+    const int sc = a.src_c[p_cs];
+    const char* sp = reinterpret_cast<const char*>(a.src[p_cs] + ((size_t)p_bn * sc + p_cc0) * plane);
+    const char* xp = FUSE ? reinterpret_cast<const char*>(a.ca_x + ((size_t)p_bn * sc + p_cc0) * plane) : nullptr;
+    const char* zp = reinterpret_cast<const char*>(g_wino_zero);
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int seg = i * NW + wave;
-      if (voff[i] != 0xFFFFFFFFu) {
-        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(sp) + voff[i]), (lptr_t)(s_in + seg * 256), 16, 0, 0);
-        if (FUSE) {
-          const float* xp = a.ca_x + ((size_t)bn * sc + cc0) * plane;
-          __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(xp) + voff[i]),
-                                           (lptr_t)(s_in + F_OFF_X + seg * 256), 16, 0, 0);
-        }
+      if (seg < IN_SEGS) {   // wave-uniform
+        const bool ok = voff[i] != 0xFFFFFFFFu;
+        __builtin_amdgcn_global_load_lds((gptr_t)(ok ? sp + voff[i] : zp), (lptr_t)(s_in + seg * 256), 16, 0, 0);
+        if (FUSE)
+          __builtin_amdgcn_global_load_lds((gptr_t)(ok ? xp + voff[i] : zp), (lptr_t)(s_in + F_OFF_X + seg * 256), 16, 0, 0);
       }
     }
-    cc0 += CK;   // advance the cursor over the virtual concatenation of the sources
-    if (cc0 >= a.src_c[cs]) {
-      ++cs;
-      cc0 = 0;
+    p_cc0 += CK;   // advance over the virtual concatenation of the sources, then over this workgroup's tiles
+    if (p_cc0 >= a.src_c[p_cs]) {
+      ++p_cs;
+      p_cc0 = 0;
+      if (p_cs >= a.n_src) {
+        p_cs = 0;
+        ++p_k;
+        if (p_k < my_tiles) p_setup_tile();
+      }
     }
   };
   auto issue_u = [&](int g, int stage) {
@@ -217,34 +239,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
 #endif
   };
 
-  // Pipeline (one barrier per chunk): iteration c multiplies chunk c (V[c&1], U[c&1]) right after transforming chunk
-  // c+1 (patch[(c+1)&1] -> V[(c+1)&1]); the weight slab runs one chunk ahead of its GEMM, the input patch two.
-  // FUSE (one V stage): iteration c transforms chunk c, barrier, multiplies it; everything runs one chunk ahead.
+  // Pipeline (one barrier per chunk): iteration j multiplies chunk j (V[j&1], U[j&1]) right after transforming chunk
+  // j+1 (patch[(j+1)&1] -> V[(j+1)&1]); the weight slab runs one chunk ahead of its GEMM, the input patch two.
+  // FUSE (one V stage): iteration j transforms chunk j, barrier, multiplies it; everything runs one chunk ahead.
+  // j runs over ALL (tile, chunk) pairs of this workgroup.
   issue_patch(0);
   issue_u(0, 0);
   if (!FUSE) {
-    if (total_chunks > 1) issue_patch(1);
+    if (total_iters > 1) issue_patch(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     transform(0, 0, 0);
   }
-  for (int it = 0; it < total_chunks; ++it) {
-    // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of chunk it-1
+  int chunk = 0;   // chunk of iteration `it` within its tile
+  for (int it = 0; it < total_iters; ++it) {
+    // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of iteration it-1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const int chunk_n = chunk + 1 == total_chunks ? 0 : chunk + 1;
 #ifndef EAVSR_WINO_EXP_NODMA
-    if (it + 1 < total_chunks) issue_u(it + 1, (it + 1) & 1);
+    if (it + 1 < total_iters) issue_u(chunk_n, (it + 1) & 1);
     if (FUSE) {
-      if (it + 1 < total_chunks) issue_patch((it + 1) & 1);
+      if (it + 1 < total_iters) issue_patch((it + 1) & 1);
     } else {
-      if (it + 2 < total_chunks) issue_patch(it & 1);
+      if (it + 2 < total_iters) issue_patch(it & 1);
     }
 #endif
     if (FUSE) {
-      transform(it & 1, 0, it);
+      transform(it & 1, 0, chunk);
       __syncthreads();
-    } else if (it + 1 < total_chunks) {
-      transform((it + 1) & 1, (it + 1) & 1, it + 1);
+    } else if (it + 1 < total_iters) {
+      transform((it + 1) & 1, (it + 1) & 1, chunk_n);
     }
     // ---- the 16 GEMMs of this wave's two blocks: M_xi[co, t] += sum over the chunk's 8 channels U_xi[co, c] V_xi[c, t]
     const float* su = smem + O_U + (it & 1) * UV;
@@ -273,14 +298,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the 3 reads of step i + AHEAD
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // the 2 MFMAs of step i
     }
-  }
+    chunk = chunk_n;
+    if (chunk != 0) continue;   // the tile is not finished yet
 
   // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile] for every xi ----------
-#ifdef EAVSR_WINO_EXP_NOEPI
-  if (acc[0][0][0] == 12345.678f)
-#endif
   {
-    const int tile_lin = ty * a.tiles_x + tx;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -322,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
     }
     if (a.chan_partial) {
       // per output channel: 16 lanes (tiles) x 2 blocks here, and the same again in wave ^ 1 (fixed order)
-      __syncthreads();   // the main loop is done with the LDS
+      __syncthreads();   // s_red is free (previous tile's sums were read long ago)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = csum[r];
@@ -339,8 +361,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
           a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + tile_lin) * a.cout + co] = s_red[tid] + s_red[64 + tid];
       }
     }
+    // next tile of this workgroup
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[b][x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (it + 1 < total_iters) {
+      tile_coords((it + 1) / total_chunks, bn, y0, x0, tile_lin);
+      if (FUSE) {   // visible after the barrier at the top of the next iteration; nobody reads s_y until then
+        for (int c = tid; c < a.cin; c += 64 * NW) s_y[c] = a.ca_scale[(size_t)bn * a.cin + c];
+      }
+    }
   }
+  }   // flattened (tile, chunk) loop
 }
+
 
 // weight (cout, cin, 3, 3) -> U = G g G^T laid out [cot][cin / 8][xi][c][co] (zero for co >= cout)
 __global__ void pack_wino_kernel(const float* __restrict__ wt, float* __restrict__ out, int cout, int cin, long total) {
@@ -446,7 +481,9 @@ extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* w
     eavsr::set_error("conv3x3_wino: hipFuncSetAttribute(%zu B of LDS): %s", LDS_BYTES, hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  dim3 grid((unsigned)blocks, eavsr::cdiv(d->cout, 64));
+  // persistent workgroups: one per CU (the kernel needs > 80 KB of LDS), each walking blocks / grid.x tiles
+  const long per_cot = blocks < 256 ? blocks : 256;
+  dim3 grid((unsigned)per_cot, eavsr::cdiv(d->cout, 64));
   if (fuse) hipLaunchKernelGGL(conv3x3_wino_kernel<true>, grid, dim3(64 * NW), F_LDS_BYTES, eavsr::as_stream(stream), a);
   else hipLaunchKernelGGL(conv3x3_wino_kernel<false>, grid, dim3(64 * NW), LDS_BYTES, eavsr::as_stream(stream), a);
   return eavsr::launch_status("conv3x3_wino");
