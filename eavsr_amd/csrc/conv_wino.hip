@@ -257,14 +257,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int chunk_n = chunk + 1 == total_chunks ? 0 : chunk + 1;
+    auto issue_dma = [&]() __attribute__((always_inline)) {
 #ifndef EAVSR_WINO_EXP_NODMA
-    if (it + 1 < total_iters) issue_u(chunk_n, (it + 1) & 1);
-    if (FUSE) {
-      if (it + 1 < total_iters) issue_patch((it + 1) & 1);
-    } else {
-      if (it + 2 < total_iters) issue_patch(it & 1);
-    }
+      if (it + 1 < total_iters) issue_u(chunk_n, (it + 1) & 1);
+      if (FUSE) {
+        if (it + 1 < total_iters) issue_patch((it + 1) & 1);
+      } else {
+        if (it + 2 < total_iters) issue_patch(it & 1);
+      }
 #endif
+    };
+    // The two waves of a SIMD (w and w + 4) issue their DMA pieces at different points of the iteration: if all eight
+    // waves issue right after the barrier, every wave of the CU stalls in the vector-memory issue at once and the
+    // matrix pipe idles; staggered, one wave of each pair is in its MFMAs while the other issues.
+    const bool dma_late = !FUSE && wave >= 4;
+    if (!dma_late) issue_dma();
     if (FUSE) {
       transform(it & 1, 0, chunk);
       __syncthreads();
@@ -287,6 +294,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
     for (int i = 0; i < AHEAD; ++i) { av[i] = ua[row_of(i)]; b0[i] = vb0[row_of(i)]; b1[i] = vb1[row_of(i)]; }
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {
+      if (i == NSTEP / 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_late) issue_dma();
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (i + AHEAD < NSTEP) {
         av[(i + AHEAD) % (AHEAD + 1)] = ua[row_of(i + AHEAD)];
         b0[(i + AHEAD) % (AHEAD + 1)] = vb0[row_of(i + AHEAD)];
