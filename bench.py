@@ -284,6 +284,10 @@ def main():
                 "bf16x9": "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)"}[args.conv_mode]
             line["roofline"]["avg_ms"] = dom["avg_ms"]
             line["roofline"]["share_of_step"] = dom["share_of_step"]
+            if args.conv_mode == "winograd":
+                # frac can exceed 1 for the algorithmic count: F(2x2,3x3) multiplies 16 times per 2x2 outputs instead of 36
+                line["roofline"]["performed"] = dom["achieved"] / 2.25
+                line["roofline"]["performed_frac"] = dom["achieved"] / 2.25 / PEAK_MFMA_F32_TFLOPS
         line["kernels"] = [e for e in (entry("dcnv2" if args.dcn_mode == "native" else "dcnv2_x9", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120", "mfma")) if e]
