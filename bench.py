@@ -51,6 +51,9 @@ def parse():
                          "into three bf16 terms, nine partial products on the bf16 MFMA")
     ap.add_argument("--dcn-mode", default="native", choices=["native", "bf16x9"],
                     help="DCNv2 contraction: native fp32 MFMA (default) or the exact bf16x9 split")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the forward as one captured HIP graph (eavsr_amd.graph.GraphedForward): ~1 ms of host time "
+                         "per step instead of ~180 ms of Python / ctypes launches; same kernels, same device time")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer: the BASELINE metric (default). train: BASELINE.json configs[3], a data-parallel "
                          "training step (2 clips/GPU x 7 x 3 x 96 x 96, L1 loss, Adam, one RCCL all-reduce on the "
@@ -204,15 +207,19 @@ def main():
     n, t, h, w = args.clips, args.frames, args.height, args.width
     clips = synthetic_clip(n, t, h, w, seed=rank).to(device)   # resident in HBM before the timed region
 
+    run = net
+    if args.graph:
+        from eavsr_amd.graph import GraphedForward
+        run = GraphedForward(net, clips)
     with torch.no_grad():
         for _ in range(args.warmup):
-            net(clips)
+            run(clips)
         torch.cuda.synchronize()
         shard.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = net(clips)
+            out = run(clips)
         torch.cuda.synchronize()
         shard.barrier()
         torch.cuda.synchronize()
@@ -244,7 +251,7 @@ def main():
                    "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "scale": 4, "sharding": "clips across ranks, no collective",
                    "conv3x3": {"winograd": "Winograd F(2x2,3x3), fp32 MFMA (direct fp32 kernel for the shapes it does not cover)",
                                "direct": "direct sum, fp32 MFMA", "bf16x9": "direct sum, exact bf16x9 split"}[args.conv_mode],
-                   "dcnv2": args.dcn_mode},
+                   "dcnv2": args.dcn_mode, "launch": "one HIP graph per step" if args.graph else "eager (one launch per kernel)"},
     }
 
     if rank == 0 and not args.no_kernel_profile:

@@ -206,6 +206,30 @@ def test_forward_with_winograd_convolutions_equals_the_direct_forward(nets, cuda
     assert O.psnr_255(got.cpu(), ref.cpu()) > 100.0
 
 
+def test_hip_graph_replay_reproduces_the_eager_forward(nets, cuda):
+    """eavsr_amd.graph.GraphedForward: the whole forward captured once as a HIP graph; replays on new clips are
+    bit-identical to the eager forward (same kernels, same launch order) and cost the host almost nothing."""
+    import time
+    from eavsr_amd.graph import GraphedForward
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    net, _ = _model(nets, cuda, "x4", "trained_like")
+    a, b = synthetic_clip(1, 3, 64, 64, seed=31).to(cuda), synthetic_clip(1, 3, 64, 64, seed=32).to(cuda)
+    with torch.no_grad():
+        ya, yb = net(a).clone(), net(b).clone()
+    g = GraphedForward(net, a)
+    assert torch.equal(g(a), ya)
+    assert torch.equal(g(b), yb)
+    assert torch.equal(g(a), ya)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g(b)
+    host = time.perf_counter() - t0          # enqueue only: no synchronisation
+    torch.cuda.synchronize()
+    assert host < 0.05, host
+    with pytest.raises(ValueError):
+        g(synthetic_clip(1, 3, 64, 80, seed=1).to(cuda))
+
+
 def test_model_rejects_cpu_and_small_inputs(nets, cuda):
     net, _ = _model(nets, cuda, "x4", "default")
     with pytest.raises(AssertionError):
