@@ -35,8 +35,8 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s meas
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=4, help="clips per GPU (configs[1]: 4)")
     ap.add_argument("--frames", type=int, default=7)
     ap.add_argument("--height", type=int, default=180)
