@@ -117,3 +117,25 @@ def test_harness_window_maps_and_psnr():
     a = torch.zeros(1, 2, 3, 8, 8)
     assert abs(H.calc_psnr(a + 1.0, a) - 20 * np.log10(255.0)) < 1e-4
     assert H.crop_center(torch.arange(36.0).view(1, 6, 6), 2).flatten().tolist() == [14.0, 15.0, 20.0, 21.0]
+
+
+# ---- the bench contract, checked on the committed line of the last GPU visit -------------------------------------
+def test_committed_bench_line_follows_the_contract():
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_line.json")
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "frames/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["data"] == "synthetic" and line["dtype"].startswith("f32")
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - line["n_gpus"] * 4 * 7 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1
