@@ -340,6 +340,219 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3, 8-row tiles (NT = 1), 16-byte DMA path: the small-problem variant.  A training crop (2 x 96 x 96) or a pyramid
+// level launches fewer tiles than there are CUs, each wave has only 36 MFMAs per 8-channel chunk (1 us), and with the
+// two-stage pipeline above every chunk exposed the LDS-DMA latency: 4.4 us per chunk measured against 2 us of MFMAs
+// (tools/gpu_conv_small_sweep.py).  Same tile geometry, operands, packed weights and epilogue; what changes:
+//   * FOUR LDS stages; the DMA of chunk it+3 is issued while chunk it is multiplied, behind a COUNTED vmcnt that leaves
+//     the pieces of the two chunks in between in flight
+//   * every DMA piece is always issued (zero-padding lanes copy 16 zero bytes, surplus slots repeat the last piece), so
+//     the number of outstanding pieces per wave and chunk is a compile-time constant and no LDS zero-fill is needed
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_zero_f4[4];
+
+template <int MT>
+struct SmallCfg {
+  static constexpr int CK = 8, NW = 8, NSTAGE = 4;
+  static constexpr int TH = 8, TW = EAVSR_CONV_TW, MARG = 4, PAD = 1, KK = 9;
+  static constexpr int IH = TH + 2, IW = TW + 2 * MARG;        // 10 x 40
+  static constexpr int CO = 32 * MT;
+  static constexpr int IN_ELEMS = CK * IH * IW;                // 3200 floats
+  static constexpr int IN_SEGS = (IN_ELEMS + 255) / 256;       // 13 pieces (the last one half)
+  static constexpr int IN_PAD = IN_SEGS * 256;
+  static constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;        // 2 per wave
+  static constexpr int W_ELEMS = CK * KK * CO;
+  static constexpr int W_SEGS = (W_ELEMS + 255) / 256;         // 18 pieces (MT = 2)
+  static constexpr int W_IT = (W_SEGS + NW - 1) / NW;          // 3 per wave
+  static constexpr int PIECES = IN_IT + W_IT;                  // DMA instructions per wave and chunk
+  static constexpr int BUF = IN_PAD + W_SEGS * 256;
+  static constexpr int LDS_FLOATS = NSTAGE * BUF + NW * CO;
+  static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+};
+
+// SPLIT: the weight is packed for the 64-wide output tile but each workgroup computes one 32-channel half of it
+// (blockIdx.y = 2 * tile + half) - twice the workgroups for problems that leave most of the 256 CUs idle.
+template <int MT, bool SPLIT = false>
+__global__ __launch_bounds__(512, 2) void conv3x3_small_kernel(ConvArgs a) {
+  static_assert(!SPLIT || MT == 1, "a split tile is one 32-channel M-tile");
+  using Cfg = SmallCfg<MT>;
+  constexpr int CK = Cfg::CK, NW = Cfg::NW, NSTAGE = Cfg::NSTAGE, TH = Cfg::TH, TW = Cfg::TW, MARG = Cfg::MARG, PAD = Cfg::PAD;
+  constexpr int KK = Cfg::KK, IH = Cfg::IH, IW = Cfg::IW, CO = Cfg::CO, IN_ELEMS = Cfg::IN_ELEMS, IN_SEGS = Cfg::IN_SEGS;
+  constexpr int IN_PAD = Cfg::IN_PAD, IN_IT = Cfg::IN_IT, W_ELEMS = Cfg::W_ELEMS, W_SEGS = Cfg::W_SEGS, W_IT = Cfg::W_IT;
+  constexpr int PIECES = Cfg::PIECES, BUF = Cfg::BUF;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_red = smem + NSTAGE * BUF;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int bn = bid / a.tiles_y;
+  const int cot = SPLIT ? blockIdx.y >> 1 : blockIdx.y;
+  const int co_base = SPLIT ? blockIdx.y * 32 : blockIdx.y * CO;   // first output channel of this workgroup
+  constexpr int WCO = SPLIT ? 64 : CO;                              // row length of the packed weight
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  int cs = 0, cc0 = 0, cbase = 0;   // cursor of the ISSUE stream over the virtual concatenation of the sources
+  int total_chunks = 0;
+  for (int s = 0; s < a.n_src; ++s) total_chunks += a.src_c[s] / CK;
+
+  unsigned voff[IN_IT];
+#pragma unroll
+  for (int i = 0; i < IN_IT; ++i) {
+    const int seg = min(i * NW + wave, IN_SEGS - 1);
+    const int e4 = seg * 64 + lane;
+    const int ci = e4 / (IH * (IW / 4));
+    const int rem = e4 - ci * (IH * (IW / 4));
+    const int r = rem / (IW / 4);
+    const int c4 = rem - r * (IW / 4);
+    const int gy = y0 - PAD + r, gx = x0 - MARG + 4 * c4;
+    const bool ok = e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
+    voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
+  }
+  auto issue_chunk = [&](int stage) {
+    float* s_in = smem + stage * BUF;
+    float* s_w = s_in + IN_PAD;
+    const int sc = a.src_c[cs];
+    const char* sp = reinterpret_cast<const char*>(a.src[cs] + ((size_t)bn * sc + cc0) * plane);
+    const char* zp = reinterpret_cast<const char*>(g_zero_f4);
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int seg = min(i * NW + wave, IN_SEGS - 1);
+      __builtin_amdgcn_global_load_lds((gptr_t)(voff[i] != 0xFFFFFFFFu ? sp + voff[i] : zp), (lptr_t)(s_in + seg * 256), 16, 0, 0);
+    }
+    const char* wsrc = reinterpret_cast<const char*>(a.wp + ((size_t)cot * a.cin_pad + (size_t)(cbase + cc0)) * (KK * WCO) +
+                                                     (SPLIT ? (blockIdx.y & 1) * 32 : 0));
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int seg = min(i * NW + wave, W_SEGS - 1);
+      const unsigned e4 = (unsigned)min(seg * 64 + lane, W_ELEMS / 4 - 1);
+      const unsigned goff = SPLIT ? (e4 >> 3) * (WCO * 4u) + (e4 & 7) * 16u : e4 * 16u;   // 8 float4 per 32-float row
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + goff), (lptr_t)(s_w + seg * 256), 16, 0, 0);
+    }
+    cc0 += CK;
+    if (cc0 >= a.src_c[cs]) {
+      cbase += a.src_c[cs];
+      ++cs;
+      cc0 = 0;
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < NSTAGE - 1; ++i)
+    if (i < total_chunks) issue_chunk(i);
+  for (int it = 0; it < total_chunks; ++it) {
+    // chunk `it` must have landed; the pieces of the (up to) two younger chunks stay in flight
+    const int younger = min(total_chunks - 1 - it, NSTAGE - 2);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // ... for every wave; and everyone is done with the stage chunk it+3 overwrites (chunk it-1's)
+    if (it + NSTAGE - 1 < total_chunks) issue_chunk((it + NSTAGE - 1) % NSTAGE);
+    const float* bin = smem + (it % NSTAGE) * BUF + half * (IH * IW) + wave * IW + (MARG - PAD) + l31;
+    const float* ain = smem + (it % NSTAGE) * BUF + IN_PAD + half * (KK * CO) + l31;
+    // the 12 operands of tap t+1 (4 channel pairs x (2 M-tiles + 1 row)) are read before the 8 MFMAs of tap t: with one
+    // row per wave every MFMA pair needs fresh A operands, and a read / wait / multiply sequence per pair left the
+    // matrix pipe idle half of the time
+    float av[2][CK / 2][MT], bv[2][CK / 2];
+    auto load_tap = [&](int tap, int slot) __attribute__((always_inline)) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+      for (int cp = 0; cp < CK / 2; ++cp) {
+        bv[slot][cp] = bin[cp * 2 * (IH * IW) + ky * IW + kx];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[slot][cp][m] = ain[(cp * 2 * KK + tap) * CO + m * 32];
+      }
+    };
+    load_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      if (tap + 1 < KK) load_tap(tap + 1, (tap + 1) & 1);
+#pragma unroll
+      for (int cp = 0; cp < CK / 2; ++cp)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[tap & 1][cp][m], bv[tap & 1][cp], acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (CK / 2) * (MT + 1), 0);   // the next tap's reads first
+      __builtin_amdgcn_sched_group_barrier(0x008, (CK / 2) * MT, 0);         // then this tap's MFMAs
+    }
+  }
+
+  // ---- epilogue (as conv2d_mfma_kernel with one row per wave) ------------------------------------------
+  const int gx = x0 + l31, gy = y0 + wave;
+  const bool pok = gx < w && gy < h;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int co = co_base + col;
+      const bool cok = co < a.cout;
+      float v = acc[m][r] + ((cok && a.bias) ? a.bias[co] : 0.f);
+      if (a.act == EAVSR_ACT_RELU) v = fmaxf(v, 0.f);
+      else if (a.act == EAVSR_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+      float sum = 0.f;
+      if (cok && pok) {
+        const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
+        sum = v;
+        if (a.residual) v += a.residual[o];
+        a.out[o] = v;
+      }
+      if (a.chan_partial) {
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 8);
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 1);
+        if (l31 == 0) s_red[wave * CO + col] = sum;
+      }
+    }
+  }
+  if (a.chan_partial) {
+    __syncthreads();
+    if (tid < CO) {
+      const int co = co_base + tid;
+      if (co < a.cout) {
+        float v = s_red[tid];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) v += s_red[k * CO + tid];
+        a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx) * a.cout + co] = v;
+      }
+    }
+  }
+}
+
+template <int MT, bool SPLIT = false>
+int launch_small(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  using Cfg = SmallCfg<MT>;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<MT, SPLIT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("conv2d: hipFuncSetAttribute(%zu B of LDS): %s", Cfg::LDS_BYTES, hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  if (SPLIT) grid.y *= 2;
+  hipLaunchKernelGGL((conv3x3_small_kernel<MT, SPLIT>), grid, dim3(64 * Cfg::NW), Cfg::LDS_BYTES, st, a);
+  return eavsr::launch_status("conv2d");
+}
+
 // weight (cout,cin,k,k) -> [cout_tile][cin_pad][k*k][CO], zero padded
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ p, int cout, int cin,
                                    int kk, int cin_pad, int CO, long total) {
@@ -498,7 +711,14 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
   EAVSR_REQUIRE(d->ca_x == nullptr && d->ca_out == nullptr, -1, "conv2d: ca_x / ca_out without ca_scale");
   switch (d->ksize) {
     case 1: return launch_nt<1>(a, grid, CO, vec, nt, st);
-    case 3: return launch_nt<3>(a, grid, CO, vec, nt, st);
+    case 3:
+      if (nt == 1 && vec) {
+        if (CO == 32) return launch_small<1>(a, grid, st);
+        // fewer than half of the CUs busy: one 32-channel half tile per workgroup
+        if (blocks * grid.y <= 128) return launch_small<1, true>(a, grid, st);
+        return launch_small<2>(a, grid, st);
+      }
+      return launch_nt<3>(a, grid, CO, vec, nt, st);
     case 5: return launch_nt<5>(a, grid, CO, vec, nt, st);
     default: return launch_ks<7, 4>(a, grid, CO, vec, st);
   }

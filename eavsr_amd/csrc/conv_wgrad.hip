@@ -170,19 +170,158 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// dW[co0+co][ci_dst0+ci][tap] (+)= sum_blk ws[blk][co][ci][tap]
+
+// 3x3 variant.  One workgroup owns ONE (co half, ci half) quadrant of the 64 x 64 x 9 output and all nine taps of it;
+// its eight waves split K - wave r takes pixel row r of the 8 x 32 tile - so one dY operand feeds nine MFMAs (the
+// generic kernel reads one per MFMA) and a 72-tile training crop runs 288 workgroups instead of 72 on the 256 CUs.
+// The eight per-wave partial sums are added through LDS in a fixed order before the slab is written.
+struct Wg3Cfg {
+  static constexpr int KK = 9, TH = 8, TW = 32, PX = TH * TW, IH = TH + 2, IW = TW + 2;
+  static constexpr int PA = PX + 1, PB = (IH * IW) | 1;
+  static constexpr size_t LDS_BYTES = (size_t)(32 * PA + 32 * PB) * sizeof(float);
+};
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad3_kernel(WgradArgs a) {
+  using Cfg = Wg3Cfg;
+  constexpr int KK = Cfg::KK, TW = Cfg::TW, PX = Cfg::PX, IH = Cfg::IH, IW = Cfg::IW, PA = Cfg::PA, PB = Cfg::PB;
+  static_assert(8 * 1024 <= 32 * PA + 32 * PB, "the cross-wave sum reuses the operand tiles");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;             // [32 co][PA]
+  float* sB = smem + 32 * PA;   // [32 ci][PB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int mt = blockIdx.y & 1, ct = blockIdx.y >> 1;
+  const int co_valid = min(a.co_valid - 32 * mt, 32), ci_valid = min(a.ci_valid - 32 * ct, 32);
+  if (co_valid <= 0 || ci_valid <= 0) return;   // the reduction never reads this quadrant
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+
+  f32x16 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int bn = t / a.tiles_y;
+    const int y0 = ty * Cfg::TH, x0 = tx * TW;
+    constexpr int A_N = 32 * PX, B_N = 32 * IH * IW;
+    const char* dyb = reinterpret_cast<const char*>(a.dy + ((size_t)bn * a.cout_total + a.co0 + 32 * mt) * plane);
+    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin_src + a.ci0 + 32 * ct) * plane);
+    __syncthreads();  // the previous tile's MFMAs are done with the LDS tiles
+    {
+      // one batch of loads for dY and two for the X patch, every load of a batch in flight before its first LDS
+      // write (all three at once would spill next to the 144 accumulator registers)
+      constexpr int NA = A_N / 512, NB = (B_N + 1023) / 1024;
+      float va[NA];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = tid + i * 512;
+        const int co = e / PX, p = e - co * PX;
+        const int gy = y0 + p / TW, gx = x0 + (p % TW);
+        const bool ok = co < co_valid && gy < h && gx < w;
+        const unsigned off = ((unsigned)min(co, co_valid - 1) * (unsigned)plane + (unsigned)(min(gy, h - 1) * w + min(gx, w - 1))) * 4u;
+        const float v = *reinterpret_cast<const float*>(dyb + off);
+        va[i] = ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int e = tid + i * 512;
+        const int co = e / PX, p = e - co * PX;
+        sA[co * PA + p] = va[i];
+      }
+#pragma unroll 1
+      for (int e0 = 0; e0 < B_N; e0 += NB * 512) {
+        float vb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int e = min(e0 + tid + i * 512, B_N - 1);
+          const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
+          const int r = rem / IW, c = rem - r * IW;
+          const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+          const bool ok = ci < ci_valid && gy >= 0 && gy < h && gx >= 0 && gx < w;
+          const unsigned off = ((unsigned)min(ci, ci_valid - 1) * (unsigned)plane +
+                                (unsigned)(min(max(gy, 0), h - 1) * w + min(max(gx, 0), w - 1))) * 4u;
+          const float v = *reinterpret_cast<const float*>(xb + off);
+          vb[i] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int e = e0 + tid + i * 512;
+          if (e < B_N) {
+            const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
+            sB[ci * PB + rem] = vb[i];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // K loop of this wave: the 16 pixel pairs of tile row `wave`
+    const float* ap = sA + l31 * PA + wave * TW + half;
+    const float* bp = sB + l31 * PB + wave * IW + half;
+#pragma unroll 4
+    for (int kk = 0; kk < TW / 2; ++kk) {
+      const float av = ap[2 * kk];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[ky * IW + kx + 2 * kk], acc[ky * 3 + kx], 0, 0, 0);
+    }
+  }
+
+  // partial slab of this workgroup, ws[blk][co][ci][tap]: sum of the eight waves, wave 0 first
+#pragma unroll
+  for (int tap = 0; tap < KK; ++tap) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) smem[wave * 1024 + r * 64 + lane] = acc[tap][r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * 512;
+      float v = smem[e];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v += smem[k * 1024 + e];
+      const int r = e >> 6, ln = e & 63;
+      const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+      const int ci = ct * 32 + (ln & 31);
+      a.ws[(((size_t)blockIdx.x * 64 + co) * 64 + ci) * KK + tap] = v;
+    }
+  }
+}
+
+// dW[co0+co][ci_dst0+ci][tap] (+)= sum_blk ws[blk][co][ci][tap].  64 outputs per workgroup; the four waves take every
+// fourth slab (four independent load streams per output instead of one serial chain) and are added in wave order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int blocks, int kk, int co0, int co_valid, int ci_dst0,
                                                            int ci_valid, int cin_total, int accumulate) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int total = 64 * 64 * kk;
-  if (i >= total) return;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const int total = 64 * 64 * kk;   // a multiple of 64
+  float s0 = 0.f, s1 = 0.f;
+  int b = wv;
+  for (; b + 4 < blocks; b += 8) {
+    s0 += ws[(size_t)b * total + i];
+    s1 += ws[(size_t)(b + 4) * total + i];
+  }
+  if (b < blocks) s0 += ws[(size_t)b * total + i];
+  part[wv][lane] = s0 + s1;
+  __syncthreads();
+  if (wv != 0) return;
   const int tap = i % kk;
   const int ci = (i / kk) % 64;
   const int co = i / (kk * 64);
   if (co >= co_valid || ci >= ci_valid) return;
-  float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += ws[(size_t)b * total + i];
+  const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   float* dst = dw + ((size_t)(co0 + co) * cin_total + ci_dst0 + ci) * kk + tap;
   *dst = accumulate ? *dst + s : s;
 }
@@ -201,6 +340,21 @@ int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
     return (int)attr_err;
   }
   hipLaunchKernelGGL(conv_wgrad_kernel<KS>, dim3(blocks), dim3(512), Cfg::LDS_BYTES, st, a);
+  return eavsr::launch_status("conv_wgrad");
+}
+
+int launch_wgrad3(const WgradArgs& a, int blocks, hipStream_t st) {
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg3Cfg::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(blocks, 4), dim3(512), Wg3Cfg::LDS_BYTES, st, a);
   return eavsr::launch_status("conv_wgrad");
 }
 
@@ -236,12 +390,12 @@ extern "C" int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dwei
   int rc;
   switch (ksize) {
     case 1: rc = launch_wgrad<1>(a, blocks, st); break;
-    case 3: rc = launch_wgrad<3>(a, blocks, st); break;
+    case 3: rc = launch_wgrad3(a, blocks, st); break;
     default: rc = launch_wgrad<5>(a, blocks, st); break;
   }
   if (rc) return rc;
   const int kk = ksize * ksize;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(eavsr::cdiv(64 * 64 * kk, 256)), dim3(256), 0, st, workspace, dweight,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64 * kk), dim3(256), 0, st, workspace, dweight,
                      n == 0 ? 0 : blocks, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate);
   return eavsr::launch_status("conv_wgrad_reduce");
 }
