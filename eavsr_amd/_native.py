@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -77,6 +77,7 @@ SIGNATURES = {
     # backward entry points
     "eavsr_act_bwd_f32": (C.c_int, [vp, vp, vp, i64, i32, f32, vp]),
     "eavsr_plane_sum_f32": (C.c_int, [vp, vp, vp, i32, i32, f32, vp]),
+    "eavsr_channel_sum_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "eavsr_scale_residual_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_ca_mlp_bwd_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, vp]),
     "eavsr_flow_warp_bwd_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, vp]),

@@ -95,7 +95,7 @@ class _ConvFn(Function):
                 c0 += w_.shape[0]
         dbs: List[Optional[Tensor]] = []
         if has_bias:
-            db = ops.plane_sum(g).sum(0)
+            db = ops.channel_sum(g)
             c0 = 0
             for w_ in ws:
                 dbs.append(db[c0:c0 + w_.shape[0]])
@@ -179,7 +179,7 @@ class _DcnFn(Function):
         wt = weight.reshape(cout, cin * 9).t().contiguous().view(cin * 9, cout, 1, 1)
         dcol = ops.conv2d(dout, wt, None)                                        # W^T . dOut
         dx, doff, dmask = ops.dcnv2_col2im(x, offset, mask, dcol, dg, need_dx=ctx.needs_input_grad[0])
-        db = ops.plane_sum(dout).sum(0) if ctx.has_bias and ctx.needs_input_grad[4] else None
+        db = ops.channel_sum(dout) if ctx.has_bias and ctx.needs_input_grad[4] else None
         return dx, doff, dmask, dW, db, None
 
 

@@ -26,15 +26,67 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict_
                                                         float* __restrict__ out, int hw, float scale) {
   __shared__ float red[4];
   const size_t base = (size_t)blockIdx.x * hw;
-  float s = 0.f;
-  if (b != nullptr)
-    for (int i = threadIdx.x; i < hw; i += 256) s += a[base + i] * b[base + i];
-  else
-    for (int i = threadIdx.x; i < hw; i += 256) s += a[base + i];
+  float s0 = 0.f, s1 = 0.f;
+  if ((hw & 3) == 0) {   // whole float4 groups, 16-byte aligned planes: two independent load streams per thread
+    const float4* a4 = reinterpret_cast<const float4*>(a + base);
+    const float4* b4 = b ? reinterpret_cast<const float4*>(b + base) : nullptr;
+    const int q = hw >> 2;
+    for (int i = threadIdx.x; i < q; i += 512) {
+      const int j = i + 256;
+      const float4 x0 = a4[i], x1 = j < q ? a4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b4) {
+        const float4 y0 = b4[i], y1 = j < q ? b4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s0 += (x0.x * y0.x + x0.y * y0.y) + (x0.z * y0.z + x0.w * y0.w);
+        s1 += (x1.x * y1.x + x1.y * y1.y) + (x1.z * y1.z + x1.w * y1.w);
+      } else {
+        s0 += (x0.x + x0.y) + (x0.z + x0.w);
+        s1 += (x1.x + x1.y) + (x1.z + x1.w);
+      }
+    }
+  } else if (b != nullptr) {
+    for (int i = threadIdx.x; i < hw; i += 256) s0 += a[base + i] * b[base + i];
+  } else {
+    for (int i = threadIdx.x; i < hw; i += 256) s0 += a[base + i];
+  }
+  float s = s0 + s1;
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2] + red[3]) * scale;
+}
+
+// per-channel reduction over batch and plane (bias gradients): out[c] = sum_n sum_hw a[n,c,hw].  One workgroup of
+// 1024 threads per channel, fixed summation order.
+__global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restrict__ a, float* __restrict__ out, int n,
+                                                           int c, int hw) {
+  __shared__ float red[16];
+  const int ch = blockIdx.x;
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = 0; b < n; ++b) {
+    const float* p = a + ((size_t)b * c + ch) * hw;
+    if ((hw & 3) == 0) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      const int q = hw >> 2;
+      for (int i = threadIdx.x; i < q; i += 2048) {
+        const int j = i + 1024;
+        const float4 x0 = p4[i], x1 = j < q ? p4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s0 += (x0.x + x0.y) + (x0.z + x0.w);
+        s1 += (x1.x + x1.y) + (x1.z + x1.w);
+      }
+    } else {
+      for (int i = threadIdx.x; i < hw; i += 1024) s0 += p[i];
+    }
+  }
+  float s = s0 + s1;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k];
+    out[ch] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -63,53 +115,67 @@ __global__ __launch_bounds__(256) void ca_mlp_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ b2, const float* __restrict__ ds,
                                                          float* __restrict__ dmean, float* __restrict__ dw1,
                                                          float* __restrict__ db1, float* __restrict__ dw2,
-                                                         float* __restrict__ db2, int n, int c, int cr) {
-  extern __shared__ float sm[];  // m[c] hid[cr] dz2[c] dz1[cr]
+                                                         float* __restrict__ db2, int n, int c, int cr, int staged) {
+  extern __shared__ float sm[];  // m[c] hid[cr] dz2[c] dz1[cr] (w1[cr*c] w2[c*cr] when `staged`)
   float* m = sm;
   float* hid = m + c;
   float* dz2 = hid + cr;
   float* dz1 = dz2 + c;
   const int tid = threadIdx.x;
-  // zero the parameter gradients (this kernel owns them)
-  for (int i = tid; i < cr * c; i += 256) { dw1[i] = 0.f; dw2[i] = 0.f; }
-  for (int i = tid; i < cr; i += 256) db1[i] = 0.f;
-  for (int i = tid; i < c; i += 256) db2[i] = 0.f;
+  // the two weight matrices are read 2n times each: keep them in LDS when they are small (64 x 4 on the path)
+  const float* W1 = w1;
+  const float* W2 = w2;
+  if (staged) {
+    float* s1 = dz1 + cr;
+    float* s2 = s1 + cr * c;
+    for (int i = tid; i < cr * c; i += 256) { s1[i] = w1[i]; s2[i] = w2[i]; }
+    W1 = s1;
+    W2 = s2;
+  }
+  if (n == 0) {   // this kernel owns the parameter gradients
+    for (int i = tid; i < cr * c; i += 256) { dw1[i] = 0.f; dw2[i] = 0.f; }
+    for (int i = tid; i < cr; i += 256) db1[i] = 0.f;
+    for (int i = tid; i < c; i += 256) db2[i] = 0.f;
+  }
   __syncthreads();
   for (int b = 0; b < n; ++b) {
+    const bool first = b == 0;   // the first clip writes the parameter gradients, the others add (fixed order)
     for (int i = tid; i < c; i += 256) m[i] = mean[(size_t)b * c + i];
     __syncthreads();
     for (int j = tid; j < cr; j += 256) {
       float v = b1[j];
-      for (int k = 0; k < c; ++k) v += w1[j * c + k] * m[k];
+      for (int k = 0; k < c; ++k) v += W1[j * c + k] * m[k];
       hid[j] = fmaxf(v, 0.f);
     }
     __syncthreads();
     for (int i = tid; i < c; i += 256) {
       float v = b2[i];
-      for (int j = 0; j < cr; ++j) v += w2[i * cr + j] * hid[j];
+      for (int j = 0; j < cr; ++j) v += W2[i * cr + j] * hid[j];
       const float s = 1.f / (1.f + expf(-v));
       dz2[i] = ds[(size_t)b * c + i] * s * (1.f - s);
     }
     __syncthreads();
     for (int j = tid; j < cr; j += 256) {
       float v = 0.f;
-      for (int i = 0; i < c; ++i) v += w2[i * cr + j] * dz2[i];
+      for (int i = 0; i < c; ++i) v += W2[i * cr + j] * dz2[i];
       dz1[j] = hid[j] > 0.f ? v : 0.f;
     }
     __syncthreads();
     for (int i = tid; i < c * cr; i += 256) {
       const int ci = i / cr, j = i - ci * cr;   // dw2[ci][j]
-      dw2[i] += dz2[ci] * hid[j];
+      const float g2 = dz2[ci] * hid[j];
+      dw2[i] = first ? g2 : dw2[i] + g2;
       const int j1 = i / c, k = i - j1 * c;      // dw1[j1][k]
-      dw1[i] += dz1[j1] * m[k];
+      const float g1 = dz1[j1] * m[k];
+      dw1[i] = first ? g1 : dw1[i] + g1;
     }
     for (int i = tid; i < c; i += 256) {
-      db2[i] += dz2[i];
+      db2[i] = first ? dz2[i] : db2[i] + dz2[i];
       float v = 0.f;
-      for (int j = 0; j < cr; ++j) v += w1[j * c + i] * dz1[j];
+      for (int j = 0; j < cr; ++j) v += W1[j * c + i] * dz1[j];
       dmean[(size_t)b * c + i] = v;
     }
-    for (int j = tid; j < cr; j += 256) db1[j] += dz1[j];
+    for (int j = tid; j < cr; j += 256) db1[j] = first ? dz1[j] : db1[j] + dz1[j];
     __syncthreads();
   }
 }
@@ -262,6 +328,14 @@ extern "C" int eavsr_plane_sum_f32(const float* a, const float* b, float* out, i
   return eavsr::launch_status("plane_sum");
 }
 
+extern "C" int eavsr_channel_sum_f32(const float* a, float* out, int32_t n, int32_t c, int32_t hw, void* stream) {
+  EAVSR_REQUIRE(a && out, -1, "channel_sum: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c >= 0 && hw > 0, -1, "channel_sum: bad dims");
+  if (c == 0) return 0;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(1024), 0, eavsr::as_stream(stream), a, out, n, c, hw);
+  return eavsr::launch_status("channel_sum");
+}
+
 extern "C" int eavsr_scale_residual_bwd_f32(const float* d, const float* scale, const float* dmean, float* dr,
                                             int32_t n, int32_t c, int32_t hw, void* stream) {
   EAVSR_REQUIRE(d && scale && dr, -1, "scale_residual_bwd: NULL pointer");
@@ -278,8 +352,10 @@ extern "C" int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const fl
                                     float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, void* stream) {
   EAVSR_REQUIRE(mean && w1 && b1 && w2 && b2 && dscale && dmean && dw1 && db1 && dw2 && db2, -1, "ca_mlp_bwd: NULL pointer");
   EAVSR_REQUIRE(n >= 0 && c > 0 && cr > 0 && c <= 1024 && cr <= 1024, -1, "ca_mlp_bwd: bad dims");
-  hipLaunchKernelGGL(ca_mlp_bwd_kernel, dim3(1), dim3(256), (size_t)(2 * c + 2 * cr) * sizeof(float),
-                     eavsr::as_stream(stream), mean, w1, b1, w2, b2, dscale, dmean, dw1, db1, dw2, db2, n, c, cr);
+  const int staged = (size_t)c * cr <= 4096;
+  hipLaunchKernelGGL(ca_mlp_bwd_kernel, dim3(1), dim3(256),
+                     (size_t)(2 * c + 2 * cr + (staged ? 2 * c * cr : 0)) * sizeof(float), eavsr::as_stream(stream), mean,
+                     w1, b1, w2, b2, dscale, dmean, dw1, db1, dw2, db2, n, c, cr, staged);
   return eavsr::launch_status("ca_mlp_bwd");
 }
 

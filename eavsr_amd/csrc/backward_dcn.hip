@@ -147,10 +147,10 @@ __global__ __launch_bounds__(256) void gconv3x3_dgrad_kernel(const float* __rest
 }
 
 // dw[o][j][tap] = sum_{n,y,x} g[n,o,y,x] x[n,o*cpg+j,y+ky-1,x+kx-1] ; db[o] = sum g   one workgroup per (o, j)
-__global__ __launch_bounds__(256) void gconv3x3_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                                             float* __restrict__ dw, float* __restrict__ db, int n,
-                                                             int co, int cpg, int h, int w) {
-  __shared__ float red[4][10];
+__global__ __launch_bounds__(1024) void gconv3x3_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                              float* __restrict__ dw, float* __restrict__ db, int n,
+                                                              int co, int cpg, int h, int w) {
+  __shared__ float red[16][10];
   const int o = blockIdx.x / cpg, j = blockIdx.x - o * cpg;
   float acc[10];
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void gconv3x3_wgrad_kernel(const float* __rest
   for (int bn = 0; bn < n; ++bn) {
     const float* gq = g + ((size_t)bn * co + o) * hw;
     const float* xq = x + ((size_t)bn * co * cpg + (size_t)o * cpg + j) * hw;
-    for (int p = threadIdx.x; p < hw; p += 256) {
+    for (int p = threadIdx.x; p < hw; p += 1024) {
       const int py = p / w, px = p - py * w;
       const float gv = gq[p];
       acc[9] += gv;
@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void gconv3x3_wgrad_kernel(const float* __rest
   }
   __syncthreads();
   if (threadIdx.x < 10) {
-    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
     if (threadIdx.x < 9) dw[((size_t)o * cpg + j) * 9 + threadIdx.x] = v;
     else if (j == 0 && db != nullptr) db[o] = v;
   }
@@ -236,6 +238,6 @@ extern "C" int eavsr_gconv3x3_bwd_f32(const float* g, const float* x, const floa
   hipStream_t st = eavsr::as_stream(stream);
   dim3 grid(eavsr::cdiv(w, 64), eavsr::cdiv(h, 4), n * cout * cpg), block(64, 4, 1);
   hipLaunchKernelGGL(gconv3x3_dgrad_kernel, grid, block, 0, st, g, weight, dx, cout, cpg, h, w);
-  hipLaunchKernelGGL(gconv3x3_wgrad_kernel, dim3(cout * cpg), dim3(256), 0, st, g, x, dweight, dbias, n, cout, cpg, h, w);
+  hipLaunchKernelGGL(gconv3x3_wgrad_kernel, dim3(cout * cpg), dim3(1024), 0, st, g, x, dweight, dbias, n, cout, cpg, h, w);
   return eavsr::launch_status("gconv3x3_bwd");
 }

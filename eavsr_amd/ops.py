@@ -688,6 +688,19 @@ def plane_sum(a: Tensor, b: Optional[Tensor] = None, scale: float = 1.0) -> Tens
     return out
 
 
+def channel_sum(a: Tensor) -> Tensor:
+    """(n,c,h,w) -> (c,): sum over batch and plane (bias gradient)"""
+    a = _chk(a, "a")
+    n, c, h, w = a.shape
+    if n == 0 or c == 0:
+        return torch.zeros((c,), device=a.device, dtype=torch.float32)
+    out = torch.empty((c,), device=a.device, dtype=torch.float32)
+    st = _stream(a)
+    _launch("channel_sum", float(a.numel()), 4.0 * a.numel(), a,
+            lambda: lib().eavsr_channel_sum_f32(_p(a), _p(out), n, c, h * w, st), "channel_sum")
+    return out
+
+
 def scale_residual_bwd(d: Tensor, scale: Tensor, dmean: Optional[Tensor]) -> Tensor:
     d, scale = _chk(d, "d"), _chk(scale, "scale")
     n, c, h, w = d.shape

@@ -407,3 +407,20 @@ def test_two_rank_data_parallel_gradients_equal_the_mean_of_per_clip_gradients(A
         assert torch.equal(res[0][k], res[1][k]), k
         scale = max(1e-8, acc[k].abs().max().item())
         assert H.maxabs(res[0][k], acc[k]) <= 2e-3 * scale, (k, H.maxabs(res[0][k], acc[k]), scale)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 64, 96, 96), (3, 5, 19, 37), (1, 120, 8, 4), (0, 7, 4, 4)])
+def test_channel_and_plane_sums(cuda, n, c, h, w):
+    """bias-gradient reduction (sum over n, h, w) and the per-plane sums of the RCAB tail, both the float4 and the
+    ragged path, against float64 sums"""
+    from eavsr_amd import ops
+    a, b = cases.randn(70, n, c, h, w), cases.randn(71, n, c, h, w)
+    got = ops.channel_sum(a.to(cuda)).cpu()
+    want = a.double().sum(dim=(0, 2, 3))
+    assert got.shape == (c,)
+    assert H.maxabs(got.double(), want) <= 1e-5 * max(1.0, want.abs().max().item() if n else 1.0) + 1e-4
+    if n:
+        for bb in (None, b):
+            got = ops.plane_sum(a.to(cuda), None if bb is None else bb.to(cuda), 0.5).cpu()
+            want = 0.5 * (a.double() * (1 if bb is None else bb.double())).sum(dim=(2, 3))
+            assert H.maxabs(got.double(), want) <= 1e-4
