@@ -492,8 +492,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_small_kernel(ConvArgs a) {
   }
 
   // ---- epilogue (as conv2d_mfma_kernel with one row per wave) ------------------------------------------
+  // Every bias / residual load is issued before the first store: vmcnt counts loads and stores in one queue and
+  // the output pointer may alias, so a load placed after a store waits for that store's acknowledgement - sixteen
+  // serialised round trips per wave cost more than the whole main loop of a 64-channel launch.
   const int gx = x0 + l31, gy = y0 + wave;
   const bool pok = gx < w && gy < h;
+  float bb[MT][16], rr[MT][16];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_base + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool cok = co < a.cout;
+      bb[m][r] = (cok && a.bias) ? a.bias[co] : 0.f;
+      rr[m][r] = (cok && pok && a.residual) ? a.residual[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] : 0.f;
+    }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -501,15 +514,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_small_kernel(ConvArgs a) {
       const int col = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const int co = co_base + col;
       const bool cok = co < a.cout;
-      float v = acc[m][r] + ((cok && a.bias) ? a.bias[co] : 0.f);
+      float v = acc[m][r] + bb[m][r];
       if (a.act == EAVSR_ACT_RELU) v = fmaxf(v, 0.f);
       else if (a.act == EAVSR_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
       float sum = 0.f;
       if (cok && pok) {
         const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
         sum = v;
-        if (a.residual) v += a.residual[o];
-        a.out[o] = v;
+        a.out[o] = v + rr[m][r];
       }
       if (a.chan_partial) {
         sum += __shfl_xor(sum, 16);

@@ -111,6 +111,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   // acc[b][xi]: M_xi of output channels 16 cb + 4 (lane >> 4) + r, tile 16 (tb0 + b) + (lane & 15)
   const int l15 = lane & 15, kq = lane >> 4;
   const int cb = wave >> 1, tb0 = 2 * (wave & 1);
+  float bias_r[4];   // this lane's four output channels are the same for every tile of the launch
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = cot * 64 + cb * 16 + 4 * kq + r;
+    bias_r[r] = (co < a.cout && a.bias != nullptr) ? a.bias[co] : 0.f;
+  }
   f32x4 acc[2][16];
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -316,10 +322,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile] for every xi ----------
   {
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
+    // Every residual load is issued before the first store (the bias was read once at kernel start): loads and
+    // stores share the vmcnt queue and the output may alias, so a load placed after a store waits for that
+    // store's acknowledgement - eight to twenty-four serialised round trips per tile otherwise.
+    const int gx = x0 + 2 * l15;   // tile block = one row of 16 tiles: 16 lanes x float2 = one 128-byte line
+    f32x2 rr[2][4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int co = cot * 64 + cb * 16 + 4 * kq + r;
+          const int gy = y0 + 2 * (tb0 + b) + dy;
+          rr[b][r][dy] = f32x2{0.f, 0.f};
+          if (a.residual != nullptr && co < a.cout && gy < h && gx < w)
+            rr[b][r][dy] = *reinterpret_cast<const f32x2*>(a.residual + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx);
+        }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int t2y = tb0 + b, t2x = l15;   // tile block = one row of 16 tiles: 16 lanes x float2 = one 128-byte line
-      const int gx = x0 + 2 * t2x;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = cot * 64 + cb * 16 + 4 * kq + r;
@@ -335,21 +356,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
         y[1][0] = s1[0] + s1[1] + s1[2];
         y[1][1] = s1[1] - s1[2] - s1[3];
         const bool cok = co < a.cout;
-        const float bb = (cok && a.bias) ? a.bias[co] : 0.f;
+        const float bb = bias_r[r];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-          const int gy = y0 + 2 * t2y + dy;
+          const int gy = y0 + 2 * (tb0 + b) + dy;
           float v0 = y[dy][0] + bb, v1 = y[dy][1] + bb;
           if (a.act == EAVSR_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
           else if (a.act == EAVSR_ACT_LRELU) { v0 = v0 > 0.f ? v0 : v0 * a.slope; v1 = v1 > 0.f ? v1 : v1 * a.slope; }
           if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
             const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
             csum[r] += v0 + v1;
-            if (a.residual) {
-              const f32x2 rr = *reinterpret_cast<const f32x2*>(a.residual + o);
-              v0 += rr.x; v1 += rr.y;
-            }
-            *reinterpret_cast<f32x2*>(a.out + o) = f32x2{v0, v1};
+            *reinterpret_cast<f32x2*>(a.out + o) = f32x2{v0 + rr[b][r][dy].x, v1 + rr[b][r][dy].y};
           }
         }
       }
