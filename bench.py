@@ -149,14 +149,21 @@ def train_bench(args, rank, world, device):
     data = {"lr_seq": synthetic_clip(n, t, h, w, seed=rank), "hr_seq": synthetic_clip(n, t, 4 * h, 4 * w, seed=100 + rank),
             "fname": "synthetic"}
     model.set_input(data, epoch=0)
-    for _ in range(args.warmup):
-        model.optimize_parameters()
+    if args.graph:
+        from eavsr_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, warmup=max(args.warmup, 1))
+        step = graphed.step
+        step()
+    else:
+        step = model.optimize_parameters
+        for _ in range(args.warmup):
+            step()
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.optimize_parameters()
+        step()
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
@@ -171,7 +178,8 @@ def train_bench(args, rank, world, device):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"eavsrp x4 training step, {n} clips/GPU x {t} x 3 x {h} x {w}, HR {4*h}x{4*w}, L1, "
                                    "Adam (1e-4 / 1e-5), DP with one bucketed RCCL all-reduce on 49.1 MB of gradients "
-                                   "(BASELINE.json configs[3])"},
+                                   "(BASELINE.json configs[3])",
+                       "launch": "one HIP graph per step" if args.graph else "eager (one launch per kernel)"},
             "loss": model.get_current_losses()}), flush=True)
     if world > 1:
         shard.barrier()

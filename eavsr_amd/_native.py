@@ -77,7 +77,7 @@ SIGNATURES = {
     # backward entry points
     "eavsr_act_bwd_f32": (C.c_int, [vp, vp, vp, i64, i32, f32, vp]),
     "eavsr_plane_sum_f32": (C.c_int, [vp, vp, vp, i32, i32, f32, vp]),
-    "eavsr_channel_sum_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "eavsr_channel_sum_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_scale_residual_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_ca_mlp_bwd_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, vp]),
     "eavsr_flow_warp_bwd_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, vp]),

@@ -33,6 +33,65 @@ def _needs_grad(*ts) -> bool:
     return False
 
 
+# ------------------------------------------------------------------------------------------ gradient sink
+class grad_sink:
+    """Context manager for `loss.backward()` of the training step.
+
+    A convolution's parameters are used once per frame and branch (7-28 times per step).  Autograd sums the
+    per-use gradients with one ATen add per use and tensor (~6,000 launches of a few microseconds per step).
+    Inside this context the wgrad / bias kernels add every use into one buffer per call site instead
+    (`accumulate` of eavsr_conv_wgrad_f32 / eavsr_channel_sum_f32, fixed order: the order of backward) and the
+    Function returns no gradient for the parameter; `flush()` (called on exit) hands the buffers to `.grad`.
+    Only leaf parameters take part; everything else goes through autograd as usual.  Gradient hooks of the sunk
+    parameters do not fire (shard.GradientAllReducer.finish() launches their buckets after the flush)."""
+
+    _active: Optional["grad_sink"] = None
+
+    def __init__(self):
+        self.entries = {}
+
+    def __enter__(self):
+        if grad_sink._active is not None:
+            raise RuntimeError("grad_sink: already active")
+        grad_sink._active = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        grad_sink._active = None
+        if et is None:
+            self.flush()
+        self.entries = {}
+        return False
+
+    @staticmethod
+    def eligible(params) -> bool:
+        return grad_sink._active is not None and all(
+            isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad and p.is_cuda for p in params)
+
+    def buffers(self, ws, bs, k):
+        """(dW buffer over the concatenated output channels, db buffer or None, first use?)"""
+        key = tuple(id(w) for w in ws)
+        e = self.entries.get(key)
+        if e is not None:
+            return e[2], e[3], False
+        cout = sum(int(w.shape[0]) for w in ws)
+        dW = torch.empty((cout, int(ws[0].shape[1]), k, k), device=ws[0].device, dtype=torch.float32)
+        db = torch.empty((cout,), device=ws[0].device, dtype=torch.float32) if bs is not None else None
+        self.entries[key] = (list(ws), None if bs is None else list(bs), dW, db)
+        return dW, db, True
+
+    def flush(self):
+        for ws, bs, dW, db in self.entries.values():
+            c0 = 0
+            for i, w_ in enumerate(ws):
+                c = int(w_.shape[0])
+                for p, g in ((w_, dW[c0:c0 + c]), (None if bs is None else bs[i], None if db is None else db[c0:c0 + c])):
+                    if p is not None:
+                        p.grad = g if p.grad is None else p.grad + g
+                c0 += c
+        self.entries = {}
+
+
 # ------------------------------------------------------------------------------------------ conv
 # dgrad operand of a conv: the weight with its taps flipped and (cout, cin) transposed, for the source channels
 # c0 .. c0+cs.  A weight is used once per frame and branch, so within a step the same operand is asked for 7-28
@@ -69,6 +128,7 @@ class _ConvFn(Function):
             raise NotImplementedError("conv2d backward: activation together with a residual is not used on the path")
         out = ops.conv2d(srcs, ws, bs if has_bias else None, act=act, slope=slope, residual=res)
         ctx.meta = (act, slope, n_w, has_bias, has_res, n_src)
+        ctx.params = (ws, bs if has_bias else None)    # the caller's tensor objects (grad_sink keys on them)
         ctx.save_for_backward(*ws, *srcs, *( [out] if act is not None else []))
         return out
 
@@ -87,6 +147,16 @@ class _ConvFn(Function):
         o += 1 if has_res else 0
         need_src = need[o:o + n_src]
         dws: List[Optional[Tensor]] = [None] * n_w
+        pw, pb = ctx.params
+        if all(need_w) and (not has_bias or all(need[n_w:2 * n_w])) and grad_sink.eligible(pw + (pb or [])):
+            dW, db, first = grad_sink._active.buffers(pw, pb, k)
+            ops.conv_wgrad(g, srcs, k, out=dW, accumulate=not first)
+            if has_bias:
+                ops.channel_sum(g, out=db, accumulate=not first)
+            need_w = [False] * n_w
+            has_bias_grad = False
+        else:
+            has_bias_grad = has_bias
         if any(need_w):
             dW = ops.conv_wgrad(g, srcs, k)
             c0 = 0
@@ -94,12 +164,14 @@ class _ConvFn(Function):
                 dws[i] = dW[c0:c0 + w_.shape[0]] if need_w[i] else None
                 c0 += w_.shape[0]
         dbs: List[Optional[Tensor]] = []
-        if has_bias:
+        if has_bias_grad:
             db = ops.channel_sum(g)
             c0 = 0
             for w_ in ws:
                 dbs.append(db[c0:c0 + w_.shape[0]])
                 c0 += w_.shape[0]
+        elif has_bias:
+            dbs = [None] * n_w
         dsrcs: List[Optional[Tensor]] = []
         c0 = 0
         for i, s in enumerate(srcs):

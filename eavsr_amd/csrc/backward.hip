@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict_
 // per-channel reduction over batch and plane (bias gradients): out[c] = sum_n sum_hw a[n,c,hw].  One workgroup of
 // 1024 threads per channel, fixed summation order.
 __global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restrict__ a, float* __restrict__ out, int n,
-                                                           int c, int hw) {
+                                                           int c, int hw, int accumulate) {
   __shared__ float red[16];
   const int ch = blockIdx.x;
   float s0 = 0.f, s1 = 0.f;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restri
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k];
-    out[ch] = t;
+    out[ch] = accumulate ? out[ch] + t : t;
   }
 }
 
@@ -328,11 +328,13 @@ extern "C" int eavsr_plane_sum_f32(const float* a, const float* b, float* out, i
   return eavsr::launch_status("plane_sum");
 }
 
-extern "C" int eavsr_channel_sum_f32(const float* a, float* out, int32_t n, int32_t c, int32_t hw, void* stream) {
+extern "C" int eavsr_channel_sum_f32(const float* a, float* out, int32_t n, int32_t c, int32_t hw, int32_t accumulate,
+                                     void* stream) {
   EAVSR_REQUIRE(a && out, -1, "channel_sum: NULL pointer");
   EAVSR_REQUIRE(n >= 0 && c >= 0 && hw > 0, -1, "channel_sum: bad dims");
   if (c == 0) return 0;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(1024), 0, eavsr::as_stream(stream), a, out, n, c, hw);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(1024), 0, eavsr::as_stream(stream), a, out, n, c, hw,
+                     accumulate);
   return eavsr::launch_status("channel_sum");
 }
 

@@ -367,7 +367,8 @@ class EAVSRPModel:
         # criterionL1(hr, sr).mean()  (eavsrp_model.py:109-113)
         self.loss_EAVSRP_L1 = (self.data_hr_seq - self.data_sr_seq).abs().mean()
         self.loss_EAVSRP_Total = self.loss_EAVSRP_L1
-        self.loss_EAVSRP_Total.backward()
+        with AG.grad_sink():         # per-use parameter gradients are summed in place by the wgrad kernels
+            self.loss_EAVSRP_Total.backward()
         self.grad_sync.finish()      # one bucketed all-reduce over the loss gradients (no-op on 1 process)
 
     def optimize_parameters(self):

@@ -1,4 +1,4 @@
-"""HIP-graph replay of a whole forward (one process, one GPU, fixed input shape).
+"""HIP-graph replay of a whole forward or training step (one process, one GPU, fixed input shape).
 
 `EAVSRP.forward` is ~3,400 kernel launches per 4 x 7 x 180 x 320 step; the host needs 170-190 ms of Python / ctypes
 time to enqueue them against 370 ms of device time (tools/gpu_enqueue_time.py).  That is hidden today, but it is the
@@ -52,3 +52,94 @@ class GraphedForward:
         self.static_in.copy_(x)
         self.graph.replay()
         return self.static_out
+
+
+def clear_weight_caches():
+    """Drop every per-(parameter, version) cache of derived weights (packed / transformed / transposed forms).
+
+    A replayed graph updates the parameters on the device without touching their Python-side version counters, so
+    a cache filled inside (or before) a capture must not serve eager calls afterwards - and a capture must not hit an
+    entry built outside it, or the replays would keep reading that stale copy."""
+    from . import autograd, ops
+    ops.pack_cache.clear()
+    for name in ("_bias_cache", "_wcat_cache", "_x9_pack_cache", "_wino_pack_cache", "_h16_pack_cache",
+                 "_dcn_x9_pack_cache"):
+        d = getattr(ops, name, None)
+        if d is not None:
+            d.clear()
+    autograd._dgrad_cache.clear()
+
+
+class GraphedTrainStep:
+    """`EAVSRPModel.optimize_parameters()` (forward, L1 loss, backward, Adam) captured once and replayed.
+
+    The training step of configs[3] is ~14,000 kernel launches of 5-40 us; eager Python needs longer to enqueue them
+    than the GPU needs to run them.  One process: the whole step, optimizer included, is one graph.  Data parallel
+    (world size > 1): the graph ends after backward; the bucketed all-reduce (`shard.GradientAllReducer.finish`) and the
+    Adam step run eagerly after each replay (hooks cannot fire from a replay, so there is no overlap - 49 MB of
+    gradients against a 0.4 s step).
+
+    `model.set_input(first_batch)` must have been called; `step(batch)` copies a batch of the same shapes into the
+    static buffers and replays.  `model.loss_*` are the graph's static loss tensors.
+    """
+
+    def __init__(self, model, warmup: int = 2):
+        import torch.distributed as dist
+        self.model = model
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        dev = model.device
+        if model.data_hr_seq is None:
+            raise RuntimeError("GraphedTrainStep: call model.set_input() with lr_seq and hr_seq first")
+        self.static_lr = model.data_lr_seq.clone()
+        self.static_hr = model.data_hr_seq.clone()
+        opt = model.optimizer_EAVSRP
+        for g in opt.param_groups:                   # Adam keeps `step` on the device and never reads it back
+            g["capturable"] = True
+        for st in opt.state.values():
+            if "step" in st and not st["step"].is_cuda:
+                st["step"] = st["step"].to(dev, torch.float32)
+        model.data_lr_seq, model.data_hr_seq = self.static_lr, self.static_hr
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):          # allocator warm-up, kernel attributes, optimizer state
+                model.optimize_parameters()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        clear_weight_caches()
+        # nothing may keep the warm-up's autograd graph (and its AccumulateGrad nodes, bound to the side stream) alive
+        model.loss_EAVSRP_L1 = model.loss_EAVSRP_Total = model.data_sr_seq = model.data_sr = None
+        self.graph = torch.cuda.CUDAGraph()
+        model.grad_sync.paused = True
+        try:
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                model.forward()
+                self._backward()
+                if self.world == 1:
+                    opt.step()
+        finally:
+            model.grad_sync.paused = False
+            clear_weight_caches()
+
+    def _backward(self):
+        from . import autograd as AG
+        m = self.model
+        m.loss_EAVSRP_L1 = (m.data_hr_seq - m.data_sr_seq).abs().mean()
+        m.loss_EAVSRP_Total = m.loss_EAVSRP_L1
+        with AG.grad_sink():
+            m.loss_EAVSRP_Total.backward()
+
+    def step(self, batch=None):
+        m = self.model
+        if batch is not None:
+            lr, hr = batch["lr_seq"], batch["hr_seq"]
+            if lr.shape != self.static_lr.shape or hr.shape != self.static_hr.shape:
+                raise ValueError(f"graph captured for lr {tuple(self.static_lr.shape)} / hr {tuple(self.static_hr.shape)}")
+            self.static_lr.copy_(lr)
+            self.static_hr.copy_(hr)
+        self.graph.replay()
+        if self.world > 1:
+            m.grad_sync.reset()
+            m.grad_sync.finish()
+            m.optimizer_EAVSRP.step()

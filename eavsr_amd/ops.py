@@ -688,16 +688,20 @@ def plane_sum(a: Tensor, b: Optional[Tensor] = None, scale: float = 1.0) -> Tens
     return out
 
 
-def channel_sum(a: Tensor) -> Tensor:
-    """(n,c,h,w) -> (c,): sum over batch and plane (bias gradient)"""
+def channel_sum(a: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """(n,c,h,w) -> (c,): sum over batch and plane (bias gradient); `out` (+)= when given"""
     a = _chk(a, "a")
     n, c, h, w = a.shape
+    if out is None:
+        out = torch.empty((c,), device=a.device, dtype=torch.float32)
+        accumulate = False
+    elif tuple(out.shape) != (c,) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != a.device:
+        raise ValueError("channel_sum: out must be a contiguous fp32 (c,) tensor on the input's device")
     if n == 0 or c == 0:
-        return torch.zeros((c,), device=a.device, dtype=torch.float32)
-    out = torch.empty((c,), device=a.device, dtype=torch.float32)
+        return out if accumulate else out.zero_()
     st = _stream(a)
     _launch("channel_sum", float(a.numel()), 4.0 * a.numel(), a,
-            lambda: lib().eavsr_channel_sum_f32(_p(a), _p(out), n, c, h * w, st), "channel_sum")
+            lambda: lib().eavsr_channel_sum_f32(_p(a), _p(out), n, c, h * w, int(accumulate), st), "channel_sum")
     return out
 
 
@@ -780,13 +784,23 @@ def affine_offsets_bwd(doff: Tensor, dmask: Optional[Tensor], mask: Optional[Ten
     return dheads
 
 
-def conv_wgrad(dy: Tensor, srcs: Sequence[Tensor], ksize: int) -> Tensor:
-    """Weight gradient (cout, cin_total, k, k) of a conv over the virtual concatenation of `srcs`."""
+def conv_wgrad(dy: Tensor, srcs: Sequence[Tensor], ksize: int, out: Optional[Tensor] = None,
+               accumulate: bool = False) -> Tensor:
+    """Weight gradient (cout, cin_total, k, k) of a conv over the virtual concatenation of `srcs`; written to (or, with
+    `accumulate`, added to) `out` when given."""
     dy = _chk(dy, "dy")
     srcs = [_chk(s, f"src{i}") for i, s in enumerate(srcs)]
     n, cout, h, w = dy.shape
     cin = sum(int(s.shape[1]) for s in srcs)
-    dw = torch.empty((cout, cin, ksize, ksize), device=dy.device, dtype=torch.float32)
+    if out is None:
+        dw = torch.empty((cout, cin, ksize, ksize), device=dy.device, dtype=torch.float32)
+        accumulate = False
+    else:
+        dw = out
+        if (tuple(dw.shape) != (cout, cin, ksize, ksize) or not dw.is_contiguous() or dw.dtype != torch.float32
+                or dw.device != dy.device):
+            raise ValueError("conv_wgrad: out must be a contiguous fp32 (cout, cin, k, k) tensor on dy's device")
+    acc = int(accumulate)
     blocks = lib().eavsr_conv_wgrad_blocks(n, h, w, ksize)
     if blocks <= 0:
         raise NotImplementedError(f"conv_wgrad: kernel size {ksize}")
@@ -800,7 +814,7 @@ def conv_wgrad(dy: Tensor, srcs: Sequence[Tensor], ksize: int) -> Tensor:
                 _launch(f"conv_wgrad{ksize}x{ksize}", 2.0 * min(64, cout - co0) * min(64, cs - ci0) * ksize * ksize * n * h * w,
                         4.0 * n * h * w * 128, dy,
                         lambda s=s, cs=cs, ci0=ci0, co0=co0, base=base: lib().eavsr_conv_wgrad_f32(
-                            _p(dy), _p(s), _p(dw), _p(ws), n, h, w, cout, co0, cs, ci0, cin, base + ci0, ksize, 0, st),
+                            _p(dy), _p(s), _p(dw), _p(ws), n, h, w, cout, co0, cs, ci0, cin, base + ci0, ksize, acc, st),
                         "conv_wgrad")
         base += cs
     return dw

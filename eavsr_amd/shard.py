@@ -128,6 +128,7 @@ class GradientAllReducer:
         self._pending = [0] * len(self.buckets)
         self._work = []
         self._hooks = []
+        self.paused = False          # graph capture: no collective from a hook (eavsr_amd.graph.GraphedTrainStep)
         if self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -146,6 +147,8 @@ class GradientAllReducer:
         self._work.append((handle, flat, bucket))
 
     def _on_grad(self, p):
+        if self.paused:
+            return
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1
         if self._pending[i] == 0:

@@ -231,8 +231,10 @@ int eavsr_act_bwd_f32(const float* dy, const float* y, float* g, int64_t count, 
 int eavsr_plane_sum_f32(const float* a, const float* b, float* out, int32_t nc, int32_t hw, float scale,
                         void* stream);
 /* out[c] = sum_n sum_hw a[n,c,hw]: the bias gradient of every nn.Conv2d on the path (autograd's sum over
- * (0, 2, 3) in the reference, models/eavsrp_model.py:109-113); n == 0 writes zeros */
-int eavsr_channel_sum_f32(const float* a, float* out, int32_t n, int32_t c, int32_t hw, void* stream);
+ * (0, 2, 3) in the reference, models/eavsrp_model.py:109-113); n == 0 gives zeros; accumulate != 0 adds to out
+ * (a parameter used once per frame sums its per-use gradients in place) */
+int eavsr_channel_sum_f32(const float* a, float* out, int32_t n, int32_t c, int32_t hw, int32_t accumulate,
+                          void* stream);
 /* backward of out = r * scale[n,c] + x w.r.t. r:  dr = d * scale[n,c] + dmean[n,c] (dmean nullable) */
 int eavsr_scale_residual_bwd_f32(const float* d, const float* scale, const float* dmean, float* dr,
                                  int32_t n, int32_t c, int32_t hw, void* stream);

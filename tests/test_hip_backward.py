@@ -424,3 +424,71 @@ def test_channel_and_plane_sums(cuda, n, c, h, w):
             got = ops.plane_sum(a.to(cuda), None if bb is None else bb.to(cuda), 0.5).cpu()
             want = 0.5 * (a.double() * (1 if bb is None else bb.double())).sum(dim=(2, 3))
             assert H.maxabs(got.double(), want) <= 1e-4
+
+
+def test_grad_sink_matches_autograd_accumulation(AG, cuda):
+    """In-place accumulation of the per-use parameter gradients (autograd.grad_sink, what optimize_parameters runs)
+    against autograd's own sum of the same per-use gradients, for every trainable parameter."""
+    from eavsr_amd.eavsrp_model import EAVSRP
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    opt = Namespace(predict=False, n_frame=7, n_flow=5, scale=4)
+    net = EAVSRP(opt, None)
+    net.load_state_dict(H.filled(H.model_shapes("x4"), "trained_like"), strict=True)
+    net = net.to(cuda).train()
+    clip, hr = synthetic_clip(1, 4, 64, 64, seed=21).to(cuda), synthetic_clip(1, 4, 256, 256, seed=22).to(cuda)
+    (net(clip) - hr).abs().mean().backward()
+    plain = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    with AG.grad_sink():
+        (net(clip) - hr).abs().mean().backward()
+    sunk = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    assert set(plain) == set(sunk) and len(plain) > 300
+    for k in plain:
+        scale = max(1e-8, plain[k].abs().max().item())
+        assert H.maxabs(sunk[k], plain[k]) <= 2e-4 * scale, (k, H.maxabs(sunk[k], plain[k]), scale)
+    # outside the context nothing is redirected, and a second context cannot be nested
+    with AG.grad_sink():
+        with pytest.raises(RuntimeError):
+            AG.grad_sink().__enter__()
+
+
+def test_graphed_training_step_matches_eager(AG, cuda):
+    """graph.GraphedTrainStep: one captured HIP graph of forward + L1 + backward + Adam replays to the same losses
+    and parameters as eager optimize_parameters (float atomics in two scatter kernels: equal to rounding)."""
+    from eavsr_amd.eavsrp_model import EAVSRPModel
+    from eavsr_amd.graph import GraphedTrainStep
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    mk = lambda: Namespace(predict=False, n_frame=3, n_flow=5, scale=4, isTrain=True, gpu_ids=[0], lr=1e-4, beta1=0.9,
+                           beta2=0.999, weight_decay=0.0, npost=350)
+    sd = H.filled(H.model_shapes("x4"), "trained_like")
+    data = {"lr_seq": synthetic_clip(1, 3, 64, 64, seed=1), "hr_seq": synthetic_clip(1, 3, 256, 256, seed=2), "fname": "x"}
+    data2 = {"lr_seq": synthetic_clip(1, 3, 64, 64, seed=3), "hr_seq": synthetic_clip(1, 3, 256, 256, seed=4), "fname": "y"}
+    eager = EAVSRPModel(mk())
+    eager.netEAVSRP.load_state_dict(sd, strict=True)
+    want = []
+    for d in (data, data, data2, data):
+        eager.set_input(d, epoch=0)
+        eager.optimize_parameters()
+        want.append(eager.get_current_losses()["EAVSRP_L1"])
+    graphed = EAVSRPModel(mk())
+    graphed.netEAVSRP.load_state_dict(sd, strict=True)
+    graphed.set_input(data, epoch=0)
+    g = GraphedTrainStep(graphed, warmup=1)           # one eager step on `data`, then the capture (not a step)
+    got = []
+    for d in (data, data2, data):
+        g.step({k: v.to(cuda) for k, v in d.items() if k != "fname"})
+        got.append(graphed.get_current_losses()["EAVSRP_L1"])
+    assert all(abs(a - b) <= 2e-5 * max(1.0, abs(b)) for a, b in zip(got, want[1:])), (got, want)
+    pe, pg = dict(eager.netEAVSRP.named_parameters()), dict(graphed.netEAVSRP.named_parameters())
+    worst = max((pe[k].detach() - pg[k].detach()).abs().max().item() for k in pe)
+    assert worst <= 2.5e-4, worst      # Adam moves a parameter by ~lr = 1e-4 per step whatever the gradient's size
+    with pytest.raises(ValueError):
+        g.step({"lr_seq": torch.zeros(1, 3, 3, 32, 32, device=cuda), "hr_seq": torch.zeros(1, 3, 3, 128, 128, device=cuda)})
+    # eager evaluation after replays sees the replayed parameters (no stale packed weights): the same output as a
+    # fresh model loaded from the replayed parameters
+    fresh = EAVSRPModel(mk())
+    fresh.netEAVSRP.load_state_dict({k: v.detach().clone() for k, v in graphed.netEAVSRP.state_dict().items()}, strict=True)
+    graphed.eval(); fresh.eval()
+    graphed.set_input(data); fresh.set_input(data)
+    graphed.test(); fresh.test()
+    assert H.maxabs(graphed.data_sr_seq.cpu(), fresh.data_sr_seq.cpu()) <= 1e-6
