@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
                     help="fp32 (default, the BASELINE headline: exact fp32 everywhere) or a 16-bit NHWC residual backbone "
                          "(BASELINE.json configs[2] / [4]); the 16-bit runs are reported under their own metric name")
-    ap.add_argument("--conv-mode", default="winograd", choices=["winograd", "direct", "bf16x9"],
+    ap.add_argument("--conv-mode", default="winograd4", choices=["winograd", "winograd4", "direct", "bf16x9"],
                     help="large 3x3 convolutions (all fp32 in / out / accumulate): winograd = F(2x2,3x3) on the fp32 MFMA "
                          "(default); direct = direct sum on the fp32 MFMA; bf16x9 = direct sum, both operands split exactly "
                          "into three bf16 terms, nine partial products on the bf16 MFMA")
@@ -258,6 +258,7 @@ def main():
                                f"(BASELINE.json configs[1]), weights: seeded '{args.preset}' init",
                    "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "scale": 4, "sharding": "clips across ranks, no collective",
                    "conv3x3": {"winograd": "Winograd F(2x2,3x3), fp32 MFMA (direct fp32 kernel for the shapes it does not cover)",
+                               "winograd4": "Winograd F(4x4,3x3), fp32 MFMA (F(2x2,3x3) / direct fp32 kernels for the shapes it does not cover)",
                                "direct": "direct sum, fp32 MFMA", "bf16x9": "direct sum, exact bf16x9 split"}[args.conv_mode],
                    "dcnv2": args.dcn_mode, "launch": "one HIP graph per step" if args.graph else "eager (one launch per kernel)"},
     }
@@ -284,7 +285,7 @@ def main():
                     "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
                     "share_of_step": v["ms"] / total_ms}
 
-        dom_name = {"winograd": "conv3x3_64to64_wino", "direct": "conv3x3_64to64", "bf16x9": "conv3x3_64to64_x9"}[args.conv_mode]
+        dom_name = {"winograd": "conv3x3_64to64_wino", "winograd4": "conv3x3_64to64_wino4", "direct": "conv3x3_64to64", "bf16x9": "conv3x3_64to64_x9"}[args.conv_mode]
         dom = entry(dom_name, "mfma")
         if args.backbone_dtype != "fp32":
             e16 = entry("conv3x3_64to64_h16", "hbm")
@@ -295,14 +296,18 @@ def main():
             line["roofline"]["kernel"] = {
                 "winograd": "conv3x3_wino_kernel (3x3 64->64, the residual backbone); `achieved` counts the ALGORITHMIC "
                             "2*cin*cout*9 FLOP per pixel (SURVEY 8d) -- the kernel performs 2.25x fewer multiplications",
+                "winograd4": "conv3x3_wino4_kernel (3x3 64->64, the residual backbone); `achieved` counts the ALGORITHMIC "
+                             "2*cin*cout*9 FLOP per pixel (SURVEY 8d) -- the kernel performs 4x fewer multiplications",
                 "direct": "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)",
                 "bf16x9": "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)"}[args.conv_mode]
             line["roofline"]["avg_ms"] = dom["avg_ms"]
             line["roofline"]["share_of_step"] = dom["share_of_step"]
-            if args.conv_mode == "winograd":
-                # frac can exceed 1 for the algorithmic count: F(2x2,3x3) multiplies 16 times per 2x2 outputs instead of 36
-                line["roofline"]["performed"] = dom["achieved"] / 2.25
-                line["roofline"]["performed_frac"] = dom["achieved"] / 2.25 / PEAK_MFMA_F32_TFLOPS
+            if args.conv_mode in ("winograd", "winograd4"):
+                # frac can exceed 1 for the algorithmic count: F(2x2,3x3) multiplies 16 times per 2x2 outputs instead of
+                # 36, F(4x4,3x3) 36 times per 4x4 outputs instead of 144
+                red = 2.25 if args.conv_mode == "winograd" else 4.0
+                line["roofline"]["performed"] = dom["achieved"] / red
+                line["roofline"]["performed_frac"] = dom["achieved"] / red / PEAK_MFMA_F32_TFLOPS
         line["kernels"] = [e for e in (entry("dcnv2" if args.dcn_mode == "native" else "dcnv2_x9", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120", "mfma")) if e]

@@ -1,0 +1,479 @@
+// 3x3 stride-1 convolution by Winograd F(4x4, 3x3) on the fp32 matrix cores: 4x fewer multiplications than the
+// direct sum, 1.78x fewer than F(2x2, 3x3) (conv_wino.hip).  Same operands / epilogue / tensors as
+// conv3x3_wino_kernel<false>; the residual backbone's convolutions (networks.py:456-458,478; eavsrp_model.py:381).
+//
+//   Y(4x4) = A^T [ (G g G^T) .* (B^T d B) ] A      per 6x6 input tile d, 3x3 filter g   (Lavin & Gray 2016, points 0, +-1, +-2, inf)
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//
+// 36 independent GEMMs (one per transform-domain position xi): M_xi[co, t] = sum_ci U_xi[co, ci] V_xi[ci, t], all fp32.
+// The larger transform costs accuracy: ~1e-5 of the output scale against 4e-7 for F(2x2, 3x3) (tests/test_hip_ops.py
+// measures both against fp64) - still fp32 arithmetic throughout and two orders inside the path's 1e-3 parity bound.
+//
+// Per workgroup (512 threads = 8 waves, one per CU): 8 x 64 output pixels = 2 x 16 Winograd tiles, 64 output channels.
+//   wave w owns output channels 16 (w >> 1) .. +15 and tile row (w & 1): 36 accumulator quads = 144 registers
+//   (v_mfma_f32_16x16x4_f32: lane (kq, l15) holds M_xi[16 cb + 4 kq + r][tile l15] for every xi), so the output
+//   transform needs no exchange between lanes or waves.
+//   per chunk of 4 input channels (= one k-step; two LDS stages each for the patch, U and V; one barrier per chunk):
+//     LDS-DMA: the (4 x 10 x 72) fp32 input patch (lanes outside the image copy zeros) and the pre-transformed weight
+//              slab U[36][4][64] (eavsr_pack_conv_weight_wino4)
+//     input transform, inside one wave: lane (p, l15), p < 3, does the column pass B^T d for columns 2p, 2p+1 of tile
+//              l15 (packed fp32 pairs), stores it at V's own locations, then the row pass for rows 2p, 2p+1 in place
+//     GEMM: 36 x (2 ds_read_b32 + 1 MFMA); U columns carry the XOR swizzle (co ^ 16 (c & 1)), V rows a pitch of 136
+//           floats per position, so that neither the operand reads nor the transform's accesses conflict
+//   epilogue in registers: output transform, + bias, activation, + residual, float4 row stores (one 256-byte line per
+//   16 lanes), optional per-tile channel sums (deterministic).
+#include "common.h"
+
+#include <mutex>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __attribute__((aligned(16))) float g_wino4_zero[4];   // source of the zero-padding DMA lanes
+
+struct W4Args {
+  const float* src[5];
+  int src_c[5];
+  int n_src;
+  const float* wu;        // [cot][cin / 4][36][4][64]
+  const float* bias;
+  const float* residual;
+  float* out;
+  float* chan_partial;
+  int n, h, w, cin, cout, tiles_x, tiles_y;
+  int act;
+  float slope;
+};
+
+constexpr int CK = 4, NW = 8, NPOS = 36;
+constexpr int TOH = 8, TOW = 64;                      // output tile: 2 x 16 Winograd tiles of 4 x 4
+constexpr int MARG = 4;                               // patch starts 4 columns left of the tile: 16-byte DMA pieces
+constexpr int IH = TOH + 2, IW = TOW + 2 * MARG;      // 10 x 72
+constexpr int IN_ELEMS = CK * IH * IW;                // 2880 floats
+constexpr int IN_SEGS = (IN_ELEMS / 4 + 63) / 64;     // 12 one-KiB pieces (the last one a quarter)
+constexpr int IN_PAD = IN_SEGS * 256;
+constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;        // 2
+constexpr int U_ELEMS = NPOS * CK * 64;               // 9216 floats = 36 KB: one 1-KiB piece per position
+constexpr int U_SEGS = U_ELEMS / 256;                 // 36
+constexpr int U_IT = (U_SEGS + NW - 1) / NW;          // 5
+constexpr int VP = CK * 32 + 8;                       // V pitch per position: 4 channels x 32 tiles + 8 (bank skew)
+constexpr int V_ELEMS = NPOS * VP;                    // 4896
+constexpr int OFF_U = 2 * IN_PAD;                     // LDS map: [patch 0][patch 1][U 0][U 1][V 0][V 1][channel sums]
+constexpr int OFF_V = OFF_U + 2 * U_ELEMS;
+constexpr int LDS_MAIN = OFF_V + 2 * V_ELEMS;         // 134.3 KB
+constexpr int LDS_FLOATS = LDS_MAIN + 128;
+constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+
+// t = B^T d for one 6-vector (works on packed pairs: two columns / rows at once)
+template <typename T>
+__device__ __forceinline__ void in1d(const T (&d)[6], T (&t)[6]) {
+  const T a = d[4] - 4.f * d[2];
+  const T b = d[3] - 4.f * d[1];
+  const T c = d[4] - d[2];
+  const T e = d[3] - d[1];
+  t[0] = 4.f * d[0] + (d[4] - 5.f * d[2]);
+  t[1] = a + b;
+  t[2] = a - b;
+  t[3] = c + 2.f * e;
+  t[4] = c - 2.f * e;
+  t[5] = 4.f * d[1] + (d[5] - 5.f * d[3]);
+}
+
+// s = A^T m for one 6-vector
+__device__ __forceinline__ void out1d(const float (&m)[6], float (&s)[4]) {
+  const float p1 = m[1] + m[2], p2 = m[1] - m[2], p3 = m[3] + m[4], p4 = m[3] - m[4];
+  s[0] = m[0] + p1 + p3;
+  s[1] = p2 + 2.f * p4;
+  s[2] = p1 + 4.f * p3;
+  s[3] = (p2 + 8.f * p4) + m[5];
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_v = smem + OFF_V;
+  float* s_red = smem + LDS_MAIN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // Persistent workgroups: workgroup b walks the tiles b, b + gridDim.x, ... as ONE flattened sequence of (tile, chunk)
+  // iterations (as conv3x3_wino_kernel): the LDS-DMA stream never drains at a tile boundary.
+  const int cot = blockIdx.y;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+  const int total_tiles = a.tiles_x * a.tiles_y * a.n;
+  const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  auto tile_coords = [&](int k, int& bn_, int& y0_, int& x0_, int& lin_) __attribute__((always_inline)) {
+    int t = eavsr_xcd_remap((int)blockIdx.x + k * (int)gridDim.x, total_tiles);
+    const int tx_ = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty_ = t % a.tiles_y;
+    bn_ = t / a.tiles_y;
+    y0_ = ty_ * TOH;
+    x0_ = tx_ * TOW;
+    lin_ = ty_ * a.tiles_x + tx_;
+  };
+
+  // acc[xi]: M_xi of output channels 16 cb + 4 kq + r, Winograd tile (row tg, column l15)
+  const int l15 = lane & 15, kq = lane >> 4;
+  const unsigned lane16 = lane * 16u;
+  const int cb = wave >> 1, tg = wave & 1;
+  float bias_r[4];   // this lane's four output channels are the same for every tile of the launch
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = cot * 64 + cb * 16 + 4 * kq + r;
+    bias_r[r] = (co < a.cout && a.bias != nullptr) ? a.bias[co] : 0.f;
+  }
+  f32x4 acc[NPOS];
+#pragma unroll
+  for (int x = 0; x < NPOS; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int total_chunks = 0;
+  for (int s = 0; s < a.n_src; ++s) total_chunks += a.src_c[s] / CK;
+  const int total_iters = my_tiles * total_chunks;
+
+  // ---- prefetch stream (runs up to two chunks ahead of the compute stream, across tile boundaries) -------------
+  int p_k = 0, p_cs = 0, p_cc0 = 0, p_bn = 0, p_y0 = 0, p_x0 = 0, p_lin = 0;
+  unsigned voff[IN_IT];   // per-lane byte offsets of this wave's patch pieces; 0xFFFFFFFF: zero padding
+  auto p_setup_tile = [&]() __attribute__((always_inline)) {
+    tile_coords(p_k, p_bn, p_y0, p_x0, p_lin);
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int seg = i * NW + wave;
+      const int e4 = seg * 64 + lane;
+      const int ci = e4 / (IH * (IW / 4));
+      const int rem = e4 - ci * (IH * (IW / 4));
+      const int r = rem / (IW / 4);
+      const int c4 = rem - r * (IW / 4);
+      const int gy = p_y0 - 1 + r, gx = p_x0 - MARG + 4 * c4;
+      const bool ok = e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
+      voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
+    }
+  };
+  p_setup_tile();
+  int bn = 0, y0 = 0, x0 = 0, tile_lin = 0;
+  tile_coords(0, bn, y0, x0, tile_lin);
+
+  // the patch of the NEXT chunk of the prefetch stream -> patch stage; every piece is always issued (zeros outside)
+  auto issue_patch = [&](int stage) {
+    float* s_in = smem + stage * IN_PAD;
+    const int sc = a.src_c[p_cs];
+    const char* sp = reinterpret_cast<const char*>(a.src[p_cs] + ((size_t)p_bn * sc + p_cc0) * plane);
+    const char* zp = reinterpret_cast<const char*>(g_wino4_zero);
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i) {
+      const int seg = i * NW + wave;
+      if (seg < IN_SEGS) {   // wave-uniform
+        const bool ok = voff[i] != 0xFFFFFFFFu;
+        __builtin_amdgcn_global_load_lds((gptr_t)(ok ? sp + voff[i] : zp), (lptr_t)(s_in + seg * 256), 16, 0, 0);
+      }
+    }
+    p_cc0 += CK;
+    if (p_cc0 >= a.src_c[p_cs]) {
+      ++p_cs;
+      p_cc0 = 0;
+      if (p_cs >= a.n_src) {
+        p_cs = 0;
+        ++p_k;
+        if (p_k < my_tiles) p_setup_tile();
+      }
+    }
+  };
+  auto issue_u = [&](int g, int stage) {
+    float* s_u = smem + OFF_U + stage * U_ELEMS;
+    // wave-uniform piece base + one per-lane offset (a per-piece vector offset costs two registers per piece)
+    const char* usrc = reinterpret_cast<const char*>(a.wu + ((size_t)cot * (a.cin / CK) + (size_t)g) * U_ELEMS) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < U_IT; ++i) {
+      const int seg = i * NW + wave;
+      if (seg < U_SEGS)
+        __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * (NW * 1024) + lane16), (lptr_t)(s_u + seg * 256), 16, 0, 0);
+    }
+  };
+
+  // input-transform job of this lane: channel tc = wave >> 1 of the chunk, tile (row wave & 1, column l15), part kq
+  const int tc = wave >> 1;
+  const int poff = tc * (IH * IW) + (4 * tg) * IW + (MARG - 1) + 4 * l15 + 2 * kq;   // column 2 kq of its 6 x 6 patch
+  const int voff_t = tc * 32 + tg * 16 + l15;                                         // + xi * VP
+
+  auto transform = [&](int ps, int vs) __attribute__((always_inline)) {
+#ifndef EAVSR_WINO_EXP_NOTRANSFORM   // timing ablations only: results are wrong
+    if (kq < 3) {
+      const float* pp = smem + ps * IN_PAD + poff;
+      float* vd = s_v + vs * V_ELEMS + voff_t;
+      {   // column pass: t[i][q] = sum_r B^T[i][r] d[r][q] for q = 2 kq, 2 kq + 1
+        f32x2 d[6], t[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW], pp[r * IW + 1]};
+        in1d(d, t);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          vd[(i * 6 + 2 * kq) * VP] = t[i].x;
+          vd[(i * 6 + 2 * kq + 1) * VP] = t[i].y;
+        }
+      }
+      asm volatile("" ::: "memory");   // same wave: the LDS executes its accesses in order
+      {   // row pass, in place: V[i][j] = sum_q t[i][q] B[q][j] for i = 2 kq, 2 kq + 1
+        f32x2 d[6], t[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) d[q] = f32x2{vd[((2 * kq) * 6 + q) * VP], vd[((2 * kq + 1) * 6 + q) * VP]};
+        in1d(d, t);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          vd[((2 * kq) * 6 + j) * VP] = t[j].x;
+          vd[((2 * kq + 1) * 6 + j) * VP] = t[j].y;
+        }
+      }
+    }
+#endif
+  };
+
+  // Pipeline (one barrier per chunk): iteration j multiplies chunk j (V[j&1], U[j&1]) right after transforming chunk
+  // j+1 (patch[(j+1)&1] -> V[(j+1)&1]); the weight slab runs one chunk ahead of its GEMM, the input patch two.
+  issue_patch(0);
+  issue_u(0, 0);
+  if (total_iters > 1) issue_patch(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  transform(0, 0);
+  int chunk = 0;   // chunk of iteration `it` within its tile
+  for (int it = 0; it < total_iters; ++it) {
+    // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of iteration it-1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int chunk_n = chunk + 1 == total_chunks ? 0 : chunk + 1;
+    auto issue_dma = [&]() __attribute__((always_inline)) {
+#ifndef EAVSR_WINO_EXP_NODMA
+      if (it + 1 < total_iters) issue_u(chunk_n, (it + 1) & 1);
+      if (it + 2 < total_iters) issue_patch(it & 1);
+#endif
+    };
+    // the two waves of a SIMD (w and w + 4) issue their DMA pieces at different points of the iteration
+    // ... and the input transform of the next chunk (two dependent LDS round trips, little arithmetic) runs before the
+    // GEMM in one wave of the pair and after it in the other, under the partner's MFMAs
+    const bool dma_late = wave >= 4;
+    if (!dma_late) {
+      issue_dma();
+      if (it + 1 < total_iters) transform((it + 1) & 1, (it + 1) & 1);
+    }
+    // ---- the 36 GEMM steps of this wave: M_xi[co, t] += sum over the chunk's 4 channels U_xi[co, c] V_xi[c, t]
+    const float* ua = smem + OFF_U + (it & 1) * U_ELEMS + kq * 64 + ((cb * 16 + l15) ^ ((kq & 1) << 4));
+    const float* vb = s_v + (it & 1) * V_ELEMS + kq * 32 + tg * 16 + l15;
+    constexpr int AHEAD = 4;
+    float av[AHEAD + 1], bv[AHEAD + 1];
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) { av[i] = ua[i * (CK * 64)]; bv[i] = vb[i * VP]; }
+#ifndef EAVSR_WINO_EXP_NOMFMA
+#pragma unroll
+    for (int i = 0; i < NPOS; ++i) {
+      if (i == NPOS / 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma_late) issue_dma();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i + AHEAD < NPOS) {
+        av[(i + AHEAD) % (AHEAD + 1)] = ua[(i + AHEAD) * (CK * 64)];
+        bv[(i + AHEAD) % (AHEAD + 1)] = vb[(i + AHEAD) * VP];
+      }
+      const int cur = i % (AHEAD + 1);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur], bv[cur], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of step i + AHEAD
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // the MFMA of step i
+    }
+#else
+    if (dma_late) issue_dma();
+    acc[0][0] += av[0] + bv[0];
+#endif
+    if (dma_late && it + 1 < total_iters) transform((it + 1) & 1, (it + 1) & 1);
+    chunk = chunk_n;
+    if (chunk != 0) continue;   // the tile is not finished yet
+
+    // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile (tg, l15)] for every xi ----
+    {
+      const int gx = x0 + 4 * l15;   // 16 lanes x float4 = one 256-byte row segment
+      float csum[4] = {0.f, 0.f, 0.f, 0.f};
+      // two output rows at a time (the four rows of a channel at once need 40 more registers than there are):
+      // their residual rows are requested first, the column pass A^T m of this half runs under the loads
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * 64 + cb * 16 + 4 * kq + r;
+        const bool cok = co < a.cout;
+        const float bb = bias_r[r];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 rr[2];
+#pragma unroll
+          for (int d2 = 0; d2 < 2; ++d2) {
+            const int gy = y0 + 4 * tg + 2 * hf + d2;
+            rr[d2] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.residual != nullptr && cok && gy < h && gx < w)
+              rr[d2] = *reinterpret_cast<const f32x4*>(a.residual + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx);
+          }
+          float s[2][6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {      // rows 2 hf, 2 hf + 1 of A^T m, column q of the 6 x 6 block
+            const float m0 = acc[0 * 6 + q][r], m1 = acc[1 * 6 + q][r], m2 = acc[2 * 6 + q][r], m3 = acc[3 * 6 + q][r],
+                        m4 = acc[4 * 6 + q][r], m5 = acc[5 * 6 + q][r];
+            if (hf == 0) {
+              s[0][q] = m0 + (m1 + m2) + (m3 + m4);
+              s[1][q] = (m1 - m2) + 2.f * (m3 - m4);
+            } else {
+              s[0][q] = (m1 + m2) + 4.f * (m3 + m4);
+              s[1][q] = ((m1 - m2) + 8.f * (m3 - m4)) + m5;
+            }
+          }
+#pragma unroll
+          for (int d2 = 0; d2 < 2; ++d2) {
+            float y[4];
+            out1d(s[d2], y);
+            const int gy = y0 + 4 * tg + 2 * hf + d2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              y[j] += bb;
+              if (a.act == EAVSR_ACT_RELU) y[j] = fmaxf(y[j], 0.f);
+              else if (a.act == EAVSR_ACT_LRELU) y[j] = y[j] > 0.f ? y[j] : y[j] * a.slope;
+            }
+            if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx % 4 == 0: gx + 3 < w as well
+              csum[r] += (y[0] + y[1]) + (y[2] + y[3]);
+              *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
+                  f32x4{y[0] + rr[d2][0], y[1] + rr[d2][1], y[2] + rr[d2][2], y[3] + rr[d2][3]};
+            }
+          }
+        }
+      }
+      if (a.chan_partial) {
+        // per output channel: 16 lanes (tiles) here and the same again in wave ^ 1 (fixed order)
+        __syncthreads();   // s_red is free (the previous tile's sums were read long ago)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = csum[r];
+          v += __shfl_xor(v, 8);
+          v += __shfl_xor(v, 4);
+          v += __shfl_xor(v, 2);
+          v += __shfl_xor(v, 1);
+          if (l15 == 0) s_red[tg * 64 + cb * 16 + 4 * kq + r] = v;
+        }
+        __syncthreads();
+        if (tid < 64) {
+          const int co = cot * 64 + tid;
+          if (co < a.cout)
+            a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + tile_lin) * a.cout + co] = s_red[tid] + s_red[64 + tid];
+        }
+      }
+      // next tile of this workgroup
+#pragma unroll
+      for (int x = 0; x < NPOS; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (it + 1 < total_iters) tile_coords((it + 1) / total_chunks, bn, y0, x0, tile_lin);
+    }
+  }   // flattened (tile, chunk) loop
+}
+
+// weight (cout, cin, 3, 3) -> U = G g G^T laid out [cot][cin / 4][xi][c][co ^ 16 (c & 1)] (zero for co >= cout);
+// evaluated in double and rounded once
+__global__ void pack_wino4_kernel(const float* __restrict__ wt, float* __restrict__ out, int cout, int cin, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int col = (int)(e & 63);
+  long u = e >> 6;
+  const int c = (int)(u % CK); u /= CK;
+  const int xi = (int)(u % NPOS); u /= NPOS;
+  const int nchunks = cin / CK;
+  const int chunk = (int)(u % nchunks);
+  const int cot = (int)(u / nchunks);
+  const int co = cot * 64 + col, ci = chunk * CK + c;
+  float v = 0.f;
+  if (co < cout) {
+    const float* g = wt + ((size_t)co * cin + ci) * 9;
+    const int r = xi / 6, q = xi - 6 * r;
+    const double G[6][3] = {{0.25, 0., 0.},
+                            {-1. / 6, -1. / 6, -1. / 6},
+                            {-1. / 6, 1. / 6, -1. / 6},
+                            {1. / 24, 1. / 12, 1. / 6},
+                            {1. / 24, -1. / 12, 1. / 6},
+                            {0., 0., 1.}};
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) s += G[r][i] * (double)g[i * 3 + j] * G[q][j];
+    v = (float)s;
+  }
+  out[e - col + (col ^ ((c & 1) << 4))] = v;
+}
+
+}  // namespace
+
+extern "C" int64_t eavsr_wino4_weight_elems(int32_t cout, int32_t cin) {
+  if (cout <= 0 || cin <= 0 || cin % CK != 0) return 0;
+  return (int64_t)eavsr::cdiv(cout, 64) * (cin / CK) * U_ELEMS;
+}
+
+extern "C" int eavsr_pack_conv_weight_wino4(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight_wino4: NULL pointer");
+  EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % CK == 0, -1, "pack_conv_weight_wino4: cin %d must be a multiple of 4", cin);
+  const long total = eavsr_wino4_weight_elems(cout, cin);
+  hipLaunchKernelGGL(pack_wino4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
+                     packed, cout, cin, total);
+  return eavsr::launch_status("pack_conv_weight_wino4");
+}
+
+extern "C" int32_t eavsr_conv3x3_wino4_tiles(int32_t h, int32_t w) { return eavsr::cdiv(h, TOH) * eavsr::cdiv(w, TOW); }
+
+extern "C" int eavsr_conv3x3_wino4_f32(const eavsr_conv2d_desc* d, const float* weight_wino4, void* stream) {
+  EAVSR_REQUIRE(d != nullptr && weight_wino4 != nullptr, -1, "conv3x3_wino4: NULL descriptor / weights");
+  EAVSR_REQUIRE(d->n_src >= 1 && d->n_src <= 5, -1, "conv3x3_wino4: n_src %d not in 1..5", d->n_src);
+  EAVSR_REQUIRE(d->ksize == 3, -2, "conv3x3_wino4: kernel size %d (3 only)", d->ksize);
+  EAVSR_REQUIRE(d->out, -1, "conv3x3_wino4: NULL out");
+  EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv3x3_wino4: bad dims");
+  EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv3x3_wino4: act %d", d->act);
+  EAVSR_REQUIRE(d->ca_scale == nullptr && d->ca_x == nullptr && d->ca_out == nullptr, -2,
+                "conv3x3_wino4: no fused channel-attention prologue (use eavsr_conv3x3_wino_f32)");
+  EAVSR_REQUIRE(d->w % 4 == 0, -2, "conv3x3_wino4: w %% 4 != 0 (use eavsr_conv2d_f32)");
+  EAVSR_REQUIRE((((uintptr_t)d->out) & 15) == 0 && (d->residual == nullptr || (((uintptr_t)d->residual) & 15) == 0), -2,
+                "conv3x3_wino4: out / residual must be 16-byte aligned");
+  W4Args a;
+  int csum = 0;
+  for (int s = 0; s < 5; ++s) {
+    a.src[s] = s < d->n_src ? d->src[s] : nullptr;
+    a.src_c[s] = s < d->n_src ? d->src_c[s] : 0;
+    if (s < d->n_src) {
+      EAVSR_REQUIRE(d->src[s] != nullptr && d->src_c[s] > 0 && d->src_c[s] % CK == 0 && (((uintptr_t)d->src[s]) & 15) == 0, -2,
+                    "conv3x3_wino4: source %d must be 16-byte aligned with a multiple of 4 channels", s);
+      csum += d->src_c[s];
+    }
+  }
+  EAVSR_REQUIRE(csum == d->cin, -1, "conv3x3_wino4: sources sum to %d channels, cin = %d", csum, d->cin);
+  if (d->n == 0) return 0;
+  a.n_src = d->n_src;
+  a.wu = weight_wino4;
+  a.bias = d->bias; a.residual = d->residual; a.out = d->out; a.chan_partial = d->chan_partial;
+  a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
+  a.tiles_x = eavsr::cdiv(d->w, TOW);
+  a.tiles_y = eavsr::cdiv(d->h, TOH);
+  a.act = d->act; a.slope = d->slope;
+  const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
+  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_wino4: too many tiles");
+  EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv3x3_wino4: image plane too large for 32-bit tile offsets");
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("conv3x3_wino4: hipFuncSetAttribute(%zu B of LDS): %s", LDS_BYTES, hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  // persistent workgroups: one per CU, each walking blocks / grid.x tiles
+  const long per_cot = blocks < 256 ? blocks : 256;
+  dim3 grid((unsigned)per_cot, eavsr::cdiv(d->cout, 64));
+  hipLaunchKernelGGL(conv3x3_wino4_kernel, grid, dim3(64 * NW), LDS_BYTES, eavsr::as_stream(stream), a);
+  return eavsr::launch_status("conv3x3_wino4");
+}

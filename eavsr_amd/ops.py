@@ -273,7 +273,7 @@ def _conv3x3_smallco(x: Tensor, weights, biases, act, slope, residual):
 # dense conv  (nn.Conv2d, stride 1, "same" padding)
 # ------------------------------------------------------------------------------------------
 def _wino_fusable(x: Tensor) -> bool:
-    return (CONV_MODE == "winograd" and x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[1] % 8 == 0 and x.shape[1] <= 256
+    return (CONV_MODE in ("winograd", "winograd4") and x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[1] % 8 == 0 and x.shape[1] <= 256
             and x.is_contiguous() and x.data_ptr() % 16 == 0
             and int(x.shape[0]) * lib().eavsr_conv3x3_wino_tiles(int(x.shape[2]), int(x.shape[3])) >= WINO_MIN_TILES)
 
@@ -324,11 +324,17 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
     base_ok = (k == 3 and w % 4 == 0 and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs))
     x9_ok = base_ok and ca is None
-    use_wino = (CONV_MODE == "winograd" and base_ok and n * lib().eavsr_conv3x3_wino_tiles(h, w) >= WINO_MIN_TILES
+    use_wino = (CONV_MODE in ("winograd", "winograd4") and base_ok
+                and n * lib().eavsr_conv3x3_wino_tiles(h, w) >= WINO_MIN_TILES
                 and (ca is None or (len(srcs) == 1 and cin <= 256 and ca[1].data_ptr() % 16 == 0)))
+    # F(4x4, 3x3): same 512-pixel-per-workgroup granularity (8 x 64), no fused channel-attention prologue
+    use_wino4 = (use_wino and CONV_MODE == "winograd4" and ca is None and out.data_ptr() % 16 == 0
+                 and (residual is None or residual.data_ptr() % 16 == 0)
+                 and 2 * n * lib().eavsr_conv3x3_wino4_tiles(h, w) >= WINO_MIN_TILES)
     part = None
     if chan_partial:
-        tiles = lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino else lib().eavsr_conv2d_tiles(n, h, w, k)
+        tiles = (lib().eavsr_conv3x3_wino4_tiles(h, w) if use_wino4 else lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino
+                 else lib().eavsr_conv2d_tiles(n, h, w, k))
         part = torch.empty((n, tiles, cout), device=out.device, dtype=torch.float32)
     if residual is not None:
         residual = _chk(residual, "residual")
@@ -364,6 +370,12 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError("ca_out needs ca")
     st = _stream(out)
     px = float(n) * h * w
+    if use_wino4:
+        wu = _packed_wino(weights, four=True)
+        _launch(f"conv3x3_{cin}to{cout}_wino4", 2.0 * cin * cout * 9 * px,
+                4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+                lambda: lib().eavsr_conv3x3_wino4_f32(C.byref(d), _p(wu), st), "conv3x3_wino4")
+        return out if not chan_partial else (out, part)
     if use_wino:
         wu = _packed_wino(weights)
         _launch(f"conv3x3_{cin}to{cout}_wino" + ("_ca" if ca is not None else ""), 2.0 * cin * cout * 9 * px,
@@ -500,21 +512,24 @@ def _packed_dcn_x9(weight: Tensor) -> Tensor:
 
 
 # How the large 3x3 convolutions are computed (all fp32 in, fp32 out, fp32 accumulation):
-#   "winograd" (default) = Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32 (eavsr_conv3x3_wino_f32): 2.25x fewer
+#   "winograd" = Winograd F(2x2, 3x3) on v_mfma_f32_16x16x4_f32 (eavsr_conv3x3_wino_f32): 2.25x fewer
 #                multiplications, what cuDNN / MIOpen run for fp32 3x3 convolutions; measured closer to fp64 than the
 #                direct sum (tests/test_hip_ops.py)
+#   "winograd4" (default) = Winograd F(4x4, 3x3) (eavsr_conv3x3_wino4_f32): 4x fewer multiplications, ~1e-5 relative
+#                error per convolution instead of 4e-7 (end to end on the bench clip: 2.4e-7 against 1.8e-7, the path's
+#                bound is 1e-3); falls back to F(2x2, 3x3) for the fused channel-attention prologue
 #   "direct"   = direct sum on v_mfma_f32_32x32x2_f32 (eavsr_conv2d_f32) -- also what every shape the Winograd kernel
 #                does not cover runs (small images, widths not a multiple of 4, channels not a multiple of 8, 1x1/5x5/7x7)
 #   "bf16x9"   = direct sum with an exact three-way bf16 split of both operands, nine partial products in fp32
 #                (eavsr_conv3x3_f32x9), opt-in
 def _norm_conv_mode(mode: str) -> str:
     mode = {"native": "direct"}.get(mode, mode)
-    if mode not in ("direct", "winograd", "bf16x9"):
-        raise ValueError(f"conv mode {mode!r}: 'winograd', 'direct' or 'bf16x9'")
+    if mode not in ("direct", "winograd", "winograd4", "bf16x9"):
+        raise ValueError(f"conv mode {mode!r}: 'winograd', 'winograd4', 'direct' or 'bf16x9'")
     return mode
 
 
-CONV_MODE = _norm_conv_mode(os.environ.get("EAVSR_CONV_MODE", "winograd"))
+CONV_MODE = _norm_conv_mode(os.environ.get("EAVSR_CONV_MODE", "winograd4"))
 WINO_MIN_TILES = int(os.environ.get("EAVSR_WINO_MIN_TILES", "192"))   # 8 x 32-px tiles per launch below which the direct kernel runs
 
 
@@ -526,23 +541,25 @@ def set_conv_mode(mode: str) -> None:
 _wino_pack_cache = {}
 
 
-def _packed_wino(weights: Sequence[Tensor]) -> Tensor:
-    """G g G^T of a 3x3 weight (or of several stacked along cout); cached per weight objects and versions."""
-    key = tuple((id(w), w._version) for w in weights)
+def _packed_wino(weights: Sequence[Tensor], four: bool = False) -> Tensor:
+    """G g G^T of a 3x3 weight (or of several stacked along cout) for F(2x2, 3x3) or (`four`) F(4x4, 3x3); cached per
+    weight objects and versions."""
+    key = tuple((id(w), w._version) for w in weights) + (("f4", 0),) * bool(four)
     hit = _wino_pack_cache.get(key)
     if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
         return hit[1]
     w = weights[0] if len(weights) == 1 else torch.cat([x.detach() for x in weights], 0)
     w = _chk(w.detach(), "weight")
     cout, cin = int(w.shape[0]), int(w.shape[1])
-    elems = lib().eavsr_wino_weight_elems(cout, cin)
+    elems = (lib().eavsr_wino4_weight_elems if four else lib().eavsr_wino_weight_elems)(cout, cin)
     if elems <= 0 or tuple(w.shape[2:]) != (3, 3):
         raise NotImplementedError(f"winograd weight shape {tuple(w.shape)} unsupported")
     packed = torch.empty(elems, device=w.device, dtype=torch.float32)
     with _DeviceOf(w):
-        N.check(lib().eavsr_pack_conv_weight_wino(_p(w), _p(packed), cout, cin, _stream(w)), "pack_conv_weight_wino")
+        fn = lib().eavsr_pack_conv_weight_wino4 if four else lib().eavsr_pack_conv_weight_wino
+        N.check(fn(_p(w), _p(packed), cout, cin, _stream(w)), "pack_conv_weight_wino")
     ids = {id(x) for x in weights}
-    for k in [k for k in _wino_pack_cache if any(i in ids for i, _ in k)]:
+    for k in [k for k in _wino_pack_cache if (k[-1] == ("f4", 0)) == bool(four) and any(i in ids for i, _ in k)]:
         _wino_pack_cache.pop(k, None)
     refs = tuple(weakref.ref(x, lambda _r, k=key: _wino_pack_cache.pop(k, None)) for x in weights)
     _wino_pack_cache[key] = (refs, packed)

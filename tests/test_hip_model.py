@@ -11,7 +11,7 @@ from tests.golden import cases
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_CONV_MODE = "winograd"   # eavsr_amd.ops.CONV_MODE's default; tests that switch modes restore it
+DEFAULT_CONV_MODE = "winograd4"   # eavsr_amd.ops.CONV_MODE's default; tests that switch modes restore it
 
 OPT = Namespace(predict=False, n_frame=7, n_flow=5, scale=4)
 
@@ -183,9 +183,11 @@ def test_forward_with_bf16x9_contractions_equals_the_native_forward(nets, cuda):
     assert O.psnr_255(got.cpu(), ref.cpu()) > 100.0
 
 
-def test_forward_with_winograd_convolutions_equals_the_direct_forward(nets, cuda):
-    """Winograd F(2x2, 3x3) is fp32 arithmetic with a different summation order: at the BASELINE size, where the kernel
-    engages, the whole forward agrees with the direct-convolution forward far inside the 1e-3 parity tolerance."""
+@pytest.mark.parametrize("mode,kernel", [("winograd", "conv3x3_64to64_wino"), ("winograd4", "conv3x3_64to64_wino4")])
+def test_forward_with_winograd_convolutions_equals_the_direct_forward(nets, cuda, mode, kernel):
+    """Winograd F(2x2, 3x3) / F(4x4, 3x3) are fp32 arithmetic with a different summation order: at the BASELINE size,
+    where the kernels engage, the whole forward agrees with the direct-convolution forward far inside the 1e-3 parity
+    tolerance."""
     from eavsr_amd import ops
     from eavsr_amd.utils.synthetic import synthetic_clip
     net, _ = _model(nets, cuda, "x4", "trained_like")
@@ -193,14 +195,14 @@ def test_forward_with_winograd_convolutions_equals_the_direct_forward(nets, cuda
     with torch.no_grad():
         ops.set_conv_mode("direct")
         ref = net(clips)
-        ops.set_conv_mode("winograd")
+        ops.set_conv_mode(mode)
         try:
             with ops.profile() as prof:
                 got = net(clips)
             names = set(prof.summary())
         finally:
             ops.set_conv_mode(DEFAULT_CONV_MODE)
-    assert "conv3x3_64to64_wino" in names and "conv3x3_64to64" not in names
+    assert kernel in names and "conv3x3_64to64" not in names
     diff = H.maxabs(got.cpu(), ref.cpu())
     assert diff <= 2e-5, diff
     assert O.psnr_255(got.cpu(), ref.cpu()) > 100.0

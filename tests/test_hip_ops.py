@@ -10,7 +10,7 @@ from tests.golden import cases
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_CONV_MODE = "winograd"   # eavsr_amd.ops.CONV_MODE's default; tests that switch modes restore it
+DEFAULT_CONV_MODE = "winograd4"   # eavsr_amd.ops.CONV_MODE's default; tests that switch modes restore it
 
 
 @pytest.fixture(scope="module")
@@ -360,6 +360,71 @@ def test_conv3x3_winograd_error_against_fp64(ops, cuda):
         ops.set_conv_mode(DEFAULT_CONV_MODE)
     print("relative max error vs fp64: direct", e_native, "winograd", e_wino)
     assert e_native < 3e-6 and e_wino < 6e-6, (e_native, e_wino)
+
+
+# ---- 3x3 conv by Winograd F(4x4, 3x3): same descriptor / tensors / epilogue, 8 x 64-pixel tiles -------------------
+@pytest.fixture()
+def conv_wino4(ops):
+    ops.set_conv_mode("winograd4")
+    yield ops
+    ops.set_conv_mode(DEFAULT_CONV_MODE)
+
+
+@pytest.mark.parametrize("case", [([64], 64, "relu", True, True, 10, 133, 156), ([64, 64], 64, "lrelu", True, False, 10, 133, 156),
+                                  ([64], 256, None, False, False, 4, 100, 128), ([64, 64, 64, 64, 64], 64, "lrelu", False, False, 3, 180, 320),
+                                  ([8], 40, None, False, True, 13, 65, 68), ([128], 64, "relu", False, True, 1, 400, 320),
+                                  ([64], 64, None, True, True, 4, 180, 320), ([4, 12], 7, "relu", False, False, 9, 37, 200)],
+                         ids=lambda c: f"c{'+'.join(map(str, c[0]))}_o{c[1]}_{c[5]}x{c[6]}x{c[7]}")
+def test_conv3x3_winograd4_vs_torch_cpu(conv_wino4, cuda, case):
+    chans, cout, act, use_res, use_part, n, h, w = case
+    cin = sum(chans)
+    srcs = [cases.randn(10 + i, n, c, h, w) for i, c in enumerate(chans)]
+    wt = cases.randn(20, cout, cin, 3, 3, scale=1.0 / (cin * 9) ** 0.5)
+    b = cases.randn(21, cout, scale=0.1)
+    res = cases.randn(22, n, cout, h, w) if use_res else None
+    ref = F.conv2d(torch.cat(srcs, 1), wt, b, 1, 1)
+    ref = F.relu(ref) if act == "relu" else (F.leaky_relu(ref, 0.1) if act == "lrelu" else ref)
+    pre = ref
+    if use_res:
+        ref = ref + res
+    with conv_wino4.profile() as prof:
+        out = conv_wino4.conv2d([g(s_, cuda) for s_ in srcs], g(wt, cuda), g(b, cuda), act=act, slope=0.1,
+                                residual=None if res is None else g(res, cuda), chan_partial=use_part)
+    assert list(prof.summary()) == [f"conv3x3_{cin}to{cout}_wino4"]
+    if use_part:
+        out, part = out
+        assert part.shape[1] == conv_wino4.lib().eavsr_conv3x3_wino4_tiles(h, w)
+        sums = pre.sum(dim=(2, 3))
+        assert H.maxabs(part.sum(dim=1).cpu(), sums) <= 1e-5 * sums.abs().max().item() + 5e-3
+    assert H.maxabs(out.cpu(), ref) <= 6e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_winograd4_error_against_fp64_and_fallbacks(ops, cuda):
+    """F(4x4, 3x3) in fp32: ~1e-5 of the output scale (the 6 x 6 transforms amplify rounding), the documented price of
+    4x fewer multiplications; the fused channel-attention prologue and small problems fall back to F(2x2, 3x3) / direct."""
+    n, h, w = 10, 133, 156
+    x = cases.randn(1, n, 64, h, w) * 2.0 + 0.7
+    wt = cases.randn(2, 64, 64, 3, 3, scale=0.05)
+    ref64 = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    scale = ref64.abs().max().item()
+    ops.set_conv_mode("winograd4")
+    try:
+        e4 = (ops.conv2d(g(x, cuda), g(wt, cuda), None).cpu().double() - ref64).abs().max().item() / scale
+        print("relative max error vs fp64: winograd4", e4)
+        assert e4 < 3e-5, e4
+        with ops.profile() as prof:
+            xs, wsm = cases.randn(3, 1, 64, 20, 32), cases.randn(4, 64, 64, 3, 3, scale=0.05)
+            small = ops.conv2d(g(xs, cuda), g(wsm, cuda), None)
+        assert list(prof.summary()) == ["conv3x3_64to64"]
+        assert H.maxabs(small.cpu(), F.conv2d(xs, wsm, None, 1, 1)) <= 2e-5
+        r, xx, sc = cases.randn(5, n, 64, h, w), cases.randn(6, n, 64, h, w), cases.rand(7, n, 64)
+        with ops.profile() as prof:
+            out = ops.conv2d(g(r, cuda), g(wt, cuda), None, ca=(g(sc, cuda), g(xx, cuda)))
+        assert list(prof.summary()) == ["conv3x3_64to64_wino_ca"]
+        ref = F.conv2d(r * sc.view(n, 64, 1, 1) + xx, wt, None, 1, 1)
+        assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+    finally:
+        ops.set_conv_mode(DEFAULT_CONV_MODE)
 
 
 # ---- 3x3 conv, bf16x9 contraction (opt-in): same descriptor / tensors / epilogue as the native kernel -------------

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Diagnostic libraries eavsr_amd/lib/libwino4_*.so: conv_wino4.hip + capi.hip with -DEAVSR_WINO_EXP_* (timing ablations,
+# results wrong).  Built here (hipcc cross-compiles), they travel to the GPU box with the snapshot.
+set -e
+cd "$(dirname "$0")/.."
+F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -Iinclude -Ieavsr_amd/csrc -shared"
+rm -f eavsr_amd/lib/libwino4_*.so
+for v in base:"" nodma:-DEAVSR_WINO_EXP_NODMA notransform:-DEAVSR_WINO_EXP_NOTRANSFORM nomfma:-DEAVSR_WINO_EXP_NOMFMA \
+         nodma_notransform:"-DEAVSR_WINO_EXP_NODMA -DEAVSR_WINO_EXP_NOTRANSFORM"; do
+  name=${v%%:*}; flags=${v#*:}
+  /opt/rocm/bin/hipcc $F $flags eavsr_amd/csrc/conv_wino4.hip eavsr_amd/csrc/capi.hip -o eavsr_amd/lib/libwino4_$name.so 2>/dev/null
+done
+ls eavsr_amd/lib/libwino4_*.so
