@@ -18,10 +18,10 @@
 //   per chunk of 4 input channels (= one k-step; two LDS stages each for the patch, U and V; one barrier per chunk):
 //     LDS-DMA: the (4 x 10 x 72) fp32 input patch (lanes outside the image copy zeros) and the pre-transformed weight
 //              slab U[36][4][64] (eavsr_pack_conv_weight_wino4)
-//     input transform, inside one wave: lane (p, l15), p < 3, does the column pass B^T d for columns 2p, 2p+1 of tile
-//              l15 (packed fp32 pairs), stores it at V's own locations, then the row pass for rows 2p, 2p+1 in place
-//     GEMM: 36 x (2 ds_read_b32 + 1 MFMA); U columns carry the XOR swizzle (co ^ 16 (c & 1)), V rows a pitch of 136
-//           floats per position, so that neither the operand reads nor the transform's accesses conflict
+//     input transform: the 128 (channel, tile) jobs of a chunk are the lanes of two waves; the pair on duty rotates with
+//              the chunk; both passes (packed fp32 pairs) stay in registers
+//     GEMM: 18 x (2 ds_read_b64 + 2 MFMA): U and V keep the positions in pairs, columns XOR-swizzled (^ 16 (c & 1)), so
+//           that the operand reads run at the 256 B/clk of ds_read_b64 without bank conflicts
 //   epilogue in registers: output transform, + bias, activation, + residual, float4 row stores (one 256-byte line per
 //   16 lanes), optional per-tile channel sums (deterministic).
 #include "common.h"
@@ -40,7 +40,7 @@ struct W4Args {
   const float* src[5];
   int src_c[5];
   int n_src;
-  const float* wu;        // [cot][cin / 4][36][4][64]
+  const float* wu;        // [cot][cin / 4][18][4][64][2]
   const float* bias;
   const float* residual;
   float* out;
@@ -61,8 +61,7 @@ constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;        // 2
 constexpr int U_ELEMS = NPOS * CK * 64;               // 9216 floats = 36 KB: one 1-KiB piece per position
 constexpr int U_SEGS = U_ELEMS / 256;                 // 36
 constexpr int U_IT = (U_SEGS + NW - 1) / NW;          // 5
-constexpr int VP = CK * 32 + 8;                       // V pitch per position: 4 channels x 32 tiles + 8 (bank skew)
-constexpr int V_ELEMS = NPOS * VP;                    // 4896
+constexpr int V_ELEMS = NPOS * CK * 32;               // 4608 floats = 18 KB
 constexpr int OFF_U = 2 * IN_PAD;                     // LDS map: [patch 0][patch 1][U 0][U 1][V 0][V 1][channel sums]
 constexpr int OFF_V = OFF_U + 2 * U_ELEMS;
 constexpr int LDS_MAIN = OFF_V + 2 * V_ELEMS;         // 134.3 KB
@@ -160,12 +159,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
   int bn = 0, y0 = 0, x0 = 0, tile_lin = 0;
   tile_coords(0, bn, y0, x0, tile_lin);
 
+  // The source table is read from the kernel arguments ONCE, into scalar registers, and indexed by select chains (no
+  // scalar loads inside the loop: they share the lgkmcnt counter with the LDS reads and return out of order).
+  const float* const sp0 = a.src[0]; const float* const sp1 = a.src[1]; const float* const sp2 = a.src[2];
+  const float* const sp3 = a.src[3]; const float* const sp4 = a.src[4];
+  const int sc0 = a.src_c[0], sc1 = a.src_c[1], sc2 = a.src_c[2], sc3 = a.src_c[3], sc4 = a.src_c[4];
+  auto src_of = [&](int i) __attribute__((always_inline)) { return i == 0 ? sp0 : i == 1 ? sp1 : i == 2 ? sp2 : i == 3 ? sp3 : sp4; };
+  auto src_c_of = [&](int i) __attribute__((always_inline)) { return i == 0 ? sc0 : i == 1 ? sc1 : i == 2 ? sc2 : i == 3 ? sc3 : sc4; };
+  const char* zero_src = reinterpret_cast<const char*>(g_wino4_zero);   // its address comes from a scalar load too:
+  asm volatile("" : "+s"(zero_src));                                     // taken once, not rematerialised in the loop
+  const float* const wu_base = a.wu + (size_t)cot * (a.cin / CK) * U_ELEMS;
+  const int n_src = a.n_src;
   // the patch of the NEXT chunk of the prefetch stream -> patch stage; every piece is always issued (zeros outside)
   auto issue_patch = [&](int stage) {
     float* s_in = smem + stage * IN_PAD;
-    const int sc = a.src_c[p_cs];
-    const char* sp = reinterpret_cast<const char*>(a.src[p_cs] + ((size_t)p_bn * sc + p_cc0) * plane);
-    const char* zp = reinterpret_cast<const char*>(g_wino4_zero);
+    const int sc = src_c_of(p_cs);
+    const char* sp = reinterpret_cast<const char*>(src_of(p_cs) + ((size_t)p_bn * sc + p_cc0) * plane);
+    const char* zp = zero_src;
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int seg = i * NW + wave;
@@ -175,10 +185,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
       }
     }
     p_cc0 += CK;
-    if (p_cc0 >= a.src_c[p_cs]) {
+    if (p_cc0 >= sc) {
       ++p_cs;
       p_cc0 = 0;
-      if (p_cs >= a.n_src) {
+      if (p_cs >= n_src) {
         p_cs = 0;
         ++p_k;
         if (p_k < my_tiles) p_setup_tile();
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
   auto issue_u = [&](int g, int stage) {
     float* s_u = smem + OFF_U + stage * U_ELEMS;
     // wave-uniform piece base + one per-lane offset (a per-piece vector offset costs two registers per piece)
-    const char* usrc = reinterpret_cast<const char*>(a.wu + ((size_t)cot * (a.cin / CK) + (size_t)g) * U_ELEMS) + wave * 1024;
+    const char* usrc = reinterpret_cast<const char*>(wu_base + (size_t)g * U_ELEMS) + wave * 1024;
 #pragma unroll
     for (int i = 0; i < U_IT; ++i) {
       const int seg = i * NW + wave;
@@ -197,39 +207,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
     }
   };
 
-  // input-transform job of this lane: channel tc = wave >> 1 of the chunk, tile (row wave & 1, column l15), part kq
-  const int tc = wave >> 1;
-  const int poff = tc * (IH * IW) + (4 * tg) * IW + (MARG - 1) + 4 * l15 + 2 * kq;   // column 2 kq of its 6 x 6 patch
-  const int voff_t = tc * 32 + tg * 16 + l15;                                         // + xi * VP
-
+  // Input transform of one chunk: 4 channels x 32 tiles = 128 jobs = the lanes of TWO waves (lane (kq, l15) of wave
+  // 2d + u: channel kq, tile (row u, column l15)); the wave pair on duty rotates with the chunk.  Both passes stay in
+  // registers - one LDS round trip - and the partner wave of each duty wave's SIMD has the matrix pipe to itself
+  // meanwhile.  (A version that split every job over three lanes of all eight waves, second pass in place through
+  // LDS, was 8 % slower: twice the LDS traffic, two dependent round trips in every wave.)
   auto transform = [&](int ps, int vs) __attribute__((always_inline)) {
 #ifndef EAVSR_WINO_EXP_NOTRANSFORM   // timing ablations only: results are wrong
-    if (kq < 3) {
-      const float* pp = smem + ps * IN_PAD + poff;
-      float* vd = s_v + vs * V_ELEMS + voff_t;
-      {   // column pass: t[i][q] = sum_r B^T[i][r] d[r][q] for q = 2 kq, 2 kq + 1
-        f32x2 d[6], t[6];
+    // the 6 x 6 patch of tile column l15 starts at column MARG - 1 + 4 l15 = 3 + 4 l15: one b32, one aligned b128, one b32
+    const float* pp = smem + ps * IN_PAD + kq * (IH * IW) + (4 * tg) * IW + 4 * l15;
+    float* vd = s_v + vs * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));   // + (xi / 2) * 256 + (xi & 1)
+    f32x2 t12[6], t34[6], t05[6];   // column pass B^T d, two columns per packed operation
+    {
+      f32x4 q[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW], pp[r * IW + 1]};
-        in1d(d, t);
+      for (int r = 0; r < 6; ++r) q[r] = *reinterpret_cast<const f32x4*>(pp + r * IW + 4);
+      f32x2 d[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          vd[(i * 6 + 2 * kq) * VP] = t[i].x;
-          vd[(i * 6 + 2 * kq + 1) * VP] = t[i].y;
-        }
-      }
-      asm volatile("" ::: "memory");   // same wave: the LDS executes its accesses in order
-      {   // row pass, in place: V[i][j] = sum_q t[i][q] B[q][j] for i = 2 kq, 2 kq + 1
-        f32x2 d[6], t[6];
+      for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][0], q[r][1]};
+      in1d(d, t12);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) d[q] = f32x2{vd[((2 * kq) * 6 + q) * VP], vd[((2 * kq + 1) * 6 + q) * VP]};
-        in1d(d, t);
+      for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][2], q[r][3]};
+      in1d(d, t34);
+    }
+    {
+      f32x2 d[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          vd[((2 * kq) * 6 + j) * VP] = t[j].x;
-          vd[((2 * kq + 1) * 6 + j) * VP] = t[j].y;
-        }
-      }
+      for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW + 3], pp[r * IW + 8]};
+      in1d(d, t05);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {   // row pass (.) B; positions are stored in pairs
+      const float d[6] = {t05[i].x, t12[i].x, t12[i].y, t34[i].x, t34[i].y, t05[i].y};
+      float o[6];
+      in1d(d, o);
+#pragma unroll
+      for (int j = 0; j < 6; j += 2) *reinterpret_cast<f32x2*>(vd + (i * 3 + j / 2) * (CK * 64)) = f32x2{o[j], o[j + 1]};
     }
 #endif
   };
@@ -241,13 +254,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
   if (total_iters > 1) issue_patch(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  transform(0, 0);
+  if ((wave >> 1) == 3) transform(0, 0);   // the pair on duty "before iteration 0"
   int chunk = 0;   // chunk of iteration `it` within its tile
   for (int it = 0; it < total_iters; ++it) {
     // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of iteration it-1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int chunk_n = chunk + 1 == total_chunks ? 0 : chunk + 1;
+    const bool on_duty = (wave >> 1) == (it & 3);
     auto issue_dma = [&]() __attribute__((always_inline)) {
 #ifndef EAVSR_WINO_EXP_NODMA
       if (it + 1 < total_iters) issue_u(chunk_n, (it + 1) & 1);
@@ -255,42 +269,48 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
 #endif
     };
     // the two waves of a SIMD (w and w + 4) issue their DMA pieces at different points of the iteration
-    // ... and the input transform of the next chunk (two dependent LDS round trips, little arithmetic) runs before the
-    // GEMM in one wave of the pair and after it in the other, under the partner's MFMAs
     const bool dma_late = wave >= 4;
-    if (!dma_late) {
-      issue_dma();
-      if (it + 1 < total_iters) transform((it + 1) & 1, (it + 1) & 1);
-    }
+    if (!dma_late) issue_dma();
+    // the pair on duty transforms the next chunk before its GEMM steps
+    if (on_duty && it + 1 < total_iters) transform((it + 1) & 1, (it + 1) & 1);
     // ---- the 36 GEMM steps of this wave: M_xi[co, t] += sum over the chunk's 4 channels U_xi[co, c] V_xi[c, t]
-    const float* ua = smem + OFF_U + (it & 1) * U_ELEMS + kq * 64 + ((cb * 16 + l15) ^ ((kq & 1) << 4));
-    const float* vb = s_v + (it & 1) * V_ELEMS + kq * 32 + tg * 16 + l15;
-    constexpr int AHEAD = 4;
-    float av[AHEAD + 1], bv[AHEAD + 1];
+    // U and V hold the positions in PAIRS ([xi / 2][c][column][xi & 1], column ^ 16 (c & 1)): one ds_read_b64 per operand
+    // and two positions - ds_read_b64 moves 256 B/clk against 128 for ds_read_b32 (whose 32 banks would also put the two
+    // k-rows of a half-wave on the same banks), and the swizzle keeps those two rows on disjoint banks
+    const float* ua = smem + OFF_U + (it & 1) * U_ELEMS + kq * 128 + 2 * ((cb * 16 + l15) ^ ((kq & 1) << 4));
+    const float* vb = s_v + (it & 1) * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));
+#ifndef EAVSR_W4_AHEAD
+#define EAVSR_W4_AHEAD 3
+#endif
+    constexpr int AHEAD = EAVSR_W4_AHEAD, NSTEP = NPOS / 2;
+    f32x2 av[AHEAD + 1], bv[AHEAD + 1];
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i) { av[i] = ua[i * (CK * 64)]; bv[i] = vb[i * VP]; }
+    for (int i = 0; i < AHEAD; ++i) {
+      av[i] = *reinterpret_cast<const f32x2*>(ua + i * (CK * 128));
+      bv[i] = *reinterpret_cast<const f32x2*>(vb + i * (CK * 64));
+    }
 #ifndef EAVSR_WINO_EXP_NOMFMA
 #pragma unroll
-    for (int i = 0; i < NPOS; ++i) {
-      if (i == NPOS / 2) {
+    for (int i = 0; i < NSTEP; ++i) {
+      if (i == NSTEP / 2) {
         __builtin_amdgcn_sched_barrier(0);
         if (dma_late) issue_dma();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i + AHEAD < NPOS) {
-        av[(i + AHEAD) % (AHEAD + 1)] = ua[(i + AHEAD) * (CK * 64)];
-        bv[(i + AHEAD) % (AHEAD + 1)] = vb[(i + AHEAD) * VP];
+      if (i + AHEAD < NSTEP) {
+        av[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(ua + (i + AHEAD) * (CK * 128));
+        bv[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(vb + (i + AHEAD) * (CK * 64));
       }
       const int cur = i % (AHEAD + 1);
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur], bv[cur], acc[i], 0, 0, 0);
+      acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur].x, bv[cur].x, acc[2 * i], 0, 0, 0);
+      acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur].y, bv[cur].y, acc[2 * i + 1], 0, 0, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of step i + AHEAD
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // the MFMA of step i
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // the 2 MFMAs of step i
     }
 #else
     if (dma_late) issue_dma();
-    acc[0][0] += av[0] + bv[0];
+    acc[0][0] += av[0].x + bv[0].x;
 #endif
-    if (dma_late && it + 1 < total_iters) transform((it + 1) & 1, (it + 1) & 1);
     chunk = chunk_n;
     if (chunk != 0) continue;   // the tile is not finished yet
 
@@ -375,15 +395,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
   }   // flattened (tile, chunk) loop
 }
 
-// weight (cout, cin, 3, 3) -> U = G g G^T laid out [cot][cin / 4][xi][c][co ^ 16 (c & 1)] (zero for co >= cout);
+// weight (cout, cin, 3, 3) -> U = G g G^T laid out [cot][cin / 4][xi / 2][c][co ^ 16 (c & 1)][xi & 1] (zero for co >= cout);
 // evaluated in double and rounded once
 __global__ void pack_wino4_kernel(const float* __restrict__ wt, float* __restrict__ out, int cout, int cin, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
-  const int col = (int)(e & 63);
-  long u = e >> 6;
+  // destination index: [cot][chunk][xi / 2][c][column][xi & 1]
+  const int lo = (int)(e & 1);
+  const int colsw = (int)((e >> 1) & 63);
+  long u = e >> 7;
   const int c = (int)(u % CK); u /= CK;
-  const int xi = (int)(u % NPOS); u /= NPOS;
+  const int xi = 2 * (int)(u % (NPOS / 2)) + lo; u /= NPOS / 2;
+  const int col = colsw ^ ((c & 1) << 4);
   const int nchunks = cin / CK;
   const int chunk = (int)(u % nchunks);
   const int cot = (int)(u / nchunks);
@@ -405,7 +428,7 @@ __global__ void pack_wino4_kernel(const float* __restrict__ wt, float* __restric
       for (int j = 0; j < 3; ++j) s += G[r][i] * (double)g[i * 3 + j] * G[q][j];
     v = (float)s;
   }
-  out[e - col + (col ^ ((c & 1) << 4))] = v;
+  out[e] = v;
 }
 
 }  // namespace
