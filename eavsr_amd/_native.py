@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -65,6 +65,9 @@ SIGNATURES = {
     "eavsr_pack_conv_weight_wino4": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_conv3x3_wino4_tiles": (i32, [i32, i32]),
     "eavsr_conv3x3_wino4_f32": (C.c_int, [vp, vp, vp]),
+    "eavsr_pack_conv_weight_wino5x5": (C.c_int, [vp, vp, i32, i32, vp]),
+    "eavsr_conv5x5_wino_tiles": (i32, [i32, i32]),
+    "eavsr_conv5x5_wino_f32": (C.c_int, [vp, vp, vp]),
     "eavsr_conv2d_ck": (i32, [i32]),
     "eavsr_conv2d_tile_rows": (i32, [i32, i32, i32, i32]),
     "eavsr_conv2d_tiles": (i32, [i32, i32, i32, i32]),

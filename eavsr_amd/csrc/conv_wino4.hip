@@ -51,22 +51,31 @@ struct W4Args {
 };
 
 constexpr int CK = 4, NW = 8, NPOS = 36;
-constexpr int TOH = 8, TOW = 64;                      // output tile: 2 x 16 Winograd tiles of 4 x 4
 constexpr int MARG = 4;                               // patch starts 4 columns left of the tile: 16-byte DMA pieces
-constexpr int IH = TOH + 2, IW = TOW + 2 * MARG;      // 10 x 72
-constexpr int IN_ELEMS = CK * IH * IW;                // 2880 floats
-constexpr int IN_SEGS = (IN_ELEMS / 4 + 63) / 64;     // 12 one-KiB pieces (the last one a quarter)
-constexpr int IN_PAD = IN_SEGS * 256;
-constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;        // 2
-constexpr int U_ELEMS = NPOS * CK * 64;               // 9216 floats = 36 KB: one 1-KiB piece per position
+constexpr int U_ELEMS = NPOS * CK * 64;               // 9216 floats = 36 KB: one 1-KiB piece per position pair row
 constexpr int U_SEGS = U_ELEMS / 256;                 // 36
 constexpr int U_IT = (U_SEGS + NW - 1) / NW;          // 5
 constexpr int V_ELEMS = NPOS * CK * 32;               // 4608 floats = 18 KB
-constexpr int OFF_U = 2 * IN_PAD;                     // LDS map: [patch 0][patch 1][U 0][U 1][V 0][V 1][channel sums]
-constexpr int OFF_V = OFF_U + 2 * U_ELEMS;
-constexpr int LDS_MAIN = OFF_V + 2 * V_ELEMS;         // 134.3 KB
-constexpr int LDS_FLOATS = LDS_MAIN + 128;
-constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+
+// R = 3: F(4x4, 3x3), output tile 8 x 64 px.  R = 5: F(2x2, 5x5) - the same 6 x 6 input tiles, points and B^T, 2 x 2
+// outputs per tile (2.78x fewer multiplications than the direct 5x5 sum), output tile 4 x 32 px: the predictor's
+// 5x5 offset / mask heads (networks.py:283-285).
+template <int R>
+struct WCfg {
+  static_assert(R == 3 || R == 5, "F(4x4,3x3) or F(2x2,5x5)");
+  static constexpr int M = 7 - R, PADR = R / 2;          // outputs per tile side, zero padding of the convolution
+  static constexpr int TOH = 2 * M, TOW = 16 * M;         // output tile: 2 x 16 Winograd tiles
+  static constexpr int IH = TOH + 2 * PADR, IW = TOW + 2 * MARG;   // 10 x 72 | 8 x 40
+  static constexpr int IN_ELEMS = CK * IH * IW;           // 2880 | 1280 floats
+  static constexpr int IN_SEGS = (IN_ELEMS / 4 + 63) / 64;   // 12 | 5 one-KiB pieces
+  static constexpr int IN_PAD = IN_SEGS * 256;
+  static constexpr int IN_IT = (IN_SEGS + NW - 1) / NW;   // 2 | 1
+  static constexpr int OFF_U = 2 * IN_PAD;                // LDS map: [patch 0][patch 1][U 0][U 1][V 0][V 1][channel sums]
+  static constexpr int OFF_V = OFF_U + 2 * U_ELEMS;
+  static constexpr int LDS_MAIN = OFF_V + 2 * V_ELEMS;    // 132 KB | 118 KB
+  static constexpr int LDS_FLOATS = LDS_MAIN + 128;
+  static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+};
 
 // t = B^T d for one 6-vector (works on packed pairs: two columns / rows at once)
 template <typename T>
@@ -92,7 +101,12 @@ __device__ __forceinline__ void out1d(const float (&m)[6], float (&s)[4]) {
   s[3] = (p2 + 8.f * p4) + m[5];
 }
 
-__global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
+template <int R>
+__global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
+  using C = WCfg<R>;
+  constexpr int M = C::M, PADR = C::PADR, TOH = C::TOH, TOW = C::TOW, IH = C::IH, IW = C::IW, IN_ELEMS = C::IN_ELEMS;
+  constexpr int IN_SEGS = C::IN_SEGS, IN_PAD = C::IN_PAD, IN_IT = C::IN_IT, OFF_U = C::OFF_U, OFF_V = C::OFF_V;
+  constexpr int LDS_MAIN = C::LDS_MAIN;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_v = smem + OFF_V;
   float* s_red = smem + LDS_MAIN;
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
       const int rem = e4 - ci * (IH * (IW / 4));
       const int r = rem / (IW / 4);
       const int c4 = rem - r * (IW / 4);
-      const int gy = p_y0 - 1 + r, gx = p_x0 - MARG + 4 * c4;
+      const int gy = p_y0 - PADR + r, gx = p_x0 - MARG + 4 * c4;
       const bool ok = e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
       voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
     }
@@ -214,31 +228,49 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
   // LDS, was 8 % slower: twice the LDS traffic, two dependent round trips in every wave.)
   auto transform = [&](int ps, int vs) __attribute__((always_inline)) {
 #ifndef EAVSR_WINO_EXP_NOTRANSFORM   // timing ablations only: results are wrong
-    // the 6 x 6 patch of tile column l15 starts at column MARG - 1 + 4 l15 = 3 + 4 l15: one b32, one aligned b128, one b32
-    const float* pp = smem + ps * IN_PAD + kq * (IH * IW) + (4 * tg) * IW + 4 * l15;
     float* vd = s_v + vs * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));   // + (xi / 2) * 256 + (xi & 1)
     f32x2 t12[6], t34[6], t05[6];   // column pass B^T d, two columns per packed operation
-    {
-      f32x4 q[6];
+    if (R == 3) {
+      // the 6 x 6 patch of tile column l15 starts at column MARG - 1 + 4 l15 = 3 + 4 l15: one b32, one aligned b128, one b32
+      const float* pp = smem + ps * IN_PAD + kq * (IH * IW) + (M * tg) * IW + 4 * l15;
+      {
+        f32x4 q[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) q[r] = *reinterpret_cast<const f32x4*>(pp + r * IW + 4);
+        for (int r = 0; r < 6; ++r) q[r] = *reinterpret_cast<const f32x4*>(pp + r * IW + 4);
+        f32x2 d[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][0], q[r][1]};
+        in1d(d, t12);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][2], q[r][3]};
+        in1d(d, t34);
+      }
+      {
+        f32x2 d[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW + 3], pp[r * IW + 8]};
+        in1d(d, t05);
+      }
+    } else {
+      // 5x5: the patch of tile column l15 starts at column MARG - 2 + 2 l15 (even): three aligned b64 per row.  The
+      // pairs are (c0, c1), (c2, c3), (c4, c5); they are renamed below so that both filter sizes share the row pass.
+      const float* pp = smem + ps * IN_PAD + kq * (IH * IW) + (M * tg) * IW + (MARG - PADR) + 2 * l15;
       f32x2 d[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][0], q[r][1]};
-      in1d(d, t12);
+      for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(pp + r * IW);
+      in1d(d, t05);   // .x = column 0, .y = column 1
 #pragma unroll
-      for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][2], q[r][3]};
-      in1d(d, t34);
-    }
-    {
-      f32x2 d[6];
+      for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(pp + r * IW + 2);
+      in1d(d, t12);   // columns 2, 3
 #pragma unroll
-      for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW + 3], pp[r * IW + 8]};
-      in1d(d, t05);
+      for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(pp + r * IW + 4);
+      in1d(d, t34);   // columns 4, 5
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {   // row pass (.) B; positions are stored in pairs
-      const float d[6] = {t05[i].x, t12[i].x, t12[i].y, t34[i].x, t34[i].y, t05[i].y};
+      const float d3[6] = {t05[i].x, t12[i].x, t12[i].y, t34[i].x, t34[i].y, t05[i].y};
+      const float d5[6] = {t05[i].x, t05[i].y, t12[i].x, t12[i].y, t34[i].x, t34[i].y};
+      const float (&d)[6] = R == 3 ? d3 : d5;
       float o[6];
       in1d(d, o);
 #pragma unroll
@@ -316,54 +348,100 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
 
     // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile (tg, l15)] for every xi ----
     {
-      const int gx = x0 + 4 * l15;   // 16 lanes x float4 = one 256-byte row segment
       float csum[4] = {0.f, 0.f, 0.f, 0.f};
-      // two output rows at a time (the four rows of a channel at once need 40 more registers than there are):
-      // their residual rows are requested first, the column pass A^T m of this half runs under the loads
+      if constexpr (R == 3) {
+        const int gx = x0 + 4 * l15;   // 16 lanes x float4 = one 256-byte row segment
+        // two output rows at a time (the four rows of a channel at once need 40 more registers than there are):
+        // their residual rows are requested first, the column pass A^T m of this half runs under the loads
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = cot * 64 + cb * 16 + 4 * kq + r;
+          const bool cok = co < a.cout;
+          const float bb = bias_r[r];
+  #pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 rr[2];
+  #pragma unroll
+            for (int d2 = 0; d2 < 2; ++d2) {
+              const int gy = y0 + 4 * tg + 2 * hf + d2;
+              rr[d2] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (a.residual != nullptr && cok && gy < h && gx < w)
+                rr[d2] = *reinterpret_cast<const f32x4*>(a.residual + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx);
+            }
+            float s[2][6];
+  #pragma unroll
+            for (int q = 0; q < 6; ++q) {      // rows 2 hf, 2 hf + 1 of A^T m, column q of the 6 x 6 block
+              const float m0 = acc[0 * 6 + q][r], m1 = acc[1 * 6 + q][r], m2 = acc[2 * 6 + q][r], m3 = acc[3 * 6 + q][r],
+                          m4 = acc[4 * 6 + q][r], m5 = acc[5 * 6 + q][r];
+              if (hf == 0) {
+                s[0][q] = m0 + (m1 + m2) + (m3 + m4);
+                s[1][q] = (m1 - m2) + 2.f * (m3 - m4);
+              } else {
+                s[0][q] = (m1 + m2) + 4.f * (m3 + m4);
+                s[1][q] = ((m1 - m2) + 8.f * (m3 - m4)) + m5;
+              }
+            }
+  #pragma unroll
+            for (int d2 = 0; d2 < 2; ++d2) {
+              float y[4];
+              out1d(s[d2], y);
+              const int gy = y0 + 4 * tg + 2 * hf + d2;
+  #pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                y[j] += bb;
+                if (a.act == EAVSR_ACT_RELU) y[j] = fmaxf(y[j], 0.f);
+                else if (a.act == EAVSR_ACT_LRELU) y[j] = y[j] > 0.f ? y[j] : y[j] * a.slope;
+              }
+              if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx % 4 == 0: gx + 3 < w as well
+                csum[r] += (y[0] + y[1]) + (y[2] + y[3]);
+                *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
+                    f32x4{y[0] + rr[d2][0], y[1] + rr[d2][1], y[2] + rr[d2][2], y[3] + rr[d2][3]};
+              }
+            }
+          }
+        }
+      } else {
+        // F(2x2, 5x5): A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 1], two output rows of two pixels per tile
+        const int gx = x0 + 2 * l15;   // 16 lanes x float2 = one 128-byte row segment
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = cot * 64 + cb * 16 + 4 * kq + r;
-        const bool cok = co < a.cout;
-        const float bb = bias_r[r];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        for (int r = 0; r < 4; ++r) {
+          const int co = cot * 64 + cb * 16 + 4 * kq + r;
+          const bool cok = co < a.cout;
+          const float bb = bias_r[r];
           __builtin_amdgcn_sched_barrier(0);
-          f32x4 rr[2];
+          f32x2 rr[2];
 #pragma unroll
-          for (int d2 = 0; d2 < 2; ++d2) {
-            const int gy = y0 + 4 * tg + 2 * hf + d2;
-            rr[d2] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int dy = 0; dy < 2; ++dy) {
+            const int gy = y0 + 2 * tg + dy;
+            rr[dy] = f32x2{0.f, 0.f};
             if (a.residual != nullptr && cok && gy < h && gx < w)
-              rr[d2] = *reinterpret_cast<const f32x4*>(a.residual + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx);
+              rr[dy] = *reinterpret_cast<const f32x2*>(a.residual + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx);
           }
           float s[2][6];
 #pragma unroll
-          for (int q = 0; q < 6; ++q) {      // rows 2 hf, 2 hf + 1 of A^T m, column q of the 6 x 6 block
+          for (int q = 0; q < 6; ++q) {
             const float m0 = acc[0 * 6 + q][r], m1 = acc[1 * 6 + q][r], m2 = acc[2 * 6 + q][r], m3 = acc[3 * 6 + q][r],
                         m4 = acc[4 * 6 + q][r], m5 = acc[5 * 6 + q][r];
-            if (hf == 0) {
-              s[0][q] = m0 + (m1 + m2) + (m3 + m4);
-              s[1][q] = (m1 - m2) + 2.f * (m3 - m4);
-            } else {
-              s[0][q] = (m1 + m2) + 4.f * (m3 + m4);
-              s[1][q] = ((m1 - m2) + 8.f * (m3 - m4)) + m5;
-            }
+            s[0][q] = m0 + (m1 + m2) + (m3 + m4);
+            s[1][q] = ((m1 - m2) + 2.f * (m3 - m4)) + m5;
           }
 #pragma unroll
-          for (int d2 = 0; d2 < 2; ++d2) {
-            float y[4];
-            out1d(s[d2], y);
-            const int gy = y0 + 4 * tg + 2 * hf + d2;
+          for (int dy = 0; dy < 2; ++dy) {
+            float y[2];
+            y[0] = s[dy][0] + (s[dy][1] + s[dy][2]) + (s[dy][3] + s[dy][4]);
+            y[1] = ((s[dy][1] - s[dy][2]) + 2.f * (s[dy][3] - s[dy][4])) + s[dy][5];
+            const int gy = y0 + 2 * tg + dy;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 2; ++j) {
               y[j] += bb;
               if (a.act == EAVSR_ACT_RELU) y[j] = fmaxf(y[j], 0.f);
               else if (a.act == EAVSR_ACT_LRELU) y[j] = y[j] > 0.f ? y[j] : y[j] * a.slope;
             }
-            if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx % 4 == 0: gx + 3 < w as well
-              csum[r] += (y[0] + y[1]) + (y[2] + y[3]);
-              *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
-                  f32x4{y[0] + rr[d2][0], y[1] + rr[d2][1], y[2] + rr[d2][2], y[3] + rr[d2][3]};
+            if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
+              csum[r] += y[0] + y[1];
+              *reinterpret_cast<f32x2*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
+                  f32x2{y[0] + rr[dy].x, y[1] + rr[dy].y};
             }
           }
         }
@@ -395,9 +473,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino4_kernel(W4Args a) {
   }   // flattened (tile, chunk) loop
 }
 
-// weight (cout, cin, 3, 3) -> U = G g G^T laid out [cot][cin / 4][xi / 2][c][co ^ 16 (c & 1)][xi & 1] (zero for co >= cout);
-// evaluated in double and rounded once
-__global__ void pack_wino4_kernel(const float* __restrict__ wt, float* __restrict__ out, int cout, int cin, long total) {
+// weight (cout, cin, R, R) -> U = G g G^T laid out [cot][cin / 4][xi / 2][c][co ^ 16 (c & 1)][xi & 1] (zero for
+// co >= cout); evaluated in double and rounded once.  G[p] = scale_p * (1, p, p^2, ..) for the points 0, 1, -1, 2, -2
+// (scales 1/4, -1/6, -1/6, 1/24, 1/24) and the unit vector of the highest power for the point at infinity.
+template <int R>
+__global__ void pack_wino6_kernel(const float* __restrict__ wt, float* __restrict__ out, int cout, int cin, long total) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   // destination index: [cot][chunk][xi / 2][c][column][xi & 1]
@@ -413,19 +493,22 @@ __global__ void pack_wino4_kernel(const float* __restrict__ wt, float* __restric
   const int co = cot * 64 + col, ci = chunk * CK + c;
   float v = 0.f;
   if (co < cout) {
-    const float* g = wt + ((size_t)co * cin + ci) * 9;
+    const float* g = wt + ((size_t)co * cin + ci) * (R * R);
     const int r = xi / 6, q = xi - 6 * r;
-    const double G[6][3] = {{0.25, 0., 0.},
-                            {-1. / 6, -1. / 6, -1. / 6},
-                            {-1. / 6, 1. / 6, -1. / 6},
-                            {1. / 24, 1. / 12, 1. / 6},
-                            {1. / 24, -1. / 12, 1. / 6},
-                            {0., 0., 1.}};
+    const double pt[5] = {0., 1., -1., 2., -2.}, sc[5] = {0.25, -1. / 6, -1. / 6, 1. / 24, 1. / 24};
+    double Gr[R], Gq[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      double pr = 1., pq = 1.;
+      for (int e2 = 0; e2 < k; ++e2) { pr *= pt[r < 5 ? r : 0]; pq *= pt[q < 5 ? q : 0]; }
+      Gr[k] = r < 5 ? sc[r] * pr : (k == R - 1 ? 1. : 0.);
+      Gq[k] = q < 5 ? sc[q] * pq : (k == R - 1 ? 1. : 0.);
+    }
     double s = 0.;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) s += G[r][i] * (double)g[i * 3 + j] * G[q][j];
+      for (int j = 0; j < R; ++j) s += Gr[i] * (double)g[i * R + j] * Gq[j];
     v = (float)s;
   }
   out[e] = v;
@@ -438,29 +521,33 @@ extern "C" int64_t eavsr_wino4_weight_elems(int32_t cout, int32_t cin) {
   return (int64_t)eavsr::cdiv(cout, 64) * (cin / CK) * U_ELEMS;
 }
 
-extern "C" int eavsr_pack_conv_weight_wino4(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream) {
-  EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight_wino4: NULL pointer");
-  EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % CK == 0, -1, "pack_conv_weight_wino4: cin %d must be a multiple of 4", cin);
+namespace {
+
+template <int R>
+int pack_wino6(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight_wino: NULL pointer");
+  EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % CK == 0, -1, "pack_conv_weight_wino: cin %d must be a multiple of 4", cin);
   const long total = eavsr_wino4_weight_elems(cout, cin);
-  hipLaunchKernelGGL(pack_wino4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
-                     packed, cout, cin, total);
-  return eavsr::launch_status("pack_conv_weight_wino4");
+  hipLaunchKernelGGL(pack_wino6_kernel<R>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream),
+                     weight, packed, cout, cin, total);
+  return eavsr::launch_status("pack_conv_weight_wino");
 }
 
-extern "C" int32_t eavsr_conv3x3_wino4_tiles(int32_t h, int32_t w) { return eavsr::cdiv(h, TOH) * eavsr::cdiv(w, TOW); }
-
-extern "C" int eavsr_conv3x3_wino4_f32(const eavsr_conv2d_desc* d, const float* weight_wino4, void* stream) {
-  EAVSR_REQUIRE(d != nullptr && weight_wino4 != nullptr, -1, "conv3x3_wino4: NULL descriptor / weights");
-  EAVSR_REQUIRE(d->n_src >= 1 && d->n_src <= 5, -1, "conv3x3_wino4: n_src %d not in 1..5", d->n_src);
-  EAVSR_REQUIRE(d->ksize == 3, -2, "conv3x3_wino4: kernel size %d (3 only)", d->ksize);
-  EAVSR_REQUIRE(d->out, -1, "conv3x3_wino4: NULL out");
-  EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv3x3_wino4: bad dims");
-  EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv3x3_wino4: act %d", d->act);
+template <int R>
+int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* stream) {
+  using C = WCfg<R>;
+  EAVSR_REQUIRE(d != nullptr && weight_wino != nullptr, -1, "conv_wino6: NULL descriptor / weights");
+  EAVSR_REQUIRE(d->n_src >= 1 && d->n_src <= 5, -1, "conv_wino6: n_src %d not in 1..5", d->n_src);
+  EAVSR_REQUIRE(d->ksize == R, -2, "conv_wino6: kernel size %d (this entry point: %d)", d->ksize, R);
+  EAVSR_REQUIRE(d->out, -1, "conv_wino6: NULL out");
+  EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv_wino6: bad dims");
+  EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv_wino6: act %d", d->act);
   EAVSR_REQUIRE(d->ca_scale == nullptr && d->ca_x == nullptr && d->ca_out == nullptr, -2,
-                "conv3x3_wino4: no fused channel-attention prologue (use eavsr_conv3x3_wino_f32)");
-  EAVSR_REQUIRE(d->w % 4 == 0, -2, "conv3x3_wino4: w %% 4 != 0 (use eavsr_conv2d_f32)");
-  EAVSR_REQUIRE((((uintptr_t)d->out) & 15) == 0 && (d->residual == nullptr || (((uintptr_t)d->residual) & 15) == 0), -2,
-                "conv3x3_wino4: out / residual must be 16-byte aligned");
+                "conv_wino6: no fused channel-attention prologue (use eavsr_conv3x3_wino_f32)");
+  EAVSR_REQUIRE(d->w % 4 == 0, -2, "conv_wino6: w %% 4 != 0 (use eavsr_conv2d_f32)");
+  constexpr uintptr_t AL = R == 3 ? 15 : 7;   // float4 / float2 row stores
+  EAVSR_REQUIRE((((uintptr_t)d->out) & AL) == 0 && (d->residual == nullptr || (((uintptr_t)d->residual) & AL) == 0), -2,
+                "conv_wino6: out / residual must be %d-byte aligned", (int)AL + 1);
   W4Args a;
   int csum = 0;
   for (int s = 0; s < 5; ++s) {
@@ -468,35 +555,58 @@ extern "C" int eavsr_conv3x3_wino4_f32(const eavsr_conv2d_desc* d, const float* 
     a.src_c[s] = s < d->n_src ? d->src_c[s] : 0;
     if (s < d->n_src) {
       EAVSR_REQUIRE(d->src[s] != nullptr && d->src_c[s] > 0 && d->src_c[s] % CK == 0 && (((uintptr_t)d->src[s]) & 15) == 0, -2,
-                    "conv3x3_wino4: source %d must be 16-byte aligned with a multiple of 4 channels", s);
+                    "conv_wino6: source %d must be 16-byte aligned with a multiple of 4 channels", s);
       csum += d->src_c[s];
     }
   }
-  EAVSR_REQUIRE(csum == d->cin, -1, "conv3x3_wino4: sources sum to %d channels, cin = %d", csum, d->cin);
+  EAVSR_REQUIRE(csum == d->cin, -1, "conv_wino6: sources sum to %d channels, cin = %d", csum, d->cin);
   if (d->n == 0) return 0;
   a.n_src = d->n_src;
-  a.wu = weight_wino4;
+  a.wu = weight_wino;
   a.bias = d->bias; a.residual = d->residual; a.out = d->out; a.chan_partial = d->chan_partial;
   a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
-  a.tiles_x = eavsr::cdiv(d->w, TOW);
-  a.tiles_y = eavsr::cdiv(d->h, TOH);
+  a.tiles_x = eavsr::cdiv(d->w, C::TOW);
+  a.tiles_y = eavsr::cdiv(d->h, C::TOH);
   a.act = d->act; a.slope = d->slope;
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
-  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_wino4: too many tiles");
-  EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv3x3_wino4: image plane too large for 32-bit tile offsets");
+  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv_wino6: too many tiles");
+  EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv_wino6: image plane too large for 32-bit tile offsets");
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<R>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
-    eavsr::set_error("conv3x3_wino4: hipFuncSetAttribute(%zu B of LDS): %s", LDS_BYTES, hipGetErrorString(attr_err));
+    eavsr::set_error("conv_wino6: hipFuncSetAttribute(%zu B of LDS): %s", C::LDS_BYTES, hipGetErrorString(attr_err));
     return (int)attr_err;
   }
   // persistent workgroups: one per CU, each walking blocks / grid.x tiles
   const long per_cot = blocks < 256 ? blocks : 256;
   dim3 grid((unsigned)per_cot, eavsr::cdiv(d->cout, 64));
-  hipLaunchKernelGGL(conv3x3_wino4_kernel, grid, dim3(64 * NW), LDS_BYTES, eavsr::as_stream(stream), a);
-  return eavsr::launch_status("conv3x3_wino4");
+  hipLaunchKernelGGL(conv_wino6_kernel<R>, grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
+  return eavsr::launch_status("conv_wino6");
+}
+
+}  // namespace
+
+extern "C" int eavsr_pack_conv_weight_wino4(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream) {
+  return pack_wino6<3>(weight, packed, cout, cin, stream);
+}
+extern "C" int eavsr_pack_conv_weight_wino5x5(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream) {
+  return pack_wino6<5>(weight, packed, cout, cin, stream);
+}
+
+extern "C" int32_t eavsr_conv3x3_wino4_tiles(int32_t h, int32_t w) {
+  return eavsr::cdiv(h, WCfg<3>::TOH) * eavsr::cdiv(w, WCfg<3>::TOW);
+}
+extern "C" int32_t eavsr_conv5x5_wino_tiles(int32_t h, int32_t w) {
+  return eavsr::cdiv(h, WCfg<5>::TOH) * eavsr::cdiv(w, WCfg<5>::TOW);
+}
+
+extern "C" int eavsr_conv3x3_wino4_f32(const eavsr_conv2d_desc* d, const float* weight_wino4, void* stream) {
+  return launch_wino6<3>(d, weight_wino4, stream);
+}
+extern "C" int eavsr_conv5x5_wino_f32(const eavsr_conv2d_desc* d, const float* weight_wino5x5, void* stream) {
+  return launch_wino6<5>(d, weight_wino5x5, stream);
 }

@@ -331,9 +331,14 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     use_wino4 = (use_wino and CONV_MODE == "winograd4" and ca is None and out.data_ptr() % 16 == 0
                  and (residual is None or residual.data_ptr() % 16 == 0)
                  and 2 * n * lib().eavsr_conv3x3_wino4_tiles(h, w) >= WINO_MIN_TILES)
+    # 5x5 (the predictor's offset / mask heads) by F(2x2, 5x5): the same 6 x 6 tile pipeline, 4 x 32-pixel tiles
+    use_wino5 = (CONV_MODE == "winograd4" and k == 5 and ca is None and w % 4 == 0 and out.data_ptr() % 8 == 0
+                 and all(int(s_.shape[1]) % 4 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs)
+                 and (residual is None or residual.data_ptr() % 8 == 0)
+                 and n * lib().eavsr_conv5x5_wino_tiles(h, w) * ((cout + 63) // 64) >= 2 * WINO_MIN_TILES)
     part = None
     if chan_partial:
-        tiles = (lib().eavsr_conv3x3_wino4_tiles(h, w) if use_wino4 else lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino
+        tiles = (lib().eavsr_conv5x5_wino_tiles(h, w) if use_wino5 else lib().eavsr_conv3x3_wino4_tiles(h, w) if use_wino4 else lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino
                  else lib().eavsr_conv2d_tiles(n, h, w, k))
         part = torch.empty((n, tiles, cout), device=out.device, dtype=torch.float32)
     if residual is not None:
@@ -370,6 +375,12 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError("ca_out needs ca")
     st = _stream(out)
     px = float(n) * h * w
+    if use_wino5:
+        wu = _packed_wino(weights, kind="f5")
+        _launch(f"conv5x5_{cin}to{cout}_wino", 2.0 * cin * cout * 25 * px,
+                4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+                lambda: lib().eavsr_conv5x5_wino_f32(C.byref(d), _p(wu), st), "conv5x5_wino")
+        return out if not chan_partial else (out, part)
     if use_wino4:
         wu = _packed_wino(weights, four=True)
         _launch(f"conv3x3_{cin}to{cout}_wino4", 2.0 * cin * cout * 9 * px,
@@ -541,25 +552,27 @@ def set_conv_mode(mode: str) -> None:
 _wino_pack_cache = {}
 
 
-def _packed_wino(weights: Sequence[Tensor], four: bool = False) -> Tensor:
-    """G g G^T of a 3x3 weight (or of several stacked along cout) for F(2x2, 3x3) or (`four`) F(4x4, 3x3); cached per
-    weight objects and versions."""
-    key = tuple((id(w), w._version) for w in weights) + (("f4", 0),) * bool(four)
+def _packed_wino(weights: Sequence[Tensor], four: bool = False, kind: Optional[str] = None) -> Tensor:
+    """G g G^T of a conv weight (or of several stacked along cout); kind "f2" = F(2x2, 3x3), "f4" = F(4x4, 3x3),
+    "f5" = F(2x2, 5x5); cached per weight objects and versions."""
+    kind = kind or ("f4" if four else "f2")
+    key = tuple((id(w), w._version) for w in weights) + ((kind, 0),)
     hit = _wino_pack_cache.get(key)
     if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
         return hit[1]
     w = weights[0] if len(weights) == 1 else torch.cat([x.detach() for x in weights], 0)
     w = _chk(w.detach(), "weight")
     cout, cin = int(w.shape[0]), int(w.shape[1])
-    elems = (lib().eavsr_wino4_weight_elems if four else lib().eavsr_wino_weight_elems)(cout, cin)
-    if elems <= 0 or tuple(w.shape[2:]) != (3, 3):
+    elems = (lib().eavsr_wino_weight_elems if kind == "f2" else lib().eavsr_wino4_weight_elems)(cout, cin)
+    if elems <= 0 or tuple(w.shape[2:]) != ((5, 5) if kind == "f5" else (3, 3)):
         raise NotImplementedError(f"winograd weight shape {tuple(w.shape)} unsupported")
     packed = torch.empty(elems, device=w.device, dtype=torch.float32)
     with _DeviceOf(w):
-        fn = lib().eavsr_pack_conv_weight_wino4 if four else lib().eavsr_pack_conv_weight_wino
+        fn = {"f2": lib().eavsr_pack_conv_weight_wino, "f4": lib().eavsr_pack_conv_weight_wino4,
+              "f5": lib().eavsr_pack_conv_weight_wino5x5}[kind]
         N.check(fn(_p(w), _p(packed), cout, cin, _stream(w)), "pack_conv_weight_wino")
     ids = {id(x) for x in weights}
-    for k in [k for k in _wino_pack_cache if (k[-1] == ("f4", 0)) == bool(four) and any(i in ids for i, _ in k)]:
+    for k in [k for k in _wino_pack_cache if k[-1] == (kind, 0) and any(i in ids for i, _ in k[:-1])]:
         _wino_pack_cache.pop(k, None)
     refs = tuple(weakref.ref(x, lambda _r, k=key: _wino_pack_cache.pop(k, None)) for x in weights)
     _wino_pack_cache[key] = (refs, packed)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 12
+#define EAVSR_ABI_VERSION 13
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -169,6 +169,16 @@ int64_t eavsr_wino4_weight_elems(int32_t cout, int32_t cin);
 int eavsr_pack_conv_weight_wino4(const float* weight, float* weight_wino4, int32_t cout, int32_t cin, void* stream);
 int32_t eavsr_conv3x3_wino4_tiles(int32_t h, int32_t w);
 int eavsr_conv3x3_wino4_f32(const eavsr_conv2d_desc* desc, const float* weight_wino4, void* stream);
+
+/* 5x5 stride-1 "same" convolution by Winograd F(2x2, 5x5) - the same 6x6-tile pipeline (same points and input
+ * transform), 2x2 outputs per tile, 2.78x fewer multiplications than the direct sum: the 5x5 offset / mask heads of
+ * AdaptBlockOffset (networks.py:283-285, 306-308).  Descriptor as above with ksize 5; sources a multiple of 4 channels
+ * and 16-byte aligned, w % 4 == 0, out / residual 8-byte aligned, ca_* NULL; chan_partial has
+ * eavsr_conv5x5_wino_tiles(h, w) rows per sample (4 x 32-pixel tiles).  weight: eavsr_wino4_weight_elems(cout, cin)
+ * floats written by eavsr_pack_conv_weight_wino5x5 from the (cout, cin, 5, 5) weight. */
+int eavsr_pack_conv_weight_wino5x5(const float* weight, float* weight_wino5x5, int32_t cout, int32_t cin, void* stream);
+int32_t eavsr_conv5x5_wino_tiles(int32_t h, int32_t w);
+int eavsr_conv5x5_wino_f32(const eavsr_conv2d_desc* desc, const float* weight_wino5x5, void* stream);
 /* input-channel chunk the kernel for this kernel size works in (sources must be multiples of it) */
 int32_t eavsr_conv2d_ck(int32_t ksize);
 /* rows of the spatial tile (32, 16 or 8; 32 columns) the kernel runs an (n, h, w) problem in: small images get

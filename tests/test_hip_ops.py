@@ -399,6 +399,40 @@ def test_conv3x3_winograd4_vs_torch_cpu(conv_wino4, cuda, case):
     assert H.maxabs(out.cpu(), ref) <= 6e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [([64], [32, 16, 72], None, False, False, 4, 180, 320), ([64], [64], "lrelu", True, True, 5, 133, 156),
+                                  ([4, 12], [7], "relu", False, False, 16, 61, 132), ([64, 64], [130], None, False, True, 6, 90, 160)],
+                         ids=lambda c: f"c{'+'.join(map(str, c[0]))}_o{'+'.join(map(str, c[1]))}_{c[5]}x{c[6]}x{c[7]}")
+def test_conv5x5_winograd_vs_torch_cpu(conv_wino4, cuda, case):
+    """F(2x2, 5x5): the predictor's 5x5 heads (three weights stacked along cout in one launch), ragged sizes, epilogue"""
+    chans, couts, act, use_res, use_part, n, h, w = case
+    cin, cout = sum(chans), sum(couts)
+    srcs = [cases.randn(10 + i, n, c, h, w) for i, c in enumerate(chans)]
+    wts = [cases.randn(20 + i, co, cin, 5, 5, scale=1.0 / (cin * 25) ** 0.5) for i, co in enumerate(couts)]
+    bs = [cases.randn(30 + i, co, scale=0.1) for i, co in enumerate(couts)]
+    res = cases.randn(22, n, cout, h, w) if use_res else None
+    ref = F.conv2d(torch.cat(srcs, 1), torch.cat(wts, 0), torch.cat(bs, 0), 1, 2)
+    ref = F.relu(ref) if act == "relu" else (F.leaky_relu(ref, 0.1) if act == "lrelu" else ref)
+    pre = ref
+    if use_res:
+        ref = ref + res
+    with conv_wino4.profile() as prof:
+        out = conv_wino4.conv2d([g(s_, cuda) for s_ in srcs], [g(x, cuda) for x in wts], [g(x, cuda) for x in bs], act=act,
+                                slope=0.1, residual=None if res is None else g(res, cuda), chan_partial=use_part)
+    assert list(prof.summary()) == [f"conv5x5_{cin}to{cout}_wino"]
+    if use_part:
+        out, part = out
+        assert part.shape[1] == conv_wino4.lib().eavsr_conv5x5_wino_tiles(h, w)
+        sums = pre.sum(dim=(2, 3))
+        assert H.maxabs(part.sum(dim=1).cpu(), sums) <= 1e-5 * sums.abs().max().item() + 5e-3
+    assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+    # error against fp64 for the path's head shape: same order as the direct kernel's
+    if cout == 120:
+        ref64 = F.conv2d(torch.cat(srcs, 1).double(), torch.cat(wts, 0).double(), torch.cat(bs, 0).double(), 1, 2)
+        e5 = (out.cpu().double() - ref64).abs().max().item() / ref64.abs().max().item()
+        print("5x5 winograd relative max error vs fp64:", e5)
+        assert e5 < 1.5e-5, e5
+
+
 def test_conv3x3_winograd4_error_against_fp64_and_fallbacks(ops, cuda):
     """F(4x4, 3x3) in fp32: ~1e-5 of the output scale (the 6 x 6 transforms amplify rounding), the documented price of
     4x fewer multiplications; the fused channel-attention prologue and small problems fall back to F(2x2, 3x3) / direct."""

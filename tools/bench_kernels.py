@@ -15,11 +15,11 @@ r = lambda *s: torch.randn(*s, device=dev)
 x64 = r(n, 64, h, w)
 w33, b = r(64, 64, 3, 3) * 0.05, r(64) * 0.1
 if "conv" in which:
-    for mode in ("winograd", "direct"):
+    for mode in ("winograd4", "winograd", "direct"):
         ops.set_conv_mode(mode)
         for _ in range(reps):
             ops.conv2d(x64, w33, b, act="relu")
-    ops.set_conv_mode("winograd")
+    ops.set_conv_mode("winograd4")
 if "convhr" in which:
     hr = r(n, 64, 4 * h, 4 * w)
     for _ in range(2):
