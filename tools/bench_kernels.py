@@ -20,6 +20,9 @@ if "conv" in which:
         for _ in range(reps):
             ops.conv2d(x64, w33, b, act="relu")
     ops.set_conv_mode("winograd4")
+    w55, b120 = r(120, 64, 5, 5) * 0.02, r(120) * 0.1      # the predictor's 5x5 heads, F(2x2, 5x5)
+    for _ in range(reps):
+        ops.conv2d(x64, w55, b120)
 if "convhr" in which:
     hr = r(n, 64, 4 * h, 4 * w)
     for _ in range(2):

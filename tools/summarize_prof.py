@@ -16,7 +16,7 @@ if stats:
     for r in rows[:16]:
         print(f"{float(r['Percentage']):6.2f}%  calls {int(r['Calls']):6d}  avg {float(r['AverageNs'])/1e3:10.1f} us  {r['Name'][:110]}")
 print()
-hot = ("conv3x3_wino4_kernel", "conv3x3_wino_kernel", "conv2d_mfma_kernel", "dcnv2", "flow_warp_kernel")
+hot = ("conv_wino6_kernel<3>", "conv_wino6_kernel<5>", "conv3x3_wino_kernel", "conv2d_mfma_kernel", "dcnv2", "flow_warp_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(os.path.join(root, "pmc_*", "*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(d)):
