@@ -296,7 +296,7 @@ def main():
             line["roofline"]["kernel"] = {
                 "winograd": "conv3x3_wino_kernel (3x3 64->64, the residual backbone); `achieved` counts the ALGORITHMIC "
                             "2*cin*cout*9 FLOP per pixel (SURVEY 8d) -- the kernel performs 2.25x fewer multiplications",
-                "winograd4": "conv3x3_wino4_kernel (3x3 64->64, the residual backbone); `achieved` counts the ALGORITHMIC "
+                "winograd4": "conv_wino6_kernel<3> (3x3 64->64, the residual backbone); `achieved` counts the ALGORITHMIC "
                              "2*cin*cout*9 FLOP per pixel (SURVEY 8d) -- the kernel performs 4x fewer multiplications",
                 "direct": "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)",
                 "bf16x9": "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)"}[args.conv_mode]
@@ -310,7 +310,8 @@ def main():
                 line["roofline"]["performed_frac"] = dom["achieved"] / red / PEAK_MFMA_F32_TFLOPS
         line["kernels"] = [e for e in (entry("dcnv2" if args.dcn_mode == "native" else "dcnv2_x9", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
-                                       entry("scale_residual", "hbm"), entry("conv5x5_64to120", "mfma")) if e]
+                                       entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),
+                                       entry("conv5x5_64to120", "mfma")) if e]
         line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         line["step_device_ms_instrumented"] = total_ms
         # HBM bytes per launch from the PMC passes of the last profiling visit (profiles/traffic.json:
