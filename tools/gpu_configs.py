@@ -37,13 +37,13 @@ for name, scale, (n, t, h, w), mode in [("configs[2] x2 8x7x256x256", 2, (8, 7, 
     # the other fp32 modes: direct convolutions, and the exact-split (bf16x9) contractions
     Nw.set_backbone_dtype(None)
     from eavsr_amd import ops
-    for cm, dm in (("direct", "native"), ("bf16x9", "bf16x9")):
+    for cm, dm in (("winograd", "native"), ("direct", "native"), ("bf16x9", "bf16x9")):
         ops.set_conv_mode(cm); ops.set_dcn_mode(dm)
         with torch.no_grad():
             y = net(clips); torch.cuda.synchronize()
             t0 = time.perf_counter(); y = net(clips); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"{name} fp32, conv {cm} / dcn {dm}: {dt*1e3:.0f} ms -> {n*t/dt:.1f} frames/s, max abs vs default {float((y-res[None]).abs().max()):.2e}", flush=True)
-    ops.set_conv_mode("winograd"); ops.set_dcn_mode("native")
+    ops.set_conv_mode("winograd4"); ops.set_dcn_mode("native")
     Nw.set_backbone_dtype(None)
     del net, clips, res, y
     torch.cuda.empty_cache()
