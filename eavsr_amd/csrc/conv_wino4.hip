@@ -45,6 +45,9 @@ struct W4Args {
   const float* residual;
   float* out;
   float* chan_partial;
+  const float* ca_scale;  // FUSE: effective input = src[0] * ca_scale[n, c] + ca_x (RCABlock tail, networks.py:447,463-464)
+  const float* ca_x;
+  float* ca_out;          // FUSE: optional copy of the effective input (the next block's residual stream)
   int n, h, w, cin, cout, tiles_x, tiles_y;
   int act;
   float slope;
@@ -101,12 +104,18 @@ __device__ __forceinline__ void out1d(const float (&m)[6], float (&s)[4]) {
   s[3] = (p2 + 8.f * p4) + m[5];
 }
 
-template <int R>
+// FUSE (3x3 only): the channel-attention tail of the previous residual block is applied in the input transform - the
+// patch of r and the patch of x are both staged ([r 0][r 1][x 0][x 1][U ..]), d = r * scale[n, c] + x, and the interior
+// 4 x 4 of every tile's d goes to ca_out (the next block's residual stream).
+template <int R, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
+  static_assert(!FUSE || R == 3, "the fused channel-attention prologue exists for the 3x3 kernel");
   using C = WCfg<R>;
   constexpr int M = C::M, PADR = C::PADR, TOH = C::TOH, TOW = C::TOW, IH = C::IH, IW = C::IW, IN_ELEMS = C::IN_ELEMS;
-  constexpr int IN_SEGS = C::IN_SEGS, IN_PAD = C::IN_PAD, IN_IT = C::IN_IT, OFF_U = C::OFF_U, OFF_V = C::OFF_V;
-  constexpr int LDS_MAIN = C::LDS_MAIN;
+  constexpr int IN_SEGS = C::IN_SEGS, IN_PAD = C::IN_PAD, IN_IT = C::IN_IT;
+  constexpr int X_OFF = 2 * IN_PAD;                                   // FUSE: the x patch stages follow the r stages
+  constexpr int OFF_U = C::OFF_U + (FUSE ? 2 * IN_PAD : 0), OFF_V = C::OFF_V + (FUSE ? 2 * IN_PAD : 0);
+  constexpr int LDS_MAIN = C::LDS_MAIN + (FUSE ? 2 * IN_PAD : 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_v = smem + OFF_V;
   float* s_red = smem + LDS_MAIN;
@@ -184,18 +193,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   asm volatile("" : "+s"(zero_src));                                     // taken once, not rematerialised in the loop
   const float* const wu_base = a.wu + (size_t)cot * (a.cin / CK) * U_ELEMS;
   const int n_src = a.n_src;
+  float sc_use = 0.f, sc_next = 0.f;   // FUSE: channel scale for the transform of this / the next iteration (prefetched
+                                       // with the patch, two chunks ahead)
   // the patch of the NEXT chunk of the prefetch stream -> patch stage; every piece is always issued (zeros outside)
   auto issue_patch = [&](int stage) {
     float* s_in = smem + stage * IN_PAD;
     const int sc = src_c_of(p_cs);
     const char* sp = reinterpret_cast<const char*>(src_of(p_cs) + ((size_t)p_bn * sc + p_cc0) * plane);
     const char* zp = zero_src;
+    const char* xp = FUSE ? reinterpret_cast<const char*>(a.ca_x + ((size_t)p_bn * sc + p_cc0) * plane) : nullptr;
+    if (FUSE) sc_next = a.ca_scale[(size_t)p_bn * sc + p_cc0 + kq];   // this lane's channel of that chunk (single source)
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int seg = i * NW + wave;
       if (seg < IN_SEGS) {   // wave-uniform
         const bool ok = voff[i] != 0xFFFFFFFFu;
         __builtin_amdgcn_global_load_lds((gptr_t)(ok ? sp + voff[i] : zp), (lptr_t)(s_in + seg * 256), 16, 0, 0);
+        if (FUSE)
+          __builtin_amdgcn_global_load_lds((gptr_t)(ok ? xp + voff[i] : zp), (lptr_t)(s_in + X_OFF + seg * 256), 16, 0, 0);
       }
     }
     p_cc0 += CK;
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   // registers - one LDS round trip - and the partner wave of each duty wave's SIMD has the matrix pipe to itself
   // meanwhile.  (A version that split every job over three lanes of all eight waves, second pass in place through
   // LDS, was 8 % slower: twice the LDS traffic, two dependent round trips in every wave.)
-  auto transform = [&](int ps, int vs) __attribute__((always_inline)) {
+  auto transform = [&](int ps, int vs, int t_bn, int t_y0, int t_x0, int t_chunk) __attribute__((always_inline)) {
 #ifndef EAVSR_WINO_EXP_NOTRANSFORM   // timing ablations only: results are wrong
     float* vd = s_v + vs * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));   // + (xi / 2) * 256 + (xi & 1)
     f32x2 t12[6], t34[6], t05[6];   // column pass B^T d, two columns per packed operation
@@ -237,6 +252,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
         f32x4 q[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) q[r] = *reinterpret_cast<const f32x4*>(pp + r * IW + 4);
+        if (FUSE) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            const f32x4 qx = *reinterpret_cast<const f32x4*>(pp + X_OFF + r * IW + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[r][j] = fmaf(q[r][j], sc_use, qx[j]);
+          }
+          if (a.ca_out != nullptr && cot == 0) {   // rows 1..4, columns 1..4 of the 6 x 6 patch = this tile's 4 x 4 pixels
+            const int gx = t_x0 + 4 * l15;
+#pragma unroll
+            for (int r = 1; r < 5; ++r) {
+              const int gy = t_y0 + 4 * tg + r - 1;
+              if (gy < h && gx < w)
+                *reinterpret_cast<f32x4*>(a.ca_out + ((size_t)t_bn * a.cin + t_chunk * CK + kq) * plane + (size_t)gy * w + gx) = q[r];
+            }
+          }
+        }
         f32x2 d[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][0], q[r][1]};
@@ -249,6 +281,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
         f32x2 d[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW + 3], pp[r * IW + 8]};
+        if (FUSE) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            d[r].x = fmaf(d[r].x, sc_use, pp[X_OFF + r * IW + 3]);
+            d[r].y = fmaf(d[r].y, sc_use, pp[X_OFF + r * IW + 8]);
+          }
+        }
         in1d(d, t05);
       }
     } else {
@@ -282,11 +321,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   // Pipeline (one barrier per chunk): iteration j multiplies chunk j (V[j&1], U[j&1]) right after transforming chunk
   // j+1 (patch[(j+1)&1] -> V[(j+1)&1]); the weight slab runs one chunk ahead of its GEMM, the input patch two.
   issue_patch(0);
+  const float sc_first = sc_next;
   issue_u(0, 0);
   if (total_iters > 1) issue_patch(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if ((wave >> 1) == 3) transform(0, 0);   // the pair on duty "before iteration 0"
+  if ((wave >> 1) == 3) { sc_use = sc_first; transform(0, 0, bn, y0, x0, 0); }   // the pair on duty "before iteration 0"
+  sc_use = sc_next;   // chunk 1's scale (loaded with patch 1), for the transform of iteration 0
   int chunk = 0;   // chunk of iteration `it` within its tile
   for (int it = 0; it < total_iters; ++it) {
     // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of iteration it-1
@@ -304,7 +345,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     const bool dma_late = wave >= 4;
     if (!dma_late) issue_dma();
     // the pair on duty transforms the next chunk before its GEMM steps
-    if (on_duty && it + 1 < total_iters) transform((it + 1) & 1, (it + 1) & 1);
+    if (on_duty && it + 1 < total_iters) {
+      int t_bn = bn, t_y0 = y0, t_x0 = x0, t_lin = 0;
+      if (FUSE && chunk_n == 0) tile_coords((it + 1) / total_chunks, t_bn, t_y0, t_x0, t_lin);   // first chunk of the next tile
+      transform((it + 1) & 1, (it + 1) & 1, t_bn, t_y0, t_x0, chunk_n);
+    }
     // ---- the 36 GEMM steps of this wave: M_xi[co, t] += sum over the chunk's 4 channels U_xi[co, c] V_xi[c, t]
     // U and V hold the positions in PAIRS ([xi / 2][c][column][xi & 1], column ^ 16 (c & 1)): one ds_read_b64 per operand
     // and two positions - ds_read_b64 moves 256 B/clk against 128 for ds_read_b32 (whose 32 banks would also put the two
@@ -343,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     if (dma_late) issue_dma();
     acc[0][0] += av[0].x + bv[0].x;
 #endif
+    if (FUSE) sc_use = sc_next;   // loaded by this iteration's issue_patch (chunk it + 2) for the transform of it + 1
     chunk = chunk_n;
     if (chunk != 0) continue;   // the tile is not finished yet
 
@@ -542,8 +588,15 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   EAVSR_REQUIRE(d->out, -1, "conv_wino6: NULL out");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv_wino6: bad dims");
   EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv_wino6: act %d", d->act);
-  EAVSR_REQUIRE(d->ca_scale == nullptr && d->ca_x == nullptr && d->ca_out == nullptr, -2,
-                "conv_wino6: no fused channel-attention prologue (use eavsr_conv3x3_wino_f32)");
+  const bool fuse = d->ca_scale != nullptr;
+  if (fuse) {
+    EAVSR_REQUIRE(R == 3, -2, "conv_wino6: the fused channel-attention prologue exists for the 3x3 kernel only");
+    EAVSR_REQUIRE(d->ca_x != nullptr, -1, "conv_wino6: ca_scale without ca_x");
+    EAVSR_REQUIRE(d->n_src == 1 && (((uintptr_t)d->ca_x) & 15) == 0 && (d->ca_out == nullptr || (((uintptr_t)d->ca_out) & 15) == 0),
+                  -2, "conv_wino6: the fused channel-attention prologue needs a single source and 16-byte aligned ca_x / ca_out");
+  } else {
+    EAVSR_REQUIRE(d->ca_x == nullptr && d->ca_out == nullptr, -1, "conv_wino6: ca_x / ca_out without ca_scale");
+  }
   EAVSR_REQUIRE(d->w % 4 == 0, -2, "conv_wino6: w %% 4 != 0 (use eavsr_conv2d_f32)");
   constexpr uintptr_t AL = R == 3 ? 15 : 7;   // float4 / float2 row stores
   EAVSR_REQUIRE((((uintptr_t)d->out) & AL) == 0 && (d->residual == nullptr || (((uintptr_t)d->residual) & AL) == 0), -2,
@@ -564,6 +617,7 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   a.n_src = d->n_src;
   a.wu = weight_wino;
   a.bias = d->bias; a.residual = d->residual; a.out = d->out; a.chan_partial = d->chan_partial;
+  a.ca_scale = d->ca_scale; a.ca_x = d->ca_x; a.ca_out = d->ca_out;
   a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
   a.tiles_x = eavsr::cdiv(d->w, C::TOW);
   a.tiles_y = eavsr::cdiv(d->h, C::TOH);
@@ -571,11 +625,15 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv_wino6: too many tiles");
   EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv_wino6: image plane too large for 32-bit tile offsets");
+  constexpr size_t LDS_FUSE = C::LDS_BYTES + 2 * C::IN_PAD * sizeof(float);
   static std::once_flag once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(once, [] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<R>),
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<R, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (R == 3 && attr_err == hipSuccess)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WCfg<3>::LDS_BYTES + 2 * WCfg<3>::IN_PAD * sizeof(float)));
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv_wino6: hipFuncSetAttribute(%zu B of LDS): %s", C::LDS_BYTES, hipGetErrorString(attr_err));
@@ -584,7 +642,12 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   // persistent workgroups: one per CU, each walking blocks / grid.x tiles
   const long per_cot = blocks < 256 ? blocks : 256;
   dim3 grid((unsigned)per_cot, eavsr::cdiv(d->cout, 64));
-  hipLaunchKernelGGL(conv_wino6_kernel<R>, grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
+  if (fuse) {
+    if constexpr (R == 3)
+      hipLaunchKernelGGL((conv_wino6_kernel<3, true>), grid, dim3(64 * NW), LDS_FUSE, eavsr::as_stream(stream), a);
+  } else {
+    hipLaunchKernelGGL((conv_wino6_kernel<R, false>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
+  }
   return eavsr::launch_status("conv_wino6");
 }
 

@@ -299,9 +299,10 @@ class RCABlock(nn.Module):
         return ops.scale_residual(r, scale, x)                      # res * y + x  (:463-464)
 
 
-# Fold `res * y + x` of block k into the first conv of block k+1 (eavsr_conv2d_f32's ca_* fields).  Measured
-# at 4x64x180x320: the fused conv costs +21 us (two input patches, 16 half-size chunks, side output) against
-# the 29 us scale_residual launch it removes, and leaves the step time unchanged -- so it is off by default.
+# Fold `res * y + x` of block k into the first conv of block k+1 (the ca_* fields of the conv descriptor; applied in the
+# input transform of the Winograd kernels, in the patch prologue of the direct kernel).  Measured at 4x64x180x320 on the
+# F(4x4,3x3) kernel: the fused conv costs +21 us (two input patches, the scale FMA on the transform's critical path, the
+# side output) against the 27 us scale_residual launch it removes - 314 ms vs 311 ms per step - so it is off by default.
 import os as _os
 FUSE_CA_INTO_CONV = _os.environ.get("EAVSR_FUSE_CA", "0") == "1"
 # Optional 16-bit residual backbone: None (exact fp32, the default and the BASELINE headline), "bf16" or "fp16"

@@ -328,7 +328,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
                 and n * lib().eavsr_conv3x3_wino_tiles(h, w) >= WINO_MIN_TILES
                 and (ca is None or (len(srcs) == 1 and cin <= 256 and ca[1].data_ptr() % 16 == 0)))
     # F(4x4, 3x3): same 512-pixel-per-workgroup granularity (8 x 64), no fused channel-attention prologue
-    use_wino4 = (use_wino and CONV_MODE == "winograd4" and ca is None and out.data_ptr() % 16 == 0
+    use_wino4 = (use_wino and CONV_MODE == "winograd4" and out.data_ptr() % 16 == 0
                  and (residual is None or residual.data_ptr() % 16 == 0)
                  and 2 * n * lib().eavsr_conv3x3_wino4_tiles(h, w) >= WINO_MIN_TILES)
     # 5x5 (the predictor's offset / mask heads) by F(2x2, 5x5): the same 6 x 6 tile pipeline, 4 x 32-pixel tiles
@@ -383,10 +383,11 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         return out if not chan_partial else (out, part)
     if use_wino4:
         wu = _packed_wino(weights, four=True)
-        _launch(f"conv3x3_{cin}to{cout}_wino4", 2.0 * cin * cout * 9 * px,
-                4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+        _launch(f"conv3x3_{cin}to{cout}_wino4" + ("_ca" if ca is not None else ""), 2.0 * cin * cout * 9 * px,
+                4.0 * px * (cin * (1 if ca is None else (3 if ca_out else 2)) + cout + (cout if residual is not None else 0)), out,
                 lambda: lib().eavsr_conv3x3_wino4_f32(C.byref(d), _p(wu), st), "conv3x3_wino4")
-        return out if not chan_partial else (out, part)
+        res = [out] + ([part] if chan_partial else []) + ([xs] if xs is not None else [])
+        return res[0] if len(res) == 1 else tuple(res)
     if use_wino:
         wu = _packed_wino(weights)
         _launch(f"conv3x3_{cin}to{cout}_wino" + ("_ca" if ca is not None else ""), 2.0 * cin * cout * 9 * px,

@@ -162,9 +162,10 @@ int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* desc, const float* weight_wi
 /* The same convolution by Winograd F(4x4, 3x3): 36 transform-domain GEMMs per 6x6 input tile, 4x fewer
  * multiplications than the direct sum (1.78x fewer than F(2x2, 3x3)), fp32 throughout; the larger transform costs
  * accuracy (~1e-5 of the output scale against ~4e-7).  Same descriptor, epilogue and requirements as
- * eavsr_conv3x3_wino_f32 except: sources a multiple of 4 channels, out / residual 16-byte aligned, no fused
- * channel-attention prologue (ca_* must be NULL), chan_partial has eavsr_conv3x3_wino4_tiles(h, w) rows per sample
- * (8 x 64-pixel tiles).  weight_wino4: eavsr_wino4_weight_elems(cout, cin) floats from eavsr_pack_conv_weight_wino4. */
+ * eavsr_conv3x3_wino_f32 except: sources a multiple of 4 channels, out / residual / ca_x / ca_out 16-byte aligned,
+ * chan_partial has eavsr_conv3x3_wino4_tiles(h, w) rows per sample (8 x 64-pixel tiles).  The fused channel-attention
+ * prologue (ca_scale, ca_x, optional ca_out: input = src[0] * ca_scale[n, c] + ca_x, single source) is applied in the
+ * input transform.  weight_wino4: eavsr_wino4_weight_elems(cout, cin) floats from eavsr_pack_conv_weight_wino4. */
 int64_t eavsr_wino4_weight_elems(int32_t cout, int32_t cin);
 int eavsr_pack_conv_weight_wino4(const float* weight, float* weight_wino4, int32_t cout, int32_t cin, void* stream);
 int32_t eavsr_conv3x3_wino4_tiles(int32_t h, int32_t w);
