@@ -12,6 +12,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof/pmc_write -- python3 $R/tools/bench_kernels.py > /dev/null 2>&1
 cd $R
 find gpurun_out/prof/bench -name "*kernel_trace.csv" -size +30M -delete
+cp $(ls -t gpurun_out/prof/bench/*/*kernel_stats.csv | head -1) gpurun_out/prof/bench_kernel_stats.csv   # THIS visit's (gpurun_out keeps older runs)
 python3 tools/summarize_prof.py gpurun_out/prof > gpurun_out/prof/summary.txt 2>&1
 cat gpurun_out/prof/summary.txt | head -60
 # bench.py reads profiles/traffic.json (bench kernel names -> bytes per launch): regenerate it from this visit's PMC passes
