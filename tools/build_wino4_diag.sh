@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic libraries eavsr_amd/lib/libwino4_*.so: conv_wino4.hip + capi.hip with -DEAVSR_WINO_EXP_* (timing ablations,
+# Diagnostic libraries eavsr_amd/lib/libwino4_*.so: conv_wino6.hip + capi.hip with -DEAVSR_WINO_EXP_* (timing ablations,
 # results wrong).  Built here (hipcc cross-compiles), they travel to the GPU box with the snapshot.
 set -e
 cd "$(dirname "$0")/.."
@@ -8,6 +8,6 @@ rm -f eavsr_amd/lib/libwino4_*.so
 for v in base:"" nodma:-DEAVSR_WINO_EXP_NODMA notransform:-DEAVSR_WINO_EXP_NOTRANSFORM nomfma:-DEAVSR_WINO_EXP_NOMFMA nostore:-DEAVSR_WINO_EXP_NOSTORE \
          nodma_notransform:"-DEAVSR_WINO_EXP_NODMA -DEAVSR_WINO_EXP_NOTRANSFORM" $EXTRA_VARIANTS; do
   name=${v%%:*}; flags=${v#*:}
-  /opt/rocm/bin/hipcc $F $flags eavsr_amd/csrc/conv_wino4.hip eavsr_amd/csrc/capi.hip -o eavsr_amd/lib/libwino4_$name.so 2>/dev/null
+  /opt/rocm/bin/hipcc $F $flags eavsr_amd/csrc/conv_wino6.hip eavsr_amd/csrc/capi.hip -o eavsr_amd/lib/libwino4_$name.so 2>/dev/null
 done
 ls eavsr_amd/lib/libwino4_*.so

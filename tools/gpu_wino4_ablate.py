@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing ablations of the Winograd conv kernel: diagnostic libraries eavsr_amd/lib/libwino4_*.so built from
-conv_wino4.hip + capi.hip (tools/build_wino4_diag.sh) with -DEAVSR_WINO_EXP_* (results wrong)."""
+conv_wino6.hip + capi.hip (tools/build_wino4_diag.sh) with -DEAVSR_WINO_EXP_* (results wrong)."""
 import ctypes as C
 import glob
 import os
