@@ -8,10 +8,14 @@
 A "step" is one `EAVSRP.forward` over one batch of synthetic clips already resident in HBM:
 BASELINE.json configs[1] = 4 clips x 7 frames x 3 x 180 x 320 fp32 per GPU, x4 -> 720 x 1280
 (weak scaling: every rank owns its own 4 clips; clips are independent, there is no data-path
-collective).  Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+collective).  By default the step runs as `--streams 2`: the clips as two sub-batches, each captured once as a
+HIP graph and replayed on its own stream, so that one group's streaming kernels overlap the other group's
+convolutions (same kernels per clip, bit-identical output; `--streams 1` = one eager forward over all clips).
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   roofline      the dominant kernel (3x3 64->64 MFMA conv) against the fp32 MFMA peak, and
   kernels       the same for DCNv2 / flow_warp (HBM-bound) -- durations measured with HIP events on the
-                launch stream during one extra, untimed, instrumented step,
+                launch stream during one extra, untimed, instrumented pass over one sub-batch (the launch shapes of
+                the timed region, without the overlap),
   cpu_baseline  the CPU oracle timed on this box's host cores on a bounded crop of the workload.
 """
 from __future__ import annotations
@@ -51,6 +55,9 @@ def parse():
                          "into three bf16 terms, nine partial products on the bf16 MFMA")
     ap.add_argument("--dcn-mode", default="native", choices=["native", "bf16x9"],
                     help="DCNv2 contraction: native fp32 MFMA (default) or the exact bf16x9 split")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="split the clips of a step into this many sub-batches, each replayed as its own HIP graph on its own "
+                         "stream (eavsr_amd.graph.StreamedForward)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward as one captured HIP graph (eavsr_amd.graph.GraphedForward): ~1 ms of host time "
                          "per step instead of ~180 ms of Python / ctypes launches; same kernels, same device time")
@@ -216,7 +223,12 @@ def main():
     clips = synthetic_clip(n, t, h, w, seed=rank).to(device)   # resident in HBM before the timed region
 
     run = net
-    if args.graph:
+    if args.streams < 1 or n % args.streams:
+        args.streams = 1           # the clips do not split evenly: one eager forward
+    if args.streams > 1:
+        from eavsr_amd.graph import StreamedForward
+        run = StreamedForward(net, clips, groups=args.streams)
+    elif args.graph:
         from eavsr_amd.graph import GraphedForward
         run = GraphedForward(net, clips)
     with torch.no_grad():
@@ -260,13 +272,15 @@ def main():
                    "conv3x3": {"winograd": "Winograd F(2x2,3x3), fp32 MFMA (direct fp32 kernel for the shapes it does not cover)",
                                "winograd4": "Winograd F(4x4,3x3), fp32 MFMA (F(2x2,3x3) / direct fp32 kernels for the shapes it does not cover)",
                                "direct": "direct sum, fp32 MFMA", "bf16x9": "direct sum, exact bf16x9 split"}[args.conv_mode],
-                   "dcnv2": args.dcn_mode, "launch": "one HIP graph per step" if args.graph else "eager (one launch per kernel)"},
+                   "dcnv2": args.dcn_mode, "launch": (f"{args.streams} HIP graphs on {args.streams} streams per step" if args.streams > 1 else
+                              "one HIP graph per step" if args.graph else "eager (one launch per kernel)")},
     }
 
     if rank == 0 and not args.no_kernel_profile:
-        # one extra untimed step with HIP events around every launch (events on the launch stream)
+        # one extra untimed pass with HIP events around every launch (events on the launch stream), over one sub-batch:
+        # the launch shapes of the timed region
         with torch.no_grad(), ops.profile() as prof:
-            net(clips)
+            net(clips[:n // args.streams])
         summ = prof.summary()
         total_ms = sum(v["ms"] for v in summ.values())
 
@@ -313,7 +327,7 @@ def main():
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),
                                        entry("conv5x5_64to120", "mfma")) if e]
         line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
-        line["step_device_ms_instrumented"] = total_ms
+        line["step_device_ms_instrumented"] = total_ms * args.streams   # the sub-batches back to back, no overlap
         # HBM bytes per launch from the PMC passes of the last profiling visit (profiles/traffic.json:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there)
         pmc = os.path.join(ROOT, "profiles", "traffic.json")

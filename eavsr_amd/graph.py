@@ -54,6 +54,45 @@ class GraphedForward:
         return self.static_out
 
 
+
+class StreamedForward:
+    """The clips of a step as `groups` independent sub-batches, each captured as its own HIP graph and replayed on its
+    own stream.
+
+    Clips are independent and the step is a chain of kernels with complementary bottlenecks: the Winograd
+    convolutions keep the matrix pipe and all of a CU's LDS but little HBM bandwidth, `scale_residual`, the warps and the
+    other streaming kernels the opposite.  With two sub-batches in flight one group's streaming kernels run in the wave
+    slots the other group's convolution leaves free.  Graphs are required: two eager forwards double the launches and
+    the host would become the bound.  Results are bit-identical to the single-stream forward (same kernels per clip).
+    """
+
+    def __init__(self, module, example: torch.Tensor, groups: int = 2, warmup: int = 2):
+        n = example.shape[0]
+        if groups < 1 or n % groups:
+            raise ValueError(f"{n} clips do not split into {groups} equal groups")
+        self.per = n // groups
+        self.streams = [torch.cuda.Stream(device=example.device) for _ in range(groups)]
+        self.parts = []
+        for g in range(groups):
+            self.parts.append(GraphedForward(module, example[g * self.per:(g + 1) * self.per].contiguous(), warmup=warmup))
+        self.shape, self.dtype, self.device = example.shape, example.dtype, example.device
+        out0 = self.parts[0].static_out
+        self.static_out = torch.empty((n,) + tuple(out0.shape[1:]), device=out0.device, dtype=out0.dtype)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape != self.shape or x.dtype != self.dtype or x.device != self.device:
+            raise ValueError(f"graphs captured for {tuple(self.shape)} {self.dtype} on {self.device}")
+        cur = torch.cuda.current_stream(self.device)
+        for g, (part, st) in enumerate(zip(self.parts, self.streams)):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                part.static_in.copy_(x[g * self.per:(g + 1) * self.per])
+                part.graph.replay()
+                self.static_out[g * self.per:(g + 1) * self.per].copy_(part.static_out)
+        for st in self.streams:
+            cur.wait_stream(st)
+        return self.static_out
+
 def clear_weight_caches():
     """Drop every per-(parameter, version) cache of derived weights (packed / transformed / transposed forms).
 

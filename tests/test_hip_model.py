@@ -238,3 +238,25 @@ def test_model_rejects_cpu_and_small_inputs(nets, cuda):
         net(torch.zeros(1, 3, 3, 32, 32, device=cuda))
     with pytest.raises(RuntimeError):
         net.cpu()(torch.zeros(1, 3, 3, 64, 64))
+
+
+def test_streamed_forward_is_bit_identical_to_the_eager_forward(nets, cuda):
+    """eavsr_amd.graph.StreamedForward (what bench.py runs by default): the clips as two sub-batches, each its own HIP graph
+    on its own stream; every clip goes through the same kernels, so the output equals the one-batch eager forward bit
+    for bit, also on new inputs, and odd splits are refused."""
+    from eavsr_amd.graph import StreamedForward
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    net, _ = _model(nets, cuda, "x4", "trained_like")
+    clips = synthetic_clip(4, 3, 64, 96, seed=3).to(cuda)
+    with torch.no_grad():
+        run = StreamedForward(net, clips, groups=2)
+        for seed in (3, 4):
+            x = synthetic_clip(4, 3, 64, 96, seed=seed).to(cuda)
+            got = run(x).clone()
+            want = torch.cat([net(x[:2]), net(x[2:])], 0)     # the same sub-batches, eagerly
+            assert torch.equal(got, want)
+            assert H.maxabs(got.cpu(), net(x).cpu()) <= 1e-6   # and the one-batch forward (tile policies may differ)
+    with pytest.raises(ValueError):
+        StreamedForward(net, clips[:3], groups=2)
+    with pytest.raises(ValueError):
+        run(clips[:2])

@@ -8,7 +8,7 @@ import torch  # noqa: E402
 from eavsr_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-n, h, w = 4, 180, 320
+n, h, w = int(os.environ.get("N", 2)), 180, 320   # bench.py's default launches: two clips per sub-batch
 reps = int(os.environ.get("REPS", 5))
 which = os.environ.get("WHICH", "conv,convhr,dcn,warp").split(",")
 r = lambda *s: torch.randn(*s, device=dev)

@@ -19,8 +19,8 @@ cat gpurun_out/prof/summary.txt | head -60
 python3 - <<'PY'
 import json
 r = json.load(open('gpurun_out/prof/traffic.json'))
-out = {'conv3x3_64to64_wino4': r['conv_wino6_kernel<3>']['total_bytes'], 'conv5x5_64to120_wino': r['conv_wino6_kernel<5>']['total_bytes'], 'conv3x3_64to64_wino': r['conv3x3_wino_kernel']['total_bytes'], 'conv3x3_64to64': r['conv2d_mfma_kernel']['total_bytes'], 'dcnv2': r['dcnv2']['total_bytes'], 'flow_warp': r['flow_warp_kernel']['total_bytes'],
-       'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950; bytes per launch at 4x64x180x320'}
+out = {'conv3x3_64to64_wino4': r['conv_wino6_kernel<3, false>']['total_bytes'], 'conv5x5_64to120_wino': r['conv_wino6_kernel<5, false>']['total_bytes'], 'conv3x3_64to64_wino': r['conv3x3_wino_kernel']['total_bytes'], 'conv3x3_64to64': r['conv2d_mfma_kernel']['total_bytes'], 'dcnv2': r['dcnv2']['total_bytes'], 'flow_warp': r['flow_warp_kernel']['total_bytes'],
+       'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950; bytes per launch at 2x64x180x320 (one sub-batch of the default bench.py --streams 2)'}
 json.dump(out, open('profiles/traffic.json', 'w'), indent=1)
 json.dump(out, open('gpurun_out/prof/traffic_bench.json', 'w'), indent=1)
 PY
