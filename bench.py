@@ -225,6 +225,8 @@ def main():
     run = net
     if args.streams < 1 or n % args.streams:
         args.streams = 1           # the clips do not split evenly: one eager forward
+    if world > torch.cuda.device_count():
+        args.streams = 1           # several ranks share a device (test launches): their graphs would interleave badly
     if args.streams > 1:
         from eavsr_amd.graph import StreamedForward
         run = StreamedForward(net, clips, groups=args.streams)
