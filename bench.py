@@ -229,7 +229,13 @@ def main():
         args.streams = 1           # several ranks share a device (test launches): their graphs would interleave badly
     if args.streams > 1:
         from eavsr_amd.graph import StreamedForward
-        run = StreamedForward(net, clips, groups=args.streams)
+        try:
+            run = StreamedForward(net, clips, groups=args.streams)
+        except Exception as e:   # a capture problem must not cost the measurement: the same work as one eager forward
+            print(f"[bench] rank {rank}: HIP-graph capture failed ({type(e).__name__}: {e}); running --streams 1", file=sys.stderr)
+            torch.cuda.synchronize()
+            args.streams = 1
+            run = net
     elif args.graph:
         from eavsr_amd.graph import GraphedForward
         run = GraphedForward(net, clips)

@@ -42,7 +42,8 @@ class GraphedForward:
         torch.cuda.current_stream(self.static_in.device).wait_stream(side)
         torch.cuda.synchronize(self.static_in.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread_local: a collective library's watchdog thread (RCCL, when a process group exists) must not invalidate the capture
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_out = self.module(self.static_in)
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
@@ -152,7 +153,7 @@ class GraphedTrainStep:
         model.grad_sync.paused = True
         try:
             opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 model.forward()
                 self._backward()
                 if self.world == 1:
