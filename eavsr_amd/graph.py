@@ -45,6 +45,11 @@ class GraphedForward:
         # thread_local: a collective library's watchdog thread (RCCL, when a process group exists) must not invalidate the capture
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_out = self.module(self.static_in)
+        # the captured launches read the derived weight forms (packed / Winograd-transformed) that the warm-up left in the
+        # per-parameter caches: hold them, so that clearing or refreshing a cache cannot free memory the graph still uses
+        from . import ops
+        self._weights_alive = [dict(ops.pack_cache._d)] + [dict(getattr(ops, n)) for n in (
+            "_bias_cache", "_wcat_cache", "_x9_pack_cache", "_wino_pack_cache", "_h16_pack_cache") if hasattr(ops, n)]
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype or x.device != self.static_in.device:
