@@ -397,52 +397,55 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       float csum[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (R == 3) {
         const int gx = x0 + 4 * l15;   // 16 lanes x float4 = one 256-byte row segment
-        // two output rows at a time (the four rows of a channel at once need 40 more registers than there are):
-        // their residual rows are requested first, the column pass A^T m of this half runs under the loads
-  #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = cot * 64 + cb * 16 + 4 * kq + r;
-          const bool cok = co < a.cout;
-          const float bb = bias_r[r];
-  #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
+        // Two output channels at a time as packed fp32 pairs (r = 2 rp, 2 rp + 1 are adjacent accumulator registers), one
+        // output row at a time (registers): half the vector instructions of a channel-by-channel transform - the epilogue
+        // is paid once per launch when a workgroup has a single tile.
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+          const int co0 = cot * 64 + cb * 16 + 4 * kq + 2 * rp;
+#pragma unroll
+          for (int dy = 0; dy < 4; ++dy) {
             __builtin_amdgcn_sched_barrier(0);
+            const int gy = y0 + 4 * tg + dy;
+            const bool pok = gy < h && gx < w;     // w % 4 == 0 and gx % 4 == 0: gx + 3 < w as well
             f32x4 rr[2];
-  #pragma unroll
-            for (int d2 = 0; d2 < 2; ++d2) {
-              const int gy = y0 + 4 * tg + 2 * hf + d2;
-              rr[d2] = f32x4{0.f, 0.f, 0.f, 0.f};
-              if (a.residual != nullptr && cok && gy < h && gx < w)
-                rr[d2] = *reinterpret_cast<const f32x4*>(a.residual + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+              rr[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (a.residual != nullptr && co0 + ch < a.cout && pok)
+                rr[ch] = *reinterpret_cast<const f32x4*>(a.residual + ((size_t)bn * a.cout + co0 + ch) * plane + (size_t)gy * w + gx);
             }
-            float s[2][6];
-  #pragma unroll
-            for (int q = 0; q < 6; ++q) {      // rows 2 hf, 2 hf + 1 of A^T m, column q of the 6 x 6 block
-              const float m0 = acc[0 * 6 + q][r], m1 = acc[1 * 6 + q][r], m2 = acc[2 * 6 + q][r], m3 = acc[3 * 6 + q][r],
-                          m4 = acc[4 * 6 + q][r], m5 = acc[5 * 6 + q][r];
-              if (hf == 0) {
-                s[0][q] = m0 + (m1 + m2) + (m3 + m4);
-                s[1][q] = (m1 - m2) + 2.f * (m3 - m4);
-              } else {
-                s[0][q] = (m1 + m2) + 4.f * (m3 + m4);
-                s[1][q] = ((m1 - m2) + 8.f * (m3 - m4)) + m5;
-              }
+            f32x2 s[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {      // row dy of A^T m, column q of the 6 x 6 block
+              f32x2 m[6];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[i * 6 + q][2 * rp], acc[i * 6 + q][2 * rp + 1]};
+              if (dy == 0) s[q] = m[0] + (m[1] + m[2]) + (m[3] + m[4]);
+              else if (dy == 1) s[q] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
+              else if (dy == 2) s[q] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
+              else s[q] = ((m[1] - m[2]) + 8.f * (m[3] - m[4])) + m[5];
             }
-  #pragma unroll
-            for (int d2 = 0; d2 < 2; ++d2) {
-              float y[4];
-              out1d(s[d2], y);
-              const int gy = y0 + 4 * tg + 2 * hf + d2;
-  #pragma unroll
+            const f32x2 p1 = s[1] + s[2], p2 = s[1] - s[2], p3 = s[3] + s[4], p4 = s[3] - s[4];
+            f32x2 y[4];
+            y[0] = s[0] + p1 + p3;
+            y[1] = p2 + 2.f * p4;
+            y[2] = p1 + 4.f * p3;
+            y[3] = (p2 + 8.f * p4) + s[5];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+              const int r = 2 * rp + ch, co = co0 + ch;
+              float v[4];
+#pragma unroll
               for (int j = 0; j < 4; ++j) {
-                y[j] += bb;
-                if (a.act == EAVSR_ACT_RELU) y[j] = fmaxf(y[j], 0.f);
-                else if (a.act == EAVSR_ACT_LRELU) y[j] = y[j] > 0.f ? y[j] : y[j] * a.slope;
+                v[j] = (ch == 0 ? y[j].x : y[j].y) + bias_r[r];
+                if (a.act == EAVSR_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+                else if (a.act == EAVSR_ACT_LRELU) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
               }
-              if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx % 4 == 0: gx + 3 < w as well
-                csum[r] += (y[0] + y[1]) + (y[2] + y[3]);
+              if (co < a.cout && pok) {
+                csum[r] += (v[0] + v[1]) + (v[2] + v[3]);
                 *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
-                    f32x4{y[0] + rr[d2][0], y[1] + rr[d2][1], y[2] + rr[d2][2], y[3] + rr[d2][3]};
+                    f32x4{v[0] + rr[ch][0], v[1] + rr[ch][1], v[2] + rr[ch][2], v[3] + rr[ch][3]};
               }
             }
           }
