@@ -11,12 +11,19 @@ BASELINE.json configs[1] = 4 clips x 7 frames x 3 x 180 x 320 fp32 per GPU, x4 -
 collective).  By default the step runs as `--streams 2`: the clips as two sub-batches, each captured once as a
 HIP graph and replayed on its own stream, so that one group's streaming kernels overlap the other group's
 convolutions (same kernels per clip, bit-identical output; `--streams 1` = one eager forward over all clips).
+`python bench.py --gpus N` with N > 1 and no launcher environment starts the N ranks itself: before anything touches
+the GPU the parent spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays rank
+0's JSON line and exits with the children's status (a process that has initialised HIP is never re-executed).
 Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      the dominant kernel (3x3 64->64 MFMA conv) against the fp32 MFMA peak, and
+  roofline      the dominant kernel (3x3 64->64 MFMA conv) against the fp32 MFMA peak: `achieved` / `frac` count the
+                multiplications the kernel PERFORMS (Winograd F(4x4,3x3): a quarter of the direct sum's), the
+                algorithmic-equivalent rate is reported beside it under its own key,
   kernels       the same for DCNv2 / flow_warp (HBM-bound) -- durations measured with HIP events on the
                 launch stream during one extra, untimed, instrumented pass over one sub-batch (the launch shapes of
                 the timed region, without the overlap),
-  cpu_baseline  the CPU oracle timed on this box's host cores on a bounded crop of the workload.
+  cpu_baseline  the CPU oracle timed on this box's host cores on ONE full-size clip of the workload (no extrapolation).
+`--dry` replaces the kernels by a sleep and the GPU by the CPU (gloo): it exists only so that the launch / barrier /
+max-over-ranks / JSON plumbing of `--gpus N` can be tested in a container without a GPU; its line says so.
 """
 from __future__ import annotations
 
@@ -67,7 +74,15 @@ def parse():
                          "loss gradients); reported under its own metric name")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[64, 96], help="h w of the CPU-baseline crop")
+    ap.add_argument("--cpu-crop", type=int, nargs=2, default=[64, 96],
+                    help="h w of the CPU-baseline FALLBACK crop (used only if one full-size clip does not finish in time)")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed full-clip runs of the CPU oracle after one warm-up run")
+    ap.add_argument("--cpu-budget", type=float, default=300.0,
+                    help="seconds the CPU baseline may take in total; further timed runs are skipped once it is spent")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every usable core)")
+    ap.add_argument("--dry", action="store_true",
+                    help="plumbing test without a GPU: the step is a sleep, ranks talk over gloo; the line is labelled "
+                         "as such and is not a measurement")
     return ap.parse_args()
 
 
@@ -104,40 +119,66 @@ sd0 = net.state_dict()
 sd = fill_state_dict(shapes_of(sd0), {preset!r}, fixed=sd0)
 del net
 clip = synthetic_clip(1, {frames}, {h}, {w}, seed=0)
-t0 = time.time()
+t_start = time.time()
+times = []
 with torch.no_grad():
-    O.eavsrp_forward(sd, clip, 4)
-print(json.dumps({{"seconds": time.time() - t0}}))
+    for i in range({runs} + 1):          # run 0 is the warm-up (the reference discards its first iteration too)
+        if i > 1 and time.time() - t_start + times[-1] > {budget}:
+            break
+        t0 = time.time()
+        O.eavsrp_forward(sd, clip, 4)
+        times.append(time.time() - t0)
+        print(json.dumps({{"run": i, "seconds": times[-1]}}), flush=True)
 """
 
 
-def cpu_baseline(preset, frames, crop_h, crop_w, full_h, full_w, timeout_s=240):
-    """The oracle (a port of the reference's algorithm, oracle/eavsr_oracle.py) timed on the host cores, in
-    a child process (never initialises the GPU) with a hard timeout so the bench always finishes."""
+def _run_cpu_child(preset, frames, h, w, cores, runs, budget, timeout_s):
     import subprocess
-    cores = min(usable_cores(), 32)
-    code = _CPU_CHILD.format(root=ROOT, cores=cores, preset=preset, frames=frames, h=crop_h, w=crop_w)
+    code = _CPU_CHILD.format(root=ROOT, cores=cores, preset=preset, frames=frames, h=h, w=w, runs=runs, budget=budget)
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="",
                CUDA_VISIBLE_DEVICES="")
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     try:
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=env)
-        dt = json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
+        out, err = p.communicate(timeout=timeout_s)
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": f"1 clip x {frames} x 3 x {crop_h} x {crop_w} did not finish within {timeout_s} s on {cores} threads"}
-    except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": f"failed: {e!r}"}
-    fps_crop = frames / dt
-    return {
-        "value": fps_crop * (crop_h * crop_w) / float(full_h * full_w),
-        "unit": "frames/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"1 clip x {frames} frames x 3 x {crop_h} x {crop_w} (crop of the {full_h}x{full_w} workload) "
-                  f"in {dt:.1f} s = {fps_crop:.3f} frames/s at the crop size; value is scaled by the pixel ratio "
-                  f"to {full_h}x{full_w} (per-pixel work is size-independent); torch {torch.__version__} CPU, "
-                  f"{cores} threads",
-    }
+        p.kill()
+        out, err = p.communicate()
+    secs = []
+    for ln in out.splitlines():
+        try:
+            secs.append(json.loads(ln)["seconds"])
+        except Exception:  # noqa: BLE001
+            pass
+    return secs, err
+
+
+def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=420.0, threads=0):
+    """The oracle (a port of the reference's algorithm, oracle/eavsr_oracle.py) timed on the host cores the way the
+    reference times its own forward (models/eavsrp_model.py:100-107: wall time around one forward of one clip, the
+    first iteration discarded): ONE full-size clip, one warm-up run, then up to `runs` timed runs, median; no
+    extrapolation.  Child process (never initialises the GPU), hard time budget.  Only if not even the warm-up + one
+    timed run of the full clip fit the budget does it fall back to a crop scaled by the pixel ratio, and says so."""
+    import statistics
+    cores = threads if threads > 0 else usable_cores()
+    base = {"unit": "frames/s", "cores": cores, "kind": "port"}
+    secs, err = _run_cpu_child(preset, frames, full_h, full_w, cores, runs, budget, timeout_s=budget + 60)
+    if len(secs) >= 2:
+        timed = secs[1:]
+        med = statistics.median(timed)
+        return dict(base, value=frames / med,
+                    sample=f"1 clip x {frames} frames x 3 x {full_h} x {full_w} (one clip of the timed workload, full size), "
+                           f"oracle/eavsr_oracle.py eavsrp_forward on torch {torch.__version__} CPU with {cores} threads: "
+                           f"1 warm-up run ({secs[0]:.1f} s, discarded) + {len(timed)} timed run(s) "
+                           f"{[round(x, 1) for x in timed]} s, median {med:.1f} s; no extrapolation")
+    # fallback: the full clip did not finish twice within the budget
+    secs_c, err_c = _run_cpu_child(preset, frames, crop_h, crop_w, cores, 1, 120.0, timeout_s=180)
+    if len(secs_c) >= 2:
+        dt = secs_c[-1]
+        return dict(base, value=frames / dt * (crop_h * crop_w) / float(full_h * full_w),
+                    sample=f"FALLBACK (the full {full_h}x{full_w} clip did not finish a warm-up + one timed run within "
+                           f"{budget:.0f} s; finished runs: {[round(x, 1) for x in secs]}): 1 clip x {frames} x 3 x {crop_h} x "
+                           f"{crop_w} crop in {dt:.1f} s, scaled by the pixel ratio; {cores} threads")
+    return dict(base, value=None, sample=f"failed: {(err or err_c)[-300:]!r}")
 
 
 def train_bench(args, rank, world, device):
@@ -193,22 +234,96 @@ def train_bench(args, rank, world, device):
         torch.distributed.destroy_process_group()
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as children of THIS process, which has
+    not touched the GPU (no torch.cuda call, no HIP call), through torch.distributed.run -- one process per GPU, RCCL
+    rendezvous on 127.0.0.1 -- relay rank 0's JSON line and return the children's exit status.  Nothing is re-executed."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if r.returncode == 0 and line is None:
+        print("[bench] the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
+def dry_bench(args):
+    """Plumbing only (no GPU, no kernels): rendezvous over gloo, barrier, K sleeps as 'steps', MAX over ranks, one JSON
+    line.  Lets a CPU container test what `--gpus N` does around the kernels."""
+    from eavsr_amd import shard
+    os.environ.setdefault("EAVSR_DIST_BACKEND", "gloo")
+    rank, local_rank, world = shard.env_rank_world()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if args.gpus != world:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    n, t = args.clips, args.frames
+    for _ in range(args.warmup):
+        time.sleep(0.01)
+    shard.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))          # ranks differ on purpose: the line must carry the MAX
+    shard.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "DRY RUN -- no kernels, no GPU: launch / barrier / max-over-ranks plumbing only (not a measurement)",
+            "value": world * n * t * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "none", "data": "none", "dry": True,
+            "config": {"workload": "sleep", "world_size": world,
+                       "backend": torch.distributed.get_backend() if world > 1 else "none"}}), flush=True)
+    if world > 1:
+        shard.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # before anything can initialise the GPU in this process
+    if args.dry:
+        return dry_bench(args)
     from eavsr_amd import ops, shard
     rank, local_rank, world = shard.init_process_group()
     if args.gpus != world:
         if rank == 0:
-            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher started a different number of ranks",
+                  file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("[bench] no GPU visible: eavsr_amd has no CPU path", file=sys.stderr)
         sys.exit(2)
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     ops.lib()  # fail loudly if the HIP extension is missing
+    if world > 1:
+        # the N ranks the line reports are N live RCCL ranks, one per GPU (or EAVSR_DIST_BACKEND=gloo in shared-GPU tests)
+        assert torch.distributed.get_world_size() == args.gpus, (torch.distributed.get_world_size(), args.gpus)
 
     from eavsr_amd.utils.synthetic import synthetic_clip
     if args.mode == "train":
@@ -245,9 +360,12 @@ def main():
         torch.cuda.synchronize()
         shard.barrier()
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             out = run(clips)
+            marks[i + 1].record()          # device-side step boundaries (no host sync inside the timed region)
         torch.cuda.synchronize()
         shard.barrier()
         torch.cuda.synchronize()
@@ -256,6 +374,9 @@ def main():
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
     frames_total = world * n * t * args.steps
     value = frames_total / elapsed
+    import statistics
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    med_ms = shard.max_over_ranks(statistics.median(step_ms), device=device if on_dev else None)
 
     line = {
         "metric": "SR frames/sec at 4x 7-frame 180x320->720x1280" +
@@ -267,9 +388,15 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        # median over the timed steps (device-side step boundaries; max over ranks of the per-rank medians)
+        "ms_per_step_median": med_ms,
+        "value_median": world * n * t / (med_ms * 1e-3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
+        "world_size": torch.distributed.get_world_size() if world > 1 else 1,
+        "backend": (torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else ""))
+                   if world > 1 else "none (one process)",
         "dtype": ("f32" if args.backbone_dtype == "fp32" else f"{args.backbone_dtype} backbone + f32") +
                  ("" if args.conv_mode != "bf16x9" and args.dcn_mode == "native"
                   else " (contractions in bf16x9 mode: exact 3 x bf16 operand split, 9 products, f32 accumulate)"),
@@ -292,16 +419,33 @@ def main():
         summ = prof.summary()
         total_ms = sum(v["ms"] for v in summ.values())
 
+        def mult_reduction(name):
+            """algorithmic multiplications / multiplications the kernel performs (1 for direct sums)"""
+            if name.endswith("_wino4") or name.endswith("_wino4_ca"):
+                return 4.0, "Winograd F(4x4,3x3): 36 products per 4x4 outputs instead of 144"
+            if name.startswith("conv5x5") and name.endswith("_wino"):
+                return 100.0 / 36.0, "Winograd F(2x2,5x5): 36 products per 2x2 outputs instead of 100"
+            if name.endswith("_wino") or name.endswith("_wino_ca"):
+                return 2.25, "Winograd F(2x2,3x3): 16 products per 2x2 outputs instead of 36"
+            return 1.0, "direct sum"
+
         def entry(name, bound):
             v = summ.get(name)
             if not v:
                 return None
             avg_ms = v["ms"] / v["calls"]
             if bound == "mfma":
-                ach = v["flops"] / v["calls"] / (avg_ms * 1e-3) / 1e12
+                alg = v["flops"] / v["calls"] / (avg_ms * 1e-3) / 1e12
+                red, how = mult_reduction(name)
+                ach = alg / red
+                # `achieved` / `frac`: FLOP the matrix pipe actually performs per second against its fp32 peak (<= 1 by
+                # construction); the algorithmic-equivalent rate (SURVEY 8d's 2*cin*cout*k*k per pixel) is its own key
                 return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
-                        "share_of_step": v["ms"] / total_ms}
+                        "share_of_step": v["ms"] / total_ms, "algorithm": how,
+                        "algorithmic_equivalent": {"achieved": alg, "unit": "TFLOP/s", "x_peak": alg / PEAK_MFMA_F32_TFLOPS,
+                                                   "note": "direct-sum FLOP count / time; exceeds the peak when the algorithm "
+                                                           "multiplies less -- not a roofline fraction"}}
             ach = v["bytes"] / v["calls"] / (avg_ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
@@ -314,22 +458,13 @@ def main():
             if e16:
                 line.setdefault("kernels_16bit", []).append(e16)
         if dom is not None:
-            line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+            line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_ms",
+                                                    "share_of_step", "algorithm", "algorithmic_equivalent")}
             line["roofline"]["kernel"] = {
-                "winograd": "conv3x3_wino_kernel (3x3 64->64, the residual backbone); `achieved` counts the ALGORITHMIC "
-                            "2*cin*cout*9 FLOP per pixel (SURVEY 8d) -- the kernel performs 2.25x fewer multiplications",
-                "winograd4": "conv_wino6_kernel<3> (3x3 64->64, the residual backbone); `achieved` counts the ALGORITHMIC "
-                             "2*cin*cout*9 FLOP per pixel (SURVEY 8d) -- the kernel performs 4x fewer multiplications",
+                "winograd": "conv3x3_wino_kernel (3x3 64->64, the residual backbone)",
+                "winograd4": "conv_wino6_kernel<3> (3x3 64->64, the residual backbone)",
                 "direct": "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)",
                 "bf16x9": "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)"}[args.conv_mode]
-            line["roofline"]["avg_ms"] = dom["avg_ms"]
-            line["roofline"]["share_of_step"] = dom["share_of_step"]
-            if args.conv_mode in ("winograd", "winograd4"):
-                # frac can exceed 1 for the algorithmic count: F(2x2,3x3) multiplies 16 times per 2x2 outputs instead of
-                # 36, F(4x4,3x3) 36 times per 4x4 outputs instead of 144
-                red = 2.25 if args.conv_mode == "winograd" else 4.0
-                line["roofline"]["performed"] = dom["achieved"] / red
-                line["roofline"]["performed_frac"] = dom["achieved"] / red / PEAK_MFMA_F32_TFLOPS
         line["kernels"] = [e for e in (entry("dcnv2" if args.dcn_mode == "native" else "dcnv2_x9", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),
@@ -350,7 +485,8 @@ def main():
                 pass
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(args.preset, t, args.cpu_crop[0], args.cpu_crop[1], h, w)
+        line["cpu_baseline"] = cpu_baseline(args.preset, t, h, w, args.cpu_crop[0], args.cpu_crop[1], runs=args.cpu_runs,
+                                            budget=args.cpu_budget, threads=args.cpu_threads)
 
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <mutex>
+
 #include "../../include/eavsr_hip.h"
 
 namespace eavsr {
@@ -17,6 +19,18 @@ int launch_status(const char* what);
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// per-device one-time initialisation (hipFuncSetAttribute applies to the device that is current when it is called;
+// ops._DeviceOf launches on whichever device owns the tensors)
+constexpr int kMaxDevices = 64;
+struct PerDeviceOnce {
+  std::once_flag flag[kMaxDevices];
+};
+static inline int current_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d >= 0 && d < kMaxDevices) ? d : 0;
+}
 
 }  // namespace eavsr
 

@@ -342,9 +342,12 @@ __global__ void pack_weight_h16_kernel(const float* __restrict__ w, unsigned sho
 
 template <bool BF16>
 int launch_conv_h16(const H16Args& a, int blocks, hipStream_t st) {
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_h16_kernel<BF16>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES);
   });

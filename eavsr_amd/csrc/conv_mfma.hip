@@ -550,9 +550,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_small_kernel(ConvArgs a) {
 template <int MT, bool SPLIT = false>
 int launch_small(const ConvArgs& a, dim3 grid, hipStream_t st) {
   using Cfg = SmallCfg<MT>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<MT, SPLIT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
   });
@@ -586,9 +589,12 @@ inline int co_tile_of(int cout) { return cout <= 32 ? 32 : 64; }
 template <int KS, int MT, bool VEC, bool FUSE = false, int NT_ = 4>
 int launch_one(const ConvArgs& a, dim3 grid, hipStream_t st) {
   using Cfg = ConvCfg<KS, MT, VEC, FUSE, NT_>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_mfma_kernel<KS, MT, VEC, FUSE, NT_>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
   });

@@ -329,9 +329,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <int KS>
 int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
   using Cfg = WgCfg<KS>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<KS>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
   });
@@ -344,9 +347,12 @@ int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
 }
 
 int launch_wgrad3(const WgradArgs& a, int blocks, hipStream_t st) {
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wg3Cfg::LDS_BYTES);
   });

@@ -497,9 +497,12 @@ extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* w
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_wino: too many tiles");
   EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv3x3_wino: image plane too large for 32-bit tile offsets");
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
     if (attr_err == hipSuccess)

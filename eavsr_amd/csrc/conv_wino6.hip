@@ -629,9 +629,12 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv_wino6: too many tiles");
   EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv_wino6: image plane too large for 32-bit tile offsets");
   constexpr size_t LDS_FUSE = C::LDS_BYTES + 2 * C::IN_PAD * sizeof(float);
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<R, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (R == 3 && attr_err == hipSuccess)

@@ -346,9 +346,12 @@ extern "C" int eavsr_conv3x3_f32x9(const eavsr_conv2d_desc* d, const void* weigh
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_f32x9: too many tiles");
   EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv3x3_f32x9: image plane too large for 32-bit tile offsets");
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)LDS_BYTES);
   });

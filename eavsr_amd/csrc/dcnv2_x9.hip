@@ -449,9 +449,12 @@ extern "C" int eavsr_dcnv2_f32x9(const float* x, const float* offset, const floa
   a.tiles_y = eavsr::cdiv(h, XT_ROWS);
   const long blocks = (long)a.tiles_x * a.tiles_y * n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "dcnv2_f32x9: too many tiles");
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [] {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
     attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnv2_x9_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)XLDS_BYTES);
   });

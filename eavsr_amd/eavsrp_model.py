@@ -292,6 +292,21 @@ class EAVSRPx2(EAVSRP):
 # ---------------------------------------------------------------------------------------------
 # model wrapper (eavsrp_model.py:18-119), inference side
 # ---------------------------------------------------------------------------------------------
+def make_optimizer(net: "EAVSRP", opt) -> torch.optim.Adam:
+    """Adam with the reference's two parameter groups (eavsrp_model.py:45-59): the alignment modules at lr 1e-5, the
+    rest at opt.lr -- both built from ALL of `net.parameters()` in registration order exactly as the reference builds
+    them, the 60 frozen SPyNet tensors included.  Those never receive a gradient, so Adam skips them, but they count in
+    the state_dict's parameter indices: an `EAVSRP_optimizer_Adam.pth` written by either implementation resumes in the
+    other (base_model.py:251-270)."""
+    align_ids = {id(p) for p in net.deform_align.parameters()}
+    every = list(net.parameters())
+    basic = [p for p in every if id(p) not in align_ids]
+    align = [p for p in every if id(p) in align_ids]
+    return torch.optim.Adam([{"params": basic}, {"params": align, "lr": 1e-5}], lr=getattr(opt, "lr", 1e-4),
+                            betas=(getattr(opt, "beta1", 0.9), getattr(opt, "beta2", 0.999)),
+                            weight_decay=getattr(opt, "weight_decay", 0.0))
+
+
 class EAVSRPModel:
     """Stand-in of EAVSRPModel / EAVSRPx2Model (models/eavsrp_model.py:18-119): set_input / forward / test /
     optimize_parameters / get_current_visuals / load_networks / save_networks with the reference's
@@ -315,15 +330,8 @@ class EAVSRPModel:
         self.time, self.isfirst, self.num = 0.0, True, 0
         self.epoch = 0
         if self.isTrain:
-            # two parameter groups: alignment modules at lr 1e-5, the rest at opt.lr (eavsrp_model.py:45-59)
-            align_ids = {id(p) for p in self.netEAVSRP.deform_align.parameters()}
-            trainable = [p for p in self.netEAVSRP.parameters() if p.requires_grad]
-            basic = [p for p in trainable if id(p) not in align_ids]
-            align = [p for p in trainable if id(p) in align_ids]
-            self.optimizer_EAVSRP = torch.optim.Adam(
-                [{"params": basic}, {"params": align, "lr": 1e-5}], lr=getattr(opt, "lr", 1e-4),
-                betas=(getattr(opt, "beta1", 0.9), getattr(opt, "beta2", 0.999)),
-                weight_decay=getattr(opt, "weight_decay", 0.0))
+            self.optimizer_EAVSRP = make_optimizer(self.netEAVSRP, opt)
+            trainable = [p for p in self.netEAVSRP.parameters() if p.requires_grad]   # what the gradient all-reduce carries
             self.optimizers = [self.optimizer_EAVSRP]
             from .shard import GradientAllReducer
             self.grad_sync = GradientAllReducer(trainable)

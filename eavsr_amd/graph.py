@@ -138,6 +138,7 @@ class GraphedTrainStep:
         self.static_lr = model.data_lr_seq.clone()
         self.static_hr = model.data_hr_seq.clone()
         opt = model.optimizer_EAVSRP
+        self._capturable_before = [g.get("capturable", False) for g in opt.param_groups]
         for g in opt.param_groups:                   # Adam keeps `step` on the device and never reads it back
             g["capturable"] = True
         for st in opt.state.values():
@@ -166,6 +167,17 @@ class GraphedTrainStep:
         finally:
             model.grad_sync.paused = False
             clear_weight_caches()
+        # the replayed backward writes into THESE gradient tensors (graph-pool memory).  An eager
+        # `model.optimize_parameters()` in between rebinds `p.grad` (zero_grad(set_to_none=True)); `step()` binds them back
+        # so that the all-reduce and Adam that follow a replay never see stale eager gradients.
+        self._grads = [(p, p.grad) for g in opt.param_groups for p in g["params"] if p.grad is not None]
+
+    def close(self):
+        """Give the optimizer back its pre-capture flags (`capturable`) and drop the graph."""
+        for g, c in zip(self.model.optimizer_EAVSRP.param_groups, self._capturable_before):
+            g["capturable"] = c
+        self.graph = None
+        self._grads = []
 
     def _backward(self):
         from . import autograd as AG
@@ -183,6 +195,11 @@ class GraphedTrainStep:
                 raise ValueError(f"graph captured for lr {tuple(self.static_lr.shape)} / hr {tuple(self.static_hr.shape)}")
             self.static_lr.copy_(lr)
             self.static_hr.copy_(hr)
+        if self.graph is None:
+            raise RuntimeError("GraphedTrainStep: closed")
+        m.data_lr_seq, m.data_hr_seq = self.static_lr, self.static_hr
+        for p, g in self._grads:
+            p.grad = g
         self.graph.replay()
         if self.world > 1:
             m.grad_sync.reset()

@@ -10,10 +10,15 @@ Training is plain data parallelism: every rank holds th
 forward + backward on its own clips, and the ONLY data-path communication is one all-reduce(sum) of the
 loss gradients of the 12.28 M trainable parameters (49.1 MB fp32) per step -- `GradientAllReducer`
 below: gradients are packed into ~8 MB buckets in reverse registration order (the order backward
-produces them), each bucket's all-reduce is launched asynchronously as soon as its last gradient has
-been accumulated (overlapping RCCL over xGMI with the rest of backward), and `finish()` waits, divides
-by the world size and scatters the result back into `.grad`.  No parameter broadcast per step (the
-reference's nn.DataParallel re-broadcasts all 54.9 MB every forward).
+produces them); a bucket's all-reduce is launched asynchronously from a post-accumulate-grad hook once
+every one of its parameters has received its gradient through autograd, and `finish()` launches the
+remaining buckets, waits, divides by the world size and scatters the result back into `.grad`.
+What overlaps in practice: the training step accumulates the convolution weight / bias gradients in
+`autograd.grad_sink` buffers that reach `.grad` only when backward ends (no hook fires for them), and
+nearly every bucket holds a convolution parameter -- so almost all of the 49 MB is reduced in `finish()`,
+AFTER backward, not under it.  That is a deliberate trade: the sink removes ~12,000 launches per step,
+while the whole all-reduce is ~0.6 ms at the per-link xGMI bound against a 0.4 s step.  No parameter
+broadcast per step (the reference's nn.DataParallel re-broadcasts all 54.9 MB every forward).
 """
 from __future__ import annotations
 
@@ -109,7 +114,10 @@ def gather_outputs(local: torch.Tensor, n_clips: int, rank: int, world: int) -> 
 
 
 class GradientAllReducer:
-    """Bucketed, backward-overlapped all-reduce of `.grad` (the one collective of the training step)."""
+    """Bucketed all-reduce of `.grad` (the one collective of the training step).  Buckets whose parameters all get their
+    gradient through autograd hooks are launched during backward; the rest (every bucket with a grad_sink'd convolution
+    parameter, i.e. most of them) in finish().  Bucket layouts are fixed at construction and identical on every rank:
+    a parameter without a gradient on this rank contributes zeros, never a shorter buffer."""
 
     def __init__(self, params, bucket_bytes: int = 8 << 20):
         self.params = [p for p in params if p.requires_grad]
@@ -139,10 +147,11 @@ class GradientAllReducer:
         self._work = []
 
     def _launch(self, i: int):
-        bucket = [p for p in self.buckets[i] if p.grad is not None]
-        if not bucket:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        # rank-invariant size: every parameter of the bucket has its slot, zero-filled where this rank produced no
+        # gradient (ranks that disagreed on which parameters got one would otherwise exchange buffers of different
+        # lengths -- a hang or silent corruption)
+        bucket = self.buckets[i]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
         handle = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
         self._work.append((handle, flat, bucket))
 
@@ -168,7 +177,10 @@ class GradientAllReducer:
                 o = 0
                 for p in bucket:
                     n = p.numel()
-                    p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                    if p.grad is None:           # no local gradient: it still receives the other ranks' average
+                        p.grad = flat[o:o + n].view_as(p).clone()
+                    else:
+                        p.grad.copy_(flat[o:o + n].view_as(p.grad))
                     o += n
         self.reset()
 

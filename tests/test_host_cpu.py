@@ -139,3 +139,38 @@ def test_committed_bench_line_follows_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+
+
+# ---- optimizer files are interchangeable with the reference's ------------------------------------------
+def test_optimizer_groups_follow_the_reference_grouping_and_state_dicts_round_trip():
+    """models/eavsrp_model.py:45-59 builds Adam's groups from ALL parameters() (frozen SPyNet tensors included): group 0 =
+    every non-alignment parameter in registration order, group 1 = the alignment modules at lr 1e-5.  The parameter
+    indices of an optimizer state_dict depend on exactly that, so the same construction is required here."""
+    from eavsr_amd.eavsrp_model import EAVSRP, make_optimizer
+    opt = Namespace(predict=False, n_frame=7, n_flow=5, scale=4, lr=1e-4, beta1=0.9, beta2=0.999, weight_decay=0.0)
+    net = EAVSRP(opt, None)
+    ours = make_optimizer(net, opt)
+    # the reference's construction, restated from the cited lines (filter over module.parameters())
+    align_id = []
+    for name in ["backward_1", "forward_1", "backward_2", "forward_2"]:
+        align_id += list(map(id, net.deform_align[name].parameters()))
+    basic = list(filter(lambda p: id(p) not in align_id, net.parameters()))
+    align = list(filter(lambda p: id(p) in align_id, net.parameters()))
+    ref = torch.optim.Adam([{"params": basic}, {"params": align, "lr": 1e-5}], lr=opt.lr, betas=(opt.beta1, opt.beta2),
+                           weight_decay=opt.weight_decay)
+    g_ours, g_ref = ours.state_dict()["param_groups"], ref.state_dict()["param_groups"]
+    assert [g["params"] for g in g_ours] == [g["params"] for g in g_ref]
+    assert [g["lr"] for g in g_ours] == [1e-4, 1e-5]
+    n_frozen = sum(1 for p in net.spynet.parameters())
+    assert n_frozen == 60 and len(g_ours[0]["params"]) == len(basic) and len(basic) + len(align) == len(list(net.parameters()))
+    assert all(p1 is p2 for p1, p2 in zip(ours.param_groups[0]["params"], basic))
+    # one step of the reference-grouped optimizer (frozen tensors get no gradient, hence no state), then its state_dict
+    # loads here and ours loads there
+    for p in net.parameters():
+        if p.requires_grad:
+            p.grad = torch.full_like(p, 1e-3)
+    ref.step()
+    ours.load_state_dict(ref.state_dict())
+    assert len(ours.state_dict()["state"]) == len(ref.state_dict()["state"]) == len(list(net.parameters())) - n_frozen
+    ours.step()
+    ref.load_state_dict(ours.state_dict())

@@ -126,3 +126,45 @@ def test_gradient_allreduce_averages_over_ranks():
             assert p0 is None
         else:
             assert torch.allclose(a, (p0 + p1) / 2, atol=1e-7)
+
+
+# ---- bench.py --gpus N starts its own ranks (VERDICT r1 / ADVICE r1) ---------------------------------------------------
+def _run_bench(*argv, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=e,
+                       timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_2_launches_its_own_ranks_and_reports_the_max_over_ranks():
+    """`python bench.py --gpus 2` with no launcher environment: the parent (which never touches the GPU) starts two
+    ranks through torch.distributed.run, they rendezvous on 127.0.0.1, and rank 0's single JSON line comes back through
+    the parent.  --dry: sleeps instead of kernels, gloo instead of RCCL -- the plumbing around the kernels is the same
+    code path as the measured run."""
+    r, lines = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["backend"] == "gloo"
+    assert line["dry"] is True and "DRY RUN" in line["metric"]
+    # rank r sleeps 10 ms * (1 + r) per step: the job time is the slower rank's
+    assert line["ms_per_step"] >= 19.0, line
+    assert abs(line["value"] - 2 * 4 * 7 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]   # whole-job aggregate
+
+
+def test_bench_single_rank_line_is_unchanged_by_the_launcher_and_child_failures_propagate():
+    r, lines = _run_bench("--steps", "2", "--dry")
+    assert r.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1
+    # a launcher that started a different number of ranks than --gpus is an error, not a silently different job
+    r, lines = _run_bench("--gpus", "2", "--dry", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and not lines
+    # no GPU here: the real (non-dry) 2-rank job must fail loudly, through the parent, with a non-zero status
+    r, lines = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                          env={"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert r.returncode != 0 and not lines
