@@ -90,3 +90,48 @@ def g8_clip(n=1, t=7, h=64, w=64):
 def subsample(out):
     """The part of an end-to-end output kept in the fixture."""
     return out[..., 1::4, 2::4].contiguous()
+
+
+# G4 / G9 ----------------------------------------------------------------------------
+# DCNv2 known answers: (n, c, h, w, cout, dg, sigma, seed).  c = cout = 64, dg = 8 is the reference's configuration
+# (eavsrp_model.py:143); sigma = 8 px on a 12 x 16 image puts most samples across or beyond the border, the 'edge' case
+# pins offsets to the exact validity boundary p in {-1, -1 + eps, size - eps, size} of the `-1 < p < size` gate.
+G4_CASES = {
+    "dg8_s0p5": (1, 64, 12, 16, 64, 8, 0.5, 401),
+    "dg8_s2": (2, 64, 12, 16, 64, 8, 2.0, 402),
+    "dg8_s8": (1, 64, 12, 16, 64, 8, 8.0, 403),
+    "dg8_edge": (1, 64, 8, 12, 64, 8, -1.0, 404),
+    "dg2_s2_c16": (1, 16, 9, 11, 8, 2, 2.0, 405),
+    "dg1_s1p5_ragged": (1, 8, 7, 5, 4, 1, 1.5, 406),
+}
+
+
+def g4_inputs(name):
+    n, c, h, w, co, dg, sigma, seed = G4_CASES[name]
+    x = randn(seed, n, c, h, w)
+    if sigma >= 0:
+        off = randn(seed + 1, n, dg * 18, h, w, scale=sigma)
+    else:
+        # every tap's sampling position lands on / next to the validity boundary of the image, by construction:
+        # p = y - 1 + i + dy  ->  dy = target - (y - 1 + i), target cycling through the boundary values
+        eps = 2.0 ** -10
+        ty = torch.tensor([-1.0, -1.0 + eps, -0.5, h - 1.0, h - eps, float(h), h - 0.5, 0.0])
+        tx = torch.tensor([-1.0, -1.0 + eps, -0.5, w - 1.0, w - eps, float(w), w - 0.5, 0.0])
+        off = torch.zeros(n, dg, 9, 2, h, w)
+        ys = torch.arange(h, dtype=torch.float32).view(h, 1)
+        xs = torch.arange(w, dtype=torch.float32).view(1, w)
+        pick = torch.randint(0, 8, (n, dg, 9, 2, h, w), generator=_g(seed + 1))
+        for k in range(9):
+            i, j = k // 3, k % 3
+            off[:, :, k, 0] = ty[pick[:, :, k, 0]] - (ys - 1 + i)
+            off[:, :, k, 1] = tx[pick[:, :, k, 1]] - (xs - 1 + j)
+        off = off.view(n, dg * 18, h, w)
+    mask = rand(seed + 2, n, dg * 9, h, w)
+    wt = randn(seed + 3, co, c, 3, 3, scale=1.0 / (3.0 * c ** 0.5))
+    b = randn(seed + 4, co, scale=0.1)
+    return x, off, mask, wt, b, dg
+
+
+def g9_cotangent(name, shape):
+    """the seeded upstream gradient of the G9 gradient fixtures"""
+    return randn(900 + sum(map(ord, name)), *shape)

@@ -206,6 +206,22 @@ def test_dcnv2_vs_oracle(ops, cuda, shape, sigma):
     assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("mode", ["native", "bf16x9"])
+@pytest.mark.parametrize("name", list(cases.G4_CASES))
+def test_dcnv2_committed_known_answers(ops, cuda, name, mode):
+    """the stored outputs of the plain-C restatement (tests/golden/g4_dcnv2.npz) -- borders, |offset| > 1,
+    dg = 8, sigma in {0.5, 2, 8}, exact validity-boundary positions -- through every DCNv2 kernel variant."""
+    gold = H.golden("g4_dcnv2")[name]
+    x, off, mask, wt, b, dg = cases.g4_inputs(name)
+    prev = ops.DCN_MODE
+    ops.set_dcn_mode(mode)
+    try:
+        out = ops.modulated_deform_conv2d(g(x, cuda), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), 1, 1, 1, 1, dg)
+    finally:
+        ops.set_dcn_mode(prev)
+    assert H.maxabs(out.cpu(), gold) <= 3e-5 * max(1.0, gold.abs().max().item())
+
+
 def test_dcnv2_zero_offset_unit_mask_is_conv2d(ops, cuda):
     x, off, mask, wt, b = _dcn_inputs(1, 64, 20, 30, 64, 8, 0.0)
     out = ops.modulated_deform_conv2d(g(x, cuda), g(off * 0, cuda), g(torch.ones_like(mask), cuda), g(wt, cuda),

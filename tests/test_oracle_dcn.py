@@ -84,3 +84,41 @@ def test_half_pixel_offset_is_the_mean_of_neighbours_and_border_is_zero_padded()
 def test_c_flow_warp_agrees_with_oracle():
     for name, (x, flow, pad) in cases.g1_flow_warp_cases().items():
         assert H.maxabs(c_ref.flow_warp(x, flow, pad), O.flow_warp(x, flow, pad)) <= 5e-5 * max(1, x.abs().max().item()), name
+
+
+# ---- committed known answers (tests/golden/gen_known_answers.py) ---------------------------------------
+@pytest.mark.parametrize("name", list(cases.G4_CASES))
+def test_every_restatement_reproduces_the_committed_known_answers(name):
+    """G4 was computed by the plain-C restatement with double accumulation; the two PyTorch restatements and a fresh
+    run of the C code must reproduce the stored outputs -- borders, |offset| > 1, dg = 8, exact boundary positions."""
+    gold = H.golden("g4_dcnv2")[name]
+    x, off, mask, wt, b, dg = cases.g4_inputs(name)
+    tol = 2e-5 * max(1.0, gold.abs().max().item())
+    assert H.maxabs(c_ref.dcnv2(x, off, mask, wt, b, 1, 1, 1, dg), gold) == 0.0
+    assert H.maxabs(O.dcnv2(x, off, mask, wt, b, 1, 1, 1, 1, dg), gold) <= tol
+    if name != "dg8_edge":   # grid_sample's normalise / un-normalise round trip moves exact-boundary positions by an ulp
+        assert H.maxabs(O.dcnv2_via_grid_sample(x, off, mask, wt, b, 1, 1, 1, 1, dg), gold) <= tol
+
+
+@pytest.mark.parametrize("name", ["dg8_s2", "dg2_s2_c16", "dg1_s1p5_ragged"])
+def test_oracle_autograd_reproduces_the_committed_gradients(name):
+    """G9: fp64 autograd gradients, stored as fp32; the fp32 oracle the GPU tests differentiate must agree with them."""
+    gold = H.golden("g9_gradients")
+    x, off, mask, wt, b, dg = cases.g4_inputs(name)
+    leaves = [t.clone().requires_grad_(True) for t in (x, off, mask, wt, b)]
+    out = O.dcnv2(*leaves, 1, 1, 1, 1, dg)
+    grads = torch.autograd.grad((out * cases.g9_cotangent(name, out.shape)).sum(), leaves)
+    for key, gr in zip(("dx", "doffset", "dmask", "dweight", "dbias"), grads):
+        want = gold[f"dcn_{name}__{key}"]
+        assert H.maxabs(gr, want) <= 1e-4 * max(1.0, want.abs().max().item()), key
+    for wname, (xw, flow, pad) in cases.g1_flow_warp_cases().items():
+        lv = [xw.clone().requires_grad_(True), flow.clone().requires_grad_(True)]
+        o = O.flow_warp(lv[0], lv[1], pad)
+        dx, dflow = torch.autograd.grad((o * cases.g9_cotangent(wname, o.shape)).sum(), lv)
+        for key, gr in (("dx", dx), ("dflow", dflow)):
+            if (wname, key) == ("c4_int_zeros", "dflow"):
+                continue    # exact-integer positions: d/dflow is discontinuous there and the side taken depends on the
+                            # last ulp of the normalise / un-normalise round trip (fp32 vs the fixture's fp64)
+            want = gold[f"warp_{wname}__{key}"]
+            bad = ((gr - want).abs() > 2e-4 * max(1.0, want.abs().max().item())).float().mean().item()
+            assert bad <= 0.002, (wname, key, bad)     # fp32 vs fp64 floor() may differ at a handful of positions
