@@ -159,7 +159,25 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
     extrapolation.  Child process (never initialises the GPU), hard time budget.  Only if not even the warm-up + one
     timed run of the full clip fit the budget does it fall back to a crop scaled by the pixel ratio, and says so."""
     import statistics
-    cores = threads if threads > 0 else usable_cores()
+    probe = ""
+    if threads > 0:
+        cores = threads
+    else:
+        # every usable core is offered; torch's CPU kernels do not always scale to all of them (a 256-thread host ran this
+        # workload slower than with 32 threads), so the thread count is the fastest of a short probe on the fallback crop
+        usable = usable_cores()
+        cands = sorted({c for c in (16, 32, 64, 128, usable) if c <= usable})
+        best = None
+        for c in cands:
+            secs_p, _ = _run_cpu_child(preset, frames, crop_h, crop_w, c, 1, 40.0, timeout_s=60)
+            if len(secs_p) >= 2:
+                probe += f"{c}: {secs_p[-1]:.1f} s; "
+                if best is None or secs_p[-1] < best[1]:
+                    best = (c, secs_p[-1])
+            else:
+                probe += f"{c}: > 60 s; "
+        cores = best[0] if best else min(usable, 32)
+        probe = f" (thread count chosen by a probe on a {crop_h}x{crop_w} clip over {usable} usable cores -- {probe.rstrip('; ')})"
     base = {"unit": "frames/s", "cores": cores, "kind": "port"}
     secs, err = _run_cpu_child(preset, frames, full_h, full_w, cores, runs, budget, timeout_s=budget + 60)
     if len(secs) >= 2:
@@ -169,7 +187,7 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
                     sample=f"1 clip x {frames} frames x 3 x {full_h} x {full_w} (one clip of the timed workload, full size), "
                            f"oracle/eavsr_oracle.py eavsrp_forward on torch {torch.__version__} CPU with {cores} threads: "
                            f"1 warm-up run ({secs[0]:.1f} s, discarded) + {len(timed)} timed run(s) "
-                           f"{[round(x, 1) for x in timed]} s, median {med:.1f} s; no extrapolation")
+                           f"{[round(x, 1) for x in timed]} s, median {med:.1f} s; no extrapolation" + probe)
     # fallback: the full clip did not finish twice within the budget
     secs_c, err_c = _run_cpu_child(preset, frames, crop_h, crop_w, cores, 1, 120.0, timeout_s=180)
     if len(secs_c) >= 2:

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -50,11 +50,14 @@ SIGNATURES = {
     "eavsr_last_error": (C.c_char_p, []),
     "eavsr_selftest_mfma_f32": (C.c_int, [vp, vp]),
     "eavsr_flow_warp_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_flow_warp_pair_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_generic_f32": (C.c_int, [vp] * 6 + [i32] * 15 + [vp]),
     "eavsr_dcn_weight_x9_bytes": (C.c_int64, [i32, i32]),
     "eavsr_pack_dcn_weight_x9": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_dcnv2_f32x9": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_nchw_to_il8_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_dcnv2_il_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "eavsr_conv3x3_f32x9": (C.c_int, [vp, vp, vp]),
     "eavsr_wino_weight_elems": (C.c_int64, [i32, i32]),

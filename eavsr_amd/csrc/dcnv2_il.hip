@@ -1,0 +1,522 @@
+// DCNv2 forward, the hot-path kernel of round 2 (a7; north star: >= 30 % of the HBM roofline).
+//
+// Reference semantics: mmcv.ops.modulated_deform_conv2d as called at models/networks.py:627-630 (see dcnv2.hip for
+// the restated algorithm), optionally with the affine -> 18 offsets expansion and the mask sigmoid of
+// AdaptBlockOffset (networks.py:302-315) folded into the sampler's per-group set-up ("heads" mode: the kernel reads
+// the 15 D head channels of the predictor instead of 27 D offset / mask channels that another kernel wrote).
+//
+// What changed against dcnv2_x9.hip (round 1), and why -- that kernel was bound three ways at once (matrix pipe,
+// LDS and vector issue all near 100 % of the same interval, so nothing overlapped):
+//   * INPUT LAYOUT "IL8": the sampled feature map arrives as [n][c/8][h][w][8] (the 8 channels of a deformable group
+//     interleaved per pixel, 32 bytes).  The producer is the flow_warp just before it (networks.py:623), which writes
+//     that layout for free; eavsr_nchw_to_il8_f32 converts for every other caller.  A bilinear corner of a (pixel, tap)
+//     is then ONE contiguous 32-byte read: a sample is 8 ds_read_b128 (256 B/clk) instead of 16 ds_read2_b32
+//     (128 B/clk) -- half the LDS time of the sampler -- and the 8 values a lane needs for its MFMA B operand
+//     (k = 8 channels of one tap) arrive already in k order.  The window DMA moves whole 1536-byte window rows.
+//   * PRODUCTS: NPROD = 9 is the exact bf16x9 contraction of round 1 (every fp32 operand split exactly into three
+//     bf16 terms, all nine partial products); NPROD = 6 drops the three products below 2^-23 of the result
+//     (mid*lo, lo*mid, lo*lo): per product that is at most 2 * 2^-24 relative, the size of ONE fp32 rounding, and a
+//     third less matrix work.  Both are fp32-faithful; tests compare both with an fp64 evaluation.
+//   * persistent workgroups over a flattened (tile, group) sequence: the window / weight DMA of the next tile's first
+//     group runs under the last group of the current one.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16): M = 32 output channels (2 tiles), N = 32 pixels of one image row,
+// k-step = 16 k = 2 taps x 8 channels of one group; lane (n = lane & 31, kg = lane >> 5) samples pixel n for tap
+// 2 s + kg of k-step s and feeds its 8 blended, split values straight from registers (no column tile in LDS).
+#include "common.h"
+
+#include <mutex>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float ld_b(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+__device__ __attribute__((aligned(16))) float g_il_zero[4];
+
+constexpr int IT_ROWS = 8, IT_W = 32;                 // pixel tile: one 32-pixel row per wave
+constexpr int IG = 8;                                 // channels per group = k of one tap
+constexpr int IK = 9, ISTEPS = 5;                     // taps; k-steps per group (taps 2s, 2s+1; tap 9 is zero)
+constexpr int IPH = IT_ROWS + 12, IPW = 48;           // LDS window rows y0-6 .. y0+13, columns x0-8 .. x0+39
+constexpr int IPY0 = 6, IPX0 = 8;
+constexpr int IWIN_F = IPH * IPW * IG;                // 7680 floats = 30 one-KiB DMA pieces
+constexpr int IWIN_SEGS = IWIN_F / 256;               // 30
+constexpr int IW_U4 = ISTEPS * 3 * 2 * 64;            // 16-byte elements of one group's weight slab (CO = 64)
+constexpr int IW_SEGS = IW_U4 / 64;                   // 30
+constexpr int INPIECE = IWIN_SEGS + IW_SEGS;          // 60
+constexpr int IP_IT = (INPIECE + 7) / 8;              // pieces per wave: 8
+constexpr size_t ILDS_BYTES = 2 * (size_t)IWIN_F * 4 + 2 * (size_t)IW_U4 * 16;   // 122,880
+
+struct ILArgs {
+  const float* xil;      // [n][cin/8][h][w][8]
+  const float* offset;   // explicit mode: (n, dg*18, h, w);  heads mode: (n, 15*dg, h, w)
+  const float* mask;     // explicit mode: (n, dg*9, h, w);   heads mode: unused
+  const u32x4* wsplit;   // [cot][group][step][term][mt][lane] 16-byte elements (eavsr_pack_dcn_weight_x9)
+  const float* bias;
+  float* out;            // (n, cout, h, w)
+  int n, cin, h, w, cout, dg, cpg, tiles_x, tiles_y, ntiles;
+};
+
+// exact three-way split of two fp32 values into packed bf16 pairs (low half = first value)
+__device__ __forceinline__ void il_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
+  const unsigned uma = __float_as_uint(ra), umb = __float_as_uint(rb);
+  const float la = ra - __uint_as_float(uma & 0xFFFF0000u), lb = rb - __uint_as_float(umb & 0xFFFF0000u);
+  hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+  mid = __builtin_amdgcn_perm(umb, uma, 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+}
+
+__device__ __forceinline__ f32x16 il_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int NPROD, bool HEADS>
+__global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_win = smem;                                                   // [2][IWIN_F]
+  u32x4* s_w = reinterpret_cast<u32x4*>(smem + 2 * IWIN_F);              // [2][IW_U4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+  const unsigned uplane = (unsigned)plane;
+  const int ngroups = a.cin / IG;
+  const int cot = blockIdx.y;
+
+  // persistent tile walk, XCD-aware: workgroups b, b + 8, .. share an XCD (and its L2); XCD x owns a contiguous run of
+  // tiles, so that tiles sharing halo rows / columns are fetched through the same L2
+  const int nb = gridDim.x;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_xcd_wg = (nb + 7 - xcd) >> 3;                      // workgroups on this XCD
+  const int q = a.ntiles >> 3, r = a.ntiles & 7;
+  const int t_begin = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int t_count = q + (xcd < r ? 1 : 0);
+  const int my_tiles = slot < t_count ? (t_count - slot + per_xcd_wg - 1) / per_xcd_wg : 0;
+  if (my_tiles == 0) return;
+  auto tile_of = [&](int i, int& bn, int& y0, int& x0) __attribute__((always_inline)) {
+    int t = t_begin + slot + i * per_xcd_wg;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    bn = t / a.tiles_y;
+    y0 = ty * IT_ROWS;
+    x0 = tx * IT_W;
+  };
+
+  // DMA pieces of a (tile, group): window piece p = i * 8 + wave (p < IWIN_SEGS; 64 lanes x 16 bytes = 32 window
+  // positions, the window row is 96 such 16-byte units) and weight-slab piece seg = i * 8 + wave (seg < IW_SEGS)
+  constexpr int WIN_IT = (IWIN_SEGS + 7) / 8, W_IT = (IW_SEGS + 7) / 8;
+  int prc[WIN_IT];                   // (window row << 8) | 16-byte column of this lane's unit in piece i
+#pragma unroll
+  for (int i = 0; i < WIN_IT; ++i) {
+    const int e4 = (i * 8 + wave) * 64 + lane;
+    const int rr = e4 / (2 * IPW);
+    prc[i] = (rr << 8) | (e4 - rr * (2 * IPW));
+  }
+  auto issue = [&](int bn, int y0, int x0, int g, int stage) __attribute__((always_inline)) {
+    const char* xb = reinterpret_cast<const char*>(a.xil + ((size_t)bn * ngroups + g) * plane * IG);
+    const char* wsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)cot * ngroups + g) * IW_U4);
+#pragma unroll
+    for (int i = 0; i < WIN_IT; ++i) {
+      const int p = i * 8 + wave;  // wave-uniform
+      if (p < IWIN_SEGS) {
+        const int pcol = prc[i] & 255;
+        const int yy = y0 - IPY0 + (prc[i] >> 8), xx = x0 - IPX0 + (pcol >> 1);
+        const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        const unsigned off = (unsigned)((yy * w + xx) * 32 + (pcol & 1) * 16);
+        const char* src = ok ? xb + off : reinterpret_cast<const char*>(g_il_zero);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_win + stage * IWIN_F + p * 256), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int seg = i * 8 + wave;
+      if (seg < IW_SEGS)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (unsigned)(seg * 64 + lane) * 16u),
+                                         (lptr_t)(s_w + stage * IW_U4 + seg * 64), 16, 0, 0);
+    }
+  };
+
+  // per-lane tap of k-step s: 2 s + kg (tap 9 does not exist: kg = 1 lanes idle in the last step); its regular-grid
+  // coordinates (-1, 0, 1) are recomputed where needed (s is a compile-time constant, kg one bit)
+  auto grid_of = [&](int s, float& ry, float& rx) __attribute__((always_inline)) {
+    const int tap = min(2 * s + kg, IK - 1);
+    const int ti = (tap * 11) >> 5;          // tap / 3 for tap < 9
+    ry = (float)(ti - 1);
+    rx = (float)(tap - 3 * ti - 1);
+  };
+
+  // raw per-group sampling parameters (dead once set-up has turned them into weights and addresses; the next
+  // group's values are loaded straight into them).  explicit: (dy, dx, mask) per k-step; heads: the 2x2 transform,
+  // the translation and the mask logits of the lane's taps
+  float pa[ISTEPS], pb[ISTEPS], pm[ISTEPS];
+  float tf[6];
+  auto load_slot = [&](int bn, unsigned pix, int g, int s) __attribute__((always_inline)) {
+    const int dgi = g * IG / a.cpg;
+    const unsigned tap = (unsigned)min(2 * s + kg, IK - 1);
+    if (HEADS) {
+      const float* hb = a.offset + (size_t)bn * 15 * a.dg * plane;
+      pm[s] = ld_b(hb, ((unsigned)(6 * a.dg + dgi * 9) * uplane + tap * uplane + pix) * 4u);
+    } else {
+      const float* offb = a.offset + ((size_t)bn * a.dg + dgi) * 18 * plane;
+      const float* mkb = a.mask + ((size_t)bn * a.dg + dgi) * 9 * plane;
+      pa[s] = ld_b(offb, (2u * tap * uplane + pix) * 4u);
+      pb[s] = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
+      pm[s] = ld_b(mkb, (tap * uplane + pix) * 4u);
+    }
+  };
+  auto load_affine = [&](int bn, unsigned pix, int g) __attribute__((always_inline)) {
+    if (HEADS) {
+      const int dgi = g * IG / a.cpg;
+      const float* hb = a.offset + (size_t)bn * 15 * a.dg * plane;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tf[j] = ld_b(hb, ((unsigned)(dgi * 4 + j) * uplane + pix) * 4u);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tf[4 + j] = ld_b(hb, ((unsigned)(4 * a.dg + dgi * 2 + j) * uplane + pix) * 4u);
+    }
+  };
+
+  struct Pos {
+    float w1, w2, w3, w4;   // bilinear corner weights x mask (0 when the sample is outside the image / the tap idle)
+    int q;                  // float offset of the top-left corner in the LDS window stage
+  };
+
+  // ---- current tile -------------------------------------------------------------------------------------------
+  int bn, y0, x0;
+  tile_of(0, bn, y0, x0);
+  int gy = y0 + wave, gx = x0 + l31;
+  bool pix_ok = gy < h && gx < w;
+  unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
+
+  constexpr int WAIT_VM0 = 0x0F70;
+  // every window position is (re)written by each step's DMA, from the image or from the zero line: no LDS pre-fill
+  issue(bn, y0, x0, 0, 0);
+  load_affine(bn, pix, 0);
+#pragma unroll
+  for (int s = 0; s < ISTEPS; ++s) load_slot(bn, pix, 0, s);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+
+  const int total = my_tiles * ngroups;
+  int g = 0, ti_ = 0;
+  for (int it = 0; it < total; ++it) {
+    const int stage = it & 1;
+    // window, weights and parameters of this step have landed; every wave is done with the other stage
+    __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+    __syncthreads();
+    // the step after this one: next group of this tile, or group 0 of the next tile
+    const bool last_g = g + 1 == ngroups;
+    const bool more = it + 1 < total;
+    int nbn = bn, ny0 = y0, nx0 = x0;
+    if (last_g && more) tile_of(ti_ + 1, nbn, ny0, nx0);
+    const int ng = last_g ? 0 : g + 1;
+    if (more) issue(nbn, ny0, nx0, ng, stage ^ 1);
+    const int ngy = ny0 + wave, ngx = nx0 + l31;
+    const bool npix_ok = ngy < h && ngx < w;
+    const unsigned npix = npix_ok ? (unsigned)(ngy * w + ngx) : 0u;
+
+    const float* wst_win = s_win + stage * IWIN_F;
+    const u32x4* wst = s_w + stage * IW_U4 + lane;
+    const float fgy = (float)gy, fgx = (float)gx;
+
+    // set-up of one (pixel, tap) position; its parameter registers are then free for the next step's values
+    Pos pos[2];
+    unsigned slow_steps = 0;
+    auto setup = [&](int s) __attribute__((always_inline)) {
+      float ryk, rxk;
+      grid_of(s, ryk, rxk);
+      float dy, dx, m;
+      if (HEADS) {
+        // (T . R)[:,k] - R[:,k] + t   (matmul, subtract, add: networks.py:304-311)
+        dy = (tf[0] * ryk + tf[1] * rxk) - ryk + tf[4];
+        dx = (tf[2] * ryk + tf[3] * rxk) - rxk + tf[5];
+        m = 1.f / (1.f + __expf(-pm[s]));
+      } else {
+        dy = pa[s]; dx = pb[s]; m = pm[s];
+      }
+      const bool tap_ok = (s < ISTEPS - 1) || kg == 0;
+      const float py = (fgy + ryk) + dy;
+      const float px = (fgx + rxk) + dx;
+      const bool in = pix_ok && tap_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+      const float fy0 = floorf(py), fx0 = floorf(px);
+      const float lh = py - fy0, lw = px - fx0;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
+      const int ry = hl - (y0 - IPY0), rx = wl - (x0 - IPX0);
+      const bool in_win = ry >= 0 && ry <= IPH - 2 && rx >= 0 && rx <= IPW - 2;
+      const bool fast = in && in_win;
+      const float mf = fast ? m : 0.f;
+      const float hm = hh * mf, lm = lh * mf;
+      Pos& ps = pos[s & 1];
+      ps.w1 = hm * hw; ps.w2 = hm * lw; ps.w3 = lm * hw; ps.w4 = lm * lw;
+      ps.q = fast ? (ry * IPW + rx) * IG : 0;
+      slow_steps |= (in && !in_win) ? (1u << s) : 0u;
+    };
+
+    // three-deep software pipeline over the k-steps in one scheduled block:
+    //   A: the 8 ds_read_b128 of step s+2   B: blend + split of step s+1   C: A-operand reads + MFMAs of step s
+    f32x4 gat[2][8];
+    u32x4 bop[2][3];
+    const int lbn = more ? nbn : bn, lg = more ? ng : g;       // the last step reloads its own values: no branch in the block
+    const unsigned lpix = more ? npix : pix;
+    auto stage_a = [&](int t) __attribute__((always_inline)) {
+      setup(t);
+      const f32x4* qq = reinterpret_cast<const f32x4*>(wst_win + pos[t & 1].q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gat[t & 1][j] = qq[j];                      // top-left, top-right: 64 contiguous bytes
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gat[t & 1][4 + j] = qq[IPW * IG / 4 + j];   // bottom-left, bottom-right
+      load_slot(lbn, lpix, lg, t);
+      if (t == ISTEPS - 1) load_affine(lbn, lpix, lg);
+    };
+    auto stage_b = [&](int t) __attribute__((always_inline)) {
+      const Pos& ps = pos[t & 1];
+      float v[IG];
+#pragma unroll
+      for (int c = 0; c < IG; ++c) {
+        const int j = c >> 2, e = c & 3;
+        float tv = ps.w1 * gat[t & 1][j][e];
+        tv += ps.w2 * gat[t & 1][2 + j][e];
+        tv += ps.w3 * gat[t & 1][4 + j][e];
+        tv += ps.w4 * gat[t & 1][6 + j][e];
+        v[c] = tv;
+      }
+#pragma unroll
+      for (int c = 0; c < IG / 2; ++c) {
+        unsigned h2, m2, l2;
+        il_split2(v[2 * c], v[2 * c + 1], h2, m2, l2);
+        bop[t & 1][0][c] = h2; bop[t & 1][1][c] = m2; bop[t & 1][2][c] = l2;
+      }
+    };
+    auto stage_c = [&](int t, const u32x4 (&b)[3], f32x16 (&ac)[2]) __attribute__((always_inline)) {
+      const u32x4* ws = wst + t * (3 * 2 * 64);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const u32x4 ah = ws[(0 * 2 + mt) * 64], am = ws[(1 * 2 + mt) * 64], al = ws[(2 * 2 + mt) * 64];
+        // partial products, smallest first
+        if (NPROD == 9) {
+          ac[mt] = il_mfma(al, b[2], ac[mt]);
+          ac[mt] = il_mfma(al, b[1], ac[mt]);
+          ac[mt] = il_mfma(am, b[2], ac[mt]);
+        }
+        ac[mt] = il_mfma(al, b[0], ac[mt]);
+        ac[mt] = il_mfma(ah, b[2], ac[mt]);
+        ac[mt] = il_mfma(am, b[1], ac[mt]);
+        ac[mt] = il_mfma(am, b[0], ac[mt]);
+        ac[mt] = il_mfma(ah, b[1], ac[mt]);
+        ac[mt] = il_mfma(ah, b[0], ac[mt]);
+      }
+    };
+    stage_a(0);
+    stage_a(1);
+    stage_b(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < ISTEPS; ++t) {
+      if (t + 2 < ISTEPS) stage_a(t + 2);
+      if (t + 1 < ISTEPS) stage_b(t + 1);
+      stage_c(t, bop[t & 1], acc);
+#pragma unroll
+      for (int i = 0; i < 2 * NPROD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, NPROD == 9 ? 5 : 7, 0);      // vector work in its shadow
+        __builtin_amdgcn_sched_group_barrier(0x100, NPROD == 9 ? 1 : 2, 0);      // LDS reads
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // rare: a corner left the LDS window.  Those lanes contributed exactly zero above; their samples are redone from
+    // global memory (IL8: one corner = 32 contiguous bytes) with corner-wise zero padding and multiplied in.
+    if (__builtin_amdgcn_ballot_w64(slow_steps != 0) != 0) {
+      const int dgi = g * IG / a.cpg;
+      const float* xg = a.xil + ((size_t)bn * ngroups + g) * plane * IG;
+      for (int t = 0; t < ISTEPS; ++t) {
+        const bool mine = (slow_steps >> t) & 1u;
+        if (__builtin_amdgcn_ballot_w64(mine) == 0) continue;
+        float v[IG];
+#pragma unroll
+        for (int c = 0; c < IG; ++c) v[c] = 0.f;
+        if (mine) {
+          const unsigned tap = (unsigned)min(2 * t + kg, IK - 1);
+          const float ryt = (float)((int)tap / 3 - 1), rxt = (float)((int)tap % 3 - 1);
+          float dy, dx, m;
+          if (HEADS) {
+            const float* hb = a.offset + (size_t)bn * 15 * a.dg * plane;
+            float tt[6];
+            for (int j = 0; j < 4; ++j) tt[j] = ld_b(hb, ((unsigned)(dgi * 4 + j) * uplane + pix) * 4u);
+            for (int j = 0; j < 2; ++j) tt[4 + j] = ld_b(hb, ((unsigned)(4 * a.dg + dgi * 2 + j) * uplane + pix) * 4u);
+            dy = (tt[0] * ryt + tt[1] * rxt) - ryt + tt[4];
+            dx = (tt[2] * ryt + tt[3] * rxt) - rxt + tt[5];
+            m = 1.f / (1.f + __expf(-ld_b(hb, ((unsigned)(6 * a.dg + dgi * 9) * uplane + tap * uplane + pix) * 4u)));
+          } else {
+            const float* offb = a.offset + ((size_t)bn * a.dg + dgi) * 18 * plane;
+            const float* mkb = a.mask + ((size_t)bn * a.dg + dgi) * 9 * plane;
+            dy = ld_b(offb, (2u * tap * uplane + pix) * 4u);
+            dx = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
+            m = ld_b(mkb, (tap * uplane + pix) * 4u);
+          }
+          const float py = (fgy + ryt) + dy;
+          const float px = (fgx + rxt) + dx;
+          const float fy0 = floorf(py), fx0 = floorf(px);
+          const float lh = py - fy0, lw = px - fx0;
+          const float hm = (1.f - lh) * m, lm = lh * m, hw = 1.f - lw;
+          const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
+          const int hh_i = hl + 1, wh_i = wl + 1;
+          const bool t_ok = hl >= 0, b_ok = hh_i <= h - 1, l_ok = wl >= 0, r_ok = wh_i <= w - 1;
+          const float cw[4] = {(t_ok & l_ok) ? hm * hw : 0.f, (t_ok & r_ok) ? hm * lw : 0.f,
+                               (b_ok & l_ok) ? lm * hw : 0.f, (b_ok & r_ok) ? lm * lw : 0.f};
+          const int cy[2] = {min(max(hl, 0), h - 1), min(max(hh_i, 0), h - 1)};
+          const int cx[2] = {min(max(wl, 0), w - 1), min(max(wh_i, 0), w - 1)};
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const f32x4* cp = reinterpret_cast<const f32x4*>(xg + ((size_t)cy[k4 >> 1] * w + cx[k4 & 1]) * IG);
+            const f32x4 lo4 = cp[0], hi4 = cp[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] += cw[k4] * lo4[e];
+              v[4 + e] += cw[k4] * hi4[e];
+            }
+          }
+        }
+        u32x4 b[3];
+#pragma unroll
+        for (int c = 0; c < IG / 2; ++c) {
+          unsigned h2, m2, l2;
+          il_split2(v[2 * c], v[2 * c + 1], h2, m2, l2);
+          b[0][c] = h2; b[1][c] = m2; b[2][c] = l2;
+        }
+        stage_c(t, b, acc);
+      }
+    }
+
+    // ---- end of a tile: bias, store, next tile's coordinates ------------------------------------------------------
+    if (last_g) {
+      if (pix_ok) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int co = cot * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (co < a.cout) {
+              const float b = a.bias ? a.bias[co] : 0.f;
+              a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = acc[m][e] + b;
+            }
+          }
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+      bn = nbn; y0 = ny0; x0 = nx0;
+      gy = ngy; gx = ngx; pix_ok = npix_ok; pix = npix;
+      g = 0;
+      ++ti_;
+    } else {
+      ++g;
+    }
+  }
+}
+
+// (n, c, h, w) fp32 -> IL8 [n][c/8][h][w][8]: one thread per (pixel, octet), 8 coalesced plane reads, two float4 writes
+__global__ __launch_bounds__(256) void nchw_to_il8_kernel(const float* __restrict__ x, float* __restrict__ out, int oct,
+                                                          int hw) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int o = blockIdx.y, bn = blockIdx.z;
+  const float* xp = x + ((size_t)bn * oct + o) * 8 * hw + p;
+  f32x4 lo, hi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    lo[e] = xp[(size_t)e * hw];
+    hi[e] = xp[(size_t)(4 + e) * hw];
+  }
+  f32x4* op = reinterpret_cast<f32x4*>(out + (((size_t)bn * oct + o) * hw + p) * 8);
+  op[0] = lo;
+  op[1] = hi;
+}
+
+template <int NPROD, bool HEADS>
+int launch_il(const ILArgs& a, dim3 grid, hipStream_t st) {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnv2_il_kernel<NPROD, HEADS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)ILDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("dcnv2_il: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  hipLaunchKernelGGL((dcnv2_il_kernel<NPROD, HEADS>), grid, dim3(512), ILDS_BYTES, st, a);
+  return eavsr::launch_status("dcnv2_il");
+}
+
+}  // namespace
+
+extern "C" int eavsr_nchw_to_il8_f32(const float* x, float* out, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+  EAVSR_REQUIRE(x && out, -1, "nchw_to_il8: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c > 0 && h > 0 && w > 0 && c % 8 == 0, -1, "nchw_to_il8: bad dims (c %% 8 == 0 required)");
+  EAVSR_REQUIRE((long)h * w < (1L << 28) && c / 8 <= 65535 && n <= 65535, -1, "nchw_to_il8: too large");
+  if (n == 0) return 0;
+  const int hw = h * w;
+  hipLaunchKernelGGL(nchw_to_il8_kernel, dim3(eavsr::cdiv(hw, 256), c / 8, n), dim3(256), 0, eavsr::as_stream(stream), x, out,
+                     c / 8, hw);
+  return eavsr::launch_status("nchw_to_il8");
+}
+
+extern "C" int eavsr_dcnv2_il_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
+                                  const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                                  int32_t deform_groups, int32_t nprod, int32_t heads, void* stream) {
+  EAVSR_REQUIRE(x_il8 && offset_or_heads && weight_x9 && out && (heads || mask), -1, "dcnv2_il: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && cin > 0 && h > 0 && w > 0 && cout > 0 && deform_groups > 0, -1, "dcnv2_il: bad dims");
+  EAVSR_REQUIRE(cin % deform_groups == 0, -1, "dcnv2_il: cin %d not divisible by deform_groups %d", cin, deform_groups);
+  const int cpg = cin / deform_groups;
+  EAVSR_REQUIRE(cpg % 8 == 0, -2, "dcnv2_il: %d channels per deformable group unsupported (must be a multiple of 8)", cpg);
+  EAVSR_REQUIRE(nprod == 6 || nprod == 9, -2, "dcnv2_il: nprod %d (6 or 9)", nprod);
+  EAVSR_REQUIRE((long)h * w * 32 < (1L << 31), -1, "dcnv2_il: plane too large for 32-bit byte offsets");
+  EAVSR_REQUIRE((long)h * w * 15 * deform_groups * 4 < (1L << 32) || !heads, -1, "dcnv2_il: heads tensor too large");
+  EAVSR_REQUIRE((((uintptr_t)x_il8) & 15) == 0, -2, "dcnv2_il: x must be 16-byte aligned");
+  if (n == 0) return 0;
+  ILArgs a;
+  a.xil = x_il8; a.offset = offset_or_heads; a.mask = mask; a.wsplit = reinterpret_cast<const u32x4*>(weight_x9);
+  a.bias = bias; a.out = out;
+  a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout; a.dg = deform_groups; a.cpg = cpg;
+  a.tiles_x = eavsr::cdiv(w, IT_W);
+  a.tiles_y = eavsr::cdiv(h, IT_ROWS);
+  const long tiles = (long)a.tiles_x * a.tiles_y * n;
+  EAVSR_REQUIRE(tiles < (1L << 31), -1, "dcnv2_il: too many tiles");
+  a.ntiles = (int)tiles;
+  int cus = 256;
+  {
+    static int cu_cache[eavsr::kMaxDevices] = {};
+    const int dev = eavsr::current_device();
+    if (cu_cache[dev] == 0) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cu_cache[dev] = v;
+      else cu_cache[dev] = 256;
+    }
+    cus = cu_cache[dev];
+  }
+  dim3 grid((unsigned)(tiles < cus ? tiles : cus), eavsr::cdiv(cout, 64));
+  hipStream_t st = eavsr::as_stream(stream);
+  if (nprod == 9) return heads ? launch_il<9, true>(a, grid, st) : launch_il<9, false>(a, grid, st);
+  return heads ? launch_il<6, true>(a, grid, st) : launch_il<6, false>(a, grid, st);
+}

@@ -85,6 +85,91 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(
   }
 }
 
+// Two feature maps warped by the SAME flow in one launch (networks.py:621 and :623: `nbr_feat_l[0]` and `feat_prop` are
+// both warped by the refined offset): the flow is read and the corner weights are computed once per (pixel, channel
+// chunk) as before, but one launch covers both tensors.  The second output may be written in the "IL8" layout
+// [n][c/8][h][w][8] that eavsr_dcnv2_il_f32 samples from (the warp of feat_prop feeds DCNv2 and nothing else).
+__global__ __launch_bounds__(256) void flow_warp_pair_kernel(
+    const float* __restrict__ xa, const float* __restrict__ xb, const float* __restrict__ flow,
+    const float* __restrict__ flow2, float* __restrict__ outa, float* __restrict__ outb, int n, int c, int h, int w,
+    int c_chunks, int tiles_x, int tiles_y, int b_il8) {
+  int lid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = lid % tiles_x;
+  lid /= tiles_x;
+  const int ty = lid % tiles_y;
+  lid /= tiles_y;
+  const int chunk = lid % (2 * c_chunks);
+  const int bn = lid / (2 * c_chunks);
+  const bool second = chunk >= c_chunks;
+  const int c0 = (second ? chunk - c_chunks : chunk) * kChanPerThread;
+  const int px = tx * 64 + threadIdx.x;
+  const int py = ty * 4 + threadIdx.y;
+  if (px >= w || py >= h) return;
+  const size_t plane = (size_t)h * w;
+  const size_t fo = (size_t)bn * 2 * plane + (size_t)py * w + px;
+  float fx = flow[fo];
+  float fy = flow[fo + plane];
+  if (flow2 != nullptr) {
+    fx += flow2[fo];
+    fy += flow2[fo + plane];
+  }
+  // the reference's op sequence (networks.py:727-731 + grid_sample align_corners=True), as flow_warp_kernel
+  const float gx = (float)px + fx;
+  const float gy = (float)py + fy;
+  const float nx = 2.0f * gx / (float)max(w - 1, 1) - 1.0f;
+  const float ny = 2.0f * gy / (float)max(h - 1, 1) - 1.0f;
+  float ix = ((nx + 1.0f) / 2.0f) * (float)(w - 1);
+  float iy = ((ny + 1.0f) / 2.0f) * (float)(h - 1);
+  ix = fminf(fmaxf(ix, -4.0f), (float)w + 4.0f);
+  iy = fminf(fmaxf(iy, -4.0f), (float)h + 4.0f);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const int x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx0, wy1 = iy - fy0;
+  const float wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
+  const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x1 >= 0) & (x1 < w);
+  const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y1 >= 0) & (y1 < h);
+  const float w_nw = (vx0 & vy0) ? wx0 * wy0 : 0.0f;
+  const float w_ne = (vx1 & vy0) ? wx1 * wy0 : 0.0f;
+  const float w_sw = (vx0 & vy1) ? wx0 * wy1 : 0.0f;
+  const float w_se = (vx1 & vy1) ? wx1 * wy1 : 0.0f;
+  const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
+  const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
+  const int i_nw = cy0 * w + cx0, i_ne = cy0 * w + cx1, i_sw = cy1 * w + cx0, i_se = cy1 * w + cx1;
+
+  const float* xp = (second ? xb : xa) + ((size_t)bn * c + c0) * plane;
+  const int cend = min(kChanPerThread, c - c0);
+  if (second && b_il8) {
+    // c % 8 == 0 (checked on the host): this thread owns whole octets; 32 contiguous bytes per (pixel, octet)
+    for (int o = 0; o < cend / 8; ++o) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float* p = xp + (size_t)(o * 8 + e) * plane;
+        float t = p[i_nw] * w_nw;
+        t += p[i_ne] * w_ne;
+        t += p[i_sw] * w_sw;
+        t += p[i_se] * w_se;
+        v[e] = t;
+      }
+      f32x4* op = reinterpret_cast<f32x4*>(outb + ((((size_t)bn * (c / 8) + (c0 / 8 + o)) * h + py) * w + px) * 8);
+      op[0] = f32x4{v[0], v[1], v[2], v[3]};
+      op[1] = f32x4{v[4], v[5], v[6], v[7]};
+    }
+    return;
+  }
+  float* op = (second ? outb : outa) + ((size_t)bn * c + c0) * plane + (size_t)py * w + px;
+#pragma unroll 4
+  for (int cc = 0; cc < cend; ++cc) {
+    const float* p = xp + (size_t)cc * plane;
+    float v = p[i_nw] * w_nw;
+    v += p[i_ne] * w_ne;
+    v += p[i_sw] * w_sw;
+    v += p[i_se] * w_se;
+    op[(size_t)cc * plane] = v;
+  }
+}
+
 // The other grid_sample modes the reference's signature admits (interpolation='nearest', padding_mode=
 // 'reflection', align_corners=False; networks.py:699-739 passes them straight to F.grid_sample).  Off the hot path:
 // one kernel with run-time switches, same thread mapping, coordinate arithmetic as aten's grid_sampler.
@@ -203,4 +288,22 @@ extern "C" int eavsr_flow_warp_f32(const float* x, const float* flow, const floa
     hipLaunchKernelGGL(flow_warp_kernel<EAVSR_PAD_BORDER>, grid, block, 0, eavsr::as_stream(stream), x, flow,
                        flow2, out, n, c, h, w, fs_n, fs_c, fs_y, fs_x, c_chunks, tiles_x, tiles_y);
   return eavsr::launch_status("flow_warp");
+}
+
+extern "C" int eavsr_flow_warp_pair_f32(const float* xa, const float* xb, const float* flow, const float* flow2, float* outa,
+                                        float* outb, int32_t n, int32_t c, int32_t h, int32_t w, int32_t outb_il8,
+                                        void* stream) {
+  EAVSR_REQUIRE(xa && xb && flow && outa && outb, -1, "flow_warp_pair: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c >= 0 && h >= 0 && w >= 0, -1, "flow_warp_pair: negative dimension");
+  EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "flow_warp_pair: plane too large");
+  EAVSR_REQUIRE(!outb_il8 || (c % 8 == 0 && (((uintptr_t)outb) & 15) == 0), -2,
+                "flow_warp_pair: the IL8 output needs c %% 8 == 0 and a 16-byte aligned buffer");
+  if (n == 0 || c == 0 || h == 0 || w == 0) return 0;
+  const int c_chunks = eavsr::cdiv(c, kChanPerThread);
+  const int tiles_x = eavsr::cdiv(w, 64), tiles_y = eavsr::cdiv(h, 4);
+  const long nblk = (long)tiles_x * tiles_y * c_chunks * 2 * n;
+  EAVSR_REQUIRE(nblk < (1L << 31), -1, "flow_warp_pair: too many tiles");
+  hipLaunchKernelGGL(flow_warp_pair_kernel, dim3((unsigned)nblk), dim3(64, 4, 1), 0, eavsr::as_stream(stream), xa, xb, flow,
+                     flow2, outa, outb, n, c, h, w, c_chunks, tiles_x, tiles_y, outb_il8);
+  return eavsr::launch_status("flow_warp_pair");
 }

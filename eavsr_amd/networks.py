@@ -191,11 +191,15 @@ class AdaptBlockOffset(_AdaptBase):
         self.mask_conv = Conv2d(inplanes, 9 * self.D, 5, 1, 2, bias=True)
         self.relu = _Act("lrelu", 0.2)  # unused by forward in the reference as well
 
-    def forward(self, x, h_hr):
+    def heads(self, x, h_hr):
+        """the three 5x5 heads as one (n, 15 D, h, w) tensor: transform g*4+{0..3}, translation 4D + g*2+{0,1}, mask logits
+        6D + g*9+k -- what `forward` expands into (offset, mask) and what the fused DCNv2 kernel consumes directly"""
         f = self._frontend(x, h_hr)
-        heads = AG.conv2d(f, [self.transform_matrix_conv.weight, self.translation_conv.weight, self.mask_conv.weight],
-                          [self.transform_matrix_conv.bias, self.translation_conv.bias, self.mask_conv.bias])
-        return AG.affine_offsets(heads, self.D, with_mask=True)
+        return AG.conv2d(f, [self.transform_matrix_conv.weight, self.translation_conv.weight, self.mask_conv.weight],
+                         [self.transform_matrix_conv.bias, self.translation_conv.bias, self.mask_conv.bias])
+
+    def forward(self, x, h_hr):
+        return AG.affine_offsets(self.heads(x, h_hr), self.D, with_mask=True)
 
 
 class TransOffsetworelu(nn.Module):
@@ -227,6 +231,13 @@ class MultiAdSTN(ModulatedDeformConv2d):
         self.trans_l1 = TransOffsetworelu()
         self.center = getattr(opt, "n_frame", 7) // 2
 
+    def _fused_alignment(self, nbr, feat_prop, offset) -> bool:
+        return (ops.DCN_MODE in ("il6", "il9") and not AG.needs_grad(nbr, feat_prop, offset, list(self.parameters()))
+                and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.groups == 1 and self.in_channels % 8 == 0
+                and (self.in_channels // self.deform_groups) % 8 == 0 and self.adastn.D == self.deform_groups
+                and nbr.shape == feat_prop.shape)
+
     def forward(self, nbr_feat_l, ref_feat_l, feat_prop, offset, flag=False):
         n, _, h, w = offset.shape
         if not flag:
@@ -246,6 +257,14 @@ class MultiAdSTN(ModulatedDeformConv2d):
             warp1 = AG.flow_warp(nbr_feat_l[0], offset, flow2=p2_up)
             p3 = self.trans_l1(self.flow_l1(warp1, ref_feat_l[0]))
             offset = AG.add(p3, p2_up, offset)
+        if self._fused_alignment(nbr_feat_l[0], feat_prop, offset):
+            # inference hot path: both warps by the refined offset in ONE launch, the second one written in the IL8 layout the
+            # DCNv2 kernel samples from; the predictor's 15 D head channels go to that kernel as they are (affine -> offsets
+            # and the mask sigmoid, networks.py:302-315, happen in its per-group set-up): de_offset / mask never reach HBM
+            nbr, feat_il = ops.flow_warp_pair(nbr_feat_l[0], feat_prop, offset, b_il8=True)          # :621, :623
+            heads = self.adastn.heads(nbr, ref_feat_l[0])                                            # :625
+            return ops.dcnv2_il(feat_il, heads, None, self.weight, self.bias, self.deform_groups,
+                                nprod=int(ops.DCN_MODE[2]), heads=True)                              # :627-630
         nbr = AG.flow_warp(nbr_feat_l[0], offset)                             # :621
         feat = AG.flow_warp(feat_prop, offset)                                # :623
         de_offset, mask = self.adastn(nbr, ref_feat_l[0])                      # :625

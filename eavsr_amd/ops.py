@@ -163,6 +163,28 @@ def flow_warp(x: Tensor, flow: Tensor, padding_mode: str = "zeros", flow2: Optio
     return out
 
 
+def flow_warp_pair(xa: Tensor, xb: Tensor, flow: Tensor, flow2: Optional[Tensor] = None, b_il8: bool = False):
+    """(flow_warp(xa, flow [+ flow2]), flow_warp(xb, flow [+ flow2])) in one launch (networks.py:621,623); with b_il8 the
+    second result comes in the IL8 layout (n, c/8, h, w, 8) of `dcnv2_il`."""
+    xa, xb, flow = _chk(xa, "xa"), _chk(xb, "xb"), _chk(flow, "flow")
+    n, c, h, w = xa.shape
+    if xb.shape != xa.shape or tuple(flow.shape) != (n, 2, h, w):
+        raise ValueError("flow_warp_pair: xa, xb (n,c,h,w) and flow (n,2,h,w)")
+    if flow2 is not None:
+        flow2 = _chk(flow2, "flow2")
+        if flow2.shape != flow.shape:
+            raise ValueError("flow2 must have the shape of flow")
+    if b_il8 and c % 8:
+        raise ValueError("flow_warp_pair: IL8 output needs c % 8 == 0")
+    outa = torch.empty_like(xa)
+    outb = torch.empty((n, c // 8, h, w, 8) if b_il8 else tuple(xb.shape), device=xa.device, dtype=torch.float32)
+    st = _stream(xa)
+    _launch("flow_warp_pair", 16.0 * n * c * h * w, 4.0 * n * h * w * (4 * c + 2 + (2 if flow2 is not None else 0)), xa,
+            lambda: lib().eavsr_flow_warp_pair_f32(_p(xa), _p(xb), _p(flow), _p(flow2), _p(outa), _p(outb), n, c, h, w,
+                                                   1 if b_il8 else 0, st), "flow_warp_pair")
+    return outa, outb
+
+
 # ------------------------------------------------------------------------------------------
 # packed conv weights (cached per parameter version)
 # ------------------------------------------------------------------------------------------
@@ -464,6 +486,10 @@ def modulated_deform_conv2d(input: Tensor, offset: Tensor, mask: Tensor, weight:
     st = _stream(x)
     px = float(n) * h * w
     flops, nbytes = 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * deform_groups + cout)
+    if DCN_MODE in ("il6", "il9"):
+        # generic callers hold an NCHW tensor: one conversion pass to the IL8 layout, then the hot-path kernel (inside
+        # MultiAdSTN the warp before the call writes IL8 itself and the predictor heads are passed instead of offset / mask)
+        return dcnv2_il(to_il8(x), offset, mask, weight, b, deform_groups, nprod=int(DCN_MODE[2]), heads=False)
     if DCN_MODE == "bf16x9" and w % 4 == 0 and x.data_ptr() % 16 == 0:
         wx = _packed_dcn_x9(weight)
         _launch("dcnv2_x9", flops, nbytes, x,
@@ -477,6 +503,57 @@ def modulated_deform_conv2d(input: Tensor, offset: Tensor, mask: Tensor, weight:
     return out
 
 
+def to_il8(x: Tensor) -> Tensor:
+    """(n, c, h, w) fp32 -> "IL8" (n, c/8, h, w, 8): the 8 channels of a deformable group interleaved per pixel, the input
+    layout of eavsr_dcnv2_il_f32"""
+    x = _chk(x, "x")
+    n, c, h, w = x.shape
+    if c % 8:
+        raise ValueError("to_il8: channels must be a multiple of 8")
+    out = torch.empty((n, c // 8, h, w, 8), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    _launch("nchw_to_il8", 0.0, 8.0 * x.numel(), x,
+            lambda: lib().eavsr_nchw_to_il8_f32(_p(x), _p(out), n, c, h, w, st), "nchw_to_il8")
+    return out
+
+
+def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
+             deform_groups: int, nprod: int = 6, heads: bool = False) -> Tensor:
+    """DCNv2 (3x3, stride 1, pad 1) on an IL8 input.  heads=False: `offset_or_heads` / `mask` as mmcv's offset (n,18D,h,w)
+    and mask (n,9D,h,w).  heads=True: `offset_or_heads` is the (n,15D,h,w) output of AdaptBlockOffset's three 5x5 heads and
+    the kernel applies networks.py:302-315 (affine -> offsets, sigmoid) itself.  nprod: 9 = exact bf16x9, 6 = the three
+    products below 2^-23 dropped."""
+    x_il8 = _chk(x_il8, "x_il8")
+    n, oct_, h, w, e = x_il8.shape
+    if e != 8:
+        raise ValueError("dcnv2_il: input must be IL8 (n, c/8, h, w, 8)")
+    cin = oct_ * 8
+    cout = int(weight.shape[0])
+    if tuple(weight.shape[1:]) != (cin, 3, 3):
+        raise ValueError("dcnv2_il: weight / input channel mismatch")
+    oh = _chk(offset_or_heads, "offset_or_heads")
+    D = int(deform_groups)
+    if heads:
+        if tuple(oh.shape) != (n, 15 * D, h, w):
+            raise ValueError(f"dcnv2_il: heads shape {tuple(oh.shape)} != {(n, 15 * D, h, w)}")
+        mask = None
+    else:
+        mask = _chk(mask, "mask")
+        if tuple(oh.shape) != (n, 18 * D, h, w) or tuple(mask.shape) != (n, 9 * D, h, w):
+            raise ValueError("dcnv2_il: offset / mask shape")
+    b = None if bias is None else _chk(bias.detach(), "bias")
+    wx = _packed_dcn_x9(weight)
+    out = torch.empty((n, cout, h, w), device=x_il8.device, dtype=torch.float32)
+    st = _stream(out)
+    px = float(n) * h * w
+    # algorithmic bytes of the DCNv2 op as SURVEY 8d defines them (input + 27 D offset/mask + output); in heads mode the
+    # kernel itself moves (cin + 15 D + cout) floats per pixel
+    _launch("dcnv2_il" + ("_heads" if heads else ""), 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * D + cout), out,
+            lambda: lib().eavsr_dcnv2_il_f32(_p(x_il8), _p(oh), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout, D,
+                                             int(nprod), 1 if heads else 0, st), "dcnv2_il")
+    return out
+
+
 # How the fp32 contraction of the DCNv2 kernel is carried: "native" = v_mfma_f32_32x32x2_f32 (an fp32 fma chain, the
 # default), "bf16x9" = exact three-way bf16 split of both operands, nine bf16 MFMA partial products accumulated in
 # fp32 (eavsr_dcnv2_f32x9: no operand is rounded, only the accumulation order differs).  Opt-in.
@@ -485,8 +562,8 @@ DCN_MODE = os.environ.get("EAVSR_DCN_MODE", "native")
 
 def set_dcn_mode(mode: str) -> None:
     global DCN_MODE
-    if mode not in ("native", "bf16x9"):
-        raise ValueError(f"dcn mode {mode!r}: 'native' or 'bf16x9'")
+    if mode not in ("native", "bf16x9", "il6", "il9"):
+        raise ValueError(f"dcn mode {mode!r}: 'native', 'bf16x9', 'il6' or 'il9'")
     DCN_MODE = mode
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 13
+#define EAVSR_ABI_VERSION 14
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -69,6 +69,13 @@ int eavsr_flow_warp_f32(const float* x, const float* flow, const float* flow2, f
                         int32_t n, int32_t c, int32_t h, int32_t w,
                         int32_t flow_layout, int32_t padding_mode, void* stream);
 
+/* networks.py:621 + :623: two feature maps (the neighbour's features and the propagated features) warped by the SAME
+ * NCHW flow (+ optional flow2, summed first), bilinear, zeros padding, align_corners=True, in ONE launch.  outa is NCHW;
+ * outb is NCHW (outb_il8 = 0) or the IL8 layout [n][c/8][h][w][8] that eavsr_dcnv2_il_f32 samples from (outb_il8 = 1,
+ * c % 8 == 0). */
+int eavsr_flow_warp_pair_f32(const float* xa, const float* xb, const float* flow, const float* flow2, float* outa,
+                             float* outb, int32_t n, int32_t c, int32_t h, int32_t w, int32_t outb_il8, void* stream);
+
 /* ---- a7: DCNv2 ------------------------------------------------------------------------------
  * replaces mmcv.ops.modulated_deform_conv2d as called at models/networks.py:627-630 (module
  * parameters from the ModulatedDeformConv2d base class, networks.py:575-583).
@@ -94,6 +101,22 @@ int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask,
                       const void* weight_x9, const float* bias, float* out,
                       int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
                       int32_t deform_groups, void* stream);
+
+/* Round-2 hot-path form of the same operation (csrc/dcnv2_il.hip).  Differences from eavsr_dcnv2_f32x9:
+ *   x_il8   the sampled feature map in "IL8" layout [n][cin/8][h][w][8] (the 8 channels of a deformable group interleaved
+ *           per pixel): written directly by eavsr_flow_warp_pair_f32 (the warp of networks.py:623 that precedes the call)
+ *           or by eavsr_nchw_to_il8_f32 from a plain NCHW tensor.
+ *   heads   0: offset (n, dg*18, h, w) / mask (n, dg*9, h, w) exactly as mmcv's signature;
+ *           1: `offset_or_heads` is the (n, 15*dg, h, w) output of AdaptBlockOffset's three 5x5 convolutions
+ *              (transform g*4+{0..3}, translation 4dg + g*2+{0,1}, mask logits 6dg + g*9+k) and the kernel applies
+ *              networks.py:302-315 itself (offset = T.R - R + t, mask = sigmoid): de_offset / mask never exist in HBM.
+ *   nprod   9: exact bf16x9 contraction; 6: the three partial products below 2^-23 of the result are dropped
+ *           (error per product <= one fp32 rounding).
+ * weight_x9 from eavsr_pack_dcn_weight_x9.  Requires (cin/dg) % 8 == 0, 16-byte aligned x_il8; any h, w. */
+int eavsr_nchw_to_il8_f32(const float* x, float* out_il8, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+int eavsr_dcnv2_il_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
+                       const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                       int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
 
 /* The rest of mmcv.ops.modulated_deform_conv2d's signature (any kernel size, stride, padding, dilation, conv groups,
  * deformable groups; networks.py:575-583 declares them, the reference never uses them): a plain one-thread-per-pixel

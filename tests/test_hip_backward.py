@@ -309,7 +309,10 @@ def test_model_wrapper_training_step(AG, cuda):
     assert groups[0]["lr"] == 1e-4 and groups[1]["lr"] == 1e-5
     n_align = sum(p.numel() for p in model.netEAVSRP.deform_align.parameters())
     assert sum(p.numel() for p in groups[1]["params"]) == n_align
-    assert sum(p.numel() for g_ in groups for p in g_["params"]) == 12277799   # 13,718,099 parameters - 1,440,300 frozen SPyNet (SURVEY 2a counts the 6 mean/std buffer values as SPyNet parameters)
+    # the groups hold ALL 13,718,099 parameters, as the reference builds them (eavsrp_model.py:45-59); 12,277,799 of them are
+    # trainable (1,440,300 frozen SPyNet parameters never get a gradient, so Adam never touches them)
+    assert sum(p.numel() for g_ in groups for p in g_["params"]) == 13718099
+    assert sum(p.numel() for g_ in groups for p in g_["params"] if p.requires_grad) == 12277799
     data = {"lr_seq": synthetic_clip(1, 3, 64, 64, seed=1), "hr_seq": synthetic_clip(1, 3, 256, 256, seed=2), "fname": "x"}
     before = model.netEAVSRP.conv_last.weight.detach().clone()
     losses = []

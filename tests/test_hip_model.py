@@ -68,6 +68,32 @@ def test_multiadstn_golden(nets, cuda, preset):
     assert H.maxabs(out.cpu(), gold["out"]) <= 1e-4
 
 
+@pytest.mark.parametrize("mode", ["native", "il6", "il9"])
+@pytest.mark.parametrize("preset", ["default", "trained_like"])
+def test_multiadstn_golden_in_every_dcn_mode(nets, cuda, preset, mode):
+    """the reference's MultiAdSTN output (golden G5) through the un-fused path (two warps, affine_offsets kernel, NCHW DCNv2)
+    and through the fused alignment path (paired warp with an IL8 output, predictor heads straight into the DCNv2 kernel)"""
+    from eavsr_amd import ops
+    Nw, _ = nets
+    gold = H.golden(f"g5_multiadstn_{preset}")
+    sd = H.filled(H.multiadstn_shapes("g5.align."), preset)
+    m = load(Nw.MultiAdSTN(OPT, 64, 64, deformable_groups=8), sd, "g5.align.", cuda)
+    nbr, ref, fp, flow = cases.g5_inputs()
+    prev = ops.DCN_MODE
+    ops.set_dcn_mode(mode)
+    try:
+        with torch.no_grad(), ops.profile() as prof:
+            out = m(dev(nbr, cuda), dev(ref, cuda), fp.to(cuda), flow.to(cuda))
+        names = set(prof.summary())
+    finally:
+        ops.set_dcn_mode(prev)
+    if mode == "native":
+        assert "dcnv2" in names and "affine_offsets" in names
+    else:
+        assert {"dcnv2_il_heads", "flow_warp_pair"} <= names and "dcnv2" not in names, names
+    assert H.maxabs(out.cpu(), gold["out"]) <= 1e-4
+
+
 @pytest.mark.parametrize("preset", ["default", "trained_like"])
 def test_backbone_blocks_golden(nets, cuda, preset):
     Nw, Mw = nets

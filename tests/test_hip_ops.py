@@ -185,6 +185,22 @@ def test_flow_warp_all_grid_sample_modes(ops, cuda, pad, interp, align):
     assert bad <= (0.002 if interp == "nearest" else 0.0), bad
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 24, 40), (1, 64, 13, 37), (1, 8, 9, 70), (3, 24, 5, 3)])
+def test_flow_warp_pair_equals_two_single_warps(ops, cuda, shape):
+    """networks.py:621 + :623 as one launch: bit-identical to the single warps, second output optionally IL8"""
+    n, c, h, w = shape
+    xa, xb = cases.randn(1, n, c, h, w), cases.randn(2, n, c, h, w)
+    f1, f2 = cases.randn(3, n, 2, h, w, scale=3.0), cases.randn(4, n, 2, h, w)
+    for flow2 in (None, f2):
+        a1 = ops.flow_warp(g(xa, cuda), g(f1, cuda), flow2=None if flow2 is None else g(flow2, cuda))
+        b1 = ops.flow_warp(g(xb, cuda), g(f1, cuda), flow2=None if flow2 is None else g(flow2, cuda))
+        a2, b2 = ops.flow_warp_pair(g(xa, cuda), g(xb, cuda), g(f1, cuda), None if flow2 is None else g(flow2, cuda))
+        assert torch.equal(a1, a2) and torch.equal(b1, b2)
+        a3, b3 = ops.flow_warp_pair(g(xa, cuda), g(xb, cuda), g(f1, cuda), None if flow2 is None else g(flow2, cuda), b_il8=True)
+        assert torch.equal(a1, a3) and torch.equal(ops.to_il8(b1), b3)
+    assert H.maxabs(a1.cpu(), O.flow_warp(xa, f1 + f2)) <= 2e-5 * max(1.0, xa.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------ a7
 def _dcn_inputs(n, c, h, w, cout, dg, sigma, seed=0):
     x = cases.randn(seed + 1, n, c, h, w)
@@ -206,7 +222,7 @@ def test_dcnv2_vs_oracle(ops, cuda, shape, sigma):
     assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("mode", ["native", "bf16x9"])
+@pytest.mark.parametrize("mode", ["native", "bf16x9", "il6", "il9"])
 @pytest.mark.parametrize("name", list(cases.G4_CASES))
 def test_dcnv2_committed_known_answers(ops, cuda, name, mode):
     """the stored outputs of the plain-C restatement (tests/golden/g4_dcnv2.npz) -- borders, |offset| > 1,
@@ -616,6 +632,82 @@ def test_dcnv2_x9_error_against_fp64_is_that_of_the_fp32_kernel(ops, cuda):
         ops.set_dcn_mode("native")
     assert e_native < 5e-6 and e_x9 < 5e-6, (e_native, e_x9)      # measured: 2.1e-6 and 2.2e-6 (sampler rounding dominates)
     assert e_x9 <= 1.5 * e_native + 1e-7, (e_native, e_x9)
+
+
+# ---- round-2 hot-path DCNv2: IL8 input layout, bf16 x6 / x9 products, optional fused affine + sigmoid ("heads") ----------
+def test_to_il8_layout(ops, cuda):
+    x = cases.randn(3, 2, 24, 7, 9)
+    il = ops.to_il8(g(x, cuda)).cpu()
+    assert il.shape == (2, 3, 7, 9, 8)
+    assert torch.equal(il, x.view(2, 3, 8, 7, 9).permute(0, 1, 3, 4, 2))
+
+
+@pytest.mark.parametrize("nprod", [6, 9])
+@pytest.mark.parametrize("sigma", [0.0, 0.5, 2.0, 8.0])
+@pytest.mark.parametrize("shape", [(1, 64, 24, 40, 64, 8), (2, 64, 13, 37, 64, 8), (1, 64, 10, 12, 64, 1),
+                                   (1, 16, 9, 33, 32, 2), (1, 64, 7, 5, 40, 8), (1, 64, 21, 68, 96, 4),
+                                   (3, 64, 45, 80, 64, 8)])
+def test_dcnv2_il_vs_oracle(ops, cuda, shape, sigma, nprod):
+    """explicit offsets / mask (mmcv's signature) through the IL8 kernel: any width (no w % 4 restriction), several tiles per
+    persistent workgroup, ragged edges, out-of-window taps (sigma = 8) through the global fix-up"""
+    n, c, h, w, cout, dg = shape
+    x, off, mask, wt, b = _dcn_inputs(n, c, h, w, cout, dg, sigma)
+    ref = O.dcnv2(x, off, mask, wt, b, 1, 1, 1, 1, dg)
+    out = ops.dcnv2_il(ops.to_il8(g(x, cuda)), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), dg, nprod=nprod)
+    assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("nprod", [6, 9])
+@pytest.mark.parametrize("shape", [(1, 24, 40, 8), (2, 13, 37, 8), (1, 45, 80, 8), (1, 9, 11, 2)])
+def test_dcnv2_il_heads_mode_applies_the_affine_expansion_and_the_sigmoid(ops, cuda, shape, nprod):
+    """heads mode == AdaptBlockOffset's tail (networks.py:302-315: offset = T.R - R + t per group, mask = sigmoid) followed
+    by DCNv2, without de_offset / mask ever existing in memory"""
+    n, h, w, D = shape
+    c = 8 * D
+    x = cases.randn(11, n, c, h, w)
+    heads = torch.cat([cases.randn(12, n, 4 * D, h, w, scale=0.4) + torch.tensor([1.0, 0, 0, 1.0]).repeat(D).view(1, 4 * D, 1, 1),
+                       cases.randn(13, n, 2 * D, h, w, scale=1.5), cases.randn(14, n, 9 * D, h, w, scale=2.0)], 1)
+    wt = cases.randn(15, 64, c, 3, 3, scale=1.0 / (c * 9) ** 0.5)
+    b = cases.randn(16, 64, scale=0.1)
+    off = O.affine_offsets(heads[:, :4 * D], heads[:, 4 * D:6 * D], D)
+    mask = torch.sigmoid(heads[:, 6 * D:])
+    ref = O.dcnv2(x, off, mask, wt, b, 1, 1, 1, 1, D)
+    out = ops.dcnv2_il(ops.to_il8(g(x, cuda)), g(heads, cuda), None, g(wt, cuda), g(b, cuda), D, nprod=nprod, heads=True)
+    assert H.maxabs(out.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+    # and the explicit form of the same thing agrees with it to rounding
+    out2 = ops.dcnv2_il(ops.to_il8(g(x, cuda)), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), D, nprod=nprod)
+    assert H.maxabs(out.cpu(), out2.cpu()) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_dcnv2_il_error_against_fp64(ops, cuda):
+    """x9 keeps every partial product (exact operands, fp32 accumulation); x6 drops the three products below 2^-23 of the
+    result.  Against an fp64 evaluation both must be as accurate as the native fp32-MFMA kernel."""
+    x, off, mask, wt, b = _dcn_inputs(2, 64, 32, 64, 64, 8, 1.5, seed=10)
+    x = x * 3.0 + 0.5
+    ref64 = O.dcnv2(x.double(), off.double(), mask.double(), wt.double(), b.double(), 1, 1, 1, 1, 8)
+    scale = ref64.abs().max().item()
+    args = (g(x, cuda), g(off, cuda), g(mask, cuda), g(wt, cuda), g(b, cuda), 1, 1, 1, 1, 8)
+    errs = {}
+    prev = ops.DCN_MODE
+    try:
+        for mode in ("native", "il9", "il6"):
+            ops.set_dcn_mode(mode)
+            errs[mode] = (ops.modulated_deform_conv2d(*args).cpu().double() - ref64).abs().max().item() / scale
+    finally:
+        ops.set_dcn_mode(prev)
+    print("DCNv2 relative max error vs fp64:", errs)
+    assert all(e < 5e-6 for e in errs.values()), errs
+    assert errs["il9"] <= 1.5 * errs["native"] + 1e-7 and errs["il6"] <= 1.5 * errs["native"] + 2e-7, errs
+
+
+def test_dcnv2_il_bad_arguments(ops, cuda):
+    z = lambda *s_: torch.zeros(*s_, device=cuda)
+    with pytest.raises(ValueError):
+        ops.dcnv2_il(z(1, 8, 8, 8, 4), z(1, 144, 8, 8), z(1, 72, 8, 8), z(64, 64, 3, 3), None, 8)       # not IL8
+    with pytest.raises(ValueError):
+        ops.dcnv2_il(z(1, 8, 8, 8, 8), z(1, 100, 8, 8), None, z(64, 64, 3, 3), None, 8, heads=True)     # heads channels
+    with pytest.raises(RuntimeError):
+        ops.dcnv2_il(z(1, 8, 8, 8, 8), z(1, 144, 8, 8), z(1, 72, 8, 8), z(64, 64, 3, 3), None, 8, nprod=7)
 
 
 # ------------------------------------------------------------------------------------------ a3/a6 pieces

@@ -32,6 +32,15 @@ if "dcn" in which:
     mask = torch.rand(n, 72, h, w, device=dev)
     for _ in range(reps):
         ops.modulated_deform_conv2d(x64, off, mask, w33, b, 1, 1, 1, 1, 8)
+    if "dcnil" in which:
+        xil = ops.to_il8(x64)
+        heads = torch.cat([r(n, 32, h, w) * 0.25 + torch.tensor([1.0, 0, 0, 1.0], device=dev).repeat(8).view(1, 32, 1, 1),
+                           r(n, 16, h, w) * float(os.environ.get("SIGMA", 1.5)), r(n, 72, h, w)], 1)
+        for nprod in (6, 9):
+            for _ in range(reps):
+                ops.dcnv2_il(xil, off, mask, w33, b, 8, nprod=nprod)
+            for _ in range(reps):
+                ops.dcnv2_il(xil, heads, None, w33, b, 8, nprod=nprod, heads=True)
 if "warp" in which:
     flow = r(n, 2, h, w) * 2
     for _ in range(reps):
