@@ -60,8 +60,10 @@ def parse():
                     help="large 3x3 convolutions (all fp32 in / out / accumulate): winograd = F(2x2,3x3) on the fp32 MFMA "
                          "(default); direct = direct sum on the fp32 MFMA; bf16x9 = direct sum, both operands split exactly "
                          "into three bf16 terms, nine partial products on the bf16 MFMA")
-    ap.add_argument("--dcn-mode", default="native", choices=["native", "bf16x9"],
-                    help="DCNv2 contraction: native fp32 MFMA (default) or the exact bf16x9 split")
+    ap.add_argument("--dcn-mode", default="il6", choices=["il6", "il9", "native", "bf16x9"],
+                    help="DCNv2: il6 (default) = IL8-layout kernel fed by the paired warp and the predictor heads, fp32 operands "
+                         "split into 3 bf16 terms, 6 partial products (dropped ones < 2^-23 relative); il9 = all 9 products "
+                         "(exact); native / bf16x9 = round 1's NCHW kernels behind affine_offsets + two warps")
     ap.add_argument("--streams", type=int, default=2,
                     help="split the clips of a step into this many sub-batches, each replayed as its own HIP graph on its own "
                          "stream (eavsr_amd.graph.StreamedForward)")
@@ -399,7 +401,7 @@ def main():
     line = {
         "metric": "SR frames/sec at 4x 7-frame 180x320->720x1280" +
                   ("" if args.backbone_dtype == "fp32" else f" [{args.backbone_dtype} residual backbone, not the fp32 headline]") +
-                  ("" if args.conv_mode != "bf16x9" and args.dcn_mode == "native" else " [fp32 via exact bf16x9 split products, opt-in mode]"),
+                  ("" if args.conv_mode != "bf16x9" and args.dcn_mode != "bf16x9" else " [fp32 via exact bf16x9 split products, opt-in mode]"),
         "value": value,
         "unit": "frames/s",
         "n_gpus": world,
@@ -416,7 +418,7 @@ def main():
         "backend": (torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else ""))
                    if world > 1 else "none (one process)",
         "dtype": ("f32" if args.backbone_dtype == "fp32" else f"{args.backbone_dtype} backbone + f32") +
-                 ("" if args.conv_mode != "bf16x9" and args.dcn_mode == "native"
+                 ("" if args.conv_mode != "bf16x9" and args.dcn_mode != "bf16x9"
                   else " (contractions in bf16x9 mode: exact 3 x bf16 operand split, 9 products, f32 accumulate)"),
         "data": "synthetic",
         "config": {"workload": f"eavsrp x4 inference, {n} clips/GPU x {t} frames x 3 x {h} x {w} fp32 "
@@ -425,7 +427,11 @@ def main():
                    "conv3x3": {"winograd": "Winograd F(2x2,3x3), fp32 MFMA (direct fp32 kernel for the shapes it does not cover)",
                                "winograd4": "Winograd F(4x4,3x3), fp32 MFMA (F(2x2,3x3) / direct fp32 kernels for the shapes it does not cover)",
                                "direct": "direct sum, fp32 MFMA", "bf16x9": "direct sum, exact bf16x9 split"}[args.conv_mode],
-                   "dcnv2": args.dcn_mode, "launch": (f"{args.streams} HIP graphs on {args.streams} streams per step" if args.streams > 1 else
+                   "dcnv2": {"il6": "IL8 kernel, fp32 operands as 3 exact bf16 terms, 6 of 9 partial products (dropped < 2^-23 each), "
+                                    "f32 accumulate; predictor heads + paired warp fused in",
+                             "il9": "IL8 kernel, exact bf16x9 products, f32 accumulate; predictor heads + paired warp fused in",
+                             "native": "fp32 MFMA, NCHW LDS-window kernel (round 1)", "bf16x9": "round-1 bf16x9 kernel"}[args.dcn_mode],
+                   "launch": (f"{args.streams} HIP graphs on {args.streams} streams per step" if args.streams > 1 else
                               "one HIP graph per step" if args.graph else "eager (one launch per kernel)")},
     }
 
@@ -483,7 +489,8 @@ def main():
                 "winograd4": "conv_wino6_kernel<3> (3x3 64->64, the residual backbone)",
                 "direct": "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)",
                 "bf16x9": "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)"}[args.conv_mode]
-        line["kernels"] = [e for e in (entry("dcnv2" if args.dcn_mode == "native" else "dcnv2_x9", "hbm"), entry("flow_warp", "hbm"),
+        dcn_name = {"il6": "dcnv2_il_heads", "il9": "dcnv2_il_heads", "native": "dcnv2", "bf16x9": "dcnv2_x9"}[args.dcn_mode]
+        line["kernels"] = [e for e in (entry(dcn_name, "hbm"), entry("flow_warp_pair", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),
                                        entry("conv5x5_64to120", "mfma")) if e]

@@ -38,8 +38,6 @@ __device__ __forceinline__ float ld_b(const float* base, unsigned byte_off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-__device__ __attribute__((aligned(16))) float g_il_zero[4];
-
 constexpr int IT_ROWS = 8, IT_W = 32;                 // pixel tile: one 32-pixel row per wave
 constexpr int IG = 8;                                 // channels per group = k of one tap
 constexpr int IK = 9, ISTEPS = 5;                     // taps; k-steps per group (taps 2s, 2s+1; tap 9 is zero)
@@ -51,7 +49,7 @@ constexpr int IW_U4 = ISTEPS * 3 * 2 * 64;            // 16-byte elements of one
 constexpr int IW_SEGS = IW_U4 / 64;                   // 30
 constexpr int INPIECE = IWIN_SEGS + IW_SEGS;          // 60
 constexpr int IP_IT = (INPIECE + 7) / 8;              // pieces per wave: 8
-constexpr size_t ILDS_BYTES = 2 * (size_t)IWIN_F * 4 + 2 * (size_t)IW_U4 * 16;   // 122,880
+constexpr size_t ILDS_BYTES = 2 * (size_t)IWIN_F * 4 + 2 * (size_t)IW_U4 * 16 + 64 * 4;   // 123,136 (+ the bias)
 
 struct ILArgs {
   const float* xil;      // [n][cin/8][h][w][8]
@@ -78,11 +76,25 @@ __device__ __forceinline__ f32x16 il_mfma(const u32x4& a, const u32x4& b, const 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+#ifdef EAVSR_IL_STAMPS
+// diagnostic build only (tools/build_il_diag.sh): shader cycles per phase, summed over wave 0 and wave 4 of every workgroup
+__device__ unsigned long long g_il_stamps[16];
+#define IL_STAMP(i)                                                   \
+  do {                                                                \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+    st_acc[i] += t_ - st_last;                                        \
+    st_last = t_;                                                     \
+  } while (0)
+#else
+#define IL_STAMP(i) do { } while (0)
+#endif
+
 template <int NPROD, bool HEADS>
 __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_win = smem;                                                   // [2][IWIN_F]
   u32x4* s_w = reinterpret_cast<u32x4*>(smem + 2 * IWIN_F);              // [2][IW_U4]
+  float* s_bias = smem + 2 * IWIN_F + 2 * IW_U4 * 4;                      // [64]: the accumulators start from it
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -117,35 +129,43 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
   // DMA pieces of a (tile, group): window piece p = i * 8 + wave (p < IWIN_SEGS; 64 lanes x 16 bytes = 32 window
   // positions, the window row is 96 such 16-byte units) and weight-slab piece seg = i * 8 + wave (seg < IW_SEGS)
   constexpr int WIN_IT = (IWIN_SEGS + 7) / 8, W_IT = (IW_SEGS + 7) / 8;
-  int prc[WIN_IT];                   // (window row << 8) | 16-byte column of this lane's unit in piece i
+  int prc[WIN_IT];                   // (window row << 8) | window column of this lane's 16-byte unit in piece i
+  unsigned poff[WIN_IT];             // its byte offset from the window's origin pixel in the IL8 image: fixed per kernel
 #pragma unroll
   for (int i = 0; i < WIN_IT; ++i) {
     const int e4 = (i * 8 + wave) * 64 + lane;
     const int rr = e4 / (2 * IPW);
-    prc[i] = (rr << 8) | (e4 - rr * (2 * IPW));
+    const int cc = e4 - rr * (2 * IPW);
+    prc[i] = (rr << 8) | (cc >> 1);
+    poff[i] = (unsigned)((rr * w + (cc >> 1)) * 32 + (cc & 1) * 16);
   }
-  auto issue = [&](int bn, int y0, int x0, int g, int stage) __attribute__((always_inline)) {
-    const char* xb = reinterpret_cast<const char*>(a.xil + ((size_t)bn * ngroups + g) * plane * IG);
+  // Window units inside the image are fetched by LDS-DMA from (wave-uniform window origin) + (per-lane constant offset);
+  // units outside the image are written as zeros (that IS the sampler's zero padding).  Every unit of a stage is
+  // rewritten by every step, one way or the other.
+  auto issue_win = [&](int i, int bn, int y0, int x0, int g, int stage) __attribute__((always_inline)) {
+    const char* xorg = reinterpret_cast<const char*>(a.xil + ((size_t)bn * ngroups + g) * plane * IG) +
+                       ((long)(y0 - IPY0) * w + (x0 - IPX0)) * 32;          // may point before the image: only `ok` lanes use it
+    const int ylo = y0 - IPY0, xlo = x0 - IPX0;
+    const int p = i * 8 + wave;  // wave-uniform
+    if (p < IWIN_SEGS) {
+      const bool ok = (unsigned)(ylo + (prc[i] >> 8)) < (unsigned)h && (unsigned)(xlo + (prc[i] & 255)) < (unsigned)w;
+      float* dst = s_win + stage * IWIN_F + p * 256;
+      if (ok) __builtin_amdgcn_global_load_lds((gptr_t)(xorg + poff[i]), (lptr_t)dst, 16, 0, 0);
+      else *reinterpret_cast<f32x4*>(dst + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto issue_wgt = [&](int i, int g, int stage) __attribute__((always_inline)) {
     const char* wsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)cot * ngroups + g) * IW_U4);
+    const int seg = i * 8 + wave;
+    if (seg < IW_SEGS)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (unsigned)(seg * 64 + lane) * 16u),
+                                       (lptr_t)(s_w + stage * IW_U4 + seg * 64), 16, 0, 0);
+  };
+  auto issue = [&](int bn, int y0, int x0, int g, int stage) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < WIN_IT; ++i) {
-      const int p = i * 8 + wave;  // wave-uniform
-      if (p < IWIN_SEGS) {
-        const int pcol = prc[i] & 255;
-        const int yy = y0 - IPY0 + (prc[i] >> 8), xx = x0 - IPX0 + (pcol >> 1);
-        const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
-        const unsigned off = (unsigned)((yy * w + xx) * 32 + (pcol & 1) * 16);
-        const char* src = ok ? xb + off : reinterpret_cast<const char*>(g_il_zero);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_win + stage * IWIN_F + p * 256), 16, 0, 0);
-      }
-    }
+    for (int i = 0; i < WIN_IT; ++i) issue_win(i, bn, y0, x0, g, stage);
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int seg = i * 8 + wave;
-      if (seg < IW_SEGS)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (unsigned)(seg * 64 + lane) * 16u),
-                                         (lptr_t)(s_w + stage * IW_U4 + seg * 64), 16, 0, 0);
-    }
+    for (int i = 0; i < W_IT; ++i) issue_wgt(i, g, stage);
   };
 
   // per-lane tap of k-step s: 2 s + kg (tap 9 does not exist: kg = 1 lanes idle in the last step); its regular-grid
@@ -162,35 +182,53 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
   // the translation and the mask logits of the lane's taps
   float pa[ISTEPS], pb[ISTEPS], pm[ISTEPS];
   float tf[6];
-  auto load_slot = [&](int bn, unsigned pix, int g, int s) __attribute__((always_inline)) {
+  // Addressing: wave-uniform base (SGPRs: image, group, 2 s) + per-lane 32-bit byte offset (pixel, and the lane half's
+  // tap parity) -- three VGPRs for all 15 loads of a step instead of one hoisted offset register per load.
+  struct POff { unsigned p4, po, pm; };     // pix * 4;  + kg * 2 planes (offset channels);  + kg * 1 plane (mask channels)
+  auto make_poff = [&](unsigned pix) __attribute__((always_inline)) {
+    POff o;
+    o.p4 = pix * 4u;
+    o.po = (pix + (kg ? 2u * uplane : 0u)) * 4u;
+    o.pm = (pix + (kg ? uplane : 0u)) * 4u;
+    return o;
+  };
+  auto load_slot = [&](int bn, const POff& o, int g, int s) __attribute__((always_inline)) {
     const int dgi = g * IG / a.cpg;
-    const unsigned tap = (unsigned)min(2 * s + kg, IK - 1);
+    const bool lastslot = s == ISTEPS - 1;          // taps 8 / (9): both lane halves read tap 8
+#ifdef EAVSR_IL_EXP_NO_PARAMS
+    pa[s] = 0.25f; pb[s] = 0.25f; pm[s] = 0.5f;
+    (void)dgi; (void)bn; (void)o; (void)lastslot;
+    return;
+#endif
     if (HEADS) {
-      const float* hb = a.offset + (size_t)bn * 15 * a.dg * plane;
-      pm[s] = ld_b(hb, ((unsigned)(6 * a.dg + dgi * 9) * uplane + tap * uplane + pix) * 4u);
+      const float* hb = a.offset + ((size_t)bn * 15 * a.dg + 6 * a.dg + dgi * 9 + 2 * s) * plane;
+      pm[s] = ld_b(hb, lastslot ? o.p4 : o.pm);
     } else {
-      const float* offb = a.offset + ((size_t)bn * a.dg + dgi) * 18 * plane;
-      const float* mkb = a.mask + ((size_t)bn * a.dg + dgi) * 9 * plane;
-      pa[s] = ld_b(offb, (2u * tap * uplane + pix) * 4u);
-      pb[s] = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
-      pm[s] = ld_b(mkb, (tap * uplane + pix) * 4u);
+      const float* offb = a.offset + (((size_t)bn * a.dg + dgi) * 18 + 4 * s) * plane;
+      const float* mkb = a.mask + (((size_t)bn * a.dg + dgi) * 9 + 2 * s) * plane;
+      pa[s] = ld_b(offb, lastslot ? o.p4 : o.po);
+      pb[s] = ld_b(offb + plane, lastslot ? o.p4 : o.po);
+      pm[s] = ld_b(mkb, lastslot ? o.p4 : o.pm);
     }
   };
-  auto load_affine = [&](int bn, unsigned pix, int g) __attribute__((always_inline)) {
+  auto load_affine = [&](int bn, const POff& o, int g) __attribute__((always_inline)) {
+#ifdef EAVSR_IL_EXP_NO_PARAMS
+    tf[0] = 1.1f; tf[1] = 0.1f; tf[2] = -0.1f; tf[3] = 0.9f; tf[4] = 0.3f; tf[5] = -0.3f;
+    return;
+#endif
     if (HEADS) {
       const int dgi = g * IG / a.cpg;
       const float* hb = a.offset + (size_t)bn * 15 * a.dg * plane;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tf[j] = ld_b(hb, ((unsigned)(dgi * 4 + j) * uplane + pix) * 4u);
+      for (int j = 0; j < 4; ++j) tf[j] = ld_b(hb + (size_t)(dgi * 4 + j) * plane, o.p4);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) tf[4 + j] = ld_b(hb, ((unsigned)(4 * a.dg + dgi * 2 + j) * uplane + pix) * 4u);
+      for (int j = 0; j < 2; ++j) tf[4 + j] = ld_b(hb + (size_t)(4 * a.dg + dgi * 2 + j) * plane, o.p4);
     }
   };
 
-  struct Pos {
-    float w1, w2, w3, w4;   // bilinear corner weights x mask (0 when the sample is outside the image / the tap idle)
-    int q;                  // float offset of the top-left corner in the LDS window stage
-  };
+  // waves 4-7 are dispatched second and lose every age-based arbitration on their SIMD (in-kernel stamps: waves 0-3 wait
+  // 20 % of the step at the barrier for them): static priority for that half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   // ---- current tile -------------------------------------------------------------------------------------------
   int bn, y0, x0;
@@ -199,151 +237,271 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
   bool pix_ok = gy < h && gx < w;
   unsigned pix = pix_ok ? (unsigned)(gy * w + gx) : 0u;
 
-  constexpr int WAIT_VM0 = 0x0F70;
   // every window position is (re)written by each step's DMA, from the image or from the zero line: no LDS pre-fill
   issue(bn, y0, x0, 0, 0);
-  load_affine(bn, pix, 0);
+  {
+    const POff o0 = make_poff(pix);
+    load_affine(bn, o0, 0);
 #pragma unroll
-  for (int s = 0; s < ISTEPS; ++s) load_slot(bn, pix, 0, s);
+    for (int s = 0; s < ISTEPS; ++s) load_slot(bn, o0, 0, s);
+  }
 
+  if (tid < 64) {
+    const int co = blockIdx.y * 64 + tid;
+    s_bias[tid] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+  }
+  __syncthreads();
   f32x16 acc[2];
+  auto init_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[m][e] = s_bias[m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg];
+  };
+  init_acc();
+
+  // finished tile whose accumulators still have to leave: stored at the TOP of the next step, in front of that step's
+  // DMA / parameter loads, so that the stores drain under a whole step instead of in front of a barrier
+  bool st_pending = false;
+  int st_bn = 0, st_gy = 0, st_gx = 0;
+  bool st_ok = false;
+  auto store_tile = [&]() __attribute__((always_inline)) {
+#ifdef EAVSR_IL_EXP_NO_STORE
+    if (st_ok && acc[0][0] == 12345.678f) {
+#else
+    if (st_ok) {
+#endif
+      // lane part of the address: pixel + this lane half's 4 channels; the channel stride is added as the loop goes.
+      // `pl4` is laundered through an empty asm so that the 32 channel offsets are computed here, once per tile, instead
+      // of being hoisted out of the step loop into 32 long-lived scalar registers (which then spill).
+      unsigned pl4 = uplane * 4u;
+      asm volatile("" : "+s"(pl4));
+      const char* ob = reinterpret_cast<const char*>(a.out + ((size_t)st_bn * a.cout + (size_t)cot * 64) * plane);
+      unsigned voff = ((unsigned)(st_gy * w + st_gx)) * 4u + (kg ? 4u * pl4 : 0u);
+      const bool full = cot * 64 + 64 <= a.cout;      // wave-uniform
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int cu = m * 32 + (e & 3) + 8 * (e >> 2);
+          // channel cu + 4 kg: offsets advance by 1 plane, and by 5 planes across a group of four
+          float* q = reinterpret_cast<float*>(const_cast<char*>(ob) + voff);
+          if (full || cot * 64 + cu + 4 * kg < a.cout) *q = acc[m][e];
+          voff += ((e & 3) == 3 ? 5u : 1u) * pl4;
+        }
+    }
+    init_acc();
+  };
 
   const int total = my_tiles * ngroups;
   int g = 0, ti_ = 0;
+#ifdef EAVSR_IL_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   for (int it = 0; it < total; ++it) {
     const int stage = it & 1;
-    // window, weights and parameters of this step have landed; every wave is done with the other stage
-    __builtin_amdgcn_s_waitcnt(WAIT_VM0);
+    IL_STAMP(0);
+    // window, weights and sampling parameters of this step have landed (all were requested at the top of the previous
+    // step: a whole step of latency cover); the barrier publishes everybody's DMA share and retires the other stage
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) lgkmcnt(0)
+    IL_STAMP(1);
     __syncthreads();
+    IL_STAMP(2);
+    if (st_pending) {      // wave-uniform
+      store_tile();
+      st_pending = false;
+    }
+    IL_STAMP(3);
     // the step after this one: next group of this tile, or group 0 of the next tile
     const bool last_g = g + 1 == ngroups;
     const bool more = it + 1 < total;
     int nbn = bn, ny0 = y0, nx0 = x0;
     if (last_g && more) tile_of(ti_ + 1, nbn, ny0, nx0);
     const int ng = last_g ? 0 : g + 1;
-    if (more) issue(nbn, ny0, nx0, ng, stage ^ 1);
+    // (the DMA and the parameter loads of the next step are issued piecewise inside the pipeline below: all eight waves
+    // issuing 8 LDS-DMAs + 15 loads each right behind the barrier cost 20 % of the step in in-kernel stamps)
     const int ngy = ny0 + wave, ngx = nx0 + l31;
     const bool npix_ok = ngy < h && ngx < w;
     const unsigned npix = npix_ok ? (unsigned)(ngy * w + ngx) : 0u;
+
+    // Sampling parameters: this step's move to working registers; the NEXT step's are requested inside the pipeline (the
+    // last step reloads its own values so that the code has no branch there).
+    float ca[ISTEPS], cb[ISTEPS], cm[ISTEPS], ctf[6];
+#pragma unroll
+    for (int s = 0; s < ISTEPS; ++s) { ca[s] = pa[s]; cb[s] = pb[s]; cm[s] = pm[s]; }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) ctf[j] = HEADS ? tf[j] : 0.f;
+    const int lbn = more ? nbn : bn, lg = more ? ng : g;
+    const POff lo = make_poff(more ? npix : pix);
+    __builtin_amdgcn_sched_barrier(0);
+    IL_STAMP(4);
 
     const float* wst_win = s_win + stage * IWIN_F;
     const u32x4* wst = s_w + stage * IW_U4 + lane;
     const float fgy = (float)gy, fgx = (float)gx;
 
-    // set-up of one (pixel, tap) position; its parameter registers are then free for the next step's values
+    struct Pos {
+      float w1, w2, w3, w4;   // bilinear corner weights x mask (0 when the tap is idle or the sample is not served from LDS)
+      int q;                  // float offset of the top-left corner in the LDS window stage
+    };
     Pos pos[2];
     unsigned slow_steps = 0;
+    // Set-up of one (pixel, tap).  The window is zero outside the image, which IS the sampler's corner-wise zero padding
+    // and also its validity gate (-1 < p < size: outside it both corners of that axis lie outside the image), so the fast
+    // path needs no image-bounds test at all; samples whose corners leave the WINDOW are flagged and redone from global
+    // memory, where the gate and the padding are applied explicitly.
     auto setup = [&](int s) __attribute__((always_inline)) {
       float ryk, rxk;
       grid_of(s, ryk, rxk);
       float dy, dx, m;
       if (HEADS) {
         // (T . R)[:,k] - R[:,k] + t   (matmul, subtract, add: networks.py:304-311)
-        dy = (tf[0] * ryk + tf[1] * rxk) - ryk + tf[4];
-        dx = (tf[2] * ryk + tf[3] * rxk) - rxk + tf[5];
-        m = 1.f / (1.f + __expf(-pm[s]));
+        dy = (ctf[0] * ryk + ctf[1] * rxk) - ryk + ctf[4];
+        dx = (ctf[2] * ryk + ctf[3] * rxk) - rxk + ctf[5];
+        m = 1.f / (1.f + __expf(-cm[s]));
       } else {
-        dy = pa[s]; dx = pb[s]; m = pm[s];
+        dy = ca[s]; dx = cb[s]; m = cm[s];
       }
-      const bool tap_ok = (s < ISTEPS - 1) || kg == 0;
+      const bool live = pix_ok && ((s < ISTEPS - 1) || kg == 0);
       const float py = (fgy + ryk) + dy;
       const float px = (fgx + rxk) + dx;
-      const bool in = pix_ok && tap_ok && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
       const float fy0 = floorf(py), fx0 = floorf(px);
       const float lh = py - fy0, lw = px - fx0;
       const float hh = 1.f - lh, hw = 1.f - lw;
-      const int hl = (int)fminf(fmaxf(fy0, -2.f), (float)h), wl = (int)fminf(fmaxf(fx0, -2.f), (float)w);
-      const int ry = hl - (y0 - IPY0), rx = wl - (x0 - IPX0);
-      const bool in_win = ry >= 0 && ry <= IPH - 2 && rx >= 0 && rx <= IPW - 2;
-      const bool fast = in && in_win;
+      // v_cvt_i32_f32 saturates (and maps NaN to 0): wild offsets stay defined and simply fail the window test
+      const int ry = (int)fy0 - (y0 - IPY0), rx = (int)fx0 - (x0 - IPX0);
+      const bool in_win = (unsigned)ry <= (unsigned)(IPH - 2) && (unsigned)rx <= (unsigned)(IPW - 2);
+      const bool fast = live && in_win;
       const float mf = fast ? m : 0.f;
       const float hm = hh * mf, lm = lh * mf;
       Pos& ps = pos[s & 1];
       ps.w1 = hm * hw; ps.w2 = hm * lw; ps.w3 = lm * hw; ps.w4 = lm * lw;
-      ps.q = fast ? (ry * IPW + rx) * IG : 0;
-      slow_steps |= (in && !in_win) ? (1u << s) : 0u;
+      ps.q = fast ? (int)((__umul24((unsigned)ry, (unsigned)IPW) + (unsigned)rx) * IG) : 0;
+      // outside the window: needs the global path only if the sample can be non-zero (inside the validity gate)
+      const bool maybe = live && !in_win && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
+      slow_steps |= maybe ? (1u << s) : 0u;
     };
 
-    // three-deep software pipeline over the k-steps in one scheduled block:
-    //   A: the 8 ds_read_b128 of step s+2   B: blend + split of step s+1   C: A-operand reads + MFMAs of step s
-    f32x4 gat[2][8];
+    // Software pipeline over the k-steps, written out as fenced chunks so that the order below IS the issue order:
+    // iteration t (MFMAs of k-step t) = [8 gathers + 6 A-operand reads of step t+1]  then per chunk a few MFMAs of step t
+    // followed by vector work that runs in their shadow: the set-up of step t+2, an empty chunk (LDS latency cover), then
+    // blend + exact split of step t+1 one channel pair at a time.  Every MFMA operand was in registers one iteration
+    // before its use.
+    f32x4 gat[4];         // one channel half (4 channels) of the four corners: TL, TR, BL, BR
+    u32x4 aop[6];         // [term * 2 + mt]; the two output-channel tiles are refilled at different times (below)
     u32x4 bop[2][3];
-    const int lbn = more ? nbn : bn, lg = more ? ng : g;       // the last step reloads its own values: no branch in the block
-    const unsigned lpix = more ? npix : pix;
-    auto stage_a = [&](int t) __attribute__((always_inline)) {
-      setup(t);
+    auto gather = [&](int t, int half) __attribute__((always_inline)) {
       const f32x4* qq = reinterpret_cast<const f32x4*>(wst_win + pos[t & 1].q);
+#ifdef EAVSR_IL_EXP_NO_GATHER
 #pragma unroll
-      for (int j = 0; j < 4; ++j) gat[t & 1][j] = qq[j];                      // top-left, top-right: 64 contiguous bytes
-#pragma unroll
-      for (int j = 0; j < 4; ++j) gat[t & 1][4 + j] = qq[IPW * IG / 4 + j];   // bottom-left, bottom-right
-      load_slot(lbn, lpix, lg, t);
-      if (t == ISTEPS - 1) load_affine(lbn, lpix, lg);
+      for (int j = 0; j < 4; ++j) gat[j] = f32x4{pos[t & 1].w1, pos[t & 1].w2, (float)pos[t & 1].q, pos[t & 1].w4};
+      (void)qq; (void)half;
+#else
+      gat[0] = qq[half];                        // top-left      (a corner is 8 channels = 2 x 16 bytes)
+      gat[1] = qq[2 + half];                    // top-right
+      gat[2] = qq[IPW * IG / 4 + half];         // bottom-left
+      gat[3] = qq[IPW * IG / 4 + 2 + half];     // bottom-right
+#endif
     };
-    auto stage_b = [&](int t) __attribute__((always_inline)) {
-      const Pos& ps = pos[t & 1];
-      float v[IG];
-#pragma unroll
-      for (int c = 0; c < IG; ++c) {
-        const int j = c >> 2, e = c & 3;
-        float tv = ps.w1 * gat[t & 1][j][e];
-        tv += ps.w2 * gat[t & 1][2 + j][e];
-        tv += ps.w3 * gat[t & 1][4 + j][e];
-        tv += ps.w4 * gat[t & 1][6 + j][e];
-        v[c] = tv;
-      }
-#pragma unroll
-      for (int c = 0; c < IG / 2; ++c) {
-        unsigned h2, m2, l2;
-        il_split2(v[2 * c], v[2 * c + 1], h2, m2, l2);
-        bop[t & 1][0][c] = h2; bop[t & 1][1][c] = m2; bop[t & 1][2][c] = l2;
-      }
-    };
-    auto stage_c = [&](int t, const u32x4 (&b)[3], f32x16 (&ac)[2]) __attribute__((always_inline)) {
+    auto load_a = [&](int t, int mt) __attribute__((always_inline)) {
       const u32x4* ws = wst + t * (3 * 2 * 64);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const u32x4 ah = ws[(0 * 2 + mt) * 64], am = ws[(1 * 2 + mt) * 64], al = ws[(2 * 2 + mt) * 64];
-        // partial products, smallest first
-        if (NPROD == 9) {
-          ac[mt] = il_mfma(al, b[2], ac[mt]);
-          ac[mt] = il_mfma(al, b[1], ac[mt]);
-          ac[mt] = il_mfma(am, b[2], ac[mt]);
-        }
-        ac[mt] = il_mfma(al, b[0], ac[mt]);
-        ac[mt] = il_mfma(ah, b[2], ac[mt]);
-        ac[mt] = il_mfma(am, b[1], ac[mt]);
-        ac[mt] = il_mfma(am, b[0], ac[mt]);
-        ac[mt] = il_mfma(ah, b[1], ac[mt]);
-        ac[mt] = il_mfma(ah, b[0], ac[mt]);
-      }
+      for (int term = 0; term < 3; ++term) aop[term * 2 + mt] = ws[(term * 2 + mt) * 64];
     };
-    stage_a(0);
-    stage_a(1);
-    stage_b(0);
-    __builtin_amdgcn_sched_barrier(0);
+    // blend + split of channels 2c, 2c+1 of step t
+    auto blend_pair = [&](int t, int c) __attribute__((always_inline)) {
+      const Pos& ps = pos[t & 1];
+      float v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = (2 * c + u) & 3;      // channel within the half that `gat` holds (c < 2: low half, else high half)
+        float tv = ps.w1 * gat[0][e];
+        tv = __builtin_fmaf(ps.w2, gat[1][e], tv);
+        tv = __builtin_fmaf(ps.w3, gat[2][e], tv);
+        tv = __builtin_fmaf(ps.w4, gat[3][e], tv);
+        v[u] = tv;
+      }
+      unsigned h2, m2, l2;
+#ifdef EAVSR_IL_EXP_NO_SPLIT
+      h2 = __float_as_uint(v[0]); m2 = __float_as_uint(v[1]); l2 = h2 ^ m2;
+#else
+      il_split2(v[0], v[1], h2, m2, l2);
+#endif
+      bop[t & 1][0][c] = h2; bop[t & 1][1][c] = m2; bop[t & 1][2][c] = l2;
+    };
+    // partial product i of a k-step (smallest first within each output-channel tile); a = [hi0 hi1 mid0 mid1 lo0 lo1]
+    auto mfma_i = [&](int i, const u32x4 (&av)[6], const u32x4 (&b)[3], f32x16 (&ac)[2]) __attribute__((always_inline)) {
+#ifdef EAVSR_IL_EXP_NO_MFMA
+      ac[0][i & 15] += __uint_as_float(b[i % 3][i & 3] ^ av[i % 6][i & 3]);
+#else
+      constexpr int TA9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, TB9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+      constexpr int TA6[6] = {2, 0, 1, 1, 0, 0}, TB6[6] = {0, 2, 1, 0, 1, 0};
+      const int mt = i / NPROD, j = i % NPROD;
+      const int ta = NPROD == 9 ? TA9[j] : TA6[j], tb = NPROD == 9 ? TB9[j] : TB6[j];
+      ac[mt] = il_mfma(av[ta * 2 + mt], b[tb], ac[mt]);
+#endif
+    };
+    constexpr int NM = 2 * NPROD, CH = NM / 6;      // MFMAs per k-step; per chunk (2 for x6, 3 for x9)
+#define IL_FENCE() __builtin_amdgcn_sched_barrier(0)
+    setup(0);
+    gather(0, 0);
+    load_a(0, 0);
+    setup(1);
+    blend_pair(0, 0);
+    blend_pair(0, 1);
+    IL_FENCE();
+    gather(0, 1);
+    IL_FENCE();
+    blend_pair(0, 2);
+    blend_pair(0, 3);
+    IL_FENCE();
+    IL_STAMP(5);
 #pragma unroll
     for (int t = 0; t < ISTEPS; ++t) {
-      if (t + 2 < ISTEPS) stage_a(t + 2);
-      if (t + 1 < ISTEPS) stage_b(t + 1);
-      stage_c(t, bop[t & 1], acc);
+      // the MFMAs run tile 0 first (chunks 0-2), tile 1 second (chunks 3-5): tile 1's A operands of THIS step are
+      // requested now (three chunks ahead), tile 0's of the NEXT step as soon as chunk 2 has issued its last MFMA.
+      // chunk:   0: set-up(t+2)   1: pair 0   2: pair 1   3: gathers of the high channel half   4: pair 2   5: pair 3
+      if (t + 1 < ISTEPS) gather(t + 1, 0);
+      load_a(t, 1);
+      IL_FENCE();
 #pragma unroll
-      for (int i = 0; i < 2 * NPROD; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, NPROD == 9 ? 5 : 7, 0);      // vector work in its shadow
-        __builtin_amdgcn_sched_group_barrier(0x100, NPROD == 9 ? 1 : 2, 0);      // LDS reads
+      for (int k = 0; k < 6; ++k) {
+        if (k == 3 && t + 1 < ISTEPS) {
+          gather(t + 1, 1);
+          load_a(t + 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) mfma_i(k * CH + i, aop, bop[t & 1], acc);
+        if (k == 0 && t + 2 < ISTEPS) setup(t + 2);
+        // next step's DMA and parameter loads, spread over the iterations (every piece has >= 1 k-step to land)
+#ifndef EAVSR_IL_EXP_NO_DMA      // timing ablations (tools/gpu_il_ablate.py): results are wrong by construction
+        if (k == 1 && t < WIN_IT && more) issue_win(t, nbn, ny0, nx0, ng, stage ^ 1);
+        if (k == 4 && t < W_IT && more) issue_wgt(t, ng, stage ^ 1);
+#endif
+        if (k == 2) {
+          if (t == 0) { load_slot(lbn, lo, lg, 0); load_slot(lbn, lo, lg, 1); }
+          if (t == 1) { load_slot(lbn, lo, lg, 2); load_slot(lbn, lo, lg, 3); }
+          if (t == 2) { load_slot(lbn, lo, lg, 4); load_affine(lbn, lo, lg); }
+        }
+        if (t + 1 < ISTEPS) {
+          if (k == 1) blend_pair(t + 1, 0);
+          if (k == 2) blend_pair(t + 1, 1);
+          if (k == 4) blend_pair(t + 1, 2);
+          if (k == 5) blend_pair(t + 1, 3);
+        }
+        IL_FENCE();
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
+#undef IL_FENCE
+    IL_STAMP(6);
 
     // rare: a corner left the LDS window.  Those lanes contributed exactly zero above; their samples are redone from
     // global memory (IL8: one corner = 32 contiguous bytes) with corner-wise zero padding and multiplied in.
+#ifdef EAVSR_IL_EXP_NO_FIXUP
+    slow_steps = 0;
+#endif
     if (__builtin_amdgcn_ballot_w64(slow_steps != 0) != 0) {
-      const int dgi = g * IG / a.cpg;
       const float* xg = a.xil + ((size_t)bn * ngroups + g) * plane * IG;
       for (int t = 0; t < ISTEPS; ++t) {
         const bool mine = (slow_steps >> t) & 1u;
@@ -352,26 +510,31 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
 #pragma unroll
         for (int c = 0; c < IG; ++c) v[c] = 0.f;
         if (mine) {
-          const unsigned tap = (unsigned)min(2 * t + kg, IK - 1);
-          const float ryt = (float)((int)tap / 3 - 1), rxt = (float)((int)tap % 3 - 1);
+          const int tap = min(2 * t + kg, IK - 1);
+          const float ryt = (float)(tap / 3 - 1), rxt = (float)(tap % 3 - 1);
+          // rare path: the parameters are read again (their registers were recycled as the set-ups consumed them)
+          const int dgi = g * IG / a.cpg;
           float dy, dx, m;
           if (HEADS) {
             const float* hb = a.offset + (size_t)bn * 15 * a.dg * plane;
             float tt[6];
+#pragma unroll
             for (int j = 0; j < 4; ++j) tt[j] = ld_b(hb, ((unsigned)(dgi * 4 + j) * uplane + pix) * 4u);
+#pragma unroll
             for (int j = 0; j < 2; ++j) tt[4 + j] = ld_b(hb, ((unsigned)(4 * a.dg + dgi * 2 + j) * uplane + pix) * 4u);
             dy = (tt[0] * ryt + tt[1] * rxt) - ryt + tt[4];
             dx = (tt[2] * ryt + tt[3] * rxt) - rxt + tt[5];
-            m = 1.f / (1.f + __expf(-ld_b(hb, ((unsigned)(6 * a.dg + dgi * 9) * uplane + tap * uplane + pix) * 4u)));
+            m = 1.f / (1.f + __expf(-ld_b(hb, ((unsigned)(6 * a.dg + dgi * 9) * uplane + (unsigned)tap * uplane + pix) * 4u)));
           } else {
             const float* offb = a.offset + ((size_t)bn * a.dg + dgi) * 18 * plane;
             const float* mkb = a.mask + ((size_t)bn * a.dg + dgi) * 9 * plane;
-            dy = ld_b(offb, (2u * tap * uplane + pix) * 4u);
-            dx = ld_b(offb, ((2u * tap + 1u) * uplane + pix) * 4u);
-            m = ld_b(mkb, (tap * uplane + pix) * 4u);
+            dy = ld_b(offb, (2u * (unsigned)tap * uplane + pix) * 4u);
+            dx = ld_b(offb, ((2u * (unsigned)tap + 1u) * uplane + pix) * 4u);
+            m = ld_b(mkb, ((unsigned)tap * uplane + pix) * 4u);
           }
           const float py = (fgy + ryt) + dy;
           const float px = (fgx + rxt) + dx;
+          if (!(py > -1.f && px > -1.f && py < (float)h && px < (float)w)) m = 0.f;     // validity gate (flagged lanes pass it)
           const float fy0 = floorf(py), fx0 = floorf(px);
           const float lh = py - fy0, lw = px - fx0;
           const float hm = (1.f - lh) * m, lm = lh * m, hw = 1.f - lw;
@@ -393,35 +556,25 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
             }
           }
         }
-        u32x4 b[3];
+        u32x4 b[3], av[6];
 #pragma unroll
         for (int c = 0; c < IG / 2; ++c) {
           unsigned h2, m2, l2;
           il_split2(v[2 * c], v[2 * c + 1], h2, m2, l2);
           b[0][c] = h2; b[1][c] = m2; b[2][c] = l2;
         }
-        stage_c(t, b, acc);
+        const u32x4* ws = wst + t * (3 * 2 * 64);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) av[j] = ws[j * 64];
+#pragma unroll
+        for (int i = 0; i < 2 * NPROD; ++i) mfma_i(i, av, b, acc);
       }
     }
 
-    // ---- end of a tile: bias, store, next tile's coordinates ------------------------------------------------------
+    // ---- end of a tile: the accumulators leave at the top of the next step (or after the loop) --------------------------
     if (last_g) {
-      if (pix_ok) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int co = cot * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kg;
-            if (co < a.cout) {
-              const float b = a.bias ? a.bias[co] : 0.f;
-              a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = acc[m][e] + b;
-            }
-          }
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+      st_pending = true;
+      st_bn = bn; st_gy = gy; st_gx = gx; st_ok = pix_ok;
       bn = nbn; y0 = ny0; x0 = nx0;
       gy = ngy; gx = ngx; pix_ok = npix_ok; pix = npix;
       g = 0;
@@ -430,6 +583,13 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
       ++g;
     }
   }
+  if (st_pending) store_tile();
+#ifdef EAVSR_IL_STAMPS
+  IL_STAMP(7);
+  if (lane == 0 && (wave == 0 || wave == 4)) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_il_stamps[(wave == 4 ? 8 : 0) + i], st_acc[i]);
+  }
+#endif
 }
 
 // (n, c, h, w) fp32 -> IL8 [n][c/8][h][w][8]: one thread per (pixel, octet), 8 coalesced plane reads, two float4 writes
@@ -470,6 +630,18 @@ int launch_il(const ILArgs& a, dim3 grid, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef EAVSR_IL_STAMPS
+extern "C" int eavsr_debug_il_stamps(unsigned long long* host_out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_il_stamps), sizeof(g_il_stamps));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_il_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" int eavsr_nchw_to_il8_f32(const float* x, float* out, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
   EAVSR_REQUIRE(x && out, -1, "nchw_to_il8: NULL pointer");

@@ -554,10 +554,16 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
     return out
 
 
-# How the fp32 contraction of the DCNv2 kernel is carried: "native" = v_mfma_f32_32x32x2_f32 (an fp32 fma chain, the
-# default), "bf16x9" = exact three-way bf16 split of both operands, nine bf16 MFMA partial products accumulated in
-# fp32 (eavsr_dcnv2_f32x9: no operand is rounded, only the accumulation order differs).  Opt-in.
-DCN_MODE = os.environ.get("EAVSR_DCN_MODE", "native")
+# How DCNv2 runs (fp32 tensors in and out in every mode):
+#   "il6" (default) = the round-2 hot-path kernel eavsr_dcnv2_il_f32: IL8 input layout, both fp32 operands split exactly into
+#              three bf16 terms, the six partial products that matter on the bf16 MFMA, fp32 accumulation (the three dropped
+#              products are < 2^-23 of the result each: one fp32 rounding).  Inside MultiAdSTN (inference) it is fed by the
+#              paired warp (IL8 output) and by the predictor's head channels directly (affine -> offsets and the mask sigmoid
+#              happen in the kernel); a plain modulated_deform_conv2d call converts its NCHW input first.
+#   "il9"    = the same kernel with all nine partial products (exact operands, only the fp32 accumulation rounds)
+#   "native" = round 1's LDS-window kernel on v_mfma_f32_32x32x2_f32 (an fp32 fma chain)
+#   "bf16x9" = round 1's bf16x9 kernel (NCHW input, LDS window per channel plane)
+DCN_MODE = os.environ.get("EAVSR_DCN_MODE", "il6")
 
 
 def set_dcn_mode(mode: str) -> None:

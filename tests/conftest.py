@@ -19,3 +19,12 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu and needs a GPU; none is visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """The CPU oracle (torch on the host cores) is what the GPU tests compare with; on a 256-thread host torch's default
+    (one thread per core) runs it several times slower than 32 threads do."""
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    yield

@@ -41,7 +41,7 @@ def test_config1_full_size_clip_matches_the_cpu_oracle(cuda):
     `eavsrp_forward` (models/eavsrp_model.py:202-240) within 1e-3 max abs.  The 64 x 64 golden clip is too small for the
     Winograd kernels to engage; this is the size the bench times."""
     from eavsr_amd import ops
-    assert ops.CONV_MODE == "winograd4" and ops.DCN_MODE in ("native", "auto")
+    assert ops.CONV_MODE == "winograd4" and ops.DCN_MODE == "il6"
     net, sd = _net(cuda)
     clip = _clip(1, 7, 180, 320, seed=0)
     with torch.no_grad():
@@ -55,8 +55,7 @@ def test_config1_full_size_clip_matches_the_cpu_oracle(cuda):
     assert tuple(y.shape) == (1, 7, 3, 720, 1280)
     ran = {"conv3x3_64to64_wino4", "conv5x5_64to120_wino"}
     assert ran <= names, names
-    assert any(k.startswith("dcnv2") and k != "dcnv2_generic" for k in names), names
-    assert "flow_warp" in names or "flow_warp2" in names, names
+    assert "dcnv2_il_heads" in names and "flow_warp_pair" in names and "flow_warp" in names, names
     err = H.maxabs(y, ref)
     assert err <= 1e-3, err
     assert H.maxabs(y2, ref) <= 1e-3

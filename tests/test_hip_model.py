@@ -12,6 +12,7 @@ from tests.golden import cases
 pytestmark = pytest.mark.gpu
 
 DEFAULT_CONV_MODE = "winograd4"   # eavsr_amd.ops.CONV_MODE's default; tests that switch modes restore it
+DEFAULT_DCN_MODE = "il6"           # eavsr_amd.ops.DCN_MODE's default
 
 OPT = Namespace(predict=False, n_frame=7, n_flow=5, scale=4)
 
@@ -202,7 +203,7 @@ def test_forward_with_bf16x9_contractions_equals_the_native_forward(nets, cuda):
             names = set(prof.summary())
         finally:
             ops.set_conv_mode(DEFAULT_CONV_MODE)
-            ops.set_dcn_mode("native")
+            ops.set_dcn_mode(DEFAULT_DCN_MODE)
     assert "conv3x3_64to64_x9" in names and "dcnv2_x9" in names and "conv3x3_64to64" not in names
     diff = H.maxabs(got.cpu(), ref.cpu())
     assert diff <= 2e-5, diff

@@ -11,6 +11,7 @@ from tests.golden import cases
 pytestmark = pytest.mark.gpu
 
 DEFAULT_CONV_MODE = "winograd4"   # eavsr_amd.ops.CONV_MODE's default; tests that switch modes restore it
+DEFAULT_DCN_MODE = "il6"           # eavsr_amd.ops.DCN_MODE's default
 
 
 @pytest.fixture(scope="module")
@@ -187,7 +188,7 @@ def test_flow_warp_all_grid_sample_modes(ops, cuda, pad, interp, align):
 
 @pytest.mark.parametrize("shape", [(2, 64, 24, 40), (1, 64, 13, 37), (1, 8, 9, 70), (3, 24, 5, 3)])
 def test_flow_warp_pair_equals_two_single_warps(ops, cuda, shape):
-    """networks.py:621 + :623 as one launch: bit-identical to the single warps, second output optionally IL8"""
+    """networks.py:621 + :623 as one launch: the NCHW outputs bit-identical to the single warps, second output optionally IL8"""
     n, c, h, w = shape
     xa, xb = cases.randn(1, n, c, h, w), cases.randn(2, n, c, h, w)
     f1, f2 = cases.randn(3, n, 2, h, w, scale=3.0), cases.randn(4, n, 2, h, w)
@@ -197,7 +198,9 @@ def test_flow_warp_pair_equals_two_single_warps(ops, cuda, shape):
         a2, b2 = ops.flow_warp_pair(g(xa, cuda), g(xb, cuda), g(f1, cuda), None if flow2 is None else g(flow2, cuda))
         assert torch.equal(a1, a2) and torch.equal(b1, b2)
         a3, b3 = ops.flow_warp_pair(g(xa, cuda), g(xb, cuda), g(f1, cuda), None if flow2 is None else g(flow2, cuda), b_il8=True)
-        assert torch.equal(a1, a3) and torch.equal(ops.to_il8(b1), b3)
+        assert torch.equal(a1, a3)
+        # same samples; the octet loop may contract multiply-adds differently from the plane loop (one rounding)
+        assert H.maxabs(ops.to_il8(b1).cpu(), b3.cpu()) <= 1e-6 * max(1.0, xb.abs().max().item())
     assert H.maxabs(a1.cpu(), O.flow_warp(xa, f1 + f2)) <= 2e-5 * max(1.0, xa.abs().max().item())
 
 
@@ -589,7 +592,7 @@ def test_conv3x3_x9_error_against_fp64_is_that_of_the_fp32_kernel(ops, cuda):
 def dcn_x9(ops):
     ops.set_dcn_mode("bf16x9")
     yield ops
-    ops.set_dcn_mode("native")
+    ops.set_dcn_mode(DEFAULT_DCN_MODE)
 
 
 @pytest.mark.parametrize("sigma", [0.0, 0.5, 2.0, 8.0])
@@ -629,7 +632,7 @@ def test_dcnv2_x9_error_against_fp64_is_that_of_the_fp32_kernel(ops, cuda):
     try:
         e_x9 = (ops.modulated_deform_conv2d(*args).cpu().double() - ref64).abs().max().item() / scale
     finally:
-        ops.set_dcn_mode("native")
+        ops.set_dcn_mode(DEFAULT_DCN_MODE)
     assert e_native < 5e-6 and e_x9 < 5e-6, (e_native, e_x9)      # measured: 2.1e-6 and 2.2e-6 (sampler rounding dominates)
     assert e_x9 <= 1.5 * e_native + 1e-7, (e_native, e_x9)
 

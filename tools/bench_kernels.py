@@ -28,6 +28,7 @@ if "convhr" in which:
     for _ in range(2):
         ops.conv2d(hr, w33, b, act="relu")
 if "dcn" in which:
+    ops.set_dcn_mode(os.environ.get("EAVSR_DCN_MODE", "native"))     # the NCHW kernel of round 1; the IL8 one is "dcnil" below
     off = r(n, 144, h, w) * float(os.environ.get("SIGMA", 1.5))
     mask = torch.rand(n, 72, h, w, device=dev)
     for _ in range(reps):
@@ -45,5 +46,7 @@ if "warp" in which:
     flow = r(n, 2, h, w) * 2
     for _ in range(reps):
         ops.flow_warp(x64, flow)
+    for _ in range(reps):
+        ops.flow_warp_pair(x64, x64, flow, b_il8=True)
 torch.cuda.synchronize()
 print("done")
