@@ -80,6 +80,7 @@ SIGNATURES = {
     "eavsr_ca_scale_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_scale_residual_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_adapt_frontend_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_flow_level_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, vp]),
     "eavsr_affine_offsets_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_resize_bilinear_ac_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_pyramid_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),

@@ -16,6 +16,8 @@
 //     (networks.py:313-314).  Pure streaming.
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr int FT_H = 16, FT_W = 64;  // output tile per workgroup
@@ -161,4 +163,278 @@ extern "C" int eavsr_affine_offsets_f32(const float* heads, float* offset, float
   hipLaunchKernelGGL(affine_offsets_kernel, grid, dim3(256), 0, eavsr::as_stream(stream), heads, offset, mask, D,
                      hw, head_c);
   return eavsr::launch_status("affine_offsets");
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (3) flow_level: one pyramid level of MultiAdSTN's residual-flow refinement as ONE kernel (networks.py:604-619):
+//        f      = concat2(concat(cat(x, h_hr)))                      AdaptBlock2_3x3 front end (networks.py:327-328,336)
+//        heads  = conv3x3(f; transform_matrix_conv ++ translation_conv)     64 -> 4 + 2          (networks.py:330-331,337)
+//        off18  = T . R - R + t                                       (networks.py:338-346)
+//        p      = conv3x3(off18; TransOffsetworelu.conv_first)        18 -> 2, no activation     (networks.py:566-571)
+//     Round 1 ran this as four launches (adapt_frontend, conv3x3 64->6, affine_offsets, conv3x3 18->2) whose intermediates
+//     (64, 6 and 18 channels) all went through HBM; here a workgroup reads the 2 x 64 input channels of its tile (+ 4 px
+//     halo) once and writes 2 channels.  Channel o of f depends on cat channels 2o, 2o+1 only, so f is produced one
+//     channel at a time in LDS and folded at once into the six head accumulators that every thread keeps in registers
+//     for its pixels; off18 then lives in LDS for the last convolution.  Every stage is zero outside the IMAGE (each conv
+//     of the chain zero-pads its own input), which the staged tiles reproduce explicitly.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int LT_H = 16, LT_W = 32;           // output tile
+// Every stage lives in an LDS image of 24 rows x 48 columns with the SAME origin (y0 - 4, x0 - 8): stage k of the chain is
+// valid one row / column further in than stage k-1, and every stencil is evaluated on aligned groups of four columns (one
+// ds_read_b128 + two ds_read_b32 per stencil row feed 4 outputs x 3 taps), columns 4 .. 43.  Groups at the rim compute a
+// few values nobody reads.
+constexpr int LP = 48, LR = 24;               // pitch, rows
+constexpr int LG0 = 1, LGN = 10;              // column groups 1 .. 10  (columns 4 .. 43)
+constexpr int LOP = 40;                       // pitch of the off18 image (columns 4 .. 43 -> 0 .. 39), rows 3 .. 20 -> 0 .. 17
+
+// 3 rows x 6 columns around an aligned group of four: v[r][0..5] = img[row + r][col4 - 1 .. col4 + 4]
+__device__ __forceinline__ void ld_3x6(const float* img, int pitch, float (&v)[3][6]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const f32x4 m = *reinterpret_cast<const f32x4*>(img + r * pitch);
+    v[r][0] = img[r * pitch - 1];
+    v[r][1] = m[0]; v[r][2] = m[1]; v[r][3] = m[2]; v[r][4] = m[3];
+    v[r][5] = img[r * pitch + 4];
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_level_kernel(
+    const float* __restrict__ x, const float* __restrict__ hh, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ wh, const float* __restrict__ bh,
+    const float* __restrict__ wt, const float* __restrict__ bt, float* __restrict__ out, int c, int h, int w, int tiles_x,
+    int tiles_y) {
+  // LDS: the three stage images, the off18 image, and ALL per-channel weights of the chain (staged once per workgroup:
+  // fetching each channel's 93 coefficients by scalar loads put four exposed SMEM round trips into every channel step)
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  float (*s_in)[LR * LP] = reinterpret_cast<float (*)[LR * LP]>(lsm);
+  float (*s_mid)[LR * LP] = reinterpret_cast<float (*)[LR * LP]>(lsm + 2 * LR * LP);
+  float* s_f = lsm + 4 * LR * LP;
+  float (*s_off)[18 * LOP] = reinterpret_cast<float (*)[18 * LOP]>(lsm + 5 * LR * LP);
+  float* s_wgt = lsm + 5 * LR * LP + 18 * 18 * LOP;      // per f-channel o, 96 floats: [w1 pair 18][b1 pair 2][w2 18][b2 1][pad 3][wh 6 x 9]
+  const int tid = threadIdx.x;
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int bn = bid / tiles_y;
+  const int y0 = ty * LT_H, x0 = tx * LT_W;
+  const int gy0 = y0 - 4, gx0 = x0 - 8;        // image coordinates of LDS (row 0, column 0)
+  const size_t plane = (size_t)h * w;
+
+  // the LDS images start as zeros: rim columns / rows that no stage writes must hold finite values
+  for (int e = tid; e < 2 * LR * LP; e += 256) { (&s_in[0][0])[e] = 0.f; (&s_mid[0][0])[e] = 0.f; }
+  for (int e = tid; e < LR * LP; e += 256) s_f[e] = 0.f;
+  for (int e = tid; e < c * 96; e += 256) {
+    const int o = e / 96, j = e - o * 96;
+    float v = 0.f;
+    if (j < 18) v = w1[(size_t)(2 * o) * 9 + j];                 // cat channels 2o, 2o+1: 9 taps each (contiguous)
+    else if (j < 20) v = b1[2 * o + (j - 18)];
+    else if (j < 38) v = w2[(size_t)o * 18 + (j - 20)];
+    else if (j == 38) v = b2[o];
+    else if (j >= 42) v = wh[((size_t)((j - 42) / 9) * c + o) * 9 + (j - 42) % 9];
+    s_wgt[e] = v;
+  }
+
+  // input patch: 2 channels x 24 rows x columns 4 .. 43 (= x0 - 4 .. x0 + 35): 1920 values, 7.5 per thread; the offsets
+  // are the same for every channel pair
+  constexpr int P_N = 2 * LR * 40, P_IT = (P_N + 255) / 256;
+  int poff[P_IT], pdst[P_IT];      // offset inside a plane (-1: outside the image), LDS destination
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) {
+    const int e = tid + i * 256;
+    const int ch = e >= LR * 40 ? 1 : 0;
+    const int rem = e - ch * (LR * 40);
+    const int r = rem / 40, cc = rem - r * 40;
+    const int gy = gy0 + r, gx = gx0 + 4 + cc;
+    poff[i] = (e < P_N && gy >= 0 && gy < h && gx >= 0 && gx < w) ? gy * w + gx : -1;
+    pdst[i] = e < P_N ? ch * (LR * LP) + r * LP + 4 + cc : -1;
+  }
+  auto load_pair = [&](int o, float (&t)[P_IT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const int ch = (tid + i * 256) >= LR * 40 ? 1 : 0;
+      const int cat_c = 2 * o + ch;
+      const float* src = cat_c < c ? x + ((size_t)bn * c + cat_c) * plane : hh + ((size_t)bn * c + (cat_c - c)) * plane;
+      t[i] = poff[i] >= 0 ? src[poff[i]] : 0.f;
+    }
+  };
+
+  // work items: (row, group of four columns)
+  //   t1    rows 1 .. 22, 10 groups, 2 channels: 440 items      f rows 2 .. 21: 200 items      heads rows 3 .. 20: 180 items
+  const bool h_item = tid < 18 * LGN;
+  const int h_r = 3 + tid / LGN, h_g = LG0 + tid % LGN;
+  float hacc[6][4];
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hacc[k][j] = 0.f;
+
+  float tin[P_IT];
+  load_pair(0, tin);
+  for (int o = 0; o < c; ++o) {
+    __syncthreads();      // the previous channel's passes are done with s_in / s_mid / s_f (and the zero fill is complete)
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i)
+      if (pdst[i] >= 0) (&s_in[0][0])[pdst[i]] = tin[i];
+    if (o + 1 < c) load_pair(o + 1, tin);      // next channel pair: in flight under this channel's arithmetic
+    __syncthreads();
+    // t1 = lrelu(depthwise 3x3 + b1), zero outside the image
+    for (int it = tid; it < 2 * 22 * LGN; it += 256) {
+      const int ch = it >= 22 * LGN ? 1 : 0;
+      const int rem = it - ch * (22 * LGN);
+      const int r = 1 + rem / LGN, g = LG0 + rem % LGN;
+      float v[3][6];
+      ld_3x6(&s_in[ch][(r - 1) * LP + 4 * g], LP, v);
+      const float* wk = s_wgt + o * 96 + ch * 9;      // wave-uniform LDS addresses: broadcast reads
+      const float bb = s_wgt[o * 96 + 18 + ch];
+      f32x4 res;
+      const int gy = gy0 + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = bb;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) a += wk[ky * 3 + kx] * v[ky][j + kx];
+        const int gx = gx0 + 4 * g + j;
+        res[j] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? lrelu02(a) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(&s_mid[ch][r * LP + 4 * g]) = res;
+    }
+    __syncthreads();
+    // f_o = lrelu(grouped 3x3 over the two t1 channels + b2), zero outside the image
+    if (tid < 20 * LGN) {
+      const int r = 2 + tid / LGN, g = LG0 + tid % LGN;
+      const float* wk2 = s_wgt + o * 96 + 20;
+      float a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = s_wgt[o * 96 + 38];
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        float v[3][6];
+        ld_3x6(&s_mid[ch][(r - 1) * LP + 4 * g], LP, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a[j] += wk2[ch * 9 + ky * 3 + kx] * v[ky][j + kx];
+      }
+      f32x4 res;
+      const int gy = gy0 + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gx = gx0 + 4 * g + j;
+        res[j] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? lrelu02(a[j]) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(&s_f[r * LP + 4 * g]) = res;
+    }
+    __syncthreads();
+    // heads += wh[:, o] * f_o  (3x3, six outputs for the item's four pixels)
+    if (h_item) {
+      float v[3][6];
+      ld_3x6(&s_f[(h_r - 1) * LP + 4 * h_g], LP, v);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float* wk = s_wgt + o * 96 + 42 + k * 9;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float ww = wk[ky * 3 + kx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hacc[k][j] += ww * v[ky][j + kx];
+          }
+      }
+    }
+  }
+  // off18 = T . R - R + t per position, zero outside the image (the padding of TransOffsetworelu's conv)
+  if (h_item) {
+    const int gy = gy0 + h_r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gx = gx0 + 4 * h_g + j;
+      const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+      const float t00 = hacc[0][j] + bh[0], t01 = hacc[1][j] + bh[1], t10 = hacc[2][j] + bh[2], t11 = hacc[3][j] + bh[3];
+      const float try_ = hacc[4][j] + bh[4], trx = hacc[5][j] + bh[5];
+      const int e = (h_r - 3) * LOP + 4 * (h_g - LG0) + j;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float ry = (float)(k / 3 - 1), rx = (float)(k % 3 - 1);
+        // (T . R)[:,k] - R[:,k] + t     (matmul then subtract then add, networks.py:338-346)
+        const float oy = (t00 * ry + t01 * rx) - ry + try_;
+        const float ox = (t10 * ry + t11 * rx) - rx + trx;
+        s_off[2 * k][e] = in ? oy : 0.f;
+        s_off[2 * k + 1][e] = in ? ox : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // p = conv3x3(off18) + bt: rows 4 .. 19, columns 8 .. 39 = off18-image rows 1 .. 16, columns 4 .. 35; 128 items of 4 pixels
+  if (tid < LT_H * (LT_W / 4)) {
+    const int r = tid / (LT_W / 4), g = tid % (LT_W / 4);      // output row r, pixels 4 g .. 4 g + 3 of the tile
+    const int gy = y0 + r, gx = x0 + 4 * g;
+    float p0[4], p1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { p0[j] = bt[0]; p1[j] = bt[1]; }
+    for (int ch = 0; ch < 18; ++ch) {
+      float v[3][6];
+      ld_3x6(&s_off[ch][r * LOP + 4 + 4 * g], LOP, v);      // rows r .. r + 2 of the off18 image = image rows gy - 1 .. gy + 1
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float wa = wt[(0 * 18 + ch) * 9 + ky * 3 + kx], wb = wt[(1 * 18 + ch) * 9 + ky * 3 + kx];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            p0[j] += wa * v[ky][j + kx];
+            p1[j] += wb * v[ky][j + kx];
+          }
+        }
+    }
+    if (gy < h) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (gx + j < w) {
+          out[((size_t)bn * 2 + 0) * plane + (size_t)gy * w + gx + j] = p0[j];
+          out[((size_t)bn * 2 + 1) * plane + (size_t)gy * w + gx + j] = p1[j];
+        }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int eavsr_flow_level_f32(const float* x, const float* h_hr, const float* w1, const float* b1, const float* w2,
+                                    const float* b2, const float* w_heads, const float* b_heads, const float* w_trans,
+                                    const float* b_trans, float* out, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+  EAVSR_REQUIRE(x && h_hr && w1 && b1 && w2 && b2 && w_heads && b_heads && w_trans && b_trans && out, -1, "flow_level: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && c > 0 && h > 0 && w > 0, -1, "flow_level: bad dims");
+  EAVSR_REQUIRE(c % 2 == 0, -2, "flow_level: channel count %d must be even", c);
+  EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "flow_level: plane too large");
+  if (n == 0) return 0;
+  const int tiles_x = eavsr::cdiv(w, LT_W), tiles_y = eavsr::cdiv(h, LT_H);
+  const long nblk = (long)tiles_x * tiles_y * n;
+  EAVSR_REQUIRE(nblk < (1L << 31), -1, "flow_level: too many tiles");
+  const size_t lds = (size_t)(5 * LR * LP + 18 * 18 * LOP + c * 96) * sizeof(float);
+  EAVSR_REQUIRE(lds <= 160 * 1024, -2, "flow_level: %d channels need %zu bytes of LDS", c, lds);
+  if (lds > 64 * 1024) {
+    static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+    const int dev_ = eavsr::current_device();
+    static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+    hipError_t& attr_err = attr_err_pd[dev_];
+    std::call_once(once_pd.flag[dev_], [&] {
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_level_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024);
+    });
+    if (attr_err != hipSuccess) {
+      eavsr::set_error("flow_level: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+      return (int)attr_err;
+    }
+  }
+  hipLaunchKernelGGL(flow_level_kernel, dim3((unsigned)nblk), dim3(256), lds, eavsr::as_stream(stream), x, h_hr, w1, b1, w2, b2,
+                     w_heads, b_heads, w_trans, b_trans, out, c, h, w, tiles_x, tiles_y);
+  return eavsr::launch_status("flow_level");
 }

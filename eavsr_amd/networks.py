@@ -231,6 +231,21 @@ class MultiAdSTN(ModulatedDeformConv2d):
         self.trans_l1 = TransOffsetworelu()
         self.center = getattr(opt, "n_frame", 7) // 2
 
+    @staticmethod
+    def _level(flow_blk, trans_blk, warp, ref):
+        """trans(flow(warp, ref)): one pyramid level's residual flow (networks.py:605-607 etc.).  Inference: ONE kernel
+        (front end, 64 -> 4 + 2 heads, affine -> 18 offsets, 18 -> 2 conv, nothing but the two inputs and the 2-channel flow
+        touch HBM); with gradients: the un-fused ops, each with its backward kernel."""
+        tconv = trans_blk.conv_first[0] if isinstance(trans_blk.conv_first, nn.Sequential) else trans_blk.conv_first
+        params = [warp, ref] + list(flow_blk.parameters()) + list(trans_blk.parameters())
+        if FUSE_FLOW_LEVEL and not AG.needs_grad(params) and warp.shape[1] % 2 == 0:
+            c1, c2 = flow_blk.concat[0], flow_blk.concat2[0]
+            return ops.flow_level(warp, ref, c1.weight, c1.bias, c2.weight, c2.bias,
+                                  [flow_blk.transform_matrix_conv.weight, flow_blk.translation_conv.weight],
+                                  [flow_blk.transform_matrix_conv.bias, flow_blk.translation_conv.bias],
+                                  tconv.weight, tconv.bias)
+        return trans_blk(flow_blk(warp, ref))
+
     def _fused_alignment(self, nbr, feat_prop, offset) -> bool:
         return (ops.DCN_MODE in ("il6", "il9") and not AG.needs_grad(nbr, feat_prop, offset, list(self.parameters()))
                 and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
@@ -247,15 +262,15 @@ class MultiAdSTN(ModulatedDeformConv2d):
             off_d2 = AG.resize_bilinear_ac(offset, (h2, w2), 0.5)             # :601
             # level 3 (:604-608)
             warp4 = AG.flow_warp(nbr_feat_l[2], off_d4)
-            p1 = self.trans_l3(self.flow_l3(warp4, ref_feat_l[2]))
+            p1 = self._level(self.flow_l3, self.trans_l3, warp4, ref_feat_l[2])
             p1_up = AG.resize_bilinear_ac(p1, (2 * h4, 2 * w4), 2.0)
             # level 2 (:609-613)
             warp2 = AG.flow_warp(nbr_feat_l[1], off_d2, flow2=p1_up)
-            p2 = self.trans_l2(self.flow_l2(warp2, ref_feat_l[1]))
+            p2 = self._level(self.flow_l2, self.trans_l2, warp2, ref_feat_l[1])
             p2_up = AG.resize_bilinear_ac(p2, (2 * h2, 2 * w2), 2.0, pre_add=p1_up)
             # level 1 (:614-619)
             warp1 = AG.flow_warp(nbr_feat_l[0], offset, flow2=p2_up)
-            p3 = self.trans_l1(self.flow_l1(warp1, ref_feat_l[0]))
+            p3 = self._level(self.flow_l1, self.trans_l1, warp1, ref_feat_l[0])
             offset = AG.add(p3, p2_up, offset)
         if self._fused_alignment(nbr_feat_l[0], feat_prop, offset):
             # inference hot path: both warps by the refined offset in ONE launch, the second one written in the IL8 layout the
@@ -324,6 +339,20 @@ class RCABlock(nn.Module):
 # side output) against the 27 us scale_residual launch it removes - 314 ms vs 311 ms per step - so it is off by default.
 import os as _os
 FUSE_CA_INTO_CONV = _os.environ.get("EAVSR_FUSE_CA", "0") == "1"
+# One kernel per pyramid level of the residual-flow refinement (eavsr_flow_level_f32: front end + 64 -> 6 heads + affine +
+# 18 -> 2 conv, only the two inputs and the 2-channel flow touch HBM) instead of four launches.  Correct (goldens G2 / G5,
+# tests/test_hip_ops.py) but OFF by default: measured 28.5 ms per 2-clip forward against 13.0 ms for the four launches --
+# a tile's 64 channel steps are serial inside one 4-wave workgroup (4 barriers each) and the 240 tiles of a 2 x 180 x 320
+# launch leave no second workgroup per CU to hide them, while the un-fused kernels run 64x more workgroups.  EAVSR_FUSE_LEVEL=1
+# / set_fuse_flow_level(True) turns it on (DESIGN.md has the analysis and what a channel-parallel version would need).
+FUSE_FLOW_LEVEL = _os.environ.get("EAVSR_FUSE_LEVEL", "0") == "1"
+
+
+def set_fuse_flow_level(on: bool) -> None:
+    global FUSE_FLOW_LEVEL
+    FUSE_FLOW_LEVEL = bool(on)
+
+
 # Optional 16-bit residual backbone: None (exact fp32, the default and the BASELINE headline), "bf16" or "fp16"
 # (set_backbone_dtype / EAVSR_BACKBONE_DTYPE).  Only the RCAGroup internals change precision.
 BACKBONE_DTYPE = _os.environ.get("EAVSR_BACKBONE_DTYPE") or None

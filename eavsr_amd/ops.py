@@ -682,6 +682,28 @@ def adapt_frontend(x: Tensor, h_hr: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, 
     return out
 
 
+def flow_level(x: Tensor, h_hr: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, head_ws: Sequence[Tensor],
+               head_bs: Sequence[Tensor], wt: Tensor, bt: Tensor) -> Tensor:
+    """TransOffsetworelu(AdaptBlock2_3x3(x, h_hr)) as one kernel (networks.py:334-348 + 566-571): (n,c,h,w) x 2 -> (n,2,h,w).
+    head_ws / head_bs: [transform_matrix_conv, translation_conv] parameters (4 + 2 output channels)."""
+    x, h_hr = _chk(x, "x"), _chk(h_hr, "h_hr")
+    if x.shape != h_hr.shape:
+        raise ValueError("x and h_hr must have the same shape")
+    n, c, h, w = x.shape
+    wh, bh = _cat_weights(list(head_ws)), _bias_of(list(head_bs))
+    if tuple(w1.shape) != (2 * c, 1, 3, 3) or tuple(w2.shape) != (c, 2, 3, 3) or tuple(wh.shape) != (6, c, 3, 3) or \
+            tuple(wt.shape) != (2, 18, 3, 3) or bh is None:
+        raise ValueError("flow_level: parameter shapes")
+    w1, b1, w2, b2, wt, bt = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2, wt, bt))
+    out = torch.empty((n, 2, h, w), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch("flow_level", 2.0 * px * (27 * c + 54 * c + 324), 4.0 * px * (2 * c + 2), x,
+            lambda: lib().eavsr_flow_level_f32(_p(x), _p(h_hr), _p(w1), _p(b1), _p(w2), _p(b2), _p(wh), _p(bh), _p(wt), _p(bt),
+                                               _p(out), n, c, h, w, st), "flow_level")
+    return out
+
+
 def affine_offsets(heads: Tensor, D: int, with_mask: bool) -> Tuple[Tensor, Optional[Tensor]]:
     heads = _chk(heads, "heads")
     n, hc, h, w = heads.shape

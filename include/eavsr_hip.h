@@ -76,6 +76,16 @@ int eavsr_flow_warp_f32(const float* x, const float* flow, const float* flow2, f
 int eavsr_flow_warp_pair_f32(const float* xa, const float* xb, const float* flow, const float* flow2, float* outa,
                              float* outb, int32_t n, int32_t c, int32_t h, int32_t w, int32_t outb_il8, void* stream);
 
+/* One pyramid level of MultiAdSTN's residual-flow refinement as ONE kernel (networks.py:604-619): AdaptBlock2_3x3
+ * (front end `concat` + `concat2`, the 3x3 heads transform_matrix_conv (4) ++ translation_conv (2), the affine -> 18 offsets
+ * expansion, networks.py:334-348) followed by TransOffsetworelu's 3x3 conv 18 -> 2 (networks.py:566-571).
+ * x, h_hr (n, c, h, w); w1 (2c,1,3,3) b1 (2c); w2 (c,2,3,3) b2 (c); w_heads (6, c, 3, 3) b_heads (6); w_trans (2, 18, 3, 3)
+ * b_trans (2); out (n, 2, h, w).  Replaces eavsr_adapt_frontend_f32 + eavsr_conv3x3_smallco_f32 (64 -> 6) +
+ * eavsr_affine_offsets_f32 + eavsr_conv3x3_smallco_f32 (18 -> 2) and their three HBM round trips. */
+int eavsr_flow_level_f32(const float* x, const float* h_hr, const float* w1, const float* b1, const float* w2,
+                         const float* b2, const float* w_heads, const float* b_heads, const float* w_trans,
+                         const float* b_trans, float* out, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+
 /* ---- a7: DCNv2 ------------------------------------------------------------------------------
  * replaces mmcv.ops.modulated_deform_conv2d as called at models/networks.py:627-630 (module
  * parameters from the ModulatedDeformConv2d base class, networks.py:575-583).

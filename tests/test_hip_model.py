@@ -69,9 +69,10 @@ def test_multiadstn_golden(nets, cuda, preset):
     assert H.maxabs(out.cpu(), gold["out"]) <= 1e-4
 
 
+@pytest.mark.parametrize("fuse_level", [False, True])
 @pytest.mark.parametrize("mode", ["native", "il6", "il9"])
 @pytest.mark.parametrize("preset", ["default", "trained_like"])
-def test_multiadstn_golden_in_every_dcn_mode(nets, cuda, preset, mode):
+def test_multiadstn_golden_in_every_dcn_mode(nets, cuda, preset, mode, fuse_level):
     """the reference's MultiAdSTN output (golden G5) through the un-fused path (two warps, affine_offsets kernel, NCHW DCNv2)
     and through the fused alignment path (paired warp with an IL8 output, predictor heads straight into the DCNv2 kernel)"""
     from eavsr_amd import ops
@@ -80,14 +81,20 @@ def test_multiadstn_golden_in_every_dcn_mode(nets, cuda, preset, mode):
     sd = H.filled(H.multiadstn_shapes("g5.align."), preset)
     m = load(Nw.MultiAdSTN(OPT, 64, 64, deformable_groups=8), sd, "g5.align.", cuda)
     nbr, ref, fp, flow = cases.g5_inputs()
-    prev = ops.DCN_MODE
+    prev, prev_fl = ops.DCN_MODE, Nw.FUSE_FLOW_LEVEL
     ops.set_dcn_mode(mode)
+    Nw.set_fuse_flow_level(fuse_level)
     try:
         with torch.no_grad(), ops.profile() as prof:
             out = m(dev(nbr, cuda), dev(ref, cuda), fp.to(cuda), flow.to(cuda))
         names = set(prof.summary())
     finally:
         ops.set_dcn_mode(prev)
+        Nw.set_fuse_flow_level(prev_fl)
+    if fuse_level:
+        assert "flow_level" in names and "conv3x3_64to6" not in names      # one kernel per pyramid level
+    else:
+        assert "conv3x3_64to6" in names and "adapt_frontend" in names
     if mode == "native":
         assert "dcnv2" in names and "affine_offsets" in names
     else:

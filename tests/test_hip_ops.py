@@ -637,6 +637,43 @@ def test_dcnv2_x9_error_against_fp64_is_that_of_the_fp32_kernel(ops, cuda):
     assert e_x9 <= 1.5 * e_native + 1e-7, (e_native, e_x9)
 
 
+@pytest.mark.parametrize("preset", ["default", "trained_like"])
+@pytest.mark.parametrize("shape", [(1, 64, 12, 16), (2, 64, 45, 80), (1, 64, 33, 70), (1, 64, 5, 3), (1, 8, 20, 40)])
+def test_flow_level_fused_kernel_vs_oracle(ops, cuda, shape, preset):
+    """TransOffsetworelu(AdaptBlock2_3x3(x, h_hr)) (networks.py:334-348, 566-571) as one kernel: tile interiors, image
+    borders (every stage zero-pads its own input), ragged sizes, sizes below one tile"""
+    n, c, h, w = shape
+    shapes = {"f.regular_matrix": (2, 9), "f.concat.0.weight": (2 * c, 1, 3, 3), "f.concat.0.bias": (2 * c,),
+              "f.concat2.0.weight": (c, 2, 3, 3), "f.concat2.0.bias": (c,),
+              "f.transform_matrix_conv.weight": (4, c, 3, 3), "f.transform_matrix_conv.bias": (4,),
+              "f.translation_conv.weight": (2, c, 3, 3), "f.translation_conv.bias": (2,),
+              "t.conv_first.weight": (2, 18, 3, 3), "t.conv_first.bias": (2,)}
+    sd = H.filled(shapes, preset)
+    x, hh = cases.randn(1, n, c, h, w), cases.randn(2, n, c, h, w)
+    ref = O.trans_offset(sd, "t.", O.adapt_block2_3x3(sd, "f.", x, hh))
+    d = lambda k: g(sd[k], cuda)
+    out = ops.flow_level(g(x, cuda), g(hh, cuda), d("f.concat.0.weight"), d("f.concat.0.bias"), d("f.concat2.0.weight"),
+                         d("f.concat2.0.bias"), [d("f.transform_matrix_conv.weight"), d("f.translation_conv.weight")],
+                         [d("f.transform_matrix_conv.bias"), d("f.translation_conv.bias")], d("t.conv_first.weight"),
+                         d("t.conv_first.bias")).cpu()
+    assert H.maxabs(out, ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_flow_level_golden(ops, cuda):
+    """the reference's own AdaptBlock2_3x3 -> TransOffsetworelu output (golden G2 `flow2`) through the fused kernel"""
+    for preset in ("default", "trained_like"):
+        g2 = H.golden(f"g2_adapt3x3_{preset}")
+        sd = H.filled({**H.adapt3x3_shapes("g2.flow."), **H.trans_shapes("g2.trans.")}, preset)
+        x, hh = cases.g2_inputs()
+        d = lambda k: g(sd[k], cuda)
+        out = ops.flow_level(g(x, cuda), g(hh, cuda), d("g2.flow.concat.0.weight"), d("g2.flow.concat.0.bias"),
+                             d("g2.flow.concat2.0.weight"), d("g2.flow.concat2.0.bias"),
+                             [d("g2.flow.transform_matrix_conv.weight"), d("g2.flow.translation_conv.weight")],
+                             [d("g2.flow.transform_matrix_conv.bias"), d("g2.flow.translation_conv.bias")],
+                             d("g2.trans.conv_first.weight"), d("g2.trans.conv_first.bias")).cpu()
+        assert H.maxabs(out, g2["flow2"]) <= 2e-5, preset
+
+
 # ---- round-2 hot-path DCNv2: IL8 input layout, bf16 x6 / x9 products, optional fused affine + sigmoid ("heads") ----------
 def test_to_il8_layout(ops, cuda):
     x = cases.randn(3, 2, 24, 7, 9)
