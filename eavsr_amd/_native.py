@@ -11,7 +11,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeavsr_hip.so")
+LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
 ABI_VERSION = 14
 

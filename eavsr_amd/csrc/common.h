@@ -58,6 +58,21 @@ __device__ __forceinline__ int eavsr_xcd_remap(int bid, int nblk) {
 }
 #endif
 
+// Static priority for the second-dispatched half of an 8-wave workgroup.  The two waves of a SIMD (w and w + 4) run the same
+// program between the same barriers and otherwise contend cycle by cycle, in lockstep; with one of them preferred it runs
+// ahead and the pair settles into a stagger (MI355X_MICROARCH.md, "Two waves per SIMD", items 4 and 9).  Measured on the
+// F(4x4,3x3) kernel: 47.8 -> 43.9 us per 2 x 64 x 180 x 320 convolution (the priority level and which half gets it do not
+// matter: all within 1 us).  -DEAVSR_NO_WAVE_PRIO builds the A-B reference.
+#ifdef __HIPCC__
+__device__ __forceinline__ void eavsr_stagger_priority(int wave) {
+#ifndef EAVSR_NO_WAVE_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(3);
+#else
+  (void)wave;
+#endif
+}
+#endif
+
 // spatial tile of the implicit-GEMM conv kernels: (32, 16 or 8) rows x 32 columns per 512-thread workgroup,
 // wave w owns NT = 4, 2 or 1 consecutive rows, one 32-pixel MFMA N-tile per row.
 #define EAVSR_CONV_TW 32

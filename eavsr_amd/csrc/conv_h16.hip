@@ -90,6 +90,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  eavsr_stagger_priority(wave);
   const int l31 = lane & 31, half = lane >> 5;
   const int h = a.h, w = a.w;
 

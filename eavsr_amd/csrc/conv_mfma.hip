@@ -108,6 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  eavsr_stagger_priority(wave);
   const int l31 = lane & 31, half = lane >> 5;
 
   int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_small_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  eavsr_stagger_priority(wave);
   const int l31 = lane & 31, half = lane >> 5;
   int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;

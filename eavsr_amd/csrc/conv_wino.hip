@@ -87,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  eavsr_stagger_priority(wave);
 
   // Persistent workgroups: workgroup b walks the tiles b, b + gridDim.x, ... (XCD-contiguous order) as ONE flattened
   // sequence of (tile, chunk) iterations, so the LDS-DMA stream never drains at a tile boundary and the epilogue of

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   const int l15 = lane & 15, kq = lane >> 4;
   const unsigned lane16 = lane * 16u;
   const int cb = wave >> 1, tg = wave & 1;
+  eavsr_stagger_priority(wave);      // common.h: 47.8 -> 43.9 us per 2 x 64 x 180 x 320 convolution
   float bias_r[4];   // this lane's four output channels are the same for every tile of the launch
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -233,6 +234,38 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       const int seg = i * NW + wave;
       if (seg < U_SEGS)
         __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * (NW * 1024) + lane16), (lptr_t)(s_u + seg * 256), 16, 0, 0);
+    }
+  };
+
+  // the same two transfers one 1-KiB piece at a time (EAVSR_W4_SPREAD: issued between the GEMM steps instead of as a burst)
+  auto issue_u_piece = [&](int i, int g, int stage) __attribute__((always_inline)) {
+    float* s_u = smem + OFF_U + stage * U_ELEMS;
+    const char* usrc = reinterpret_cast<const char*>(wu_base + (size_t)g * U_ELEMS) + wave * 1024;
+    const int seg = i * NW + wave;
+    if (seg < U_SEGS)
+      __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * (NW * 1024) + lane16), (lptr_t)(s_u + seg * 256), 16, 0, 0);
+  };
+  auto issue_patch_piece = [&](int i, int stage) __attribute__((always_inline)) {
+    float* s_in = smem + stage * IN_PAD;
+    const int sc = src_c_of(p_cs);
+    const char* sp = reinterpret_cast<const char*>(src_of(p_cs) + ((size_t)p_bn * sc + p_cc0) * plane);
+    const int seg = i * NW + wave;
+    if (seg < IN_SEGS) {
+      const bool ok = voff[i] != 0xFFFFFFFFu;
+      __builtin_amdgcn_global_load_lds((gptr_t)(ok ? sp + voff[i] : zero_src), (lptr_t)(s_in + seg * 256), 16, 0, 0);
+    }
+  };
+  auto patch_advance = [&]() __attribute__((always_inline)) {
+    const int sc = src_c_of(p_cs);
+    p_cc0 += CK;
+    if (p_cc0 >= sc) {
+      ++p_cs;
+      p_cc0 = 0;
+      if (p_cs >= n_src) {
+        p_cs = 0;
+        ++p_k;
+        if (p_k < my_tiles) p_setup_tile();
+      }
     }
   };
 
@@ -343,7 +376,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     };
     // the two waves of a SIMD (w and w + 4) issue their DMA pieces at different points of the iteration
     const bool dma_late = wave >= 4;
+#ifndef EAVSR_W4_SPREAD
     if (!dma_late) issue_dma();
+#endif
     // the pair on duty transforms the next chunk before its GEMM steps
     if (on_duty && it + 1 < total_iters) {
       int t_bn = bn, t_y0 = y0, t_x0 = x0, t_lin = 0;
@@ -369,11 +404,29 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #ifndef EAVSR_WINO_EXP_NOMFMA
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {
+#ifdef EAVSR_W4_SPREAD
+      // one DMA piece per GEMM step, in the steps' matrix-pipe shadow (FUSE keeps the burst: its patch has two parts)
+      if (!FUSE && i < U_IT + IN_IT) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (i < U_IT) { if (it + 1 < total_iters) issue_u_piece(i, chunk_n, (it + 1) & 1); }
+        else if (it + 2 < total_iters) {
+          issue_patch_piece(i - U_IT, it & 1);
+          if (i == U_IT + IN_IT - 1) patch_advance();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (FUSE && i == NSTEP / 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
       if (i == NSTEP / 2) {
         __builtin_amdgcn_sched_barrier(0);
         if (dma_late) issue_dma();
         __builtin_amdgcn_sched_barrier(0);
       }
+#endif
       if (i + AHEAD < NSTEP) {
         av[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(ua + (i + AHEAD) * (CK * 128));
         bv[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(vb + (i + AHEAD) * (CK * 64));

@@ -58,7 +58,7 @@ struct ILArgs {
   const u32x4* wsplit;   // [cot][group][step][term][mt][lane] 16-byte elements (eavsr_pack_dcn_weight_x9)
   const float* bias;
   float* out;            // (n, cout, h, w)
-  int n, cin, h, w, cout, dg, cpg, tiles_x, tiles_y, ntiles;
+  int n, cin, h, w, cout, dg, cpg, opg_shift, tiles_x, tiles_y, ntiles;   // opg_shift: log2(octets per deformable group)
 };
 
 // exact three-way split of two fp32 values into packed bf16 pairs (low half = first value)
@@ -137,14 +137,19 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
     const int rr = e4 / (2 * IPW);
     const int cc = e4 - rr * (2 * IPW);
     prc[i] = (rr << 8) | (cc >> 1);
-    poff[i] = (unsigned)((rr * w + (cc >> 1)) * 32 + (cc & 1) * 16);
+    // LDS bank swizzle: the two 16-byte halves (channels 0-3 / 4-7) of window column x are stored swapped when bit 3 of x
+    // is set.  A wave's 16-lane ds_read_b128 groups hold pixels 8 columns apart (stride 32 B: x and x + 8 are 256 bytes
+    // apart = the same banks); reading "the low half" they collided two by two, swapped they cover all 64 banks.
+    poff[i] = (unsigned)((rr * w + (cc >> 1)) * 32 + (((cc & 1) ^ ((cc >> 4) & 1)) * 16));
   }
   // Window units inside the image are fetched by LDS-DMA from (wave-uniform window origin) + (per-lane constant offset);
   // units outside the image are written as zeros (that IS the sampler's zero padding).  Every unit of a stage is
   // rewritten by every step, one way or the other.
-  auto issue_win = [&](int i, int bn, int y0, int x0, int g, int stage) __attribute__((always_inline)) {
-    const char* xorg = reinterpret_cast<const char*>(a.xil + ((size_t)bn * ngroups + g) * plane * IG) +
-                       ((long)(y0 - IPY0) * w + (x0 - IPX0)) * 32;          // may point before the image: only `ok` lanes use it
+  auto win_origin = [&](int bn, int y0, int x0, int g) __attribute__((always_inline)) {
+    return reinterpret_cast<const char*>(a.xil + ((size_t)bn * ngroups + g) * plane * IG) +
+           ((long)(y0 - IPY0) * w + (x0 - IPX0)) * 32;          // may point before the image: only `ok` lanes use it
+  };
+  auto issue_win = [&](int i, const char* xorg, int y0, int x0, int stage) __attribute__((always_inline)) {
     const int ylo = y0 - IPY0, xlo = x0 - IPX0;
     const int p = i * 8 + wave;  // wave-uniform
     if (p < IWIN_SEGS) {
@@ -154,18 +159,19 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
       else *reinterpret_cast<f32x4*>(dst + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto issue_wgt = [&](int i, int g, int stage) __attribute__((always_inline)) {
-    const char* wsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)cot * ngroups + g) * IW_U4);
+  auto issue_wgt = [&](int i, const char* wsrc, int stage) __attribute__((always_inline)) {
     const int seg = i * 8 + wave;
     if (seg < IW_SEGS)
       __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (unsigned)(seg * 64 + lane) * 16u),
                                        (lptr_t)(s_w + stage * IW_U4 + seg * 64), 16, 0, 0);
   };
   auto issue = [&](int bn, int y0, int x0, int g, int stage) __attribute__((always_inline)) {
+    const char* xorg = win_origin(bn, y0, x0, g);
+    const char* wsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)cot * ngroups + g) * IW_U4);
 #pragma unroll
-    for (int i = 0; i < WIN_IT; ++i) issue_win(i, bn, y0, x0, g, stage);
+    for (int i = 0; i < WIN_IT; ++i) issue_win(i, xorg, y0, x0, stage);
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) issue_wgt(i, g, stage);
+    for (int i = 0; i < W_IT; ++i) issue_wgt(i, wsrc, stage);
   };
 
   // per-lane tap of k-step s: 2 s + kg (tap 9 does not exist: kg = 1 lanes idle in the last step); its regular-grid
@@ -192,37 +198,50 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
     o.pm = (pix + (kg ? uplane : 0u)) * 4u;
     return o;
   };
-  auto load_slot = [&](int bn, const POff& o, int g, int s) __attribute__((always_inline)) {
-    const int dgi = g * IG / a.cpg;
+  // wave-uniform byte strides, computed once: the per-slot bases below are then additions, not 64-bit multiplications
+  const size_t pl4 = plane * 4;
+  struct PBase { const char* off; const char* msk; const char* aff; const char* trn; };   // explicit: offset, mask;  heads: mask logits, 2x2 transform, translation
+  auto make_pbase = [&](int bn, int g) __attribute__((always_inline)) {
+    const int dgi = g >> a.opg_shift;
+    PBase b;
+    if (HEADS) {
+      const char* hb = reinterpret_cast<const char*>(a.offset) + (size_t)bn * 15 * a.dg * pl4;
+      b.off = nullptr;
+      b.msk = hb + (size_t)(6 * a.dg + dgi * 9) * pl4;
+      b.aff = hb + (size_t)(dgi * 4) * pl4;
+      b.trn = hb + (size_t)(4 * a.dg + dgi * 2) * pl4;
+    } else {
+      b.off = reinterpret_cast<const char*>(a.offset) + ((size_t)bn * a.dg + dgi) * 18 * pl4;
+      b.msk = reinterpret_cast<const char*>(a.mask) + ((size_t)bn * a.dg + dgi) * 9 * pl4;
+      b.aff = nullptr;
+      b.trn = nullptr;
+    }
+    return b;
+  };
+  auto load_slot = [&](const PBase& pb_, const POff& o, int s) __attribute__((always_inline)) {
     const bool lastslot = s == ISTEPS - 1;          // taps 8 / (9): both lane halves read tap 8
 #ifdef EAVSR_IL_EXP_NO_PARAMS
     pa[s] = 0.25f; pb[s] = 0.25f; pm[s] = 0.5f;
-    (void)dgi; (void)bn; (void)o; (void)lastslot;
+    (void)pb_; (void)o; (void)lastslot;
     return;
 #endif
-    if (HEADS) {
-      const float* hb = a.offset + ((size_t)bn * 15 * a.dg + 6 * a.dg + dgi * 9 + 2 * s) * plane;
-      pm[s] = ld_b(hb, lastslot ? o.p4 : o.pm);
-    } else {
-      const float* offb = a.offset + (((size_t)bn * a.dg + dgi) * 18 + 4 * s) * plane;
-      const float* mkb = a.mask + (((size_t)bn * a.dg + dgi) * 9 + 2 * s) * plane;
-      pa[s] = ld_b(offb, lastslot ? o.p4 : o.po);
-      pb[s] = ld_b(offb + plane, lastslot ? o.p4 : o.po);
-      pm[s] = ld_b(mkb, lastslot ? o.p4 : o.pm);
+    pm[s] = ld_b(reinterpret_cast<const float*>(pb_.msk + (size_t)(2 * s) * pl4), lastslot ? o.p4 : o.pm);
+    if (!HEADS) {
+      pa[s] = ld_b(reinterpret_cast<const float*>(pb_.off + (size_t)(4 * s) * pl4), lastslot ? o.p4 : o.po);
+      pb[s] = ld_b(reinterpret_cast<const float*>(pb_.off + (size_t)(4 * s + 1) * pl4), lastslot ? o.p4 : o.po);
     }
   };
-  auto load_affine = [&](int bn, const POff& o, int g) __attribute__((always_inline)) {
+  auto load_affine = [&](const PBase& pb_, const POff& o) __attribute__((always_inline)) {
 #ifdef EAVSR_IL_EXP_NO_PARAMS
     tf[0] = 1.1f; tf[1] = 0.1f; tf[2] = -0.1f; tf[3] = 0.9f; tf[4] = 0.3f; tf[5] = -0.3f;
+    (void)pb_; (void)o;
     return;
 #endif
     if (HEADS) {
-      const int dgi = g * IG / a.cpg;
-      const float* hb = a.offset + (size_t)bn * 15 * a.dg * plane;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tf[j] = ld_b(hb + (size_t)(dgi * 4 + j) * plane, o.p4);
+      for (int j = 0; j < 4; ++j) tf[j] = ld_b(reinterpret_cast<const float*>(pb_.aff + (size_t)j * pl4), o.p4);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) tf[4 + j] = ld_b(hb + (size_t)(4 * a.dg + dgi * 2 + j) * plane, o.p4);
+      for (int j = 0; j < 2; ++j) tf[4 + j] = ld_b(reinterpret_cast<const float*>(pb_.trn + (size_t)j * pl4), o.p4);
     }
   };
 
@@ -241,9 +260,10 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
   issue(bn, y0, x0, 0, 0);
   {
     const POff o0 = make_poff(pix);
-    load_affine(bn, o0, 0);
+    const PBase b0 = make_pbase(bn, 0);
+    load_affine(b0, o0);
 #pragma unroll
-    for (int s = 0; s < ISTEPS; ++s) load_slot(bn, o0, 0, s);
+    for (int s = 0; s < ISTEPS; ++s) load_slot(b0, o0, s);
   }
 
   if (tid < 64) {
@@ -332,8 +352,10 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
     for (int s = 0; s < ISTEPS; ++s) { ca[s] = pa[s]; cb[s] = pb[s]; cm[s] = pm[s]; }
 #pragma unroll
     for (int j = 0; j < 6; ++j) ctf[j] = HEADS ? tf[j] : 0.f;
-    const int lbn = more ? nbn : bn, lg = more ? ng : g;
     const POff lo = make_poff(more ? npix : pix);
+    const PBase lb = make_pbase(more ? nbn : bn, more ? ng : g);
+    const char* nxorg = win_origin(nbn, ny0, nx0, ng);
+    const char* nwsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)cot * ngroups + ng) * IW_U4);
     __builtin_amdgcn_sched_barrier(0);
     IL_STAMP(4);
 
@@ -343,7 +365,8 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
 
     struct Pos {
       float w1, w2, w3, w4;   // bilinear corner weights x mask (0 when the tap is idle or the sample is not served from LDS)
-      int q;                  // float offset of the top-left corner in the LDS window stage
+      int q;                  // float offset of the top-left corner in the LDS window stage, | swizzle bits of the two
+                              // corner columns in bits 0 (left) and 1 (right): the corner itself is 32-byte aligned
     };
     Pos pos[2];
     unsigned slow_steps = 0;
@@ -377,10 +400,9 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
       const float hm = hh * mf, lm = lh * mf;
       Pos& ps = pos[s & 1];
       ps.w1 = hm * hw; ps.w2 = hm * lw; ps.w3 = lm * hw; ps.w4 = lm * lw;
-      ps.q = fast ? (int)((__umul24((unsigned)ry, (unsigned)IPW) + (unsigned)rx) * IG) : 0;
-      // outside the window: needs the global path only if the sample can be non-zero (inside the validity gate)
-      const bool maybe = live && !in_win && py > -1.f && px > -1.f && py < (float)h && px < (float)w;
-      slow_steps |= maybe ? (1u << s) : 0u;
+      ps.q = fast ? (int)((__umul24((unsigned)ry, (unsigned)IPW) + (unsigned)rx) * IG) | ((rx >> 3) & 1) | ((((rx + 1) >> 3) & 1) << 1) : 0;
+      // outside the window: redone on the global path (which applies the validity gate -1 < p < size itself)
+      slow_steps |= (live && !in_win) ? (1u << s) : 0u;
     };
 
     // Software pipeline over the k-steps, written out as fenced chunks so that the order below IS the issue order:
@@ -392,16 +414,19 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
     u32x4 aop[6];         // [term * 2 + mt]; the two output-channel tiles are refilled at different times (below)
     u32x4 bop[2][3];
     auto gather = [&](int t, int half) __attribute__((always_inline)) {
-      const f32x4* qq = reinterpret_cast<const f32x4*>(wst_win + pos[t & 1].q);
+      const int pq = pos[t & 1].q;
+      const f32x4* qq = reinterpret_cast<const f32x4*>(wst_win + (pq & ~3));
 #ifdef EAVSR_IL_EXP_NO_GATHER
 #pragma unroll
       for (int j = 0; j < 4; ++j) gat[j] = f32x4{pos[t & 1].w1, pos[t & 1].w2, (float)pos[t & 1].q, pos[t & 1].w4};
       (void)qq; (void)half;
 #else
-      gat[0] = qq[half];                        // top-left      (a corner is 8 channels = 2 x 16 bytes)
-      gat[1] = qq[2 + half];                    // top-right
-      gat[2] = qq[IPW * IG / 4 + half];         // bottom-left
-      gat[3] = qq[IPW * IG / 4 + 2 + half];     // bottom-right
+      // a corner is 8 channels = 2 x 16 bytes; which of the two holds channel half `half` depends on the column (swizzle)
+      const int hl = half ^ (pq & 1), hr = half ^ ((pq >> 1) & 1);
+      gat[0] = qq[hl];                          // top-left
+      gat[1] = qq[2 + hr];                      // top-right
+      gat[2] = qq[IPW * IG / 4 + hl];           // bottom-left
+      gat[3] = qq[IPW * IG / 4 + 2 + hr];       // bottom-right
 #endif
     };
     auto load_a = [&](int t, int mt) __attribute__((always_inline)) {
@@ -461,34 +486,38 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
     for (int t = 0; t < ISTEPS; ++t) {
       // the MFMAs run tile 0 first (chunks 0-2), tile 1 second (chunks 3-5): tile 1's A operands of THIS step are
       // requested now (three chunks ahead), tile 0's of the NEXT step as soon as chunk 2 has issued its last MFMA.
-      // chunk:   0: set-up(t+2)   1: pair 0   2: pair 1   3: gathers of the high channel half   4: pair 2   5: pair 3
+      // chunk:   0: set-up(t+2)   1: next step's window DMA piece + parameter loads   2: pair 0   3: pair 1, then the
+      //          gathers of the high channel half + tile 0's next A operands   4: weight DMA piece   5: pairs 2 and 3
+      // (every LDS read has at least one whole chunk between its issue and its first use)
       if (t + 1 < ISTEPS) gather(t + 1, 0);
       load_a(t, 1);
       IL_FENCE();
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        if (k == 3 && t + 1 < ISTEPS) {
-          gather(t + 1, 1);
-          load_a(t + 1, 0);
-        }
 #pragma unroll
         for (int i = 0; i < CH; ++i) mfma_i(k * CH + i, aop, bop[t & 1], acc);
         if (k == 0 && t + 2 < ISTEPS) setup(t + 2);
         // next step's DMA and parameter loads, spread over the iterations (every piece has >= 1 k-step to land)
 #ifndef EAVSR_IL_EXP_NO_DMA      // timing ablations (tools/gpu_il_ablate.py): results are wrong by construction
-        if (k == 1 && t < WIN_IT && more) issue_win(t, nbn, ny0, nx0, ng, stage ^ 1);
-        if (k == 4 && t < W_IT && more) issue_wgt(t, ng, stage ^ 1);
+        if (k == 1 && t < WIN_IT && more) issue_win(t, nxorg, ny0, nx0, stage ^ 1);
+        if (k == 4 && t < W_IT && more) issue_wgt(t, nwsrc, stage ^ 1);
 #endif
-        if (k == 2) {
-          if (t == 0) { load_slot(lbn, lo, lg, 0); load_slot(lbn, lo, lg, 1); }
-          if (t == 1) { load_slot(lbn, lo, lg, 2); load_slot(lbn, lo, lg, 3); }
-          if (t == 2) { load_slot(lbn, lo, lg, 4); load_affine(lbn, lo, lg); }
+        if (k == 1) {
+          if (t == 0) { load_slot(lb, lo, 0); load_slot(lb, lo, 1); }
+          if (t == 1) { load_slot(lb, lo, 2); load_slot(lb, lo, 3); }
+          if (t == 2) { load_slot(lb, lo, 4); load_affine(lb, lo); }
         }
         if (t + 1 < ISTEPS) {
-          if (k == 1) blend_pair(t + 1, 0);
-          if (k == 2) blend_pair(t + 1, 1);
-          if (k == 4) blend_pair(t + 1, 2);
-          if (k == 5) blend_pair(t + 1, 3);
+          if (k == 2) blend_pair(t + 1, 0);
+          if (k == 3) {
+            blend_pair(t + 1, 1);
+            gather(t + 1, 1);
+            load_a(t + 1, 0);
+          }
+          if (k == 5) {
+            blend_pair(t + 1, 2);
+            blend_pair(t + 1, 3);
+          }
         }
         IL_FENCE();
       }
@@ -513,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il_kernel(ILArgs a) {
           const int tap = min(2 * t + kg, IK - 1);
           const float ryt = (float)(tap / 3 - 1), rxt = (float)(tap % 3 - 1);
           // rare path: the parameters are read again (their registers were recycled as the set-ups consumed them)
-          const int dgi = g * IG / a.cpg;
+          const int dgi = g >> a.opg_shift;
           float dy, dx, m;
           if (HEADS) {
             const float* hb = a.offset + (size_t)bn * 15 * a.dg * plane;
@@ -671,6 +700,12 @@ extern "C" int eavsr_dcnv2_il_f32(const float* x_il8, const float* offset_or_hea
   a.xil = x_il8; a.offset = offset_or_heads; a.mask = mask; a.wsplit = reinterpret_cast<const u32x4*>(weight_x9);
   a.bias = bias; a.out = out;
   a.n = n; a.cin = cin; a.h = h; a.w = w; a.cout = cout; a.dg = deform_groups; a.cpg = cpg;
+  {
+    const int opg = cpg / 8;
+    EAVSR_REQUIRE((opg & (opg - 1)) == 0, -2, "dcnv2_il: %d channels per deformable group: cpg / 8 must be a power of two", cpg);
+    a.opg_shift = 0;
+    while ((1 << a.opg_shift) < opg) ++a.opg_shift;
+  }
   a.tiles_x = eavsr::cdiv(w, IT_W);
   a.tiles_y = eavsr::cdiv(h, IT_ROWS);
   const long tiles = (long)a.tiles_x * a.tiles_y * n;

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from eavsr_amd import ops, _native as N  # noqa: E402
 
 dev = torch.device("cuda:0")
-n, h, w = 4, 180, 320
+n, h, w = int(os.environ.get("N", 2)), 180, 320
 x = torch.randn(n, 64, h, w, device=dev)
 wt = torch.randn(64, 64, 3, 3, device=dev) * 0.05
 b = torch.randn(64, device=dev) * 0.1
