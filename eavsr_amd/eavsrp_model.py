@@ -292,6 +292,23 @@ class EAVSRPx2(EAVSRP):
 # ---------------------------------------------------------------------------------------------
 # model wrapper (eavsrp_model.py:18-119), inference side
 # ---------------------------------------------------------------------------------------------
+def get_scheduler(optimizer, opt):
+    """models/networks.py:16-37: the four learning-rate policies of the reference's options, same constants."""
+    from torch.optim import lr_scheduler
+    policy = getattr(opt, "lr_policy", "step")
+    if policy == "linear":
+        def lambda_rule(epoch):
+            return 1 - max(0, epoch - opt.niter) / max(1, float(opt.niter_decay))
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
+    if policy == "step":
+        return lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay_iters, gamma=0.5)
+    if policy == "plateau":
+        return lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.2, threshold=0.01, patience=5)
+    if policy == "cosine":
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.niter, eta_min=0)
+    raise NotImplementedError("lr [%s] is not implemented" % policy)
+
+
 def make_optimizer(net: "EAVSRP", opt) -> torch.optim.Adam:
     """Adam with the reference's two parameter groups (eavsrp_model.py:45-59): the alignment modules at lr 1e-5, the
     rest at opt.lr -- both built from ALL of `net.parameters()` in registration order exactly as the reference builds
@@ -329,6 +346,9 @@ class EAVSRPModel:
         self.netEAVSRP = N.init_net(EAVSRP(opt, getattr(opt, "spynet_pretrained", None)), gpu_ids=gpu_ids)
         self.time, self.isfirst, self.num = 0.0, True, 0
         self.epoch = 0
+        self.start_epoch = 0
+        self.metric = 0            # learning-rate policy 'plateau' (base_model.py:34)
+        self.optimizers, self.schedulers = [], []
         if self.isTrain:
             self.optimizer_EAVSRP = make_optimizer(self.netEAVSRP, opt)
             trainable = [p for p in self.netEAVSRP.parameters() if p.requires_grad]   # what the gradient all-reduce carries
@@ -336,6 +356,40 @@ class EAVSRPModel:
             from .shard import GradientAllReducer
             self.grad_sync = GradientAllReducer(trainable)
             self.netEAVSRP.train()
+
+    def setup(self, opt=None):
+        """base_model.py:56-70, what train_basic.py:42 / test_basic.py call after construction: learning-rate schedulers
+        (training), then the checkpoint named by opt.load_iter / opt.load_path and, with opt.load_optimizers, the optimizer
+        file."""
+        opt = opt if opt is not None else self.opt
+        load_iter = getattr(opt, "load_iter", 0)
+        if self.isTrain:
+            self.schedulers = [get_scheduler(optimizer, opt) for optimizer in self.optimizers]
+            for scheduler in self.schedulers:
+                scheduler.last_epoch = load_iter
+        if (isinstance(load_iter, int) and load_iter > 0) or getattr(opt, "load_path", "") != "":
+            self.load_networks(load_iter)
+            if getattr(opt, "load_optimizers", False):
+                self.load_optimizers(load_iter)
+        self.print_networks(getattr(opt, "verbose", False))
+
+    def update_learning_rate(self):
+        """base_model.py:131-138"""
+        for i, scheduler in enumerate(self.schedulers):
+            if scheduler.__class__.__name__ == "ReduceLROnPlateau":
+                scheduler.step(getattr(self, "metric", 0))
+            else:
+                scheduler.step()
+            print("lr of %s = %.7f" % (self.optimizer_names[i], scheduler.get_last_lr()[0]))
+
+    def print_networks(self, verbose=False):
+        """base_model.py:272-284"""
+        print("---------- Networks initialized -------------")
+        num_params = sum(p.numel() for p in self.netEAVSRP.parameters())
+        if verbose:
+            print(self.netEAVSRP)
+        print("[Network %s] Total number of parameters : %.3f M" % (self.model_names[0], num_params / 1e6))
+        print("-----------------------------------------------")
 
     def eval(self):
         self.netEAVSRP.eval()

@@ -301,8 +301,10 @@ def test_model_wrapper_training_step(AG, cuda):
     from eavsr_amd.eavsrp_model import EAVSRPModel
     from eavsr_amd.utils.synthetic import synthetic_clip
     opt = Namespace(predict=False, n_frame=3, n_flow=5, scale=4, isTrain=True, gpu_ids=[0], lr=1e-4, beta1=0.9,
-                    beta2=0.999, weight_decay=0.0, npost=350)
+                    beta2=0.999, weight_decay=0.0, npost=350, lr_policy="step", lr_decay_iters=1, load_iter=0, load_path="",
+                    load_optimizers=False, verbose=False)
     model = EAVSRPModel(opt)
+    model.setup(opt)                       # what train_basic.py:42 calls: schedulers (no checkpoint named: nothing to load)
     sd = H.filled(H.model_shapes("x4"), "trained_like")
     model.netEAVSRP.load_state_dict(sd, strict=True)
     groups = model.optimizer_EAVSRP.param_groups
@@ -322,6 +324,8 @@ def test_model_wrapper_training_step(AG, cuda):
         losses.append(model.get_current_losses()["EAVSRP_L1"])
     assert losses[-1] < losses[0]
     assert not torch.equal(before, model.netEAVSRP.conv_last.weight.detach())
+    model.update_learning_rate()           # train_basic.py:80: StepLR(step_size=1, gamma=0.5) halves both groups
+    assert [g_["lr"] for g_ in groups] == pytest.approx([5e-5, 5e-6])
     model.eval()
     model.set_input(data)
     model.test()

@@ -174,3 +174,30 @@ def test_optimizer_groups_follow_the_reference_grouping_and_state_dicts_round_tr
     assert len(ours.state_dict()["state"]) == len(ref.state_dict()["state"]) == len(list(net.parameters())) - n_frozen
     ours.step()
     ref.load_state_dict(ours.state_dict())
+
+
+def test_learning_rate_schedulers_follow_the_reference_policies():
+    """models/networks.py:16-37 restated (get_scheduler): step halves every lr_decay_iters epochs, linear decays to zero over
+    niter_decay after niter, cosine reaches zero at niter; unknown policies raise."""
+    from eavsr_amd.eavsrp_model import get_scheduler
+    mk = lambda: torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    opt = Namespace(lr_policy="step", lr_decay_iters=2, niter=4, niter_decay=4)
+    o = mk(); sch = get_scheduler(o, opt)
+    lrs = []
+    for _ in range(5):
+        o.step(); sch.step(); lrs.append(o.param_groups[0]["lr"])
+    assert lrs == pytest.approx([1e-4, 5e-5, 5e-5, 2.5e-5, 2.5e-5])
+    opt.lr_policy = "linear"
+    o = mk(); sch = get_scheduler(o, opt)
+    lrs = []
+    for _ in range(8):
+        o.step(); sch.step(); lrs.append(o.param_groups[0]["lr"])
+    assert lrs[:4] == pytest.approx([1e-4] * 4) and lrs[-1] == pytest.approx(0.0) and lrs[5] == pytest.approx(5e-5)
+    opt.lr_policy = "cosine"
+    o = mk(); sch = get_scheduler(o, opt)
+    for _ in range(4):
+        o.step(); sch.step()
+    assert o.param_groups[0]["lr"] == pytest.approx(0.0, abs=1e-12)
+    opt.lr_policy = "nope"
+    with pytest.raises(NotImplementedError):
+        get_scheduler(mk(), opt)
