@@ -168,16 +168,21 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
         # every usable core is offered; torch's CPU kernels do not always scale to all of them (a 256-thread host ran this
         # workload slower than with 32 threads), so the thread count is the fastest of a short probe on the fallback crop
         usable = usable_cores()
-        cands = sorted({c for c in (16, 32, 64, 128, usable) if c <= usable})
+        cands = sorted({c for c in (8, 16, 32, 64, 128, usable) if c <= usable})
         best = None
-        for c in cands:
+        for c in cands:      # ascending; stop as soon as more threads are clearly slower (saves the slow candidates' minutes)
             secs_p, _ = _run_cpu_child(preset, frames, crop_h, crop_w, c, 1, 40.0, timeout_s=60)
             if len(secs_p) >= 2:
                 probe += f"{c}: {secs_p[-1]:.1f} s; "
                 if best is None or secs_p[-1] < best[1]:
                     best = (c, secs_p[-1])
+                elif secs_p[-1] > 1.5 * best[1]:
+                    probe += "more threads not tried; "
+                    break
             else:
                 probe += f"{c}: > 60 s; "
+                if best is not None:
+                    break
         cores = best[0] if best else min(usable, 32)
         probe = f" (thread count chosen by a probe on a {crop_h}x{crop_w} clip over {usable} usable cores -- {probe.rstrip('; ')})"
     base = {"unit": "frames/s", "cores": cores, "kind": "port"}

@@ -58,6 +58,10 @@ SIGNATURES = {
     "eavsr_dcnv2_f32x9": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_nchw_to_il8_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_il_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_dcn_il16_weight_bytes": (C.c_int64, [i32, i32]),
+    "eavsr_pack_dcn_il16_weight": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "eavsr_nchw_to_il8_h16": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "eavsr_dcnv2_il16": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "eavsr_conv3x3_f32x9": (C.c_int, [vp, vp, vp]),
     "eavsr_wino_weight_elems": (C.c_int64, [i32, i32]),

@@ -89,10 +89,11 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(
 // both warped by the refined offset): the flow is read and the corner weights are computed once per (pixel, channel
 // chunk) as before, but one launch covers both tensors.  The second output may be written in the "IL8" layout
 // [n][c/8][h][w][8] that eavsr_dcnv2_il_f32 samples from (the warp of feat_prop feeds DCNv2 and nothing else).
+template <int b_il8>      // second output: 0 NCHW fp32, 1 IL8 fp32, 2 IL8 fp16, 3 IL8 bf16
 __global__ __launch_bounds__(256) void flow_warp_pair_kernel(
     const float* __restrict__ xa, const float* __restrict__ xb, const float* __restrict__ flow,
     const float* __restrict__ flow2, float* __restrict__ outa, float* __restrict__ outb, int n, int c, int h, int w,
-    int c_chunks, int tiles_x, int tiles_y, int b_il8) {
+    int c_chunks, int tiles_x, int tiles_y) {
   int lid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = lid % tiles_x;
   lid /= tiles_x;
@@ -152,9 +153,27 @@ __global__ __launch_bounds__(256) void flow_warp_pair_kernel(
         t += p[i_se] * w_se;
         v[e] = t;
       }
-      f32x4* op = reinterpret_cast<f32x4*>(outb + ((((size_t)bn * (c / 8) + (c0 / 8 + o)) * h + py) * w + px) * 8);
-      op[0] = f32x4{v[0], v[1], v[2], v[3]};
-      op[1] = f32x4{v[4], v[5], v[6], v[7]};
+      const size_t unit = (((size_t)bn * (c / 8) + (c0 / 8 + o)) * h + py) * w + px;
+      if (b_il8 == 1) {
+        f32x4* op = reinterpret_cast<f32x4*>(outb + unit * 8);
+        op[0] = f32x4{v[0], v[1], v[2], v[3]};
+        op[1] = f32x4{v[4], v[5], v[6], v[7]};
+      } else {      // 2: fp16, 3: bf16 -- one 16-byte unit per (pixel, octet), each value rounded once
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        typedef float f2_ __attribute__((ext_vector_type(2)));
+        u32x4_ pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (b_il8 == 3) {
+            typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
+            pk[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_{v[2 * e], v[2 * e + 1]}, b2_));
+          } else {
+            typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+            pk[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f2_{v[2 * e], v[2 * e + 1]}, h2_));
+          }
+        }
+        reinterpret_cast<u32x4_*>(outb)[unit] = pk;
+      }
     }
     return;
   }
@@ -296,6 +315,7 @@ extern "C" int eavsr_flow_warp_pair_f32(const float* xa, const float* xb, const 
   EAVSR_REQUIRE(xa && xb && flow && outa && outb, -1, "flow_warp_pair: NULL pointer");
   EAVSR_REQUIRE(n >= 0 && c >= 0 && h >= 0 && w >= 0, -1, "flow_warp_pair: negative dimension");
   EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "flow_warp_pair: plane too large");
+  EAVSR_REQUIRE(outb_il8 >= 0 && outb_il8 <= 3, -1, "flow_warp_pair: outb_il8 %d (0 NCHW, 1 IL8 fp32, 2 IL8 fp16, 3 IL8 bf16)", outb_il8);
   EAVSR_REQUIRE(!outb_il8 || (c % 8 == 0 && (((uintptr_t)outb) & 15) == 0), -2,
                 "flow_warp_pair: the IL8 output needs c %% 8 == 0 and a 16-byte aligned buffer");
   if (n == 0 || c == 0 || h == 0 || w == 0) return 0;
@@ -303,7 +323,13 @@ extern "C" int eavsr_flow_warp_pair_f32(const float* xa, const float* xb, const 
   const int tiles_x = eavsr::cdiv(w, 64), tiles_y = eavsr::cdiv(h, 4);
   const long nblk = (long)tiles_x * tiles_y * c_chunks * 2 * n;
   EAVSR_REQUIRE(nblk < (1L << 31), -1, "flow_warp_pair: too many tiles");
-  hipLaunchKernelGGL(flow_warp_pair_kernel, dim3((unsigned)nblk), dim3(64, 4, 1), 0, eavsr::as_stream(stream), xa, xb, flow,
-                     flow2, outa, outb, n, c, h, w, c_chunks, tiles_x, tiles_y, outb_il8);
+  const dim3 grid((unsigned)nblk), block(64, 4, 1);
+  hipStream_t st = eavsr::as_stream(stream);
+#define EAVSR_WARP_PAIR(M) hipLaunchKernelGGL(flow_warp_pair_kernel<M>, grid, block, 0, st, xa, xb, flow, flow2, outa, outb, n, c, h, w, c_chunks, tiles_x, tiles_y)
+  if (outb_il8 == 0) EAVSR_WARP_PAIR(0);
+  else if (outb_il8 == 1) EAVSR_WARP_PAIR(1);
+  else if (outb_il8 == 2) EAVSR_WARP_PAIR(2);
+  else EAVSR_WARP_PAIR(3);
+#undef EAVSR_WARP_PAIR
   return eavsr::launch_status("flow_warp_pair");
 }

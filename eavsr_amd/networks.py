@@ -276,6 +276,12 @@ class MultiAdSTN(ModulatedDeformConv2d):
             # inference hot path: both warps by the refined offset in ONE launch, the second one written in the IL8 layout the
             # DCNv2 kernel samples from; the predictor's 15 D head channels go to that kernel as they are (affine -> offsets
             # and the mask sigmoid, networks.py:302-315, happen in its per-group set-up): de_offset / mask never reach HBM
+            if BACKBONE_DTYPE is not None:
+                # 16-bit mode (configs[2] / [4]): the warp rounds the sampled features once to bf16 / fp16 (IL8), DCNv2 runs
+                # on the 16-bit MFMA with fp32 blend and accumulation; offsets, masks, output stay fp32
+                nbr, feat_il = ops.flow_warp_pair(nbr_feat_l[0], feat_prop, offset, b_il8=BACKBONE_DTYPE)
+                heads = self.adastn.heads(nbr, ref_feat_l[0])
+                return ops.dcnv2_il16(feat_il, heads, None, self.weight, self.bias, self.deform_groups, heads=True)
             nbr, feat_il = ops.flow_warp_pair(nbr_feat_l[0], feat_prop, offset, b_il8=True)          # :621, :623
             heads = self.adastn.heads(nbr, ref_feat_l[0])                                            # :625
             return ops.dcnv2_il(feat_il, heads, None, self.weight, self.bias, self.deform_groups,

@@ -163,9 +163,10 @@ def flow_warp(x: Tensor, flow: Tensor, padding_mode: str = "zeros", flow2: Optio
     return out
 
 
-def flow_warp_pair(xa: Tensor, xb: Tensor, flow: Tensor, flow2: Optional[Tensor] = None, b_il8: bool = False):
+def flow_warp_pair(xa: Tensor, xb: Tensor, flow: Tensor, flow2: Optional[Tensor] = None, b_il8=False):
     """(flow_warp(xa, flow [+ flow2]), flow_warp(xb, flow [+ flow2])) in one launch (networks.py:621,623); with b_il8 the
-    second result comes in the IL8 layout (n, c/8, h, w, 8) of `dcnv2_il`."""
+    second result comes in the IL8 layout (n, c/8, h, w, 8) of `dcnv2_il` -- fp32 (True) or rounded to 'fp16' / 'bf16' for
+    `dcnv2_il16`."""
     xa, xb, flow = _chk(xa, "xa"), _chk(xb, "xb"), _chk(flow, "flow")
     n, c, h, w = xa.shape
     if xb.shape != xa.shape or tuple(flow.shape) != (n, 2, h, w):
@@ -177,11 +178,17 @@ def flow_warp_pair(xa: Tensor, xb: Tensor, flow: Tensor, flow2: Optional[Tensor]
     if b_il8 and c % 8:
         raise ValueError("flow_warp_pair: IL8 output needs c % 8 == 0")
     outa = torch.empty_like(xa)
-    outb = torch.empty((n, c // 8, h, w, 8) if b_il8 else tuple(xb.shape), device=xa.device, dtype=torch.float32)
+    if isinstance(b_il8, str):
+        code = h16_code(b_il8)                      # 1 fp16, 2 bf16
+        outb = torch.empty((n, c // 8, h, w, 8), device=xa.device, dtype=_H16_TORCH[code])
+        mode = 1 + code
+    else:
+        outb = torch.empty((n, c // 8, h, w, 8) if b_il8 else tuple(xb.shape), device=xa.device, dtype=torch.float32)
+        mode = 1 if b_il8 else 0
     st = _stream(xa)
     _launch("flow_warp_pair", 16.0 * n * c * h * w, 4.0 * n * h * w * (4 * c + 2 + (2 if flow2 is not None else 0)), xa,
             lambda: lib().eavsr_flow_warp_pair_f32(_p(xa), _p(xb), _p(flow), _p(flow2), _p(outa), _p(outb), n, c, h, w,
-                                                   1 if b_il8 else 0, st), "flow_warp_pair")
+                                                   mode, st), "flow_warp_pair")
     return outa, outb
 
 
@@ -551,6 +558,77 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
     _launch("dcnv2_il" + ("_heads" if heads else ""), 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * D + cout), out,
             lambda: lib().eavsr_dcnv2_il_f32(_p(x_il8), _p(oh), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout, D,
                                              int(nprod), 1 if heads else 0, st), "dcnv2_il")
+    return out
+
+
+_il16_pack_cache = {}
+
+
+def _packed_il16(weight: Tensor, code: int) -> Tensor:
+    key = (id(weight), weight._version, code)
+    hit = _il16_pack_cache.get(key)
+    if hit is not None and hit[0]() is weight:
+        return hit[1]
+    w = _chk(weight.detach(), "weight")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    if tuple(w.shape[2:]) != (3, 3):
+        raise NotImplementedError("dcnv2_il16 is 3x3")
+    nbytes = lib().eavsr_dcn_il16_weight_bytes(cout, cin)
+    if nbytes <= 0:
+        raise NotImplementedError(f"dcnv2_il16 weight shape {tuple(w.shape)} unsupported")
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.int32)
+    with _DeviceOf(w):
+        N.check(lib().eavsr_pack_dcn_il16_weight(_p(w), _p(packed), cout, cin, code, _stream(w)), "pack_dcn_il16_weight")
+    for k in [k for k in _il16_pack_cache if k[0] == id(weight)]:
+        _il16_pack_cache.pop(k, None)
+    _il16_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key: _il16_pack_cache.pop(k, None)), packed)
+    return packed
+
+
+def to_il8_h16(x: Tensor, dtype) -> Tensor:
+    """(n, c, h, w) fp32 -> IL8 (n, c/8, h, w, 8) rounded to 'fp16' / 'bf16'"""
+    x = _chk(x, "x")
+    n, c, h, w = x.shape
+    if c % 8:
+        raise ValueError("to_il8_h16: channels must be a multiple of 8")
+    code = h16_code(dtype)
+    out = torch.empty((n, c // 8, h, w, 8), device=x.device, dtype=_H16_TORCH[code])
+    st = _stream(x)
+    _launch("nchw_to_il8_h16", 0.0, 6.0 * x.numel(), x,
+            lambda: lib().eavsr_nchw_to_il8_h16(_p(x), _p(out), n, c, h, w, code, st), "nchw_to_il8_h16")
+    return out
+
+
+def dcnv2_il16(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
+               deform_groups: int, heads: bool = False) -> Tensor:
+    """DCNv2 (3x3, stride 1, pad 1) on a 16-bit IL8 input (bf16 / fp16 samples and weights, fp32 blend and accumulation,
+    fp32 output); arguments as `dcnv2_il`."""
+    x_il8 = _chk_h16(x_il8, "x_il8")
+    n, oct_, h, w, e = x_il8.shape
+    if e != 8:
+        raise ValueError("dcnv2_il16: input must be IL8 (n, c/8, h, w, 8)")
+    code = h16_code(x_il8.dtype)
+    cin, cout, D = oct_ * 8, int(weight.shape[0]), int(deform_groups)
+    if tuple(weight.shape[1:]) != (cin, 3, 3):
+        raise ValueError("dcnv2_il16: weight / input channel mismatch")
+    oh = _chk(offset_or_heads, "offset_or_heads")
+    if heads:
+        if tuple(oh.shape) != (n, 15 * D, h, w):
+            raise ValueError(f"dcnv2_il16: heads shape {tuple(oh.shape)} != {(n, 15 * D, h, w)}")
+        mask = None
+    else:
+        mask = _chk(mask, "mask")
+        if tuple(oh.shape) != (n, 18 * D, h, w) or tuple(mask.shape) != (n, 9 * D, h, w):
+            raise ValueError("dcnv2_il16: offset / mask shape")
+    b = None if bias is None else _chk(bias.detach(), "bias")
+    wp = _packed_il16(weight, code)
+    out = torch.empty((n, cout, h, w), device=x_il8.device, dtype=torch.float32)
+    st = _stream(out)
+    px = float(n) * h * w
+    # algorithmic bytes of the 16-bit DCNv2 as SURVEY 8a counts them: 344 elements x 2 bytes per pixel
+    _launch("dcnv2_il16" + ("_heads" if heads else ""), 2.0 * cin * 9 * cout * px, 2.0 * px * (cin + 27 * D + cout), out,
+            lambda: lib().eavsr_dcnv2_il16(_p(x_il8), _p(oh), _p(mask), _p(wp), _p(b), _p(out), n, cin, h, w, cout, D, code,
+                                           1 if heads else 0, st), "dcnv2_il16")
     return out
 
 

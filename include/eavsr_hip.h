@@ -71,8 +71,8 @@ int eavsr_flow_warp_f32(const float* x, const float* flow, const float* flow2, f
 
 /* networks.py:621 + :623: two feature maps (the neighbour's features and the propagated features) warped by the SAME
  * NCHW flow (+ optional flow2, summed first), bilinear, zeros padding, align_corners=True, in ONE launch.  outa is NCHW;
- * outb is NCHW (outb_il8 = 0) or the IL8 layout [n][c/8][h][w][8] that eavsr_dcnv2_il_f32 samples from (outb_il8 = 1,
- * c % 8 == 0). */
+ * outb is NCHW (outb_il8 = 0), the IL8 layout [n][c/8][h][w][8] that eavsr_dcnv2_il_f32 samples from (outb_il8 = 1,
+ * c % 8 == 0), or IL8 rounded to fp16 (outb_il8 = 2) / bf16 (outb_il8 = 3) for eavsr_dcnv2_il16. */
 int eavsr_flow_warp_pair_f32(const float* xa, const float* xb, const float* flow, const float* flow2, float* outa,
                              float* outb, int32_t n, int32_t c, int32_t h, int32_t w, int32_t outb_il8, void* stream);
 
@@ -127,6 +127,18 @@ int eavsr_nchw_to_il8_f32(const float* x, float* out_il8, int32_t n, int32_t c, 
 int eavsr_dcnv2_il_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
                        const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
                        int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
+
+/* 16-bit form of eavsr_dcnv2_il_f32 for the 16-bit mode (BASELINE.json configs[2] bf16 / configs[4] fp16; csrc/dcnv2_il16.hip):
+ * x_il8_h16 is the IL8 layout in 16 bits ([n][cin/8][h][w][8] bf16 / fp16: eavsr_flow_warp_pair_f32 with outb_il8 = 2 | 3, or
+ * eavsr_nchw_to_il8_h16), the weights are rounded once to the same 16-bit type (eavsr_pack_dcn_il16_weight), the bilinear blend
+ * and the accumulation are fp32, the blended sample is rounded once to 16 bits for the MFMA, offsets / mask / heads / bias / out
+ * stay fp32.  dtype: 1 = fp16, 2 = bf16.  Judged by PSNR against the fp32 oracle, as BASELINE.json says for these configs. */
+int64_t eavsr_dcn_il16_weight_bytes(int32_t cout, int32_t cin);
+int eavsr_pack_dcn_il16_weight(const float* weight, void* weight_il16, int32_t cout, int32_t cin, int32_t dtype, void* stream);
+int eavsr_nchw_to_il8_h16(const float* x, void* out_il8_h16, int32_t n, int32_t c, int32_t h, int32_t w, int32_t dtype, void* stream);
+int eavsr_dcnv2_il16(const void* x_il8_h16, const float* offset_or_heads, const float* mask, const void* weight_il16,
+                     const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                     int32_t deform_groups, int32_t dtype, int32_t heads, void* stream);
 
 /* The rest of mmcv.ops.modulated_deform_conv2d's signature (any kernel size, stride, padding, dilation, conv groups,
  * deformable groups; networks.py:575-583 declares them, the reference never uses them): a plain one-thread-per-pixel

@@ -109,3 +109,91 @@ def test_end_to_end_16bit_backbone_psnr(ops, cuda, dt):
     mse = ((sub.clamp(0, 1) * 255).round() - (gold["sub"].clamp(0, 1) * 255).round()).div(255).pow(2).mean().item()
     psnr = float("inf") if mse == 0 else -10 * torch.log10(torch.tensor(mse)).item()
     assert psnr >= (50.0 if dt == "bf16" else 60.0), psnr
+
+
+# ---- 16-bit alignment kernels (round 2): IL8 16-bit warp output + DCNv2 on the 16-bit MFMA --------------------------------
+def _dcn_inputs16(n, c, h, w, cout, dg, sigma, seed=0):
+    x = cases.randn(seed + 1, n, c, h, w)
+    off = cases.randn(seed + 2, n, dg * 18, h, w, scale=sigma)
+    mask = cases.rand(seed + 3, n, dg * 9, h, w)
+    wt = cases.randn(seed + 4, cout, c, 3, 3, scale=1.0 / (c * 9) ** 0.5)
+    b = cases.randn(seed + 5, cout, scale=0.1)
+    return x, off, mask, wt, b
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_to_il8_h16_layout_and_rounding(ops, cuda, dt):
+    x = cases.randn(3, 2, 24, 7, 9)
+    il = ops.to_il8_h16(x.to(cuda), dt).cpu()
+    assert il.shape == (2, 3, 7, 9, 8) and il.dtype == DT[dt]
+    assert torch.equal(il, x.view(2, 3, 8, 7, 9).permute(0, 1, 3, 4, 2).to(DT[dt]))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("sigma", [0.5, 2.0, 8.0])
+@pytest.mark.parametrize("shape", [(1, 64, 24, 40, 64, 8), (2, 64, 13, 37, 64, 8), (1, 16, 9, 33, 32, 2), (2, 64, 45, 80, 64, 8)])
+def test_dcnv2_il16_vs_oracle_on_rounded_operands(ops, cuda, shape, sigma, dt):
+    """the 16-bit DCNv2 against the fp32 oracle fed the SAME 16-bit-rounded features and weights: what remains is one
+    rounding of each blended sample to 16 bits (random signs over 9 c terms) and fp32 summation order"""
+    n, c, h, w, cout, dg = shape
+    x, off, mask, wt, b = _dcn_inputs16(n, c, h, w, cout, dg, sigma)
+    xr, wr = x.to(DT[dt]).float(), wt.to(DT[dt]).float()
+    ref = O.dcnv2(xr, off, mask, wr, b, 1, 1, 1, 1, dg)
+    out = ops.dcnv2_il16(ops.to_il8_h16(x.to(cuda), dt), off.to(cuda), mask.to(cuda), wt.to(cuda), b.to(cuda), dg).cpu()
+    rel = H.maxabs(out, ref) / max(1.0, ref.abs().max().item())
+    assert rel <= (8e-3 if dt == "bf16" else 1e-3), rel
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_dcnv2_il16_heads_mode(ops, cuda, dt):
+    n, h, w, D = 2, 21, 44, 8
+    c = 8 * D
+    x = cases.randn(11, n, c, h, w)
+    heads = torch.cat([cases.randn(12, n, 4 * D, h, w, scale=0.4) + torch.tensor([1.0, 0, 0, 1.0]).repeat(D).view(1, 4 * D, 1, 1),
+                       cases.randn(13, n, 2 * D, h, w, scale=1.5), cases.randn(14, n, 9 * D, h, w, scale=2.0)], 1)
+    wt = cases.randn(15, 64, c, 3, 3, scale=1.0 / (c * 9) ** 0.5)
+    b = cases.randn(16, 64, scale=0.1)
+    off = O.affine_offsets(heads[:, :4 * D], heads[:, 4 * D:6 * D], D)
+    mask = torch.sigmoid(heads[:, 6 * D:])
+    ref = O.dcnv2(x.to(DT[dt]).float(), off, mask, wt.to(DT[dt]).float(), b, 1, 1, 1, 1, D)
+    xil = ops.to_il8_h16(x.to(cuda), dt)
+    out = ops.dcnv2_il16(xil, heads.to(cuda), None, wt.to(cuda), b.to(cuda), D, heads=True).cpu()
+    rel = H.maxabs(out, ref) / max(1.0, ref.abs().max().item())
+    assert rel <= (8e-3 if dt == "bf16" else 1e-3), rel
+    out2 = ops.dcnv2_il16(xil, off.to(cuda), mask.to(cuda), wt.to(cuda), b.to(cuda), D).cpu()
+    assert H.maxabs(out, out2) <= (4e-3 if dt == "bf16" else 5e-4) * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_flow_warp_pair_16bit_il8_output(ops, cuda, dt):
+    xa, xb = cases.randn(1, 2, 64, 13, 37), cases.randn(2, 2, 64, 13, 37)
+    flow = cases.randn(3, 2, 2, 13, 37, scale=2.0)
+    a32, b32 = ops.flow_warp_pair(xa.to(cuda), xb.to(cuda), flow.to(cuda))
+    a16, b16 = ops.flow_warp_pair(xa.to(cuda), xb.to(cuda), flow.to(cuda), b_il8=dt)
+    assert torch.equal(a32, a16) and b16.dtype == DT[dt] and b16.shape == (2, 8, 13, 37, 8)
+    want = ops.to_il8_h16(b32, dt).float().cpu()
+    # the octet loop may contract multiply-adds differently (one fp32 rounding) before the 16-bit rounding: <= 1 ulp
+    assert H.maxabs(b16.float().cpu(), want) <= EPS[dt] * 2 * max(1.0, xb.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_multiadstn_16bit_alignment_vs_reference_golden(ops, cuda, dt):
+    """MultiAdSTN with the 16-bit warp + DCNv2 (the backbone-dtype switch turns them on) against the reference's fp32 output
+    (golden G5), by relative error -- the tolerance of the 16-bit configs is a PSNR, not 1e-3"""
+    from eavsr_amd import networks as Nw
+    gold = H.golden("g5_multiadstn_trained_like")
+    sd = H.filled(H.multiadstn_shapes("g5.align."), "trained_like")
+    m = Nw.MultiAdSTN(Namespace(predict=False, n_frame=7, n_flow=5, scale=4), 64, 64, deformable_groups=8)
+    m.load_state_dict({k[len("g5.align."):]: v for k, v in sd.items()}, strict=True)
+    m = m.to(cuda).eval()
+    nbr, ref, fp, flow = cases.g5_inputs()
+    try:
+        Nw.set_backbone_dtype(dt)
+        with torch.no_grad(), ops.profile() as prof:
+            out = m([t.to(cuda) for t in nbr], [t.to(cuda) for t in ref], fp.to(cuda), flow.to(cuda)).cpu()
+        names = set(prof.summary())
+    finally:
+        Nw.set_backbone_dtype(None)
+    assert "dcnv2_il16_heads" in names and "dcnv2_il_heads" not in names
+    rel = H.maxabs(out, gold["out"]) / gold["out"].abs().max().item()
+    assert rel <= (2e-2 if dt == "bf16" else 3e-3), rel

@@ -122,7 +122,7 @@ def test_harness_window_maps_and_psnr():
 # ---- the bench contract, checked on the committed line of the last GPU visit -------------------------------------
 def test_committed_bench_line_follows_the_contract():
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_line.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_bench_line.json")
     line = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -135,10 +135,16 @@ def test_committed_bench_line_follows_the_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["frac"] <= 1.0                      # performed FLOP/s over the peak; the algorithmic-equivalent rate is its own key
+    assert r["algorithmic_equivalent"]["achieved"] >= r["achieved"]
+    for k in line["kernels"]:
+        assert 0.0 < k["frac"] <= 1.0, k
+    assert abs(line["value_median"] - line["n_gpus"] * 4 * 7 / (line["ms_per_step_median"] * 1e-3)) < 1e-3 * line["value"]
     c = line["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+    assert "no extrapolation" in c["sample"] and "180 x 320" in c["sample"]      # one full-size clip, not a scaled crop
 
 
 # ---- optimizer files are interchangeable with the reference's ------------------------------------------
