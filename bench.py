@@ -483,9 +483,16 @@ def main():
         dom_name = {"winograd": "conv3x3_64to64_wino", "winograd4": "conv3x3_64to64_wino4", "direct": "conv3x3_64to64", "bf16x9": "conv3x3_64to64_x9"}[args.conv_mode]
         dom = entry(dom_name, "mfma")
         if args.backbone_dtype != "fp32":
-            e16 = entry("conv3x3_64to64_h16", "hbm")
-            if e16:
-                line.setdefault("kernels_16bit", []).append(e16)
+            # which kernels of the step ran in 16 bits (the rest is fp32), with their share of the step's kernel time
+            names16 = ("conv3x3_64to64_h16", "scale_residual_h16", "dcnv2_il16_heads", "dcnv2_il16", "nchw_f32_to_nhwc_h16",
+                       "nhwc_h16_to_nchw_f32")
+            line["kernels_16bit"] = [e for e in (entry(k, "hbm") for k in names16) if e]
+            if "flow_warp_pair" in summ:
+                e = entry("flow_warp_pair", "hbm")
+                e["note"] = "fp32 in, second output rounded to 16-bit IL8 for dcnv2_il16"
+                line["kernels_16bit"].append(e)
+            t16 = sum(summ[k]["ms"] for k in names16 if k in summ)
+            line["share_of_step_in_16bit"] = t16 / total_ms
         if dom is not None:
             line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_ms",
                                                     "share_of_step", "algorithm", "algorithmic_equivalent")}
@@ -495,6 +502,8 @@ def main():
                 "direct": "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)",
                 "bf16x9": "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)"}[args.conv_mode]
         dcn_name = {"il6": "dcnv2_il_heads", "il9": "dcnv2_il_heads", "native": "dcnv2", "bf16x9": "dcnv2_x9"}[args.dcn_mode]
+        if args.backbone_dtype != "fp32" and args.dcn_mode in ("il6", "il9"):
+            dcn_name = "dcnv2_il16_heads"
         line["kernels"] = [e for e in (entry(dcn_name, "hbm"), entry("flow_warp_pair", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),

@@ -107,6 +107,19 @@ __device__ __forceinline__ void out1d(const float (&m)[6], float (&s)[4]) {
 // FUSE (3x3 only): the channel-attention tail of the previous residual block is applied in the input transform - the
 // patch of r and the patch of x are both staged ([r 0][r 1][x 0][x 1][U ..]), d = r * scale[n, c] + x, and the interior
 // 4 x 4 of every tile's d goes to ca_out (the next block's residual stream).
+#ifdef EAVSR_W4_STAMPS
+// diagnostic build only: shader cycles per phase, summed over waves 0, 2, 4, 6 of every workgroup (tools/gpu_wino4_ablate.py)
+__device__ unsigned long long g_w4_stamps[32];
+#define W4_STAMP(i)                                                   \
+  do {                                                                \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+    st_acc[i] += t_ - st_last;                                        \
+    st_last = t_;                                                     \
+  } while (0)
+#else
+#define W4_STAMP(i) do { } while (0)
+#endif
+
 template <int R, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   static_assert(!FUSE || R == 3, "the fused channel-attention prologue exists for the 3x3 kernel");
@@ -353,6 +366,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 
   // Pipeline (one barrier per chunk): iteration j multiplies chunk j (V[j&1], U[j&1]) right after transforming chunk
   // j+1 (patch[(j+1)&1] -> V[(j+1)&1]); the weight slab runs one chunk ahead of its GEMM, the input patch two.
+#ifdef EAVSR_W4_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   issue_patch(0);
   const float sc_first = sc_next;
   issue_u(0, 0);
@@ -362,10 +379,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   if ((wave >> 1) == 3) { sc_use = sc_first; transform(0, 0, bn, y0, x0, 0); }   // the pair on duty "before iteration 0"
   sc_use = sc_next;   // chunk 1's scale (loaded with patch 1), for the transform of iteration 0
   int chunk = 0;   // chunk of iteration `it` within its tile
+  W4_STAMP(0);      // prologue: first DMA round trip, first transform
   for (int it = 0; it < total_iters; ++it) {
     // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of iteration it-1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W4_STAMP(1);    // waiting for this wave's DMA
     __syncthreads();
+    W4_STAMP(2);    // waiting at the barrier
     const int chunk_n = chunk + 1 == total_chunks ? 0 : chunk + 1;
     const bool on_duty = (wave >> 1) == (it & 3);
     auto issue_dma = [&]() __attribute__((always_inline)) {
@@ -380,6 +400,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     if (!dma_late) issue_dma();
 #endif
     // the pair on duty transforms the next chunk before its GEMM steps
+    W4_STAMP(3);    // DMA issue (waves 0-3)
     if (on_duty && it + 1 < total_iters) {
       int t_bn = bn, t_y0 = y0, t_x0 = x0, t_lin = 0;
       if (FUSE && chunk_n == 0) tile_coords((it + 1) / total_chunks, t_bn, t_y0, t_x0, t_lin);   // first chunk of the next tile
@@ -389,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     // U and V hold the positions in PAIRS ([xi / 2][c][column][xi & 1], column ^ 16 (c & 1)): one ds_read_b64 per operand
     // and two positions - ds_read_b64 moves 256 B/clk against 128 for ds_read_b32 (whose 32 banks would also put the two
     // k-rows of a half-wave on the same banks), and the swizzle keeps those two rows on disjoint banks
+    W4_STAMP(4);    // transform (the pair on duty)
     const float* ua = smem + OFF_U + (it & 1) * U_ELEMS + kq * 128 + 2 * ((cb * 16 + l15) ^ ((kq & 1) << 4));
     const float* vb = s_v + (it & 1) * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));
 #ifndef EAVSR_W4_AHEAD
@@ -443,6 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
     if (FUSE) sc_use = sc_next;   // loaded by this iteration's issue_patch (chunk it + 2) for the transform of it + 1
     chunk = chunk_n;
+    W4_STAMP(5);    // the 36 GEMM steps (+ the DMA issue of waves 4-7)
     if (chunk != 0) continue;   // the tile is not finished yet
 
     // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile (tg, l15)] for every xi ----
@@ -572,7 +595,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       for (int x = 0; x < NPOS; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (it + 1 < total_iters) tile_coords((it + 1) / total_chunks, bn, y0, x0, tile_lin);
     }
+    W4_STAMP(6);    // epilogue: output transform, stores
   }   // flattened (tile, chunk) loop
+#ifdef EAVSR_W4_STAMPS
+  if (lane == 0 && (wave & 1) == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_w4_stamps[(wave >> 1) * 8 + i], st_acc[i]);
+  }
+#endif
 }
 
 // weight (cout, cin, R, R) -> U = G g G^T laid out [cot][cin / 4][xi / 2][c][co ^ 16 (c & 1)][xi & 1] (zero for
@@ -617,6 +646,18 @@ __global__ void pack_wino6_kernel(const float* __restrict__ wt, float* __restric
 }
 
 }  // namespace
+
+#ifdef EAVSR_W4_STAMPS
+extern "C" int eavsr_debug_w4_stamps(unsigned long long* host_out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_w4_stamps), sizeof(g_w4_stamps));
+  if (reset) {
+    unsigned long long z[32] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_w4_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" int64_t eavsr_wino4_weight_elems(int32_t cout, int32_t cin) {
   if (cout <= 0 || cin <= 0 || cin % CK != 0) return 0;

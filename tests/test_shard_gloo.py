@@ -168,3 +168,20 @@ def test_bench_single_rank_line_is_unchanged_by_the_launcher_and_child_failures_
     r, lines = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                           env={"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
     assert r.returncode != 0 and not lines
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_over_rccl_when_two_devices_are_visible():
+    """The real N > 1 path: `python bench.py --gpus 2` starts two ranks itself, one per GPU, over RCCL (backend 'nccl'); also
+    the data-parallel training step with its gradient all-reduce.  Skipped on a single-GPU box (the round's test box has one
+    GPU: there the 2-rank code is covered by the gloo tests above and by tests/test_hip_backward.py's shared-GPU test)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    r, lines = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-profile")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["world_size"] == 2
+    assert lines[0]["backend"].startswith("nccl"), lines[0]["backend"]
+    assert lines[0]["value"] > 0 and lines[0]["scaling"] == "weak"
+    r, lines = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", "train")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["loss"]["EAVSRP_L1"] == lines[0]["loss"]["EAVSRP_L1"]

@@ -36,3 +36,13 @@ for path in sorted(glob.glob(os.path.join(ROOT, "eavsr_amd", "lib", "libwino4_*.
     e1.record()
     torch.cuda.synchronize()
     print(f"{os.path.basename(path):32s} {e0.elapsed_time(e1) / 20 * 1000:8.1f} us")
+    if "stamps" in path:
+        buf = (C.c_ulonglong * 32)()
+        lib.eavsr_debug_w4_stamps(buf, 1)
+        call()
+        lib.eavsr_debug_w4_stamps(buf, 1)
+        names = ["prologue", "wait own DMA", "barrier", "DMA issue", "transform", "GEMM", "epilogue", "-"]
+        nwg = min(256, n * 23 * 5)
+        for wv in range(4):
+            tot = sum(buf[wv * 8 + i] for i in range(8))
+            print(f"  wave {2 * wv}: " + "  ".join(f"{names[i]} {100.0 * buf[wv * 8 + i] / max(tot, 1):.1f}%" for i in range(7)) + f"  (total {tot / nwg:.0f} cycles per workgroup)")
