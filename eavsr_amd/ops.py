@@ -555,10 +555,25 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
     px = float(n) * h * w
     # algorithmic bytes of the DCNv2 op as SURVEY 8d defines them (input + 27 D offset/mask + output); in heads mode the
     # kernel itself moves (cin + 15 D + cout) floats per pixel
+    fn = lib().eavsr_dcnv2_ws_f32 if DCN_IL_IMPL == "ws" else lib().eavsr_dcnv2_il_f32
     _launch("dcnv2_il" + ("_heads" if heads else ""), 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * D + cout), out,
-            lambda: lib().eavsr_dcnv2_il_f32(_p(x_il8), _p(oh), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout, D,
-                                             int(nprod), 1 if heads else 0, st), "dcnv2_il")
+            lambda: fn(_p(x_il8), _p(oh), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout, D,
+                       int(nprod), 1 if heads else 0, st), "dcnv2_il")
     return out
+
+
+# Schedule of the IL8 DCNv2 kernel (same arithmetic, same arguments): "il" = eavsr_dcnv2_il_f32, every wave samples and
+# contracts (default: faster at the alignment's offsets, |offset| of a few pixels); "ws" = eavsr_dcnv2_ws_f32, wave-specialised
+# samplers / contractors (csrc/dcnv2_ws.hip): ~18 % slower there, 8-15 % faster when many samples leave the LDS window
+# (sigma = 4 px), because its out-of-window samples are blended in line instead of in a second MFMA pass.  DESIGN.md 4b.
+DCN_IL_IMPL = os.environ.get("EAVSR_DCN_IL_IMPL", "il")
+
+
+def set_dcn_il_impl(impl: str) -> None:
+    global DCN_IL_IMPL
+    if impl not in ("il", "ws"):
+        raise ValueError(f"dcn il impl {impl!r}: 'il' or 'ws'")
+    DCN_IL_IMPL = impl
 
 
 _il16_pack_cache = {}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 14
+#define EAVSR_ABI_VERSION 15
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -125,6 +125,12 @@ int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask,
  * weight_x9 from eavsr_pack_dcn_weight_x9.  Requires (cin/dg) % 8 == 0, 16-byte aligned x_il8; any h, w. */
 int eavsr_nchw_to_il8_f32(const float* x, float* out_il8, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 int eavsr_dcnv2_il_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
+                       const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                       int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
+/* The same operation, arguments and arithmetic as eavsr_dcnv2_il_f32, scheduled wave-specialised (csrc/dcnv2_ws.hip): four
+ * sampler waves (positions, LDS gathers, blend, 3-way bf16 split -> LDS stage) and four contractor waves (MFMAs, LDS-DMA,
+ * stores) per workgroup, so that the two waves of a SIMD use different issue ports. */
+int eavsr_dcnv2_ws_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
                        const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
                        int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
 

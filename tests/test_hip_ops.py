@@ -682,12 +682,21 @@ def test_to_il8_layout(ops, cuda):
     assert torch.equal(il, x.view(2, 3, 8, 7, 9).permute(0, 1, 3, 4, 2))
 
 
+@pytest.fixture(params=["il", "ws"])
+def il_impl(request, ops):
+    """both schedules of the IL8 DCNv2 kernel: eavsr_dcnv2_il_f32 (default) and the wave-specialised eavsr_dcnv2_ws_f32"""
+    prev = ops.DCN_IL_IMPL
+    ops.set_dcn_il_impl(request.param)
+    yield request.param
+    ops.set_dcn_il_impl(prev)
+
+
 @pytest.mark.parametrize("nprod", [6, 9])
 @pytest.mark.parametrize("sigma", [0.0, 0.5, 2.0, 8.0])
 @pytest.mark.parametrize("shape", [(1, 64, 24, 40, 64, 8), (2, 64, 13, 37, 64, 8), (1, 64, 10, 12, 64, 1),
                                    (1, 16, 9, 33, 32, 2), (1, 64, 7, 5, 40, 8), (1, 64, 21, 68, 96, 4),
                                    (3, 64, 45, 80, 64, 8)])
-def test_dcnv2_il_vs_oracle(ops, cuda, shape, sigma, nprod):
+def test_dcnv2_il_vs_oracle(ops, cuda, shape, sigma, nprod, il_impl):
     """explicit offsets / mask (mmcv's signature) through the IL8 kernel: any width (no w % 4 restriction), several tiles per
     persistent workgroup, ragged edges, out-of-window taps (sigma = 8) through the global fix-up"""
     n, c, h, w, cout, dg = shape
@@ -699,7 +708,7 @@ def test_dcnv2_il_vs_oracle(ops, cuda, shape, sigma, nprod):
 
 @pytest.mark.parametrize("nprod", [6, 9])
 @pytest.mark.parametrize("shape", [(1, 24, 40, 8), (2, 13, 37, 8), (1, 45, 80, 8), (1, 9, 11, 2)])
-def test_dcnv2_il_heads_mode_applies_the_affine_expansion_and_the_sigmoid(ops, cuda, shape, nprod):
+def test_dcnv2_il_heads_mode_applies_the_affine_expansion_and_the_sigmoid(ops, cuda, shape, nprod, il_impl):
     """heads mode == AdaptBlockOffset's tail (networks.py:302-315: offset = T.R - R + t per group, mask = sigmoid) followed
     by DCNv2, without de_offset / mask ever existing in memory"""
     n, h, w, D = shape

@@ -44,8 +44,10 @@ for n in (2, 4):
         ops.set_dcn_mode("bf16x9")
         res["x9(r1)"] = timed(lambda: ops.modulated_deform_conv2d(x, off, mask, w33, b, 1, 1, 1, 1, 8))
         ops.set_dcn_mode("native")
-        for nprod in (6, 9):
-            res[f"il{nprod}"] = timed(lambda: ops.dcnv2_il(xil, off, mask, w33, b, 8, nprod=nprod))
-            res[f"il{nprod}_heads"] = timed(lambda: ops.dcnv2_il(xil, heads, None, w33, b, 8, nprod=nprod, heads=True))
+        for impl in ("il", "ws"):
+            ops.set_dcn_il_impl(impl)
+            for nprod in (6, 9):
+                res[f"{impl}{nprod}"] = timed(lambda: ops.dcnv2_il(xil, off, mask, w33, b, 8, nprod=nprod))
+                res[f"{impl}{nprod}_heads"] = timed(lambda: ops.dcnv2_il(xil, heads, None, w33, b, 8, nprod=nprod, heads=True))
         res["to_il8"] = timed(lambda: ops.to_il8(x))
         print(f"n={n} sigma={sigma}: " + "  ".join(f"{k} {v:.1f} us ({1376.0 * px / v / 1e3 / 8000:.3f} of HBM)" for k, v in res.items()), flush=True)
