@@ -195,8 +195,13 @@ class AdaptBlockOffset(_AdaptBase):
         """the three 5x5 heads as one (n, 15 D, h, w) tensor: transform g*4+{0..3}, translation 4D + g*2+{0,1}, mask logits
         6D + g*9+k -- what `forward` expands into (offset, mask) and what the fused DCNv2 kernel consumes directly"""
         f = self._frontend(x, h_hr)
-        return AG.conv2d(f, [self.transform_matrix_conv.weight, self.translation_conv.weight, self.mask_conv.weight],
-                         [self.transform_matrix_conv.bias, self.translation_conv.bias, self.mask_conv.bias])
+        ws = [self.transform_matrix_conv.weight, self.translation_conv.weight, self.mask_conv.weight]
+        bs = [self.transform_matrix_conv.bias, self.translation_conv.bias, self.mask_conv.bias]
+        if (BACKBONE_DTYPE is not None and HEADS_IN_16BIT and f.shape[1] == 64 and 15 * self.D <= 128
+                and not AG.needs_grad(f, ws, bs)):
+            # 16-bit modes (BASELINE configs[2] / [4]): operands rounded once to bf16 / fp16, fp32 accumulation, fp32 heads out
+            return ops.conv5x5_c64_h16(ops.to_nhwc_h16(f, BACKBONE_DTYPE), ws, bs)
+        return AG.conv2d(f, ws, bs)
 
     def forward(self, x, h_hr):
         return AG.affine_offsets(self.heads(x, h_hr), self.D, with_mask=True)
@@ -359,6 +364,9 @@ def set_fuse_flow_level(on: bool) -> None:
     FUSE_FLOW_LEVEL = bool(on)
 
 
+# In the 16-bit modes the predictor's 5x5 heads run on the 16-bit matrix pipe as well (csrc/conv5_h16.hip); EAVSR_HEADS_16BIT=0
+# keeps them on the fp32 Winograd kernel.
+HEADS_IN_16BIT = _os.environ.get("EAVSR_HEADS_16BIT", "1") == "1"
 # Optional 16-bit residual backbone: None (exact fp32, the default and the BASELINE headline), "bf16" or "fp16"
 # (set_backbone_dtype / EAVSR_BACKBONE_DTYPE).  Only the RCAGroup internals change precision.
 BACKBONE_DTYPE = _os.environ.get("EAVSR_BACKBONE_DTYPE") or None

@@ -1192,6 +1192,53 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
     return (out, part) if chan_partial else out
 
 
+_h16_pack5_cache = {}
+
+
+def _packed5_h16(wcat: Tensor, code: int) -> Tensor:
+    """(cout, 64, 5, 5) fp32 (a parameter or the cached concatenation of several) -> the 16-bit MFMA-fragment order"""
+    key = (id(wcat), wcat._version, code)
+    hit = _h16_pack5_cache.get(key)
+    if hit is not None and hit[0]() is wcat:
+        return hit[1]
+    if wcat.dim() != 4 or tuple(wcat.shape[1:]) != (64, 5, 5) or wcat.shape[0] > 128:
+        raise NotImplementedError("the 16-bit heads kernel is the 5x5 convolution 64 -> (<= 128) channels")
+    packed = torch.empty(int(lib().eavsr_conv5x5_c64_h16_weight_bytes()) // 2, device=wcat.device, dtype=_H16_TORCH[code])
+    st = _stream(wcat)
+    with _DeviceOf(wcat):
+        N.check(lib().eavsr_pack_conv5x5_c64_h16(_p(wcat), _p(packed), int(wcat.shape[0]), code, st), "pack_conv5x5_c64_h16")
+    for k in [k for k in _h16_pack5_cache if k[0] == id(wcat)]:
+        _h16_pack5_cache.pop(k, None)
+    _h16_pack5_cache[key] = (weakref.ref(wcat, lambda _r, k=key: _h16_pack5_cache.pop(k, None)), packed)
+    return packed
+
+
+def conv5x5_c64_h16(x: Tensor, weights, biases) -> Tensor:
+    """the predictor's 5x5 heads in the 16-bit modes: x 16-bit NHWC (n,h,w,64); weights / biases: one fp32 (cout,64,5,5) /
+    (cout,) parameter or a list of them (concatenated along the output channels); returns fp32 NCHW (n, cout, h, w)"""
+    x = _chk_h16(x, "x")
+    n, h, w, c = x.shape
+    if c != 64:
+        raise NotImplementedError("the 16-bit heads kernel needs 64 input channels")
+    code = h16_code(x.dtype)
+    weights = list(weights) if isinstance(weights, (list, tuple)) else [weights]
+    biases = list(biases) if isinstance(biases, (list, tuple)) else [biases]
+    wcat = _cat_weights(weights)
+    wp = _packed5_h16(wcat, code)
+    cout = int(wcat.shape[0])
+    b = None
+    if any(bb is not None for bb in biases):
+        if not all(bb is not None for bb in biases):
+            raise ValueError("conv5x5_c64_h16: all heads need a bias or none")
+        b = _cat_weights(biases)
+    out = torch.empty((n, cout, h, w), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch(f"conv5x5_64to{cout}_h16", 2.0 * 64 * cout * 25 * px, px * (128 + 4.0 * cout), x,
+            lambda: lib().eavsr_conv5x5_c64_h16(_p(x), _p(wp), _p(b), _p(out), n, h, w, cout, code, st), "conv5x5_c64_h16")
+    return out
+
+
 def scale_residual_h16(r: Tensor, scale: Tensor, x: Tensor) -> Tensor:
     r, x, scale = _chk_h16(r, "r"), _chk_h16(x, "x"), _chk(scale, "scale")
     n, h, w, c = r.shape

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 15
+#define EAVSR_ABI_VERSION 16
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -373,6 +373,14 @@ int eavsr_pack_conv3x3_c64_h16(const float* weight, void* packed, int32_t dtype,
 int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float* bias, void* out,
                           float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t relu, int32_t dtype,
                           void* stream);
+/* The predictor's three 5x5 heads (transform_matrix_conv ++ translation_conv ++ mask_conv, models/networks.py:283-285,
+ * 298-301) in the 16-bit modes (csrc/conv5_h16.hip): x 16-bit NHWC (n, h, w, 64) -- the front-end feature through
+ * eavsr_nchw_f32_to_nhwc_h16 --, weight (cout, 64, 5, 5) fp32 rounded once by the pack call (cout <= 128), fp32 accumulation,
+ * out fp32 NCHW (n, cout, h, w) = conv5x5(x, pad 2) + bias: the `heads` operand of eavsr_dcnv2_il16 / eavsr_affine_offsets_f32. */
+int64_t eavsr_conv5x5_c64_h16_weight_bytes(void);
+int eavsr_pack_conv5x5_c64_h16(const float* weight, void* packed, int32_t cout, int32_t dtype, void* stream);
+int eavsr_conv5x5_c64_h16(const void* x, const void* weight_packed, const float* bias, float* out, int32_t n, int32_t h,
+                          int32_t w, int32_t cout, int32_t dtype, void* stream);
 /* fp32 NCHW -> 16-bit NHWC, and back with an optional fp32 NCHW residual added (RCAGroup's `+ x`) */
 int eavsr_nchw_f32_to_nhwc_h16(const float* in, void* out, int32_t n, int32_t c, int32_t hw, int32_t dtype,
                                void* stream);

@@ -59,6 +59,34 @@ def test_conv3x3_c64_h16_vs_fp32_on_rounded_inputs(ops, cuda, dt, shape, relu, p
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape,couts", [((1, 16, 32), (32, 16, 72)), ((2, 19, 37), (32, 16, 72)), ((1, 45, 80), (120,)),
+                                         ((1, 5, 3), (4, 2, 9)), ((3, 33, 70), (128,))])
+def test_conv5x5_c64_h16_heads_vs_fp32_on_rounded_operands(ops, cuda, dt, shape, couts):
+    """the predictor's 5x5 heads in the 16-bit modes (networks.py:283-285 as one convolution): 16-bit NHWC input, weights
+    rounded once, fp32 accumulation and fp32 NCHW output -- against an fp64 convolution of the SAME rounded operands (only the
+    summation order differs: tolerance a few fp32 roundings of the 1600-term sum)"""
+    n, h, w = shape
+    x = cases.randn(1, n, 64, h, w).to(DT[dt])
+    ws = [cases.randn(2 + i, c, 64, 5, 5, scale=1.0 / 40.0) for i, c in enumerate(couts)]
+    bs = [cases.randn(9 + i, c, scale=0.1) for i, c in enumerate(couts)]
+    ref = F.conv2d(x.double(), torch.cat(ws, 0).to(DT[dt]).double(), torch.cat(bs, 0).double(), 1, 2).float()
+    xh = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    out = ops.conv5x5_c64_h16(xh, [w_.to(cuda) for w_ in ws], [b_.to(cuda) for b_ in bs])
+    assert out.dtype == torch.float32 and tuple(out.shape) == (n, sum(couts), h, w)
+    assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv5x5_c64_h16_bad_arguments(ops, cuda):
+    z = lambda *s_, dt=torch.bfloat16: torch.zeros(*s_, device=cuda, dtype=dt)
+    with pytest.raises(NotImplementedError):
+        ops.conv5x5_c64_h16(z(1, 8, 8, 32), z(16, 32, 5, 5, dt=torch.float32), None)            # 64 input channels only
+    with pytest.raises(NotImplementedError):
+        ops.conv5x5_c64_h16(z(1, 8, 8, 64), z(130, 64, 5, 5, dt=torch.float32), None)           # cout <= 128
+    with pytest.raises(RuntimeError):
+        ops.conv5x5_c64_h16(z(1, 8, 8, 64, dt=torch.float32), z(16, 64, 5, 5, dt=torch.float32), None)   # fp32 input
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_scale_residual_h16(ops, cuda, dt):
     r, x = cases.randn(1, 2, 64, 9, 13).to(DT[dt]), cases.randn(2, 2, 64, 9, 13).to(DT[dt])
     s = cases.rand(3, 2, 64)
@@ -195,5 +223,6 @@ def test_multiadstn_16bit_alignment_vs_reference_golden(ops, cuda, dt):
     finally:
         Nw.set_backbone_dtype(None)
     assert "dcnv2_il16_heads" in names and "dcnv2_il_heads" not in names
+    assert "conv5x5_64to120_h16" in names and "conv5x5_64to120_wino" not in names, names     # the heads ran in 16 bits too
     rel = H.maxabs(out, gold["out"]) / gold["out"].abs().max().item()
     assert rel <= (2e-2 if dt == "bf16" else 3e-3), rel

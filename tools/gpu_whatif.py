@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""What-if timings of the bench step (4 clips, two streamed HIP graphs): wall time with one piece of the forward replaced by a
+cached tensor.  RESULTS ARE WRONG BY CONSTRUCTION; the point is the upper bound on what removing / fusing that piece can buy on
+the overlapped two-stream schedule (a kernel that only fills gaps of the other stream costs nothing on the wall clock)."""
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import bench  # noqa: E402
+from eavsr_amd import ops, networks as Nw  # noqa: E402
+from eavsr_amd.graph import StreamedForward  # noqa: E402
+from eavsr_amd.utils.synthetic import synthetic_clip  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+net, _ = bench.build_model(dev, "trained_like")
+clips = synthetic_clip(4, 7, 180, 320, seed=0).to(dev)
+STEPS = int(os.environ.get("STEPS", 6))
+
+
+def measure(tag):
+    run = StreamedForward(net, clips, groups=2)
+    with torch.no_grad():
+        for _ in range(2):
+            run(clips)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(STEPS):
+            run(clips)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / STEPS * 1e3
+    del run
+    print(f"{tag:34s} {ms:8.2f} ms/step", flush=True)
+    return ms
+
+
+base = measure("base")
+cache = {}
+
+# (1) channel attention MLP launch: scale from a cached tensor
+orig_ca = ops.ca_scale
+ops.ca_scale = lambda partial, hw, w1, b1, w2, b2: cache.setdefault(("ca", partial.shape[0]), torch.full(
+    (partial.shape[0], w2.shape[0]), 0.5, device=partial.device))
+measure("no ca_scale launch")
+# (2) and no scale_residual pass either (r returned as is)
+orig_sr = ops.scale_residual
+ops.scale_residual = lambda r, scale, x: r
+measure("no ca_scale, no scale_residual")
+ops.ca_scale, ops.scale_residual = orig_ca, orig_sr
+
+# (3) the four-launch pyramid level -> cached zero flow
+orig_level = Nw.MultiAdSTN._level
+Nw.MultiAdSTN._level = staticmethod(lambda fb, tb, warp, ref: cache.setdefault(
+    ("lv", tuple(warp.shape)), torch.zeros(warp.shape[0], 2, warp.shape[2], warp.shape[3], device=warp.device)))
+measure("no pyramid-level kernels")
+Nw.MultiAdSTN._level = staticmethod(orig_level)
+
+# (4) DCNv2 -> cached output
+orig_dcn = ops.dcnv2_il
+ops.dcnv2_il = lambda x, oh, m, w, b, dg, nprod=6, heads=False: cache.setdefault(
+    ("dcn", tuple(oh.shape)), torch.zeros(oh.shape[0], w.shape[0], oh.shape[2], oh.shape[3], device=oh.device))
+measure("no DCNv2 kernel")
+ops.dcnv2_il = orig_dcn
+measure("base again")
