@@ -42,6 +42,19 @@ constexpr int HW_BYTES = 64 * 576 * 2;             // 73,728 B of weights
 constexpr int HW_SEGS = HW_BYTES / 1024;           // 72
 constexpr int H_LDS_BYTES = HW_BYTES + 2 * HP_SEGS * 1024 + 8 * 64 * 4;
 
+#ifdef EAVSR_H16_STAMPS
+// diagnostic build only: shader cycles per phase, summed over wave 0 of every workgroup (tools/gpu_h16_ablate.py)
+__device__ unsigned long long g_h16_stamps[8];
+#define H16_STAMP(i)                                                  \
+  do {                                                                \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+    st_acc[i] += t_ - st_last;                                        \
+    st_last = t_;                                                     \
+  } while (0)
+#else
+#define H16_STAMP(i) do { } while (0)
+#endif
+
 struct H16Args {
   const void* x;      // (n, h, w, 64) 16-bit
   const void* wp;     // packed weights [36 k-steps][2 halves][64 co][8] 16-bit
@@ -86,6 +99,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
   unsigned char* s_w = smem;                                  // resident weights
   unsigned char* s_p = smem + HW_BYTES;                       // two patch stages
   float* s_red = reinterpret_cast<float*>(smem + HW_BYTES + 2 * HP_SEGS * 1024);
+  // the bias once per launch through LDS (the 512 never-written bytes behind patch stage 0: 43 one-KiB pieces hold 42.5 KiB):
+  // 32 global loads per lane in every tile's epilogue (8 dependent load -> wait -> convert groups) were most of a tile's time
+  float* s_bias = reinterpret_cast<float*>(s_p + HP_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -101,8 +117,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
     for (int e = tid; e < 2 * HP_SEGS * 64; e += 512) z[e] = zero;
   }
   __syncthreads();
+  if (tid < 64) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
+#ifndef EAVSR_H16_EXP_NO_WDMA
 #pragma unroll 1
   for (int seg = wave; seg < HW_SEGS; seg += 8)
+#else
+  for (int seg = wave; seg < 0; seg += 8)
+#endif
     __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.wp) + seg * 1024 + lane * 16),
                                      (lptr_t)(s_w + seg * 1024), 16, 0, 0);
 
@@ -131,13 +152,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
     }
   };
   // out-of-image pieces of a stage may hold the previous tile's data: clear them (cheap, only border tiles)
-  auto clear_border = [&](int tile, int stage) {
+  auto clear_border = [&](int tile, int stage) -> bool {   // true: something was cleared (the same answer in every wave)
     int t = tile;
     const int tx = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int y0 = ty * HT_H - 1, x0 = tx * HT_W - 1;
-    if (y0 >= 0 && x0 >= 0 && y0 + HP_H <= h && x0 + HP_W <= w) return;  // interior tile (wave-uniform)
+    if (y0 >= 0 && x0 >= 0 && y0 + HP_H <= h && x0 + HP_W <= w) return false;  // interior tile (wave-uniform)
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int e = tid; e < HP_PIX * 8; e += 512) {
       const int p = e >> 3;
@@ -146,40 +167,70 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
       if (!(gy >= 0 && gy < h && gx >= 0 && gx < w))
         *reinterpret_cast<f32x4*>(s_p + stage * (HP_SEGS * 1024) + e * 16) = zero;
     }
+    return true;
   };
 
   int tile = blockIdx.x;
   int stage = 0;
+#ifdef EAVSR_H16_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef EAVSR_H16_EXP_NO_DMA
   if (tile < a.num_tiles) issue_patch(tile, 0);
+#endif
   for (; tile < a.num_tiles; tile += gridDim.x, stage ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // weights + patch(tile) landed; the other stage is free (its epilogue stores are done)
+    H16_STAMP(0);     // prologue / waiting for the DMA and the barrier
     const int next = tile + gridDim.x;
-    if (next < a.num_tiles) {
-      clear_border(next, stage ^ 1);
-      __syncthreads();
-      issue_patch(next, stage ^ 1);
-    }
     const unsigned char* pst = s_p + stage * (HP_SEGS * 1024);
     f32x16 acc[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    // No LDS-DMA is in flight inside this loop (the next tile's patch is requested right after it, under the epilogue): with one
+    // pending the compiler turns every operand wait into lgkmcnt(0) -- each MFMA pair then waits for the reads just issued for
+    // the NEXT pair, an exposed LDS round trip per k-step (14 us per tile instead of 2).  The operands of tap t+1 (4 B + 8 A
+    // fragments) are requested before the 8 MFMAs of tap t.
+    f32x4 bq[2][4], aq[2][8];
+    auto load_tap = [&](int tap, int set) __attribute__((always_inline)) {
       const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
-        const int s = tap * 4 + cb;
-        const f32x4 bfrag = *reinterpret_cast<const f32x4*>(pst + patch_off(wave + ky, l31 + kx, cb * 2 + half));
+        bq[set][cb] = *reinterpret_cast<const f32x4*>(pst + patch_off(wave + ky, l31 + kx, cb * 2 + half));
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          aq[set][cb * 2 + m] = *reinterpret_cast<const f32x4*>(s_w + ((((tap * 4 + cb) * 2 + half) * 64 + m * 32 + l31) << 4));
+      }
+    };
+    load_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      __builtin_amdgcn_sched_barrier(0);     // keep the requests of tap t+1 in front of the MFMAs of tap t
+      if (tap + 1 < 9) load_tap(tap + 1, (tap + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const f32x4 afrag = *reinterpret_cast<const f32x4*>(s_w + (((s * 2 + half) * 64 + m * 32 + l31) << 4));
-          acc[m] = mfma16<BF16>(afrag, bfrag, acc[m]);
+#ifdef EAVSR_H16_EXP_NO_MFMA
+          acc[m][cb] += aq[tap & 1][cb * 2 + m][0] + bq[tap & 1][cb][1];
+#else
+          acc[m] = mfma16<BF16>(aq[tap & 1][cb * 2 + m], bq[tap & 1][cb], acc[m]);
+#endif
         }
-      }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    H16_STAMP(1);     // operand reads + MFMAs
+    if (next < a.num_tiles) {
+      clear_border(next, stage ^ 1);   // zero fills and DMA pieces touch disjoint slots: no barrier between them
+#ifndef EAVSR_H16_EXP_NO_DMA
+      issue_patch(next, stage ^ 1);
+#endif
+    }
+    H16_STAMP(2);     // border clear + next patch DMA issue
     // ---- epilogue ------------------------------------------------------------------------------
     int t = tile;
     const int tx = t % a.tiles_x;
@@ -199,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         unsigned short pk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float v = acc[m][4 * q + j] + (a.bias ? a.bias[co + j] : 0.f);
+          float v = acc[m][4 * q + j] + s_bias[co + j];
           if (a.relu) v = fmaxf(v, 0.f);
           pk[j] = to_h16<BF16>(ok ? v : 0.f);   // pixels outside the image stage as zeros (they are not stored)
         }
@@ -211,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
       }
     }
     __syncthreads();
+    H16_STAMP(3);     // bias / activation / rounding / staging writes
     if (a.chan_partial) {
       // per-tile channel sums from the staged tile (the 16-bit values the next layer will actually read):
       // thread -> 8 channels (one 16-byte block) of 4 pixels, then 3 shuffle steps over the 8 lanes that share
@@ -247,6 +299,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx) * 64 + tid] = v;
       }
     }
+    H16_STAMP(4);     // channel sums
     // whole pixel rows leave as 16 bytes per lane: 8 rows x 32 px x 8 blocks = 2048 pieces
     char* ob = reinterpret_cast<char*>(a.out) + (size_t)bn * h * w * 128;
     for (int e = tid; e < HT_H * HT_W * 8; e += 512) {
@@ -256,12 +309,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
       if (oy < h && ox < w) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(ost + (p << 7) + (sb << 4));
         const int lb = sb ^ ((c >> 1) & 7);
+#ifdef EAVSR_H16_EXP_NO_STORE
+        if (v[0] == 1.2345e-33f)
+#endif
         *reinterpret_cast<f32x4*>(ob + ((size_t)oy * w + ox) * 128 + lb * 16) = v;
       }
     }
     // the staging tile sits where the interior of the patch was: restore zeros where the NEXT use of this stage
     // expects "never written" (handled by clear_border before each DMA; interior pieces are always rewritten)
+    H16_STAMP(5);     // output stores
   }
+#ifdef EAVSR_H16_STAMPS
+  if (tid == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_h16_stamps[i], st_acc[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -361,6 +422,18 @@ int launch_conv_h16(const H16Args& a, int blocks, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef EAVSR_H16_STAMPS
+extern "C" int eavsr_debug_h16_stamps(unsigned long long* host_out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_h16_stamps), sizeof(g_h16_stamps));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_h16_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 extern "C" int32_t eavsr_conv_h16_tiles(int32_t h, int32_t w) { return eavsr::cdiv(h, HT_H) * eavsr::cdiv(w, HT_W); }
 
