@@ -9,21 +9,21 @@
 //
 //   v_mfma_f32_32x32x16_{bf16,f16}:  A[row = co][k = 8 h + j]  (weights),  B[k = 8 h + j][col = pixel]
 //   (h = lane >> 5, j = 0..7): a lane needs 8 consecutive input channels of its pixel at one tap -> one
-//   ds_read_b128 from the NHWC tile.  k-step s = (tap, 16-channel block): 36 steps, 2 M-tiles -> 72 MFMAs
-//   per wave and 8 x 32-pixel tile.
+//   ds_read_b128 from the NHWC tile.  k-step s = (tap, 16-channel block): 36 steps x 2 M-tiles x 2 pixel rows = 144 MFMAs
+//   per wave and 8 x 32-pixel tile (four waves per tile, see the schedule at the kernel).
 //   LDS image of the input patch: [row][col][8 x 16-byte blocks], block index XOR-swizzled with
 //   ((col >> 1) & 7) so that the 16 lanes of a ds_read_b128 group (consecutive pixels, 128-byte stride) hit
 //   16 different bank quads.  The patch arrives by 16-byte LDS-DMA, whose LDS side is lane-linear: the
-//   swizzle is applied to the per-lane SOURCE address (zero padding = never-written, zero-initialised LDS).
-//   Two patch stages: the DMA of tile t+1 runs behind the MFMAs of tile t.
+//   swizzle is applied to the per-lane SOURCE address (slots outside the image are zero-filled by ds_write).
+//   Two patch stages, one per wave group.
 //   Epilogue: fp32 accumulators (+ bias, ReLU, optional per-tile channel sums in fp32) are rounded to
-//   16-bit, staged through the consumed patch stage with the same swizzle and leave as whole 128-byte pixel
-//   rows (16 bytes per lane).
+//   16 bits and stored from the registers (8 bytes = 4 consecutive channels per lane and store).
 #include "common.h"
 
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -37,7 +37,6 @@ constexpr int HP_H = HT_H + 2, HP_W = HT_W + 2;    // patch with the 3x3 halo
 constexpr int HP_PIX = HP_H * HP_W;                // 340 pixels x 128 B = 43,520 B
 constexpr int HP_BYTES = HP_PIX * 128;
 constexpr int HP_SEGS = (HP_BYTES + 1023) / 1024;  // 1 KiB DMA pieces (43 pieces, the last one partial)
-constexpr int HP_IT = (HP_SEGS + 7) / 8;
 constexpr int HW_BYTES = 64 * 576 * 2;             // 73,728 B of weights
 constexpr int HW_SEGS = HW_BYTES / 1024;           // 72
 constexpr int H_LDS_BYTES = HW_BYTES + 2 * HP_SEGS * 1024 + 8 * 64 * 4;
@@ -80,6 +79,10 @@ template <> __device__ __forceinline__ float from_h16<false>(unsigned short v) {
   return (float)__builtin_bit_cast(_Float16, v);
 }
 
+// v + (v of the lane the DPP control selects; 0 where there is none) as ONE v_add_f32_dpp (left to the compiler the adds are
+// SLP-packed into v_pk_add_f32 and every DPP move becomes its own instruction)
+#define H16_ADD_DPP(v, ctrl) asm volatile("v_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(v) : "v"(v))
+
 template <bool BF16>
 __device__ __forceinline__ f32x16 mfma16(const f32x4& a, const f32x4& b, const f32x16& c) {
   if (BF16) {
@@ -90,240 +93,276 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4& a, const f32x4& b, const f
   }
 }
 
-// byte offset of 16-byte block b of patch pixel (r, c) in the swizzled LDS image
-__device__ __forceinline__ int patch_off(int r, int c, int b) { return ((r * HP_W + c) << 7) + ((b ^ ((c >> 1) & 7)) << 4); }
 
+// Ping-pong schedule (round 2): the workgroup's eight waves are two GROUPS of four (waves 0-3, 4-7 = one wave of each group on
+// every SIMD).  A group owns one patch stage and walks its own tiles (the workgroup's tiles alternate between the groups); a
+// wave owns two pixel rows of its group's tile (the A operands are shared by both rows: 4 operand reads per 4 MFMAs instead of
+// 3 per 2).  The groups run half a tile apart: while one group is in its COMPUTE phase (operand reads + 144 MFMAs per wave) the
+// other is in its MEMORY phase (epilogue of its previous tile: bias, activation, rounding, staging, stores, channel sums -- then
+// the zero fills and LDS-DMA pieces of its next patch), one workgroup barrier per phase.  In the one-role-at-a-time version all
+// eight waves left the matrix pipe idle for 56 % of a tile (in-kernel stamps, tools/gpu_h16_ablate.py).
+// A memory phase first requests the group's next patch (its stage was consumed in the phase before), then runs the epilogue under
+// that latency, straight from the accumulators (8-byte stores, channel sums by DPP adds): staging the outputs through the patch
+// stage put the whole patch round trip (2+ us) at the END of every phase and the schedule was no faster than the old one.
 template <bool BF16>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_w = smem;                                  // resident weights
-  unsigned char* s_p = smem + HW_BYTES;                       // two patch stages
-  float* s_red = reinterpret_cast<float*>(smem + HW_BYTES + 2 * HP_SEGS * 1024);
-  // the bias once per launch through LDS (the 512 never-written bytes behind patch stage 0: 43 one-KiB pieces hold 42.5 KiB):
-  // 32 global loads per lane in every tile's epilogue (8 dependent load -> wait -> convert groups) were most of a tile's time
+  unsigned char* s_p = smem + HW_BYTES;                       // two patch stages, one per group
+  float* s_red = reinterpret_cast<float*>(smem + HW_BYTES + 2 * HP_SEGS * 1024);   // [group][wave][64] channel sums
+  // the bias once per launch through LDS (the 512 never-written bytes behind patch stage 0: 43 one-KiB pieces hold 42.5 KiB)
   float* s_bias = reinterpret_cast<float*>(s_p + HP_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  eavsr_stagger_priority(wave);
+  const int grp = wave >> 2, w4 = wave & 3;
   const int l31 = lane & 31, half = lane >> 5;
   const int h = a.h, w = a.w;
+  unsigned char* pst = s_p + grp * (HP_SEGS * 1024);
 
-  // zero both patch stages once (pieces outside the image are never moved), fetch the weights once
-  {
-    f32x4* z = reinterpret_cast<f32x4*>(s_p);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < 2 * HP_SEGS * 64; e += 512) z[e] = zero;
-  }
-  __syncthreads();
   if (tid < 64) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
 #ifndef EAVSR_H16_EXP_NO_WDMA
 #pragma unroll 1
   for (int seg = wave; seg < HW_SEGS; seg += 8)
-#else
-  for (int seg = wave; seg < 0; seg += 8)
-#endif
     __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.wp) + seg * 1024 + lane * 16),
                                      (lptr_t)(s_w + seg * 1024), 16, 0, 0);
+#endif
 
-  // patch DMA: piece = 64 consecutive 16-byte LDS slots; slot e -> pixel e >> 3, stored block e & 7 holds the
-  // logical block (e & 7) ^ swz(col)
-  auto issue_patch = [&](int tile, int stage) {
-    int t = tile;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int bn = t / a.tiles_y;
-    const int y0 = ty * HT_H - 1, x0 = tx * HT_W - 1;
-    const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)bn * h * w * 128;
-#pragma unroll 1
-    for (int i = 0; i < HP_IT; ++i) {
-      const int seg = i * 8 + wave;
-      const int e = seg * 64 + lane;
-      const int p = e >> 3, sb = e & 7;
-      const int r = p / HP_W, c = p - r * HP_W;
-      const int gy = y0 + r, gx = x0 + c;
-      if (seg < HP_SEGS && p < HP_PIX && gy >= 0 && gy < h && gx >= 0 && gx < w) {
-        const int lb = sb ^ ((c >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((gptr_t)(xb + ((size_t)gy * w + gx) * 128 + lb * 16),
-                                         (lptr_t)(s_p + stage * (HP_SEGS * 1024) + seg * 1024), 16, 0, 0);
-      }
-    }
-  };
-  // out-of-image pieces of a stage may hold the previous tile's data: clear them (cheap, only border tiles)
-  auto clear_border = [&](int tile, int stage) -> bool {   // true: something was cleared (the same answer in every wave)
-    int t = tile;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int y0 = ty * HT_H - 1, x0 = tx * HT_W - 1;
-    if (y0 >= 0 && x0 >= 0 && y0 + HP_H <= h && x0 + HP_W <= w) return false;  // interior tile (wave-uniform)
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int e = tid; e < HP_PIX * 8; e += 512) {
-      const int p = e >> 3;
-      const int r = p / HP_W, c = p - r * HP_W;
-      const int gy = y0 + r, gx = x0 + c;
-      if (!(gy >= 0 && gy < h && gx >= 0 && gx < w))
-        *reinterpret_cast<f32x4*>(s_p + stage * (HP_SEGS * 1024) + e * 16) = zero;
-    }
-    return true;
-  };
-
-  int tile = blockIdx.x;
-  int stage = 0;
 #ifdef EAVSR_H16_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
+  const int cnt = ((int)a.num_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup
+  const int cnt_g = cnt > grp ? (cnt - grp + 1) >> 1 : 0;                                      // ... of this group
+  const int cnt_o = cnt > (grp ^ 1) ? (cnt - (grp ^ 1) + 1) >> 1 : 0;
+  const int p_end = max(grp + 2 * cnt_g, (grp ^ 1) + 2 * cnt_o) + 1;
+  auto tile_at = [&](int j, int& bn, int& ty, int& tx) __attribute__((always_inline)) {
+    int t = (int)blockIdx.x + (grp + 2 * j) * (int)gridDim.x;
+    tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    ty = t % a.tiles_y;
+    bn = t / a.tiles_y;
+  };
+
+  // per-lane source offset of this wave's 11 patch pieces relative to the patch origin (tile-invariant): interior tiles need one
+  // add per piece instead of the division / bounds / swizzle arithmetic
+  unsigned rel_off[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) {
+    const int e = (i * 4 + w4) * 64 + lane;
+    const int pp = e >> 3, sb = e & 7;
+    const int r = pp / HP_W, c = pp - r * HP_W;
+    rel_off[i] = (unsigned)((r * w + c) * 128 + ((sb ^ ((c >> 1) & 7)) << 4));
+  }
+  const bool tail_lane = ((10 * 4 + w4) * 64 + lane) >> 3 < HP_PIX;   // the last piece is partial
+
+  f32x16 acc[2][2];   // [row][m]
+  for (int p = 0; p <= p_end; ++p) {
+    const int q = p - grp;
+    const int j = q >> 1;
+    if (q >= 0 && (q & 1) == 0) {
+      // ================================================================== memory phase =======================================
+      if (j < cnt_g) {
+        // ---- the patch of tile j FIRST (the stage was consumed in the last phase; its latency hides under the epilogue below):
+        // slot e -> pixel e >> 3, stored block e & 7 holds the logical block (e & 7) ^ swz(col); slots outside the image are
+        // zero-filled.  43 one-KiB pieces over the four waves of the group.
+        int bn, ty, tx;
+        tile_at(j, bn, ty, tx);
+        const int y0 = ty * HT_H - 1, x0 = tx * HT_W - 1;
+        const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)bn * h * w * 128;
+        if (y0 >= 0 && x0 >= 0 && y0 + HP_H <= h && x0 + HP_W <= w) {      // interior tile (wave-uniform): no zero fills
+          const char* org = xb + ((size_t)y0 * w + x0) * 128;
+#pragma unroll
+          for (int i = 0; i < 11; ++i) {
+            const int seg = i * 4 + w4;
 #ifndef EAVSR_H16_EXP_NO_DMA
-  if (tile < a.num_tiles) issue_patch(tile, 0);
+            if (seg < HP_SEGS && (i < 10 || tail_lane))
+              __builtin_amdgcn_global_load_lds((gptr_t)(org + rel_off[i]), (lptr_t)(pst + seg * 1024), 16, 0, 0);
 #endif
-  for (; tile < a.num_tiles; tile += gridDim.x, stage ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // weights + patch(tile) landed; the other stage is free (its epilogue stores are done)
-    H16_STAMP(0);     // prologue / waiting for the DMA and the barrier
-    const int next = tile + gridDim.x;
-    const unsigned char* pst = s_p + stage * (HP_SEGS * 1024);
-    f32x16 acc[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    // No LDS-DMA is in flight inside this loop (the next tile's patch is requested right after it, under the epilogue): with one
-    // pending the compiler turns every operand wait into lgkmcnt(0) -- each MFMA pair then waits for the reads just issued for
-    // the NEXT pair, an exposed LDS round trip per k-step (14 us per tile instead of 2).  The operands of tap t+1 (4 B + 8 A
-    // fragments) are requested before the 8 MFMAs of tap t.
-    f32x4 bq[2][4], aq[2][8];
-    auto load_tap = [&](int tap, int set) __attribute__((always_inline)) {
-      const int ky = tap / 3, kx = tap - 3 * ky;
-#pragma unroll
-      for (int cb = 0; cb < 4; ++cb) {
-        bq[set][cb] = *reinterpret_cast<const f32x4*>(pst + patch_off(wave + ky, l31 + kx, cb * 2 + half));
+          }
+        } else {
+#pragma unroll 1
+          for (int i = 0; i < 11; ++i) {
+            const int seg = i * 4 + w4;
+            if (seg < HP_SEGS) {
+              const int e = seg * 64 + lane;
+              const int pp = e >> 3, sb = e & 7;
+              const int r = pp / HP_W, c = pp - r * HP_W;
+              const int gy = y0 + r, gx = x0 + c;
+              if (pp < HP_PIX) {
+#ifndef EAVSR_H16_EXP_NO_DMA
+                if (gy >= 0 && gy < h && gx >= 0 && gx < w)
+                  __builtin_amdgcn_global_load_lds((gptr_t)(xb + ((size_t)gy * w + gx) * 128 + ((sb ^ ((c >> 1) & 7)) << 4)),
+                                                   (lptr_t)(pst + seg * 1024), 16, 0, 0);
+                else
+#endif
+                  *reinterpret_cast<f32x4*>(pst + e * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+            }
+          }
+        }
+        H16_STAMP(2);     // zero fills + patch DMA issue
+      }
+      if (j >= 1 && j - 1 < cnt_g) {
+        // ---- epilogue of tile j - 1 straight from the accumulators: lane (pixel l31, half) holds 4 consecutive channels per
+        // (m, qd) = one 8-byte store; the two halves write adjacent 8 bytes, the eight (m, qd) stores of a pixel fill its
+        // 128-byte row (merged in L2).  No LDS staging: the patch stage is already being refilled.
+        int bn, ty, tx;
+        tile_at(j - 1, bn, ty, tx);
+        char* ob = reinterpret_cast<char*>(a.out) + (size_t)bn * h * w * 128;
+        f32x4 bq4[2][4];     // this lane's 32 bias values: 4 consecutive channels per (m, qd)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          aq[set][cb * 2 + m] = *reinterpret_cast<const f32x4*>(s_w + ((((tap * 4 + cb) * 2 + half) * 64 + m * 32 + l31) << 4));
-      }
-    };
-    load_tap(0, 0);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      __builtin_amdgcn_sched_barrier(0);     // keep the requests of tap t+1 in front of the MFMAs of tap t
-      if (tap + 1 < 9) load_tap(tap + 1, (tap + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int qd = 0; qd < 4; ++qd) bq4[m][qd] = *reinterpret_cast<const f32x4*>(s_bias + m * 32 + 8 * qd + 4 * half);
+        // the activation and the channel sums are launch constants: four straight-line variants (the sums alone are ~450 of the
+        // ~900 vector instructions of a general epilogue, as many issue cycles as the tile's MFMAs)
+        auto epilogue = [&](auto sums_c, auto relu_c) __attribute__((always_inline)) {
+          constexpr bool SUMS = decltype(sums_c)::value, RELU = decltype(relu_c)::value;
+          float csum[2][16];
+          if (SUMS) {
 #pragma unroll
-      for (int cb = 0; cb < 4; ++cb)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#ifdef EAVSR_H16_EXP_NO_MFMA
-          acc[m][cb] += aq[tap & 1][cb * 2 + m][0] + bq[tap & 1][cb][1];
-#else
-          acc[m] = mfma16<BF16>(aq[tap & 1][cb * 2 + m], bq[tap & 1][cb], acc[m]);
-#endif
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    H16_STAMP(1);     // operand reads + MFMAs
-    if (next < a.num_tiles) {
-      clear_border(next, stage ^ 1);   // zero fills and DMA pieces touch disjoint slots: no barrier between them
-#ifndef EAVSR_H16_EXP_NO_DMA
-      issue_patch(next, stage ^ 1);
-#endif
-    }
-    H16_STAMP(2);     // border clear + next patch DMA issue
-    // ---- epilogue ------------------------------------------------------------------------------
-    int t = tile;
-    const int tx = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty = t % a.tiles_y;
-    const int bn = t / a.tiles_y;
-    const int gy = ty * HT_H + wave, gx = tx * HT_W + l31;
-    const bool ok = gy < h && gx < w;
-    __syncthreads();  // every wave is done reading this patch stage: reuse it as the output staging tile
-    unsigned char* ost = s_p + stage * (HP_SEGS * 1024);   // [8 rows][32 px][128 B], same block swizzle
+              for (int e = 0; e < 16; ++e) csum[m][e] = 0.f;
+          }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+          for (int r = 0; r < 2; ++r) {
+            const int gy = ty * HT_H + 2 * w4 + r, gx = tx * HT_W + l31;
+            const bool ok = gy < h && gx < w;
+            char* orow = ob + ((size_t)gy * w + gx) * 128 + 8 * half;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        // registers 4q .. 4q+3 are 4 consecutive output channels co = m*32 + 8q + 4*half + (0..3)
-        const int co = m * 32 + 8 * q + 4 * half;
-        unsigned short pk[4];
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v = acc[m][4 * q + j] + s_bias[co + j];
-          if (a.relu) v = fmaxf(v, 0.f);
-          pk[j] = to_h16<BF16>(ok ? v : 0.f);   // pixels outside the image stage as zeros (they are not stored)
-        }
-        const int blk = co >> 3;  // 16-byte block of the pixel row, this lane writes its 8-byte half
-        const int off = ((wave * HT_W + l31) << 7) + ((blk ^ ((l31 >> 1) & 7)) << 4) + ((co & 4) << 1);
-        *reinterpret_cast<unsigned long long*>(ost + off) =
-            (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 16) | ((unsigned long long)pk[2] << 32) |
-            ((unsigned long long)pk[3] << 48);
-      }
-    }
-    __syncthreads();
-    H16_STAMP(3);     // bias / activation / rounding / staging writes
-    if (a.chan_partial) {
-      // per-tile channel sums from the staged tile (the 16-bit values the next layer will actually read):
-      // thread -> 8 channels (one 16-byte block) of 4 pixels, then 3 shuffle steps over the 8 lanes that share
-      // the block, then the 8 waves through LDS.  (A 160-shuffle reduction of the accumulators cost 22 us.)
-      const int cb = tid & 7;
-      float cs[8];
+              for (int qd = 0; qd < 4; ++qd) {
+                // registers 4 qd .. 4 qd + 3 are 4 consecutive output channels co = m*32 + 8 qd + 4 half + (0..3)
+                unsigned short pk[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) cs[j] = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = (tid >> 3) + 64 * i;
-        const int c = p & (HT_W - 1);
-        const s16x8 v = *reinterpret_cast<const s16x8*>(ost + (p << 7) + ((cb ^ ((c >> 1) & 7)) << 4));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) cs[j] += from_h16<BF16>((unsigned short)v[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v = cs[j];
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        cs[j] = v;
-      }
-      if (lane < 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s_red[wave * 64 + lane * 8 + j] = cs[j];
-      }
-      __syncthreads();
-      if (tid < 64) {
-        float v = s_red[tid];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) v += s_red[k * 64 + tid];
-        a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx) * 64 + tid] = v;
-      }
-    }
-    H16_STAMP(4);     // channel sums
-    // whole pixel rows leave as 16 bytes per lane: 8 rows x 32 px x 8 blocks = 2048 pieces
-    char* ob = reinterpret_cast<char*>(a.out) + (size_t)bn * h * w * 128;
-    for (int e = tid; e < HT_H * HT_W * 8; e += 512) {
-      const int p = e >> 3, sb = e & 7;
-      const int r = p / HT_W, c = p - r * HT_W;
-      const int oy = ty * HT_H + r, ox = tx * HT_W + c;
-      if (oy < h && ox < w) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ost + (p << 7) + (sb << 4));
-        const int lb = sb ^ ((c >> 1) & 7);
+                for (int e = 0; e < 4; ++e) {
+                  float v = acc[r][m][4 * qd + e] + bq4[m][qd][e];
+                  if (RELU) v = fmaxf(v, 0.f);
+                  pk[e] = to_h16<BF16>(v);
+                  if (SUMS) csum[m][4 * qd + e] += ok ? from_h16<BF16>(pk[e]) : 0.f;   // the 16-bit value the next layer reads
+                }
 #ifdef EAVSR_H16_EXP_NO_STORE
-        if (v[0] == 1.2345e-33f)
+                if (pk[0] == 0x1234 && pk[1] == 0x4321)
 #endif
-        *reinterpret_cast<f32x4*>(ob + ((size_t)oy * w + ox) * 128 + lb * 16) = v;
+                if (ok)
+                  *reinterpret_cast<unsigned long long*>(orow + (m * 32 + 8 * qd) * 2) =
+                      (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 16) | ((unsigned long long)pk[2] << 32) |
+                      ((unsigned long long)pk[3] << 48);
+              }
+          }
+          H16_STAMP(5);     // bias / activation / rounding / output stores
+          if (SUMS) {
+            // channel sums over this wave's 64 pixels: 32 lanes hold the same channels -> five DPP adds per value (an inclusive
+            // scan inside each row of 16 lanes, then row_bcast:15), totals in lanes 31 and 63; the four waves meet in LDS and
+            // wave 0 of the group adds them up after the phase barrier (fixed order)
+            // step-major order (volatile asm keeps it): 31 independent instructions between two DPP operations on the same
+            // register, which also covers the VALU-write -> DPP-read wait states the assembler does not insert for inline asm
+#define H16_DPP_STEP(ctrl)                                     \
+  _Pragma("unroll") for (int m = 0; m < 2; ++m)                \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) H16_ADD_DPP(csum[m][e], ctrl);
+            asm volatile("s_nop 1");   // the last csum add may sit right in front of the first DPP read of its register
+            H16_DPP_STEP("row_shr:1")
+            H16_DPP_STEP("row_shr:2")
+            H16_DPP_STEP("row_shr:4")
+            H16_DPP_STEP("row_shr:8")
+            H16_DPP_STEP("row_bcast:15")
+#undef H16_DPP_STEP
+            if (l31 == 31) {
+#pragma unroll
+              for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                  s_red[(grp * 4 + w4) * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * half] = csum[m][e];
+            }
+          }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (a.chan_partial) { if (a.relu) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
+        else { if (a.relu) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
+        H16_STAMP(4);     // channel sums
+      }
+    } else if (q >= 1) {
+      // ================================================================== compute phase ======================================
+      if (a.chan_partial && j >= 1 && j - 1 < cnt_g && w4 == 0) {   // finish the channel sums of the tile stored in the last phase
+        int bn, ty, tx;
+        tile_at(j - 1, bn, ty, tx);
+        float v = s_red[(grp * 4) * 64 + lane];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) v += s_red[(grp * 4 + k) * 64 + lane];
+        a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx) * 64 + lane] = v;
+      }
+      if (j < cnt_g) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][m][e] = 0.f;
+        // No LDS-DMA of THIS wave is in flight here (its pieces were waited for in front of the phase barrier); the operands of
+        // the next half tap (2 x (2 B + 2 A) fragments) are requested before the 8 MFMAs of this one.
+        f32x4 bq[2][4], aq[2][4];
+        // half a tap = two 16-channel blocks; i = kx * 2 + (block pair) within filter row ky.  The filter rows are a run-time
+        // loop (fully unrolled, the 27 hoisted operand addresses spilled the accumulators).
+        const unsigned char* prow = pst + (((2 * w4) * HP_W + l31) << 7);
+        const unsigned char* wrow = s_w + (((half * 64) + l31) << 4);
+        auto load_half = [&](const unsigned char* pr, const unsigned char* wr, int i, int set) __attribute__((always_inline)) {
+          const int kx = i >> 1;
+          const int swz = ((l31 + kx) >> 1) & 7;
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const int cb = (i & 1) * 2 + c2;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+              bq[set][c2 * 2 + r] = *reinterpret_cast<const f32x4*>(pr + ((r * HP_W + kx) << 7) + (((cb * 2 + half) ^ swz) << 4));
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+              aq[set][c2 * 2 + m] = *reinterpret_cast<const f32x4*>(wr + ((((kx * 4 + cb) * 2) * 64 + m * 32) << 4));
+          }
+        };
+        load_half(prow, wrow, 0, 0);
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned char* pr = prow + ky * (HP_W << 7);
+          const unsigned char* wr = wrow + ky * (3 * 4 * 2 * 64 * 16);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_barrier(0);     // keep the requests of the next half tap in front of this one's MFMAs
+            if (i + 1 < 6) load_half(pr, wr, i + 1, (i + 1) & 1);
+            else if (ky + 1 < 3) load_half(pr + (HP_W << 7), wr + 3 * 4 * 2 * 64 * 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+              for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+#ifdef EAVSR_H16_EXP_NO_MFMA
+                  acc[r][m][c2] += aq[i & 1][c2 * 2 + m][0] + bq[i & 1][c2 * 2 + r][1];
+#else
+                  acc[r][m] = mfma16<BF16>(aq[i & 1][c2 * 2 + m], bq[i & 1][c2 * 2 + r], acc[r][m]);
+#endif
+                }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        H16_STAMP(1);     // operand reads + MFMAs
       }
     }
-    // the staging tile sits where the interior of the patch was: restore zeros where the NEXT use of this stage
-    // expects "never written" (handled by clear_border before each DMA; interior pieces are always rewritten)
-    H16_STAMP(5);     // output stores
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMA pieces, zero fills and sums have landed
+    __syncthreads();
+    H16_STAMP(0);         // waiting for the DMA and the barrier
   }
 #ifdef EAVSR_H16_STAMPS
-  if (tid == 0)
+  if (tid == 0 || tid == 256)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_h16_stamps[i], st_acc[i]);
 #endif
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // layout / precision converters and the 16-bit RCAB tail

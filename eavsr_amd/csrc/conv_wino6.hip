@@ -390,7 +390,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     const bool on_duty = (wave >> 1) == (it & 3);
     auto issue_dma = [&]() __attribute__((always_inline)) {
 #ifndef EAVSR_WINO_EXP_NODMA
+#ifndef EAVSR_WINO_EXP_NOUDMA
       if (it + 1 < total_iters) issue_u(chunk_n, (it + 1) & 1);
+#endif
       if (it + 2 < total_iters) issue_patch(it & 1);
 #endif
     };
@@ -420,7 +422,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     f32x2 av[AHEAD + 1], bv[AHEAD + 1];
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) {
+#ifdef EAVSR_WINO_EXP_UREGS
+      av[i] = f32x2{bias_r[0] + (float)i, bias_r[1]};
+#else
       av[i] = *reinterpret_cast<const f32x2*>(ua + i * (CK * 128));
+#endif
       bv[i] = *reinterpret_cast<const f32x2*>(vb + i * (CK * 64));
     }
 #ifndef EAVSR_WINO_EXP_NOMFMA
@@ -450,13 +456,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       }
 #endif
       if (i + AHEAD < NSTEP) {
+#ifdef EAVSR_WINO_EXP_UREGS
+        av[(i + AHEAD) % (AHEAD + 1)] = f32x2{bias_r[(i + AHEAD) & 3], bias_r[i & 3]};
+#else
         av[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(ua + (i + AHEAD) * (CK * 128));
+#endif
         bv[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(vb + (i + AHEAD) * (CK * 64));
       }
       const int cur = i % (AHEAD + 1);
       acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur].x, bv[cur].x, acc[2 * i], 0, 0, 0);
       acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur].y, bv[cur].y, acc[2 * i + 1], 0, 0, 0);
+#ifdef EAVSR_WINO_EXP_UREGS
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#else
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of step i + AHEAD
+#endif
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // the 2 MFMAs of step i
     }
 #else
