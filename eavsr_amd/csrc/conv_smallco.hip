@@ -28,13 +28,18 @@ struct SmallArgs {
   float slope;
 };
 
-template <int COUT>
-__global__ __launch_bounds__(256) void conv3x3_smallco_kernel(SmallArgs a) {
+// KZ = 1: 256 threads.  KZ = 2: 512 threads, thread group kz = tid >> 8 sums the channels [4 kz, 4 kz + 4) of every slab for the
+// same pixels and the groups meet in LDS at the end -- for launches of less than two workgroups per CU (the predictor's heads on a
+// 2-clip sub-batch: 230 workgroups), where a workgroup is one wave per SIMD and every LDS round trip of the channel loop is exposed.
+template <int COUT, int KZ>
+__global__ __launch_bounds__(256 * KZ) void conv3x3_smallco_kernel(SmallArgs a) {
+  constexpr int NT = 256 * KZ;
   __shared__ float s_in[SCK][SP_H][SP_W + 1];
   constexpr int CP = COUT <= 4 ? 4 : 8;                      // weights of one (channel, tap): CP floats, 16-byte rows
   __shared__ __attribute__((aligned(16))) float s_wt[SCK][9][CP];
   const int tid = threadIdx.x;
-  const int lx = tid & 63, ly = tid >> 6;  // thread -> column lx, rows 2*ly and 2*ly + 1
+  const int kz = tid >> 8;
+  const int lx = tid & 63, ly = (tid >> 6) & 3;  // thread -> column lx, rows 2*ly and 2*ly + 1
   int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % a.tiles_x;
   bid /= a.tiles_x;
@@ -48,49 +53,68 @@ __global__ __launch_bounds__(256) void conv3x3_smallco_kernel(SmallArgs a) {
 #pragma unroll
   for (int co = 0; co < COUT; ++co) acc[co][0] = acc[co][1] = 0.f;
 
-  for (int c0 = 0; c0 < cin; c0 += SCK) {
-    // stage the slab: issue every global load first (straight-line, always-valid addresses, select afterwards),
-    // then write LDS -- a load / wait / write loop serialises ~20 HBM latencies per slab
-    constexpr int IN_N = SCK * SP_H * SP_W, IN_IT = (IN_N + 255) / 256;
-    constexpr int W_N = SCK * 9 * CP, W_IT = (W_N + 255) / 256;
-    float tin[IN_IT], tw[W_IT];
+  // The slabs are software-pipelined through registers: the global loads of slab c0 + 8 are issued before the FMAs of slab c0
+  // and written to LDS after them, so a slab's HBM round trip hides behind ~1,100 vector instructions.  (A 2 x 180 x 320 launch
+  // is 230 workgroups -- less than one per CU, nothing else to hide it: load -> wait -> compute per slab cost 42 us of which
+  // ~25 were exposed latency.)
+  constexpr int IN_N = SCK * SP_H * SP_W, IN_IT = (IN_N + NT - 1) / NT;
+  constexpr int W_N = SCK * 9 * CP, W_IT = (W_N + NT - 1) / NT;
+  float tin[IN_IT], tw[W_IT];
+  // Slab-invariant index arithmetic once per thread (it was ~70 instructions per element and slab, more than the FMAs): the
+  // clamped source offset and the LDS slot of each of this thread's patch elements, a validity bit per element (zero padding),
+  // and the same for the weights.
+  unsigned in_off[IN_IT], in_ok = 0u;
+  unsigned short in_slot[IN_IT];
+  unsigned short in_ci[IN_IT];
+#pragma unroll
+  for (int i = 0; i < IN_IT; ++i) {
+    const int e = tid + i * NT;
+    const int ci = min(e / (SP_H * SP_W), SCK - 1), rem = e - (e / (SP_H * SP_W)) * (SP_H * SP_W);
+    const int r = rem / SP_W, c = rem - r * SP_W;
+    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+    if (e < IN_N && gy >= 0 && gy < h && gx >= 0 && gx < w) in_ok |= 1u << i;
+    const int cgy = min(max(gy, 0), h - 1), cgx = min(max(gx, 0), w - 1);
+    in_off[i] = (unsigned)(cgy * w + cgx);
+    in_slot[i] = (unsigned short)((ci * SP_H + r) * (SP_W + 1) + c);
+    in_ci[i] = (unsigned short)ci;
+  }
+  unsigned w_off[W_IT], w_ok = 0u;
+  unsigned short w_ci[W_IT];
+#pragma unroll
+  for (int i = 0; i < W_IT; ++i) {
+    const int e = min(tid + i * NT, W_N - 1);
+    const int co = e % CP, tap = (e / CP) % 9, ci = e / (CP * 9);
+    if (tid + i * NT < W_N && co < COUT) w_ok |= 1u << i;
+    w_off[i] = (unsigned)((min(co, COUT - 1) * cin + ci) * 9 + tap);
+    w_ci[i] = (unsigned short)ci;
+  }
+  auto fetch = [&](int c0) __attribute__((always_inline)) {
+    // straight-line, always-valid addresses, raw values: every load is in flight before the first is used (the zero-padding
+    // select happens in commit(); a select here would wait for the load at once)
     const float* xb = a.x + ((size_t)bn * cin + c0) * plane;
 #pragma unroll
-    for (int i = 0; i < IN_IT; ++i) {
-      const int e = tid + i * 256;
-      const int ci = e / (SP_H * SP_W), rem = e - ci * (SP_H * SP_W);
-      const int r = rem / SP_W, c = rem - r * SP_W;
-      const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-      const bool ok = e < IN_N && c0 + ci < cin && gy >= 0 && gy < h && gx >= 0 && gx < w;
-      const int cci = min(ci, cin - c0 - 1), cgy = min(max(gy, 0), h - 1), cgx = min(max(gx, 0), w - 1);
-      const float v = xb[(size_t)cci * plane + (size_t)cgy * w + cgx];
-      tin[i] = ok ? v : 0.f;
-    }
+    for (int i = 0; i < IN_IT; ++i) tin[i] = xb[(size_t)min((int)in_ci[i], cin - c0 - 1) * plane + in_off[i]];
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int e = min(tid + i * 256, W_N - 1);
-      const int co = e % CP, tap = (e / CP) % 9, ci = e / (CP * 9);
-      const bool ok = co < COUT && c0 + ci < cin;
-      const float v = a.wt[((size_t)min(co, COUT - 1) * cin + min(c0 + ci, cin - 1)) * 9 + tap];
-      tw[i] = ok ? v : 0.f;
-    }
+    for (int i = 0; i < W_IT; ++i) tw[i] = a.wt[w_off[i] + (unsigned)(min(c0, cin - 1 - (int)w_ci[i]) * 9)];
+  };
+  auto commit = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < IN_IT; ++i)
+      if (i < IN_IT - 1 || tid + i * NT < IN_N)
+        (&s_in[0][0][0])[in_slot[i]] = ((in_ok >> i) & 1u) && c0 + (int)in_ci[i] < cin ? tin[i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i)
+      if (i < W_IT - 1 || tid + i * NT < W_N)
+        (&s_wt[0][0][0])[tid + i * NT] = ((w_ok >> i) & 1u) && c0 + (int)w_ci[i] < cin ? tw[i] : 0.f;
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < cin; c0 += SCK) {
     __syncthreads();  // the previous slab has been consumed
-#pragma unroll
-    for (int i = 0; i < IN_IT; ++i) {
-      const int e = tid + i * 256;
-      if (i < IN_IT - 1 || e < IN_N) {
-        const int ci = e / (SP_H * SP_W), rem = e - ci * (SP_H * SP_W);
-        s_in[ci][rem / SP_W][rem % SP_W] = tin[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int e = tid + i * 256;
-      if (i < W_IT - 1 || e < W_N) (&s_wt[0][0][0])[e] = tw[i];
-    }
+    commit(c0);
     __syncthreads();
+    if (c0 + SCK < cin) fetch(c0 + SCK);
     const int nci = min(SCK, cin - c0);
-    for (int ci = 0; ci < nci; ++ci) {   // uniform trip count
+    for (int ci = kz * (SCK / KZ); ci < min(nci, (kz + 1) * (SCK / KZ)); ++ci) {   // wave-uniform trip count
       // 4 input rows x 3 columns around the two pixels (rows 2ly .. 2ly+3 of the patch)
       float v[4][3];
 #pragma unroll
@@ -114,6 +138,30 @@ __global__ __launch_bounds__(256) void conv3x3_smallco_kernel(SmallArgs a) {
           }
         }
     }
+  }
+  if (KZ > 1) {
+    // the channel groups meet in LDS (the last slab's image is dead): one group at a time parks its partial sums, group 0 adds
+    float* s_acc = &s_in[0][0][0];
+    static_assert(256 * 2 * 6 <= SCK * SP_H * (SP_W + 1), "partial sums must fit the slab image");
+    for (int k = 1; k < KZ; ++k) {
+      __syncthreads();
+      if (kz == k) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          s_acc[(co * 2 + 0) * 256 + (tid & 255)] = acc[co][0];
+          s_acc[(co * 2 + 1) * 256 + (tid & 255)] = acc[co][1];
+        }
+      }
+      __syncthreads();
+      if (kz == 0) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          acc[co][0] += s_acc[(co * 2 + 0) * 256 + tid];
+          acc[co][1] += s_acc[(co * 2 + 1) * 256 + tid];
+        }
+      }
+    }
+    if (kz > 0) return;
   }
   const int gx = x0 + lx;
   if (gx < w) {
@@ -154,12 +202,18 @@ extern "C" int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, co
   const long blocks = (long)a.tiles_x * a.tiles_y * n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_smallco: too many tiles");
   hipStream_t st = eavsr::as_stream(stream);
-  dim3 grid((unsigned)blocks), block(256);
+  dim3 grid((unsigned)blocks);
+  // less than two workgroups per CU: split the channel loop over two thread groups (one more wave per SIMD to hide LDS latency)
+  const bool split = blocks < 512 && cin >= 16;
+#define EAVSR_SMALLCO(CO)                                                                                  \
+  if (split) hipLaunchKernelGGL((conv3x3_smallco_kernel<CO, 2>), grid, dim3(512), 0, st, a);               \
+  else hipLaunchKernelGGL((conv3x3_smallco_kernel<CO, 1>), grid, dim3(256), 0, st, a)
   switch (cout) {
-    case 2: hipLaunchKernelGGL(conv3x3_smallco_kernel<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(conv3x3_smallco_kernel<3>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(conv3x3_smallco_kernel<4>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(conv3x3_smallco_kernel<6>, grid, block, 0, st, a); break;
+    case 2: EAVSR_SMALLCO(2); break;
+    case 3: EAVSR_SMALLCO(3); break;
+    case 4: EAVSR_SMALLCO(4); break;
+    default: EAVSR_SMALLCO(6); break;
   }
+#undef EAVSR_SMALLCO
   return eavsr::launch_status("conv3x3_smallco");
 }
