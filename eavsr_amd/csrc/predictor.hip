@@ -99,6 +99,112 @@ __global__ __launch_bounds__(256) void adapt_frontend_kernel(
   }
 }
 
+// The same operation for w % 4 == 0 and 16-byte aligned tensors (every call of the model): register-tiled.  The patch starts 4
+// columns left of the tile, so it arrives as aligned 16-byte loads (3 per thread instead of 11 scalar ones with their index
+// arithmetic); each stage evaluates groups of 4 adjacent columns -- a stencil row is one ds_read_b128 + one b128 / b64 for 4
+// outputs x 3 taps instead of one ds_read_b32 per FMA.  2 x 64 x 180 x 320: 50 -> see DESIGN.md 4g.
+typedef float pf32x2 __attribute__((ext_vector_type(2)));
+constexpr int GP_W = FT_W + 8;        // patch columns x0 - 4 .. x0 + 67 (72, 16-byte rows)
+constexpr int GM_W = FT_W + 4;        // mid columns x0 - 1 .. x0 + 66 (68: 17 groups of 4; the last two are never used)
+__global__ __launch_bounds__(256) void adapt_frontend_v4_kernel(
+    const float* __restrict__ x, const float* __restrict__ hh, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    float* __restrict__ out, int c, int h, int w, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) float s_in[2][FP_H][GP_W];
+  __shared__ __attribute__((aligned(16))) float s_mid[2][FM_H][GM_W];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int o = blockIdx.y, bn = blockIdx.z;
+  const int y0 = ty * FT_H, x0 = tx * FT_W;
+  const size_t plane = (size_t)h * w;
+
+  // patch: 2 channels x 20 rows x 18 quads, every load issued before the first LDS write
+  constexpr int Q_N = 2 * FP_H * (GP_W / 4), Q_IT = (Q_N + 255) / 256;   // 720 quads, 3 per thread
+  f32x4 tq[Q_IT];
+#pragma unroll
+  for (int i = 0; i < Q_IT; ++i) {
+    const int e = min(tid + i * 256, Q_N - 1);
+    const int ch = e / (FP_H * (GP_W / 4));
+    const int rem = e - ch * (FP_H * (GP_W / 4));
+    const int r = rem / (GP_W / 4), q = rem - r * (GP_W / 4);
+    const int gy = y0 - 2 + r, gx = x0 - 4 + 4 * q;
+    const int cat_c = 2 * o + ch;
+    const float* src = cat_c < c ? x : hh;
+    const int sc = cat_c < c ? cat_c : cat_c - c;
+    const int cgy = min(max(gy, 0), h - 1), cgx = min(max(gx, 0), w - 4);
+    tq[i] = *reinterpret_cast<const f32x4*>(src + ((size_t)bn * c + sc) * plane + (size_t)cgy * w + cgx);
+  }
+#pragma unroll
+  for (int i = 0; i < Q_IT; ++i) {
+    const int e = tid + i * 256;
+    if (i < Q_IT - 1 || e < Q_N) {
+      const int ch = e / (FP_H * (GP_W / 4));
+      const int rem = e - ch * (FP_H * (GP_W / 4));
+      const int r = rem / (GP_W / 4), q = rem - r * (GP_W / 4);
+      const int gy = y0 - 2 + r, gx = x0 - 4 + 4 * q;
+      const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;      // w % 4 == 0: a quad is inside or outside as a whole
+      *reinterpret_cast<f32x4*>(&s_in[ch][r][4 * q]) = ok ? tq[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  // t1: mid column m <-> gx = x0 - 1 + m needs patch columns m + 2 .. m + 4; group g = columns 4g .. 4g + 3
+  for (int e = tid; e < 2 * FM_H * (GM_W / 4); e += 256) {
+    const int ch = e / (FM_H * (GM_W / 4));
+    const int rem = e - ch * (FM_H * (GM_W / 4));
+    const int r = rem / (GM_W / 4), g = rem - r * (GM_W / 4);
+    const int gy = y0 - 1 + r;
+    const float* wk = w1 + (size_t)(2 * o + ch) * 9;
+    const float bias = b1[2 * o + ch];
+    float v[4] = {bias, bias, bias, bias};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&s_in[ch][r + ky][4 * g]);        // patch columns 4g .. 4g + 3
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(&s_in[ch][r + ky][4 * g + 4]);    //               4g + 4 .. 4g + 7
+      const float p[6] = {a4[2], a4[3], b4[0], b4[1], b4[2], b4[3]};                     // columns 4g + 2 .. 4g + 7
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float wv = wk[ky * 3 + kx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += wv * p[j + kx];
+      }
+    }
+    f32x4 o4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gx = x0 - 1 + 4 * g + j;
+      o4[j] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? lrelu02(v[j]) : 0.f;   // zero padding of the second conv
+    }
+    *reinterpret_cast<f32x4*>(&s_mid[ch][r][4 * g]) = o4;
+  }
+  __syncthreads();
+  // t2: one thread = 4 adjacent output pixels (16 rows x 16 groups = 256 threads); out column j needs mid columns j .. j + 2
+  {
+    const int r = tid >> 4, g = tid & 15;
+    const int gy = y0 + r, gx = x0 + 4 * g;
+    if (gy < h && gx < w) {
+      const float* wk2 = w2 + (size_t)o * 18;
+      const float bias2 = b2[o];
+      float v[4] = {bias2, bias2, bias2, bias2};
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(&s_mid[ch][r + ky][4 * g]);
+          const pf32x2 b2v = *reinterpret_cast<const pf32x2*>(&s_mid[ch][r + ky][4 * g + 4]);
+          const float p[6] = {a4[0], a4[1], a4[2], a4[3], b2v[0], b2v[1]};
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float wv = wk2[ch * 9 + ky * 3 + kx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += wv * p[j + kx];
+          }
+        }
+      *reinterpret_cast<f32x4*>(out + ((size_t)bn * c + o) * plane + (size_t)gy * w + gx) =
+          f32x4{lrelu02(v[0]), lrelu02(v[1]), lrelu02(v[2]), lrelu02(v[3])};
+    }
+  }
+}
+
 // one thread per (n, g, pixel)
 __global__ __launch_bounds__(256) void affine_offsets_kernel(const float* __restrict__ heads,
                                                              float* __restrict__ offset,
@@ -146,8 +252,13 @@ extern "C" int eavsr_adapt_frontend_f32(const float* x, const float* h_hr, const
   if (n == 0) return 0;
   const int tiles_x = eavsr::cdiv(w, FT_W), tiles_y = eavsr::cdiv(h, FT_H);
   dim3 grid(tiles_x * tiles_y, c, n);
-  hipLaunchKernelGGL(adapt_frontend_kernel, grid, dim3(256), 0, eavsr::as_stream(stream), x, h_hr, w1, b1, w2,
-                     b2, out, c, h, w, tiles_x);
+  const bool vec = w % 4 == 0 && w >= 4 && ((((uintptr_t)x) | ((uintptr_t)h_hr) | ((uintptr_t)out)) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(adapt_frontend_v4_kernel, grid, dim3(256), 0, eavsr::as_stream(stream), x, h_hr, w1, b1, w2,
+                       b2, out, c, h, w, tiles_x);
+  else
+    hipLaunchKernelGGL(adapt_frontend_kernel, grid, dim3(256), 0, eavsr::as_stream(stream), x, h_hr, w1, b1, w2,
+                       b2, out, c, h, w, tiles_x);
   return eavsr::launch_status("adapt_frontend");
 }
 
