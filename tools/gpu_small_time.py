@@ -37,6 +37,10 @@ w1, b1, w2, b2 = r(128, 1, 3, 3) * 0.2, r(128), r(64, 2, 3, 3) * 0.2, r(64)
 res["adapt_frontend 2x64x180x320"] = timed(lambda: ops.adapt_frontend(x, hh, w1, b1, w2, b2))
 sc = torch.rand(n, 64, device=dev)
 res["scale_residual 2x64x180x320"] = timed(lambda: ops.scale_residual(x, sc, hh))
+tiles = ((h + 7) // 8) * ((w + 63) // 64)
+part = r(n, tiles, 64)
+cw1, cb1, cw2, cb2 = r(4, 64, 1, 1), r(4), r(64, 4, 1, 1), r(64)
+res["ca_scale 2 x 115 tiles x 64"] = timed(lambda: ops.ca_scale(part, h * w, cw1, cb1, cw2, cb2))
 fl = r(n, 2, h, w)
 res["flow_warp 2x64x180x320"] = timed(lambda: ops.flow_warp(x, fl))
 for k, v in res.items():
