@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("ca_scale", vp),
         ("ca_x", vp),
         ("ca_out", vp),
+        ("out_shuffle", i32),
     ]
 
 

@@ -184,14 +184,17 @@ class _ConvFn(Function):
         return (None,) * 6 + tuple(dws) + tuple(dbs) + ((dout if need_res else None,) if has_res else ()) + tuple(dsrcs)
 
 
-def conv2d(srcs, weight, bias=None, act=None, slope=0.0, residual=None, chan_partial=False, ca=None, ca_out=False):
+def conv2d(srcs, weight, bias=None, act=None, slope=0.0, residual=None, chan_partial=False, ca=None, ca_out=False,
+           pixel_shuffle2=False):
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     ws = [weight] if isinstance(weight, torch.Tensor) else list(weight)
     bs = [bias] if (bias is None or isinstance(bias, torch.Tensor)) else list(bias)
     if not _needs_grad(srcs, ws, bs, residual):
         return ops.conv2d(srcs, weight, bias, act=act, slope=slope, residual=residual, chan_partial=chan_partial,
-                          ca=ca, ca_out=ca_out)
+                          ca=ca, ca_out=ca_out, pixel_shuffle2=pixel_shuffle2)
+    if pixel_shuffle2:      # training: the plain conv (with its backward kernels), shuffled by torch
+        return torch.nn.functional.pixel_shuffle(conv2d(srcs, weight, bias, act=act, slope=slope), 2)
     if chan_partial or ca is not None:
         raise NotImplementedError("the fused channel-attention paths are inference-only; training uses rcab_tail")
     has_bias = bs[0] is not None

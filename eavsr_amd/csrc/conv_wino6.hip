@@ -51,6 +51,7 @@ struct W4Args {
   int n, h, w, cin, cout, tiles_x, tiles_y;
   int act;
   float slope;
+  int out_shuffle;        // 2: out is F.pixel_shuffle(conv, 2), (n, cout / 4, 2h, 2w); 0: (n, cout, h, w)
 };
 
 constexpr int CK = 4, NW = 8, NPOS = 36;
@@ -522,20 +523,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
             y[1] = p2 + 2.f * p4;
             y[2] = p1 + 4.f * p3;
             y[3] = (p2 + 8.f * p4) + s[5];
+            float vv[2][4];
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
-              const int r = 2 * rp + ch, co = co0 + ch;
-              float v[4];
+              const int r = 2 * rp + ch;
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                v[j] = (ch == 0 ? y[j].x : y[j].y) + bias_r[r];
-                if (a.act == EAVSR_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
-                else if (a.act == EAVSR_ACT_LRELU) v[j] = v[j] > 0.f ? v[j] : v[j] * a.slope;
+                float t = (ch == 0 ? y[j].x : y[j].y) + bias_r[r];
+                if (a.act == EAVSR_ACT_RELU) t = fmaxf(t, 0.f);
+                else if (a.act == EAVSR_ACT_LRELU) t = t > 0.f ? t : t * a.slope;
+                vv[ch][j] = t;
               }
-              if (co < a.cout && pok) {
-                csum[r] += (v[0] + v[1]) + (v[2] + v[3]);
-                *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
-                    f32x4{v[0] + rr[ch][0], v[1] + rr[ch][1], v[2] + rr[ch][2], v[3] + rr[ch][3]};
+            }
+            if (a.out_shuffle == 2) {
+              // F.pixel_shuffle(out, 2) written directly (eavsrp_model.py:343-347): channel co = 4 c' + 2 i + j goes to
+              // out'[c'][2 y + i][2 x + j].  This lane's pair (co0, co0 + 1) is (i = rp, j = 0 / 1) of one c', its four
+              // pixels x .. x + 3 become the eight adjacent floats 2 x .. 2 x + 7 of row 2 y + rp: two float4 stores.
+              if (co0 + 1 < a.cout && pok) {
+                float* o = a.out + ((size_t)bn * (a.cout >> 2) + (co0 >> 2)) * (4 * plane) + (size_t)(2 * gy + rp) * (2 * w) + 2 * gx;
+                *reinterpret_cast<f32x4*>(o) = f32x4{vv[0][0], vv[1][0], vv[0][1], vv[1][1]};
+                *reinterpret_cast<f32x4*>(o + 4) = f32x4{vv[0][2], vv[1][2], vv[0][3], vv[1][3]};
+              }
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < 2; ++ch) {
+                const int r = 2 * rp + ch, co = co0 + ch;
+                if (co < a.cout && pok) {
+                  csum[r] += (vv[ch][0] + vv[ch][1]) + (vv[ch][2] + vv[ch][3]);
+                  *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
+                      f32x4{vv[ch][0] + rr[ch][0], vv[ch][1] + rr[ch][1], vv[ch][2] + rr[ch][2], vv[ch][3] + rr[ch][3]};
+                }
               }
             }
           }
@@ -733,6 +750,11 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   a.tiles_x = eavsr::cdiv(d->w, C::TOW);
   a.tiles_y = eavsr::cdiv(d->h, C::TOH);
   a.act = d->act; a.slope = d->slope;
+  a.out_shuffle = d->out_shuffle;
+  EAVSR_REQUIRE(d->out_shuffle == 0 || d->out_shuffle == 2, -1, "conv_wino6: out_shuffle %d (0 or 2)", d->out_shuffle);
+  if (d->out_shuffle == 2)
+    EAVSR_REQUIRE(R == 3 && d->cout % 4 == 0 && d->residual == nullptr && d->chan_partial == nullptr, -2,
+                  "conv_wino6: the pixel-shuffle epilogue needs the 3x3 kernel, cout %% 4 == 0, no residual, no channel sums");
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv_wino6: too many tiles");
   EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv_wino6: image plane too large for 32-bit tile offsets");

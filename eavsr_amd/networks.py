@@ -41,12 +41,12 @@ class Conv2d(nn.Conv2d):
     Dense stride-1 "same" convolutions only; `act` fuses the activation that follows it in the
     reference's nn.Sequential."""
 
-    def forward(self, x: TensorOrList, act=None, slope=0.0, residual=None, chan_partial=False):
+    def forward(self, x: TensorOrList, act=None, slope=0.0, residual=None, chan_partial=False, pixel_shuffle2=False):
         if self.groups != 1 or self.stride != (1, 1) or self.dilation != (1, 1) or \
                 self.padding != (self.kernel_size[0] // 2,) * 2 or self.padding_mode != "zeros":
             raise NotImplementedError("eavsr_amd Conv2d: dense stride-1 same-padding convolutions only")
         return AG.conv2d(x, self.weight, self.bias, act=act, slope=slope, residual=residual,
-                         chan_partial=chan_partial)
+                         chan_partial=chan_partial, pixel_shuffle2=pixel_shuffle2)
 
 
 class _Act(nn.Module):

@@ -317,12 +317,18 @@ def ca_fusable(x: Tensor, cout: int = 64) -> bool:
             and lib().eavsr_conv2d_tile_rows(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), 3) == 32)
 
 
+# EAVSR_FUSE_SHUFFLE=0: the upsampling tail's PixelShuffle(2) as a torch copy instead of the conv kernel's store pattern (A/B switch)
+FUSE_PIXEL_SHUFFLE = os.environ.get("EAVSR_FUSE_SHUFFLE", "1") == "1"
+
+
 def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence[Tensor]],
            bias: Union[None, Tensor, Sequence[Optional[Tensor]]] = None, act: Optional[str] = None,
            slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False,
-           ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False):
+           ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False, pixel_shuffle2: bool = False):
     """conv over the virtual channel-concatenation of `srcs`; `weight` may be a list of weights
     that are concatenated along cout (several heads in one launch).
+    pixel_shuffle2=True returns F.pixel_shuffle(out, 2) -- written by the F(4x4,3x3) kernel's epilogue itself where that kernel
+    runs (the upsampling tail, eavsrp_model.py:343-347), by torch otherwise.
     ca=(scale (n,c), x (n,c,h,w)): the conv input is srcs * scale[n,c] + x (RCABlock tail fused into this
     conv); with ca_out=True that effective input is also returned.
     Returns out, then the per-tile channel sums when chan_partial=True, then the effective input when
@@ -343,8 +349,11 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     k = int(weights[0].shape[-1])
     if any(int(x.shape[1]) != cin for x in weights):
         raise ValueError(f"weight expects {[int(x.shape[1]) for x in weights]} input channels, sources give {cin}")
+    if pixel_shuffle2 and (cout % 4 or residual is not None or chan_partial or ca is not None):
+        raise ValueError("pixel_shuffle2: cout % 4 == 0, no residual / channel sums / channel-attention prologue")
     if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None:
-        return _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
+        y = _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
+        return torch.nn.functional.pixel_shuffle(y, 2) if pixel_shuffle2 else y
     ck = lib().eavsr_conv2d_ck(k)
     if any(int(s.shape[1]) % ck for s in srcs[:-1]):
         srcs = [torch.cat(srcs, 1)]  # ragged middle source: materialise (tiny SPyNet inputs only)
@@ -360,6 +369,8 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     use_wino4 = (use_wino and CONV_MODE == "winograd4" and out.data_ptr() % 16 == 0
                  and (residual is None or residual.data_ptr() % 16 == 0)
                  and 2 * n * lib().eavsr_conv3x3_wino4_tiles(h, w) >= WINO_MIN_TILES)
+    if pixel_shuffle2 and not (use_wino4 and FUSE_PIXEL_SHUFFLE):      # every other kernel: plain output, shuffled by torch
+        return torch.nn.functional.pixel_shuffle(conv2d(srcs, weights, biases, act=act, slope=slope), 2)
     # 5x5 (the predictor's offset / mask heads) by F(2x2, 5x5): the same 6 x 6 tile pipeline, 4 x 32-pixel tiles
     use_wino5 = (CONV_MODE == "winograd4" and k == 5 and ca is None and w % 4 == 0 and out.data_ptr() % 8 == 0
                  and all(int(s_.shape[1]) % 4 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs)
@@ -388,6 +399,9 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.act = ACT[act]
     d.slope = float(slope)
+    if pixel_shuffle2 and use_wino4:
+        d.out_shuffle = 2
+        out = out.view(n, cout // 4, 2 * h, 2 * w)      # the same buffer, written in the shuffled layout
     xs = None
     if ca is not None:
         scale, cx = _chk(ca[0], "ca scale"), _chk(ca[1], "ca x")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 16
+#define EAVSR_ABI_VERSION 17
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -188,6 +188,10 @@ typedef struct eavsr_conv2d_desc {
   const float* ca_scale; /* (n, cin) */
   const float* ca_x;     /* (n, cin, h, w) */
   float* ca_out;         /* (n, cin, h, w) or NULL */
+  /* 0: out is (n, cout, h, w).  2: out is F.pixel_shuffle(conv, 2) = (n, cout/4, 2h, 2w) written by the epilogue itself (the
+   * upsampling tail, eavsrp_model.py:343-347: channel 4c+2i+j -> out[c][2y+i][2x+j]); eavsr_conv3x3_wino4_f32 only, cout % 4 == 0,
+   * no residual, no channel sums -- every other entry point returns -2 for a non-zero value. */
+  int32_t out_shuffle;
 } eavsr_conv2d_desc;
 
 int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);

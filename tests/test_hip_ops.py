@@ -434,6 +434,32 @@ def test_conv3x3_winograd4_vs_torch_cpu(conv_wino4, cuda, case):
     assert H.maxabs(out.cpu(), ref) <= 6e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(64, 256, "lrelu", 4, 100, 128, True), (64, 256, None, 2, 180, 320, True), (64, 40, "relu", 3, 97, 132, True),
+                                  (16, 8, "lrelu", 1, 9, 12, False)],
+                         ids=lambda c: f"c{c[0]}_o{c[1]}_{c[3]}x{c[4]}x{c[5]}")
+def test_conv3x3_pixel_shuffle_epilogue(conv_wino4, cuda, case):
+    """the upsampling tail (eavsrp_model.py:343-347: conv -> PixelShuffle(2) -> LeakyReLU): `pixel_shuffle2=True` makes the
+    F(4x4,3x3) kernel store F.pixel_shuffle(out, 2) itself -- bit-identical to shuffling the plain output, and equal to the torch
+    CPU reference; shapes the kernel does not take fall back to torch's shuffle"""
+    cin, cout, act, n, h, w, fused = case
+    x = cases.randn(30, n, cin, h, w)
+    wt = cases.randn(31, cout, cin, 3, 3, scale=1.0 / (cin * 9) ** 0.5)
+    b = cases.randn(32, cout, scale=0.1)
+    ref = F.conv2d(x, wt, b, 1, 1)
+    ref = F.relu(ref) if act == "relu" else (F.leaky_relu(ref, 0.1) if act == "lrelu" else ref)
+    ref = F.pixel_shuffle(ref, 2)
+    xg, wg, bg = g(x, cuda), g(wt, cuda), g(b, cuda)
+    with conv_wino4.profile() as prof:
+        out = conv_wino4.conv2d(xg, wg, bg, act=act, slope=0.1, pixel_shuffle2=True)
+    assert (list(prof.summary()) == [f"conv3x3_{cin}to{cout}_wino4"]) == fused
+    plain = conv_wino4.conv2d(xg, wg, bg, act=act, slope=0.1)
+    assert tuple(out.shape) == (n, cout // 4, 2 * h, 2 * w)
+    assert torch.equal(out, F.pixel_shuffle(plain, 2))
+    assert H.maxabs(out.cpu(), ref) <= 6e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(ValueError):
+        conv_wino4.conv2d(xg, wg, bg, residual=plain, pixel_shuffle2=True)
+
+
 @pytest.mark.parametrize("case", [([64], [32, 16, 72], None, False, False, 4, 180, 320), ([64], [64], "lrelu", True, True, 5, 133, 156),
                                   ([4, 12], [7], "relu", False, False, 16, 61, 132), ([64, 64], [130], None, False, True, 6, 90, 160)],
                          ids=lambda c: f"c{'+'.join(map(str, c[0]))}_o{'+'.join(map(str, c[1]))}_{c[5]}x{c[6]}x{c[7]}")
