@@ -26,6 +26,15 @@
 //   16 lanes), optional per-tile channel sums (deterministic).
 #include "common.h"
 
+// -DEAVSR_W4_REG_WEIGHTS: the weight operands straight from global memory into registers (buffer loads, re-requested for the
+// next chunk right after the MFMAs that consumed them) instead of the slab through LDS-DMA + ds_read_b64.  Bit-identical; 5 %
+// faster back to back on hot weights (47.6 -> 45.2 us), 5.5 % SLOWER in the step (262.6 -> 277.2 ms on one box), where every
+// launch meets its 590 KB of weights cold and each is requested by two waves per CU instead of once: off by default
+// (tools/build_wino4_diag.sh builds both).
+#ifdef EAVSR_W4_REG_WEIGHTS
+#define EAVSR_W4_UREGS 1
+#endif
+
 #include <mutex>
 
 namespace {
@@ -373,7 +382,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
   issue_patch(0);
   const float sc_first = sc_next;
+#ifdef EAVSR_W4_UREGS
+  // The weight operands never touch LDS: lane (kq, l15) of the waves of channel block cb reads its float2 of position pair i
+  // straight from the packed slab (the same bytes the LDS-DMA path moves: 36 of its 48 one-KiB pieces per iteration), keeps the
+  // chunk's 18 pairs in 36 registers and re-requests pair i for the NEXT chunk right after the two MFMAs that consumed it, so
+  // every request has a whole iteration to land.
+  // Buffer loads: resource = this launch's packed weights, voffset = the lane's byte offset inside a slab (+ the pair's
+  // immediate), soffset = the slab's byte offset in a scalar register -- one instruction per request, no address arithmetic.
+  const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wu_base), 0, (int)((size_t)(a.cin / CK) * U_ELEMS * sizeof(float)), 0x00020000);
+  const int lane_uoff = (kq * 128 + 2 * ((cb * 16 + l15) ^ ((kq & 1) << 4))) * 4;
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  auto load_u = [&](int soff, int i) __attribute__((always_inline)) {
+    // the pair's offset goes into the SCALAR offset: a per-pair vector offset costs a register (or an add) per request
+    const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(u_rsrc, lane_uoff, soff + i * (CK * 128 * 4), 0);
+    return __builtin_bit_cast(f32x2, t);      // (bit-casting t.x / t.y one by one is narrowed to a single dword load by this compiler)
+  };
+  f32x2 ur[NPOS / 2];
+#pragma unroll
+  for (int i = 0; i < NPOS / 2; ++i) ur[i] = load_u(0, i);
+#else
   issue_u(0, 0);
+#endif
   if (total_iters > 1) issue_patch(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -383,7 +413,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   W4_STAMP(0);      // prologue: first DMA round trip, first transform
   for (int it = 0; it < total_iters; ++it) {
     // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of iteration it-1
+#ifdef EAVSR_W4_UREGS
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) as an instruction the wait-count pass sees: the operand registers requested
+                                          // during the last GEMM are known-complete, no conservative waits inside this iteration
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     W4_STAMP(1);    // waiting for this wave's DMA
     __syncthreads();
     W4_STAMP(2);    // waiting at the barrier
@@ -391,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     const bool on_duty = (wave >> 1) == (it & 3);
     auto issue_dma = [&]() __attribute__((always_inline)) {
 #ifndef EAVSR_WINO_EXP_NODMA
-#ifndef EAVSR_WINO_EXP_NOUDMA
+#if !defined(EAVSR_WINO_EXP_NOUDMA) && !defined(EAVSR_W4_UREGS)
       if (it + 1 < total_iters) issue_u(chunk_n, (it + 1) & 1);
 #endif
       if (it + 2 < total_iters) issue_patch(it & 1);
@@ -404,11 +439,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
     // the pair on duty transforms the next chunk before its GEMM steps
     W4_STAMP(3);    // DMA issue (waves 0-3)
-    if (on_duty && it + 1 < total_iters) {
-      int t_bn = bn, t_y0 = y0, t_x0 = x0, t_lin = 0;
-      if (FUSE && chunk_n == 0) tile_coords((it + 1) / total_chunks, t_bn, t_y0, t_x0, t_lin);   // first chunk of the next tile
-      transform((it + 1) & 1, (it + 1) & 1, t_bn, t_y0, t_x0, chunk_n);
-    }
+    auto duty_transform = [&]() __attribute__((always_inline)) {
+      if (on_duty && it + 1 < total_iters) {
+        int t_bn = bn, t_y0 = y0, t_x0 = x0, t_lin = 0;
+        if (FUSE && chunk_n == 0) tile_coords((it + 1) / total_chunks, t_bn, t_y0, t_x0, t_lin);   // first chunk of the next tile
+        transform((it + 1) & 1, (it + 1) & 1, t_bn, t_y0, t_x0, chunk_n);
+      }
+    };
+#ifndef EAVSR_W4_UREGS
+    duty_transform();
+#endif
     // ---- the 36 GEMM steps of this wave: M_xi[co, t] += sum over the chunk's 4 channels U_xi[co, c] V_xi[c, t]
     // U and V hold the positions in PAIRS ([xi / 2][c][column][xi & 1], column ^ 16 (c & 1)): one ds_read_b64 per operand
     // and two positions - ds_read_b64 moves 256 B/clk against 128 for ds_read_b32 (whose 32 banks would also put the two
@@ -421,9 +461,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
     constexpr int AHEAD = EAVSR_W4_AHEAD, NSTEP = NPOS / 2;
     f32x2 av[AHEAD + 1], bv[AHEAD + 1];
+#ifdef EAVSR_W4_UREGS
+    // the last iteration re-requests its own chunk (unconditional requests: a branch per step would cut the GEMM into 18 blocks)
+    const int u_next = (it + 1 < total_iters ? chunk_n : chunk) * (U_ELEMS * 4);
+    (void)ua; (void)av;
+#endif
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i) {
-#ifdef EAVSR_WINO_EXP_UREGS
+#if defined(EAVSR_W4_UREGS)
+      // operands in registers
+#elif defined(EAVSR_WINO_EXP_UREGS)
       av[i] = f32x2{bias_r[0] + (float)i, bias_r[1]};
 #else
       av[i] = *reinterpret_cast<const f32x2*>(ua + i * (CK * 128));
@@ -457,7 +504,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       }
 #endif
       if (i + AHEAD < NSTEP) {
-#ifdef EAVSR_WINO_EXP_UREGS
+#if defined(EAVSR_W4_UREGS)
+        // operands in registers
+#elif defined(EAVSR_WINO_EXP_UREGS)
         av[(i + AHEAD) % (AHEAD + 1)] = f32x2{bias_r[(i + AHEAD) & 3], bias_r[i & 3]};
 #else
         av[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(ua + (i + AHEAD) * (CK * 128));
@@ -465,6 +514,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
         bv[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(vb + (i + AHEAD) * (CK * 64));
       }
       const int cur = i % (AHEAD + 1);
+#ifdef EAVSR_W4_UREGS
+      acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[i].x, bv[cur].x, acc[2 * i], 0, 0, 0);
+      acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[i].y, bv[cur].y, acc[2 * i + 1], 0, 0, 0);
+      ur[i] = load_u(u_next, i);   // for the next chunk
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the LDS read of step i + AHEAD
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // the 2 MFMAs of step i
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // the operand request that reuses their registers
+    }
+#else
       acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur].x, bv[cur].x, acc[2 * i], 0, 0, 0);
       acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur].y, bv[cur].y, acc[2 * i + 1], 0, 0, 0);
 #ifdef EAVSR_WINO_EXP_UREGS
@@ -474,9 +532,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // the 2 MFMAs of step i
     }
+#endif   // EAVSR_W4_UREGS
 #else
     if (dma_late) issue_dma();
     acc[0][0] += av[0].x + bv[0].x;
+#endif
+#ifdef EAVSR_W4_UREGS
+    // the pair on duty transforms the next chunk AFTER its GEMM steps: its last operand requests land under the transform
+    __builtin_amdgcn_sched_barrier(0);
+    duty_transform();
 #endif
     if (FUSE) sc_use = sc_next;   // loaded by this iteration's issue_patch (chunk it + 2) for the transform of it + 1
     chunk = chunk_n;

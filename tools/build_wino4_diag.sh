@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -ffp-contract=fast -Iinclude -Ieavsr_amd/csrc -shared"
 rm -f eavsr_amd/lib/libwino4_*.so
-for v in base:"" spread:-DEAVSR_W4_SPREAD noprio:-DEAVSR_NO_WAVE_PRIO stamps:-DEAVSR_W4_STAMPS nodma:-DEAVSR_WINO_EXP_NODMA notransform:-DEAVSR_WINO_EXP_NOTRANSFORM nomfma:-DEAVSR_WINO_EXP_NOMFMA nostore:-DEAVSR_WINO_EXP_NOSTORE \
+for v in base:"" uregs:-DEAVSR_W4_REG_WEIGHTS spread:-DEAVSR_W4_SPREAD noprio:-DEAVSR_NO_WAVE_PRIO stamps:-DEAVSR_W4_STAMPS nodma:-DEAVSR_WINO_EXP_NODMA notransform:-DEAVSR_WINO_EXP_NOTRANSFORM nomfma:-DEAVSR_WINO_EXP_NOMFMA nostore:-DEAVSR_WINO_EXP_NOSTORE \
          nodma_notransform:"-DEAVSR_WINO_EXP_NODMA -DEAVSR_WINO_EXP_NOTRANSFORM" noudma:-DEAVSR_WINO_EXP_NOUDMA noudma_uregs:"-DEAVSR_WINO_EXP_NOUDMA -DEAVSR_WINO_EXP_UREGS" $EXTRA_VARIANTS; do
   name=${v%%:*}; flags=${v#*:}
   /opt/rocm/bin/hipcc $F $flags eavsr_amd/csrc/conv_wino6.hip eavsr_amd/csrc/capi.hip -o eavsr_amd/lib/libwino4_$name.so 2>/dev/null &

@@ -35,7 +35,12 @@ for path in sorted(glob.glob(os.path.join(ROOT, "eavsr_amd", "lib", "libwino4_*.
         call()
     e1.record()
     torch.cuda.synchronize()
-    print(f"{os.path.basename(path):32s} {e0.elapsed_time(e1) / 20 * 1000:8.1f} us")
+    note = ""
+    if "base" in path:
+        ref_out = out.clone()
+    elif "uregs" in path and "ref_out" in globals():
+        note = f"   max |out - base| = {(out - ref_out).abs().max().item():.3e}"
+    print(f"{os.path.basename(path):32s} {e0.elapsed_time(e1) / 20 * 1000:8.1f} us{note}")
     if "stamps" in path:
         buf = (C.c_ulonglong * 32)()
         lib.eavsr_debug_w4_stamps(buf, 1)
