@@ -180,6 +180,35 @@ def test_end_to_end_golden(nets, cuda, tag, preset):
     assert O.psnr_255(y.cpu(), y.cpu()) == float("inf")
 
 
+@pytest.mark.parametrize("tag", ["x4", "x2"])
+def test_encoder_and_upsampling_tail_vs_oracle(nets, cuda, tag):
+    """SURVEY 8f rows f1 / f2 on their own (they were covered only through the end-to-end goldens): the VGG-style encoder
+    (networks.py:549-552) and `EAVSRP.upsample` (eavsrp_model.py:331-364 / eavsrpx2_model.py:334-365: reconstruction backbone on the
+    5-branch virtual concatenation, conv -> PixelShuffle(2) -> LeakyReLU stages, conv_hr, conv_last + bilinear skip) against the CPU
+    oracle, at a size where the Winograd kernels and the conv kernel's own pixel-shuffle store pattern engage (2 x 3 x 96 x 128)."""
+    from eavsr_amd import ops
+    net, sd = _model(nets, cuda, tag, "trained_like")
+    scale = 4 if tag == "x4" else 2
+    n, t, h, w = 2, 3, 96, 128
+    lqs = cases.rand(41, n, t, 3, h, w)
+    # encoder
+    x = lqs.transpose(0, 1).reshape(t * n, 3, h, w)
+    with torch.no_grad():
+        f = net.encoder(x.to(cuda)).cpu()
+    ref_f = O.encoder(sd, "encoder.", x)
+    assert H.maxabs(f, ref_f) <= 1e-4 * max(1.0, ref_f.abs().max().item())
+    # tail: seeded branch features, frame lists as the propagation leaves them
+    names = ["spatial", "backward_1", "forward_1", "backward_2", "forward_2"]
+    feats = {k: [cases.randn(50 + 7 * j + i, n, 64, h, w, scale=0.5) for i in range(t)] for j, k in enumerate(names)}
+    with torch.no_grad(), ops.profile() as prof:
+        y = net.upsample(lqs.to(cuda), {k: [v.to(cuda) for v in vs] for k, vs in feats.items()}).cpu()
+    ran = set(prof.summary())
+    ref = O.upsample(sd, lqs, feats, scale)
+    assert tuple(y.shape) == (n, t, 3, scale * h, scale * w) == tuple(ref.shape)
+    assert "conv3x3_64to256_wino4" in ran and "conv3x3_320to64_wino4" in ran, ran
+    assert H.maxabs(y, ref) <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_batch_of_clips_equals_single_clips(nets, cuda):
     """clips are independent units: a batch must equal its clips run one by one."""
     net, _ = _model(nets, cuda, "x4", "trained_like")
