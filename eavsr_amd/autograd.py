@@ -364,8 +364,9 @@ class _AddFn(Function):
         return d, d, (d if ctx.needs_input_grad[2] else None)
 
 
-def add(a, b, c=None):
-    return _AddFn.apply(a, b, c) if _needs_grad(a, b, c) else ops.add(a, b, c)
+def add(a, b, c=None, out=None):
+    """`out` (inference only): write into an existing tensor; ignored when a gradient is needed"""
+    return _AddFn.apply(a, b, c) if _needs_grad(a, b, c) else ops.add(a, b, c, out=out)
 
 
 # ------------------------------------------------------------------------------------------ RCAB tail

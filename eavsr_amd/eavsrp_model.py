@@ -37,6 +37,19 @@ def flow_warp(x, flow, interpolation="bilinear", padding_mode="zeros", align_cor
 
 # ---------------------------------------------------------------------------------------------
 # residual backbone (eavsrp_model.py:366-400)
+class _FrameList(list):
+    """a list of per-frame tensors (n, c, h, w) that may know the frame-major tensor (t*n, c, h, w) its items are views of"""
+
+    def __init__(self, items, stacked=None):
+        super().__init__(items)
+        self.stacked = stacked
+
+
+def _frame_major(frames) -> Tensor:
+    st = getattr(frames, "stacked", None)
+    return st if st is not None else torch.cat(list(frames), 0)
+
+
 # ---------------------------------------------------------------------------------------------
 class ResidualBlocksWithInputConv(nn.Module):
     """conv3x3(in -> out) + LeakyReLU(0.1) -> RCAGroup(nb=num_blocks).  `feat` may be a tensor or a
@@ -214,7 +227,7 @@ class EAVSRP(nn.Module):
         f1 = self.encoder(lr_tm)                                   # :216
         f2, f4 = AG.pyramid(f1)                                    # :218-220
         feats: Dict[str, List[Tensor]] = {
-            "spatial": [f1[i * n:(i + 1) * n] for i in range(t)],
+            "spatial": _FrameList([f1[i * n:(i + 1) * n] for i in range(t)], f1),
             "spatial_d2": [f2[i * n:(i + 1) * n] for i in range(t)],
             "spatial_d4": [f4[i * n:(i + 1) * n] for i in range(t)],
         }
@@ -241,6 +254,11 @@ class EAVSRP(nn.Module):
         align, fusion, backbone = self.deform_align[module_name], self.fusion[module_name], self.backbone[module_name]
         feat_prop = flows.new_zeros(n, self.n_feats, h, w)
         zeros = None
+        # inference: the branch's features go straight into one frame-major buffer (frame idx -> rows idx*n ..), which is what the
+        # tail consumes -- the list below holds views of it and `upsample` needs no torch.cat (5 x 0.4 GB per 2-clip forward)
+        stacked = None
+        if not AG.needs_grad(flows, feats["spatial"][0], list(backbone.parameters())):
+            stacked = flows.new_empty(len(feats["spatial"]) * n, self.n_feats, h, w)
         for i, idx in enumerate(frame_idx):
             cur = [feats[k][mapping_idx[idx]] for k in _PYR]
             if i > 0:
@@ -260,17 +278,18 @@ class EAVSRP(nn.Module):
                 feat_prop = fusion([cond_n1, cur[0], cond_n2])                          # :313-314
             others = [feats[k][idx] for k in feats if k not in _PYR and k != module_name]
             res = backbone([cur[0]] + others + [feat_prop])                             # :317-323
-            feat_prop = AG.add(feat_prop, res)
+            feat_prop = AG.add(feat_prop, res, out=None if stacked is None else stacked[idx * n:(idx + 1) * n])
             feats[module_name].append(feat_prop)
         if backward:
             feats[module_name] = feats[module_name][::-1]
+        feats[module_name] = _FrameList(feats[module_name], stacked)
         return feats
 
     def upsample(self, lqs, feats):
         """eavsrp_model.py:331-364, all t frames as one batch."""
         n, t = lqs.shape[:2]
         branches = [k for k in feats if k not in _PYR]
-        srcs = [torch.cat(feats["spatial"], 0)] + [torch.cat(feats[k], 0) for k in branches]   # frame-major
+        srcs = [_frame_major(feats["spatial"])] + [_frame_major(feats[k]) for k in branches]
         hr = self.reconstruction(srcs)
         # conv -> PixelShuffle(2) -> LeakyReLU (:343-347): the activation commutes with the shuffle and the shuffle is the conv
         # kernel's own store pattern (the torch copy was 0.8 / 3.3 GB per 2-clip forward)

@@ -380,6 +380,21 @@ def set_backbone_dtype(dtype):
     BACKBONE_DTYPE = dtype
 
 
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def backbone_dtype(dtype):
+    """`with networks.backbone_dtype("bf16"): y = net(x)` -- the 16-bit modes for the body only; the previous setting is
+    restored on exit."""
+    prev = BACKBONE_DTYPE
+    set_backbone_dtype(dtype)
+    try:
+        yield
+    finally:
+        set_backbone_dtype(prev)
+
+
 class RCAGroup(nn.Module):
     def __init__(self, in_channels=64, out_channels=64, kernel_size=3, stride=1, padding=1, bias=True,
                  mode="CRC", reduction=16, nb=12):

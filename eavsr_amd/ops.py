@@ -7,6 +7,7 @@ fp32 CUDA(HIP) tensors; there is no CPU path.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import weakref
@@ -740,6 +741,27 @@ def set_conv_mode(mode: str) -> None:
     CONV_MODE = _norm_conv_mode(mode)
 
 
+@contextlib.contextmanager
+def modes(conv: Optional[str] = None, dcn: Optional[str] = None, dcn_il_impl: Optional[str] = None):
+    """Scoped kernel selection: `with ops.modes(conv="direct", dcn="native"): ...` switches the process-wide defaults for the
+    body and restores them on exit (also on an exception), so that a caller -- a test, an A/B measurement -- never leaves another
+    mode behind.  The switches select between implementations of the same arithmetic; they are process-wide (one forward runs one
+    kernel set), not per call."""
+    prev = (CONV_MODE, DCN_MODE, DCN_IL_IMPL)
+    try:
+        if conv is not None:
+            set_conv_mode(conv)
+        if dcn is not None:
+            set_dcn_mode(dcn)
+        if dcn_il_impl is not None:
+            set_dcn_il_impl(dcn_il_impl)
+        yield
+    finally:
+        set_conv_mode(prev[0])
+        set_dcn_mode(prev[1])
+        set_dcn_il_impl(prev[2])
+
+
 _wino_pack_cache = {}
 
 
@@ -863,13 +885,18 @@ def pyramid(x: Tensor) -> Tuple[Tensor, Tensor]:
     return d2, d4
 
 
-def add(a: Tensor, b: Tensor, c: Optional[Tensor] = None) -> Tensor:
+def add(a: Tensor, b: Tensor, c: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """a + b (+ c); `out`: an existing contiguous fp32 tensor of the same shape to write into (e.g. one frame's slice of a
+    frame-major buffer) instead of a new one"""
     a, b = _chk(a, "a"), _chk(b, "b")
     if a.shape != b.shape or (c is not None and c.shape != a.shape):
         raise ValueError("add: shape mismatch")
     if c is not None:
         c = _chk(c, "c")
-    out = torch.empty_like(a)
+    if out is None:
+        out = torch.empty_like(a)
+    elif out.shape != a.shape or out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous():
+        raise ValueError("add: `out` must be a contiguous fp32 GPU tensor of the operands' shape")
     st = _stream(a)
     _launch("add", float(a.numel()), 4.0 * a.numel() * (3 if c is None else 4), a,
             lambda: lib().eavsr_add_f32(_p(a), _p(b), _p(c), _p(out), a.numel(), st), "add")

@@ -207,3 +207,26 @@ def test_learning_rate_schedulers_follow_the_reference_policies():
     opt.lr_policy = "nope"
     with pytest.raises(NotImplementedError):
         get_scheduler(mk(), opt)
+
+
+def test_scoped_mode_switches_restore_the_previous_modes():
+    """`ops.modes(...)` / `networks.backbone_dtype(...)`: scoped kernel selection that never leaks (also on an exception)."""
+    from eavsr_amd import networks as Nw, ops
+    before = (ops.CONV_MODE, ops.DCN_MODE, ops.DCN_IL_IMPL, Nw.BACKBONE_DTYPE)
+    with ops.modes(conv="direct", dcn="native", dcn_il_impl="ws"):
+        assert (ops.CONV_MODE, ops.DCN_MODE, ops.DCN_IL_IMPL) == ("direct", "native", "ws")
+        with ops.modes(dcn="il9"):
+            assert (ops.CONV_MODE, ops.DCN_MODE) == ("direct", "il9")
+        assert ops.DCN_MODE == "native"
+    assert (ops.CONV_MODE, ops.DCN_MODE, ops.DCN_IL_IMPL) == before[:3]
+    with pytest.raises(ValueError):
+        with ops.modes(conv="winograd"):
+            raise ValueError("boom")
+    assert ops.CONV_MODE == before[0]
+    with pytest.raises(ValueError):
+        with ops.modes(dcn="no-such-mode"):
+            pass
+    assert (ops.CONV_MODE, ops.DCN_MODE) == before[:2]
+    with Nw.backbone_dtype("bf16"):
+        assert Nw.BACKBONE_DTYPE == "bf16"
+    assert Nw.BACKBONE_DTYPE == before[3]

@@ -43,7 +43,7 @@ for name, scale, (n, t, h, w), mode in [("configs[2] x2 8x7x256x256", 2, (8, 7, 
             y = net(clips); torch.cuda.synchronize()
             t0 = time.perf_counter(); y = net(clips); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"{name} fp32, conv {cm} / dcn {dm}: {dt*1e3:.0f} ms -> {n*t/dt:.1f} frames/s, max abs vs default {float((y-res[None]).abs().max()):.2e}", flush=True)
-    ops.set_conv_mode("winograd4"); ops.set_dcn_mode("native")
+    ops.set_conv_mode("winograd4"); ops.set_dcn_mode("il6")
     Nw.set_backbone_dtype(None)
     del net, clips, res, y
     torch.cuda.empty_cache()
