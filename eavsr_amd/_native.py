@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -85,6 +85,7 @@ SIGNATURES = {
     "eavsr_conv3x3_smallco_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_ca_scale_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_scale_residual_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "eavsr_ca_tail_f32": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_adapt_frontend_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_flow_level_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, vp]),
     "eavsr_affine_offsets_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -340,6 +340,8 @@ class RCABlock(nn.Module):
             r = _run_fused(self.res, x)
             return AG.rcab_tail(r, x, a.weight, a.bias, b.weight, b.bias)
         r, partial = _run_fused(self.res, x, chan_partial=True)     # conv-ReLU-conv, + channel sums
+        if FUSE_CA_TAIL:
+            return ops.ca_tail(r, partial, a.weight, a.bias, b.weight, b.bias, x)      # CALayer + res * y + x in one launch
         scale = self.ca.scale_from_partial(partial, x.shape[2] * x.shape[3])
         return ops.scale_residual(r, scale, x)                      # res * y + x  (:463-464)
 
@@ -349,6 +351,12 @@ class RCABlock(nn.Module):
 # F(4x4,3x3) kernel: the fused conv costs +21 us (two input patches, the scale FMA on the transform's critical path, the
 # side output) against the 27 us scale_residual launch it removes - 314 ms vs 311 ms per step - so it is off by default.
 import os as _os
+# The RCAB tail (mean -> MLP -> sigmoid -> res * y + x, networks.py:444-447,463-464) as ONE launch (eavsr_ca_tail_f32) instead of
+# ca_scale + scale_residual: EAVSR_FUSE_CA_TAIL=1.  OFF by default: bit-identical and 3 ms less kernel time per 2-clip forward
+# (18.1 against 14.7 + 6.2 ms), but the two-stream step gets SLOWER, 261.4 -> 273.8 ms (A/B on one box): its 256 workgroups of 1024
+# threads fill every CU for ~20 us and push the other stream's convolution workgroups out, where scale_residual's small
+# workgroups run beside them and ca_scale's two workgroups leave the GPU to the other stream.
+FUSE_CA_TAIL = _os.environ.get("EAVSR_FUSE_CA_TAIL", "0") == "1"
 FUSE_CA_INTO_CONV = _os.environ.get("EAVSR_FUSE_CA", "0") == "1"
 # One kernel per pyramid level of the residual-flow refinement (eavsr_flow_level_f32: front end + 64 -> 6 heads + affine +
 # 18 -> 2 conv, only the two inputs and the 2-channel flow touch HBM) instead of four launches.  Correct (goldens G2 / G5,

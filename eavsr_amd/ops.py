@@ -920,6 +920,29 @@ def ca_scale(partial: Tensor, hw: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: T
     return scale
 
 
+def ca_tail(r: Tensor, partial: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, x: Tensor) -> Tensor:
+    """the RCAB tail in one launch: r * sigmoid(W2 relu(W1 mean_hw(r) + b1) + b2) + x with mean_hw(r) from the conv's per-tile
+    channel sums `partial` (n, tiles, c); falls back to ca_scale + scale_residual where the fused kernel's alignment rules fail"""
+    r, x, partial = _chk(r, "r"), _chk(x, "x"), _chk(partial, "partial")
+    n, c, h, w = r.shape
+    if x.shape != r.shape or partial.shape[0] != n or partial.shape[2] != c:
+        raise ValueError("ca_tail: shape mismatch")
+    hw = h * w
+    # every workgroup of the fused kernel re-reduces its sample's per-tile sums: pays while a sample is <= ~256 workgroups
+    # (128 float4 columns x c channels each); larger planes keep the two launches
+    if hw % 4 or (r.data_ptr() | x.data_ptr()) % 16 or c > 256 or hw // 4 > 256 * (8192 // c):
+        return scale_residual(r, ca_scale(partial, hw, w1, b1, w2, b2), x)
+    tiles = int(partial.shape[1])
+    cr = int(w1.shape[0])
+    w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
+    out = torch.empty_like(r)
+    st = _stream(r)
+    _launch("ca_tail", 2.0 * r.numel(), 12.0 * r.numel(), r,
+            lambda: lib().eavsr_ca_tail_f32(_p(r), _p(partial), tiles, _p(w1), _p(b1), _p(w2), _p(b2), _p(x), _p(out), n, c, cr,
+                                            hw, st), "ca_tail")
+    return out
+
+
 def scale_residual(r: Tensor, scale: Tensor, x: Tensor) -> Tensor:
     """r * scale[n,c] + x"""
     r, x, scale = _chk(r, "r"), _chk(x, "x"), _chk(scale, "scale")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 17
+#define EAVSR_ABI_VERSION 18
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -264,6 +264,12 @@ int eavsr_ca_scale_f32(const float* chan_partial, int32_t tiles, int32_t hw,
 /* RCABlock tail (networks.py:447,464): out = r * scale[n,c] + x */
 int eavsr_scale_residual_f32(const float* r, const float* scale, const float* x, float* out,
                              int32_t n, int32_t c, int32_t hw, void* stream);
+/* Both of the above in one launch (networks.py:444-447,463-464): out = r * sigmoid(W2 . relu(W1 . mean_hw(r) + b1) + b2) + x from
+ * the conv's per-tile channel sums; every workgroup finishes the (fixed-order) mean + MLP of its sample itself, then streams its
+ * slice.  hw % 4 == 0, 16-byte aligned r / x / out (otherwise -2: use the two calls above). */
+int eavsr_ca_tail_f32(const float* r, const float* chan_partial, int32_t tiles, const float* w1, const float* b1,
+                      const float* w2, const float* b2, const float* x, float* out, int32_t n, int32_t c, int32_t cr,
+                      int32_t hw, void* stream);
 
 /* ---- a3 / a6 front end ----------------------------------------------------------------------
  * AdaptBlock2_3x3 / AdaptBlockOffset `concat` + `concat2` (models/networks.py:290-291,300 and

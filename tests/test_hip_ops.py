@@ -871,3 +871,31 @@ def test_conv2d_fused_channel_attention_prologue(ops, cuda):
     with pytest.raises(NotImplementedError):
         ops.conv2d(torch.zeros(1, 64, 8, 10, device=cuda), g(wt, cuda), None,
                    ca=(torch.zeros(1, 64, device=cuda), torch.zeros(1, 64, 8, 10, device=cuda)))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 180, 320), (1, 64, 24, 40), (3, 64, 45, 80), (1, 32, 12, 16), (2, 64, 9, 13)])
+def test_ca_tail_one_launch_equals_ca_scale_plus_scale_residual(ops, cuda, shape):
+    """eavsr_ca_tail_f32 (CALayer + `res * y + x`, networks.py:444-447,463-464, in one launch) against the two-launch form
+    bit for bit (same fixed-order reduction, same fma) and against the CPU oracle's ca_layer arithmetic"""
+    n, c, h, w = shape
+    r, x = cases.randn(70, n, c, h, w), cases.randn(71, n, c, h, w)
+    cr = max(c // 16, 1)
+    w1, b1 = cases.randn(72, cr, c, 1, 1, scale=0.2), cases.randn(73, cr, scale=0.1)
+    w2, b2 = cases.randn(74, c, cr, 1, 1, scale=0.5), cases.randn(75, c, scale=0.1)
+    tiles = 7
+    # per-tile channel sums that add up to the true sums (what the conv epilogue hands over)
+    sums = r.sum(dim=(2, 3))
+    frac = torch.softmax(cases.randn(76, n, tiles, c), dim=1)
+    partial = frac * sums.view(n, 1, c)
+    rg, xg, pg = g(r, cuda), g(x, cuda), g(partial, cuda)
+    args = [g(t, cuda) for t in (w1, b1, w2, b2)]
+    with ops.profile() as prof:
+        out = ops.ca_tail(rg, pg, *args, xg)
+    fused = "ca_tail" in prof.summary()
+    assert fused == ((h * w) % 4 == 0)
+    two = ops.scale_residual(rg, ops.ca_scale(pg, h * w, *args), xg)
+    assert torch.equal(out, two)
+    mean = sums / (h * w)
+    y = torch.sigmoid(F.conv2d(F.relu(F.conv2d(mean.view(n, c, 1, 1), w1, b1)), w2, b2))
+    ref = r * y + x
+    assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
