@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
+PEAK_MFMA_16BIT_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA (MI355X_MICROARCH.md); the 16-bit kernels' roofline
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured float4 copy)
 
 
@@ -469,10 +470,11 @@ def main():
                 ach = alg / red
                 # `achieved` / `frac`: FLOP the matrix pipe actually performs per second against its fp32 peak (<= 1 by
                 # construction); the algorithmic-equivalent rate (SURVEY 8d's 2*cin*cout*k*k per pixel) is its own key
-                return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
+                peak = PEAK_MFMA_16BIT_TFLOPS if name.endswith("_h16") else PEAK_MFMA_F32_TFLOPS
+                return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                        "frac": ach / peak, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
                         "share_of_step": v["ms"] / total_ms, "algorithm": how,
-                        "algorithmic_equivalent": {"achieved": alg, "unit": "TFLOP/s", "x_peak": alg / PEAK_MFMA_F32_TFLOPS,
+                        "algorithmic_equivalent": {"achieved": alg, "unit": "TFLOP/s", "x_peak": alg / peak,
                                                    "note": "direct-sum FLOP count / time; exceeds the peak when the algorithm "
                                                            "multiplies less -- not a roofline fraction"}}
             ach = v["bytes"] / v["calls"] / (avg_ms * 1e-3) / 1e9
@@ -486,7 +488,10 @@ def main():
             # which kernels of the step ran in 16 bits (the rest is fp32), with their share of the step's kernel time
             names16 = ("conv3x3_64to64_h16", "scale_residual_h16", "dcnv2_il16_heads", "dcnv2_il16", "nchw_f32_to_nhwc_h16",
                        "nhwc_h16_to_nchw_f32")
+            heads16 = tuple(k for k in summ if k.startswith("conv5x5_") and k.endswith("_h16"))     # the predictor's 5x5 heads
             line["kernels_16bit"] = [e for e in (entry(k, "hbm") for k in names16) if e]
+            line["kernels_16bit"] += [e for e in (entry(k, "mfma") for k in heads16) if e]
+            names16 = names16 + heads16
             if "flow_warp_pair" in summ:
                 e = entry("flow_warp_pair", "hbm")
                 e["note"] = "fp32 in, second output rounded to 16-bit IL8 for dcnv2_il16"
