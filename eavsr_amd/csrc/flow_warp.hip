@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(
   const float* xp = x + ((size_t)bn * c + c0) * plane;
   float* op = out + ((size_t)bn * c + c0) * plane + (size_t)py * w + px;
   const int cend = min(kChanPerThread, c - c0);
-#pragma unroll 4
+  // One channel (4 gathers) in flight per thread: 46 vector registers instead of 62 with four -- slower on its own, but a wave
+  // then fits on a SIMD BESIDE the two 232-register waves of a resident Winograd convolution workgroup of the other stream (512
+  // registers per SIMD lane; above 48 the kernel only runs on convolution-free CUs).  Step 262.1 -> 260.3 ms (A/B, one box).
+#pragma unroll 1
   for (int cc = 0; cc < cend; ++cc) {
     const float* p = xp + (size_t)cc * plane;
     float v = p[i_nw] * w_nw;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256) void flow_warp_pair_kernel(
     return;
   }
   float* op = (second ? outb : outa) + ((size_t)bn * c + c0) * plane + (size_t)py * w + px;
-#pragma unroll 4
+#pragma unroll 1
   for (int cc = 0; cc < cend; ++cc) {
     const float* p = xp + (size_t)cc * plane;
     float v = p[i_nw] * w_nw;
