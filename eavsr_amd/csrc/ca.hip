@@ -68,29 +68,15 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const float* __rest
   const float s = scale[nc];
   const size_t base = (size_t)nc * hw;
   if (VEC) {
-    // four 16-byte pieces per thread and stream, all eight loads in flight before the first use (one piece per thread left
-    // the 2 x 64 x 180 x 320 launch at 8,192 workgroups of one load-use-store each: 3.2 TB/s)
     const int hw4 = hw >> 2;
     const f32x4* r4 = reinterpret_cast<const f32x4*>(r + base);
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x + base);
     f32x4* o4 = reinterpret_cast<f32x4*>(out + base);
-    for (int i0 = blockIdx.x * 1024 + threadIdx.x; i0 < hw4; i0 += gridDim.x * 1024) {
-      f32x4 a[4], b[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = min(i0 + k * 256, hw4 - 1);
-        a[k] = r4[i];
-        b[k] = x4[i];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k * 256;
-        if (i < hw4) {
-          f32x4 o;
-          o[0] = a[k][0] * s + b[k][0]; o[1] = a[k][1] * s + b[k][1]; o[2] = a[k][2] * s + b[k][2]; o[3] = a[k][3] * s + b[k][3];
-          o4[i] = o;
-        }
-      }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw4; i += gridDim.x * 256) {
+      const f32x4 a = r4[i], b = x4[i];
+      f32x4 o;
+      o[0] = a[0] * s + b[0]; o[1] = a[1] * s + b[1]; o[2] = a[2] * s + b[2]; o[3] = a[3] * s + b[3];
+      o4[i] = o;
     }
   } else {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256)
@@ -205,7 +191,7 @@ extern "C" int eavsr_scale_residual_f32(const float* r, const float* scale, cons
   if (n * c == 0) return 0;
   const bool vec = (hw % 4) == 0 && (((uintptr_t)r | (uintptr_t)x | (uintptr_t)out) & 15) == 0;
   const int work = vec ? hw / 4 : hw;
-  int bx = eavsr::cdiv(work, vec ? 1024 : 256);
+  int bx = eavsr::cdiv(work, 256);
   if (bx > 64) bx = 64;
   dim3 grid(bx, n * c);
   if (vec)
