@@ -364,6 +364,7 @@ def main():
     clips = synthetic_clip(n, t, h, w, seed=rank).to(device)   # resident in HBM before the timed region
 
     run = net
+    degraded = None
     if args.streams < 1 or n % args.streams:
         args.streams = 1           # the clips do not split evenly: one eager forward
     if world > torch.cuda.device_count():
@@ -374,6 +375,7 @@ def main():
             run = StreamedForward(net, clips, groups=args.streams)
         except Exception as e:   # a capture problem must not cost the measurement: the same work as one eager forward
             print(f"[bench] rank {rank}: HIP-graph capture failed ({type(e).__name__}: {e}); running --streams 1", file=sys.stderr)
+            degraded = f"HIP-graph capture failed ({type(e).__name__}: {e}); the step ran as ONE eager forward (--streams 1), not as the requested graphs"
             torch.cuda.synchronize()
             args.streams = 1
             run = net
@@ -396,8 +398,20 @@ def main():
         shard.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        # What was timed is what is returned (the reference times the call whose result it keeps, models/eavsrp_model.py:100-107):
+        # the first sub-batch of the LAST timed step against one eager forward of the same clips -- the same kernels in the same
+        # order, so the two must agree bit for bit; anything above 1e-5 fails the run.
+        sub = n // args.streams
+        timed_first = out[:sub].clone()
+        eager_first = net(clips[:sub])
+        torch.cuda.synchronize()
+        timed_vs_eager = float((timed_first - eager_first).abs().max().item())
+        timed_equal = bool(torch.equal(timed_first, eager_first))
+        timed_finite = bool(torch.isfinite(timed_first).all().item())
+        del timed_first, eager_first
     on_dev = world > 1 and torch.distributed.get_backend() == "nccl"
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
+    timed_vs_eager = shard.max_over_ranks(timed_vs_eager, device=device if on_dev else None)
     frames_total = world * n * t * args.steps
     value = frames_total / elapsed
     import statistics
@@ -427,6 +441,9 @@ def main():
                  ("" if args.conv_mode != "bf16x9" and args.dcn_mode != "bf16x9"
                   else " (contractions in bf16x9 mode: exact 3 x bf16 operand split, 9 products, f32 accumulate)"),
         "data": "synthetic",
+        "timed_output_max_abs_vs_eager": timed_vs_eager,
+        "timed_output_check": {"what": f"clips 0..{n // args.streams - 1} of the last timed step vs one eager forward of the same clips after the "
+                                       "timed region (max over ranks)", "bit_identical": timed_equal, "finite": timed_finite, "bound": 1e-5},
         "config": {"workload": f"eavsrp x4 inference, {n} clips/GPU x {t} frames x 3 x {h} x {w} fp32 "
                                f"(BASELINE.json configs[1]), weights: seeded '{args.preset}' init",
                    "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "scale": 4, "sharding": "clips across ranks, no collective",
@@ -532,11 +549,17 @@ def main():
         line["cpu_baseline"] = cpu_baseline(args.preset, t, h, w, args.cpu_crop[0], args.cpu_crop[1], runs=args.cpu_runs,
                                             budget=args.cpu_budget, threads=args.cpu_threads)
 
+    if degraded is not None:
+        line["degraded"] = degraded
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         shard.barrier()
         torch.distributed.destroy_process_group()
+    if not (timed_vs_eager <= 1e-5) or not timed_finite:
+        print(f"[bench] rank {rank}: the timed output differs from the eager forward by {timed_vs_eager:.3e} (bound 1e-5) "
+              f"or is not finite: the measurement is void", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

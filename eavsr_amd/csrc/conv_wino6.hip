@@ -86,7 +86,11 @@ struct WCfg {
   static constexpr int OFF_U = 2 * IN_PAD;                // LDS map: [patch 0][patch 1][U 0][U 1][V 0][V 1][channel sums]
   static constexpr int OFF_V = OFF_U + 2 * U_ELEMS;
   static constexpr int LDS_MAIN = OFF_V + 2 * V_ELEMS;    // 132 KB | 118 KB
+#ifdef EAVSR_W4_ITSTAMP
+  static constexpr int LDS_FLOATS = LDS_MAIN + 128 + 512;   // + 256 shader-clock stamps (diagnostic build)
+#else
   static constexpr int LDS_FLOATS = LDS_MAIN + 128;
+#endif
   static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
 };
 
@@ -130,6 +134,33 @@ __device__ unsigned long long g_w4_stamps[32];
 #define W4_STAMP(i) do { } while (0)
 #endif
 
+#ifdef EAVSR_W4_TIMELINE
+// diagnostic build only: wall-clock (s_memrealtime, 100 MHz) and shader-cycle (s_memtime) stamps of wave 0 of every workgroup
+// at six points of the kernel (tools/gpu_wino4_timeline.py); six stamps per workgroup do not move the timing
+__device__ unsigned long long g_w4_tl[512 * 16];
+#define W4_TL(i)                                                                           \
+  do {                                                                                     \
+    if (tid == 0) {                                                                        \
+      g_w4_tl[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 2 * (i)] = __builtin_amdgcn_s_memrealtime(); \
+      g_w4_tl[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 2 * (i) + 1] = __builtin_amdgcn_s_memtime(); \
+    }                                                                                      \
+  } while (0)
+#else
+#define W4_TL(i) do { } while (0)
+#endif
+
+#ifdef EAVSR_W4_ITSTAMP
+// diagnostic build only: shader-clock stamps of EVERY wave at eight points of iterations 8..11 (one full rotation of the duty
+// pair), kept in LDS and dumped at the end of the kernel: the anatomy of a steady-state iteration without instrumenting the rest
+__device__ unsigned long long g_w4_it[256 * 256];
+#define W4_IT(i)                                                                                       \
+  do {                                                                                                 \
+    if (it >= 8 && it < 12 && lane == 0) s_its[((it - 8) * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define W4_IT(i) do { } while (0)
+#endif
+
 template <int R, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   static_assert(!FUSE || R == 3, "the fused channel-attention prologue exists for the 3x3 kernel");
@@ -142,10 +173,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_v = smem + OFF_V;
   float* s_red = smem + LDS_MAIN;
+#ifdef EAVSR_W4_ITSTAMP
+  unsigned long long* s_its = reinterpret_cast<unsigned long long*>(smem + LDS_MAIN + 128);
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  W4_TL(0);   // kernel entry
+#ifndef EAVSR_W4_UREGS
+  // the first weight slab does not depend on the tile: requested before the set-up arithmetic (the set-up is 1.9 us of
+  // dependent scalar loads and index arithmetic per workgroup: tools/gpu_wino4_timeline.py)
+  {
+    const char* usrc0 = reinterpret_cast<const char*>(a.wu + (size_t)blockIdx.y * (a.cin / CK) * U_ELEMS) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < U_IT; ++i) {
+      const int seg = i * NW + wave;
+      if (seg < U_SEGS)
+        __builtin_amdgcn_global_load_lds((gptr_t)(usrc0 + i * (NW * 1024) + (tid & 63) * 16u), (lptr_t)(smem + OFF_U + seg * 256), 16, 0, 0);
+    }
+  }
+#endif
 
   // Persistent workgroups: workgroup b walks the tiles b, b + gridDim.x, ... as ONE flattened sequence of (tile, chunk)
   // iterations (as conv3x3_wino_kernel): the LDS-DMA stream never drains at a tile boundary.
@@ -170,6 +218,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   const unsigned lane16 = lane * 16u;
   const int cb = wave >> 1, tg = wave & 1;
   eavsr_stagger_priority(wave);      // common.h: 47.8 -> 43.9 us per 2 x 64 x 180 x 320 convolution
+#ifdef EAVSR_W4_DUTYPRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   float bias_r[4];   // this lane's four output channels are the same for every tile of the launch
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -179,6 +230,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   f32x4 acc[NPOS];
 #pragma unroll
   for (int x = 0; x < NPOS; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // activation without a branch per value: max(t, t s) with s = 1 (none), 0 (ReLU), slope (leaky ReLU, 0 <= slope <= 1; the
+  // launcher rejects other slopes).  With `if (act == ..)` per value the epilogue carried 128 scalar compare-and-branch pairs:
+  // 15.2 K -> 11.2 K cycles per tile, 46.8 -> 43.7 us per 2 x 64 x 180 x 320 launch (bit-identical for finite values)
+  const float act_s = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope;
 
   int total_chunks = 0;
   for (int s = 0; s < a.n_src; ++s) total_chunks += a.src_c[s] / CK;
@@ -401,18 +456,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   f32x2 ur[NPOS / 2];
 #pragma unroll
   for (int i = 0; i < NPOS / 2; ++i) ur[i] = load_u(0, i);
-#else
-  issue_u(0, 0);
 #endif
   if (total_iters > 1) issue_patch(1);
+  W4_TL(1);   // set-up done, first DMA issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  W4_TL(2);   // first DMA landed for every wave
   if ((wave >> 1) == 3) { sc_use = sc_first; transform(0, 0, bn, y0, x0, 0); }   // the pair on duty "before iteration 0"
   sc_use = sc_next;   // chunk 1's scale (loaded with patch 1), for the transform of iteration 0
   int chunk = 0;   // chunk of iteration `it` within its tile
   W4_STAMP(0);      // prologue: first DMA round trip, first transform
   for (int it = 0; it < total_iters; ++it) {
     // U(it) and the patch the next transform needs have landed; every wave is done with the GEMM of iteration it-1
+    W4_IT(0);
 #ifdef EAVSR_W4_UREGS
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) as an instruction the wait-count pass sees: the operand registers requested
                                           // during the last GEMM are known-complete, no conservative waits inside this iteration
@@ -420,7 +476,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     W4_STAMP(1);    // waiting for this wave's DMA
+    W4_IT(1);
     __syncthreads();
+    W4_IT(2);
     W4_STAMP(2);    // waiting at the barrier
     const int chunk_n = chunk + 1 == total_chunks ? 0 : chunk + 1;
     const bool on_duty = (wave >> 1) == (it & 3);
@@ -438,12 +496,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     if (!dma_late) issue_dma();
 #endif
     // the pair on duty transforms the next chunk before its GEMM steps
+    W4_IT(3);
     W4_STAMP(3);    // DMA issue (waves 0-3)
     auto duty_transform = [&]() __attribute__((always_inline)) {
       if (on_duty && it + 1 < total_iters) {
         int t_bn = bn, t_y0 = y0, t_x0 = x0, t_lin = 0;
         if (FUSE && chunk_n == 0) tile_coords((it + 1) / total_chunks, t_bn, t_y0, t_x0, t_lin);   // first chunk of the next tile
+#ifdef EAVSR_W4_DUTYPRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         transform((it + 1) & 1, (it + 1) & 1, t_bn, t_y0, t_x0, chunk_n);
+#ifdef EAVSR_W4_DUTYPRIO
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
       }
     };
 #ifndef EAVSR_W4_UREGS
@@ -453,6 +520,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     // U and V hold the positions in PAIRS ([xi / 2][c][column][xi & 1], column ^ 16 (c & 1)): one ds_read_b64 per operand
     // and two positions - ds_read_b64 moves 256 B/clk against 128 for ds_read_b32 (whose 32 banks would also put the two
     // k-rows of a half-wave on the same banks), and the swizzle keeps those two rows on disjoint banks
+    W4_IT(4);
     W4_STAMP(4);    // transform (the pair on duty)
     const float* ua = smem + OFF_U + (it & 1) * U_ELEMS + kq * 128 + 2 * ((cb * 16 + l15) ^ ((kq & 1) << 4));
     const float* vb = s_v + (it & 1) * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));
@@ -499,7 +567,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #else
       if (i == NSTEP / 2) {
         __builtin_amdgcn_sched_barrier(0);
+        W4_IT(5);
         if (dma_late) issue_dma();
+        W4_IT(6);
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
@@ -544,8 +614,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
     if (FUSE) sc_use = sc_next;   // loaded by this iteration's issue_patch (chunk it + 2) for the transform of it + 1
     chunk = chunk_n;
+    W4_IT(7);
     W4_STAMP(5);    // the 36 GEMM steps (+ the DMA issue of waves 4-7)
     if (chunk != 0) continue;   // the tile is not finished yet
+    if (it + 1 == total_iters) W4_TL(3);   // last tile: GEMM loop done
 
     // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile (tg, l15)] for every xi ----
     {
@@ -594,8 +666,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 float t = (ch == 0 ? y[j].x : y[j].y) + bias_r[r];
-                if (a.act == EAVSR_ACT_RELU) t = fmaxf(t, 0.f);
-                else if (a.act == EAVSR_ACT_LRELU) t = t > 0.f ? t : t * a.slope;
+                t = fmaxf(t, t * act_s);
                 vv[ch][j] = t;
               }
             }
@@ -655,8 +726,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               y[j] += bb;
-              if (a.act == EAVSR_ACT_RELU) y[j] = fmaxf(y[j], 0.f);
-              else if (a.act == EAVSR_ACT_LRELU) y[j] = y[j] > 0.f ? y[j] : y[j] * a.slope;
+              y[j] = fmaxf(y[j], y[j] * act_s);
             }
             if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
               csum[r] += y[0] + y[1];
@@ -692,6 +762,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     }
     W4_STAMP(6);    // epilogue: output transform, stores
   }   // flattened (tile, chunk) loop
+  W4_TL(4);   // epilogue issued
+#ifdef EAVSR_W4_ITSTAMP
+  __syncthreads();
+  if (tid < 256) g_w4_it[(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid] = s_its[tid];
+#endif
+#ifdef EAVSR_W4_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  W4_TL(5);   // this wave's stores acknowledged
+#endif
 #ifdef EAVSR_W4_STAMPS
   if (lane == 0 && (wave & 1) == 0) {
     for (int i = 0; i < 8; ++i) atomicAdd(&g_w4_stamps[(wave >> 1) * 8 + i], st_acc[i]);
@@ -754,6 +833,22 @@ extern "C" int eavsr_debug_w4_stamps(unsigned long long* host_out, int reset) {
 }
 #endif
 
+#ifdef EAVSR_W4_ITSTAMP
+extern "C" int eavsr_debug_w4_itstamps(unsigned long long* host_out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_w4_it), sizeof(g_w4_it));
+  return 0;
+}
+#endif
+
+#ifdef EAVSR_W4_TIMELINE
+extern "C" int eavsr_debug_w4_timeline(unsigned long long* host_out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_w4_tl), sizeof(g_w4_tl));
+  return 0;
+}
+#endif
+
 extern "C" int64_t eavsr_wino4_weight_elems(int32_t cout, int32_t cin) {
   if (cout <= 0 || cin <= 0 || cin % CK != 0) return 0;
   return (int64_t)eavsr::cdiv(cout, 64) * (cin / CK) * U_ELEMS;
@@ -780,6 +875,8 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   EAVSR_REQUIRE(d->out, -1, "conv_wino6: NULL out");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv_wino6: bad dims");
   EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv_wino6: act %d", d->act);
+  EAVSR_REQUIRE(d->act != EAVSR_ACT_LRELU || (d->slope >= 0.f && d->slope <= 1.f), -2,
+                "conv_wino6: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(t, slope t))", (double)d->slope);
   const bool fuse = d->ca_scale != nullptr;
   if (fuse) {
     EAVSR_REQUIRE(R == 3, -2, "conv_wino6: the fused channel-attention prologue exists for the 3x3 kernel only");

@@ -278,6 +278,11 @@ class EAVSRP(nn.Module):
                 feat_prop = fusion([cond_n1, cur[0], cond_n2])                          # :313-314
             others = [feats[k][idx] for k in feats if k not in _PYR and k != module_name]
             res = backbone([cur[0]] + others + [feat_prop])                             # :317-323
+            # AG.add honours `out` only without autograd: as soon as one frame's sum carries a gradient (a frozen backbone
+            # behind a trained alignment / fusion module, an earlier branch with gradients) the buffer is dropped for the whole
+            # branch -- its rows would stay uninitialised and cut off from autograd -- and `upsample` concatenates the list
+            if stacked is not None and AG.needs_grad(feat_prop, res):
+                stacked = None
             feat_prop = AG.add(feat_prop, res, out=None if stacked is None else stacked[idx * n:(idx + 1) * n])
             feats[module_name].append(feat_prop)
         if backward:

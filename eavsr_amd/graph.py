@@ -157,14 +157,25 @@ class GraphedTrainStep:
         model.loss_EAVSRP_L1 = model.loss_EAVSRP_Total = model.data_sr_seq = model.data_sr = None
         self.graph = torch.cuda.CUDAGraph()
         model.grad_sync.paused = True
+        # A captured Adam bakes a Python-float learning rate into its kernels' arguments: later changes of
+        # `param_groups[i]['lr']` (model.update_learning_rate(), base_model.py:131-138) would be ignored by every replay.
+        # The capture therefore sees each group's rate as a DEVICE tensor (torch's capturable Adam reads it on the device);
+        # afterwards the groups hold their Python floats again, for the schedulers, and `step()` copies them into the tensors.
+        self._lr_dev = [torch.tensor(float(g["lr"]), device=dev, dtype=torch.float32) for g in opt.param_groups]
+        self._lr_seen = [float(g["lr"]) for g in opt.param_groups]
         try:
             opt.zero_grad(set_to_none=True)
+            if self.world == 1:
+                for g, lr_t in zip(opt.param_groups, self._lr_dev):
+                    g["lr"] = lr_t
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 model.forward()
                 self._backward()
                 if self.world == 1:
                     opt.step()
         finally:
+            for g, lr in zip(opt.param_groups, self._lr_seen):
+                g["lr"] = lr
             model.grad_sync.paused = False
             clear_weight_caches()
         # the replayed backward writes into THESE gradient tensors (graph-pool memory).  An eager
@@ -200,6 +211,12 @@ class GraphedTrainStep:
         m.data_lr_seq, m.data_hr_seq = self.static_lr, self.static_hr
         for p, g in self._grads:
             p.grad = g
+        if self.world == 1:      # the replayed Adam reads its learning rates from these device scalars
+            for i, g in enumerate(m.optimizer_EAVSRP.param_groups):
+                lr = float(g["lr"])
+                if lr != self._lr_seen[i]:
+                    self._lr_dev[i].fill_(lr)
+                    self._lr_seen[i] = lr
         self.graph.replay()
         if self.world > 1:
             m.grad_sync.reset()

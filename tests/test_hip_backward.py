@@ -535,3 +535,79 @@ def test_graphed_training_step_matches_eager(AG, cuda):
     graphed.set_input(data); fresh.set_input(data)
     graphed.test(); fresh.test()
     assert H.maxabs(graphed.data_sr_seq.cpu(), fresh.data_sr_seq.cpu()) <= 1e-6
+
+
+def test_graphed_training_step_follows_learning_rate_changes(AG, cuda):
+    """a captured Adam must follow `update_learning_rate()` (base_model.py:131-138).  GraphedTrainStep feeds the
+    replayed optimizer its learning rates through device scalars; after a scheduler step the replayed parameter update
+    has to equal the eager one (and differ from a replay at the old rate)."""
+    from eavsr_amd.eavsrp_model import EAVSRPModel
+    from eavsr_amd.graph import GraphedTrainStep
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    mk = lambda: Namespace(predict=False, n_frame=3, n_flow=5, scale=4, isTrain=True, gpu_ids=[0], lr=1e-4, beta1=0.9,
+                           beta2=0.999, weight_decay=0.0, npost=350, lr_policy="step", lr_decay_iters=1, niter=10,
+                           niter_decay=0, load_iter=0, load_path="", verbose=False)
+    sd = H.filled(H.model_shapes("x4"), "trained_like")
+    data = {"lr_seq": synthetic_clip(1, 3, 64, 64, seed=1), "hr_seq": synthetic_clip(1, 3, 256, 256, seed=2), "fname": "x"}
+    batch = {k: v.to(cuda) for k, v in data.items() if k != "fname"}
+    key = "backbone.backward_1.main.2.rg.0.res.0.weight"
+
+    def run(graphed: bool, schedule: bool):
+        m = EAVSRPModel(mk())
+        m.netEAVSRP.load_state_dict(sd, strict=True)
+        m.setup(m.opt)
+        m.set_input(data, epoch=0)
+        if graphed:
+            g = GraphedTrainStep(m, warmup=1)         # one eager step, then the capture
+            step = lambda: g.step(batch)
+        else:
+            m.optimize_parameters()
+            step = m.optimize_parameters
+        step()
+        before = dict(m.netEAVSRP.named_parameters())[key].detach().clone()
+        if schedule:
+            m.update_learning_rate()                  # StepLR, step 1, gamma 0.5: both groups halve
+            assert abs(m.optimizer_EAVSRP.param_groups[0]["lr"] - 5e-5) < 1e-12
+        step()
+        after = dict(m.netEAVSRP.named_parameters())[key].detach().clone()
+        return (after - before).abs().mean().item()
+
+    d_eager, d_graph, d_graph_const = run(False, True), run(True, True), run(True, False)
+    assert abs(d_graph - d_eager) <= 0.05 * d_eager, (d_graph, d_eager)
+    assert d_graph < 0.7 * d_graph_const, (d_graph, d_graph_const)     # the halved rate is what the replay applied
+
+
+def test_propagate_partial_freeze_keeps_autograd(AG, cuda):
+    """with the backbones and the encoder frozen but the alignment modules trained, `propagate` must not hand
+    `upsample` a frame-major buffer whose rows the gradient-carrying sums never wrote: the output has to equal the
+    all-trainable forward and the alignment parameters must receive gradients."""
+    from eavsr_amd.eavsrp_model import EAVSRP
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    opt = Namespace(predict=False, n_frame=3, n_flow=5, scale=4)
+    sd = H.filled(H.model_shapes("x4"), "trained_like")
+    clip, hr = synthetic_clip(1, 3, 64, 64, seed=5).to(cuda), synthetic_clip(1, 3, 256, 256, seed=6).to(cuda)
+
+    def build(freeze):
+        net = EAVSRP(opt, None)
+        net.load_state_dict(sd, strict=True)
+        net = net.to(cuda).train()
+        if freeze:
+            for name, p in net.named_parameters():
+                if not name.startswith("deform_align."):
+                    p.requires_grad_(False)
+        return net
+    full, part = build(False), build(True)
+    y_full, y_part = full(clip), part(clip)
+    assert torch.isfinite(y_part).all()
+    assert H.maxabs(y_full.detach().cpu(), y_part.detach().cpu()) <= 1e-6
+    (y_full - hr).abs().mean().backward()
+    (y_part - hr).abs().mean().backward()
+    gf, gp = dict(full.named_parameters()), dict(part.named_parameters())
+    checked = 0
+    for k, p in gp.items():
+        if k.startswith("deform_align.") and gf[k].grad is not None:
+            assert p.grad is not None, k
+            scale = max(1e-8, gf[k].grad.abs().max().item())
+            assert H.maxabs(p.grad.cpu(), gf[k].grad.cpu()) <= 2e-3 * scale, k
+            checked += 1
+    assert checked > 50

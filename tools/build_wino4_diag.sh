@@ -1,13 +1,14 @@
 #!/bin/bash
 # Diagnostic libraries eavsr_amd/lib/libwino4_*.so: conv_wino6.hip + capi.hip with -DEAVSR_WINO_EXP_* (timing ablations,
-# results wrong).  Built here (hipcc cross-compiles), they travel to the GPU box with the snapshot.
+# results wrong) or -DEAVSR_W4_* (schedule experiments, results right).  Built here (hipcc cross-compiles), they travel to the
+# GPU box with the snapshot.  VARIANTS="name:flags ..." overrides the list.
 set -e
 cd "$(dirname "$0")/.."
 F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -ffp-contract=fast -Iinclude -Ieavsr_amd/csrc -shared"
 rm -f eavsr_amd/lib/libwino4_*.so
-for v in base:"" uregs:-DEAVSR_W4_REG_WEIGHTS spread:-DEAVSR_W4_SPREAD noprio:-DEAVSR_NO_WAVE_PRIO stamps:-DEAVSR_W4_STAMPS nodma:-DEAVSR_WINO_EXP_NODMA notransform:-DEAVSR_WINO_EXP_NOTRANSFORM nomfma:-DEAVSR_WINO_EXP_NOMFMA nostore:-DEAVSR_WINO_EXP_NOSTORE \
-         nodma_notransform:"-DEAVSR_WINO_EXP_NODMA -DEAVSR_WINO_EXP_NOTRANSFORM" noudma:-DEAVSR_WINO_EXP_NOUDMA noudma_uregs:"-DEAVSR_WINO_EXP_NOUDMA -DEAVSR_WINO_EXP_UREGS" $EXTRA_VARIANTS; do
-  name=${v%%:*}; flags=${v#*:}
+DEFAULT='base: timeline:-DEAVSR_W4_TIMELINE nodma:-DEAVSR_WINO_EXP_NODMA notransform:-DEAVSR_WINO_EXP_NOTRANSFORM nomfma:-DEAVSR_WINO_EXP_NOMFMA nostore:-DEAVSR_WINO_EXP_NOSTORE'
+for v in ${VARIANTS:-$DEFAULT} $EXTRA_VARIANTS; do
+  name=${v%%:*}; flags=${v#*:}; flags=${flags//,/ }
   /opt/rocm/bin/hipcc $F $flags eavsr_amd/csrc/conv_wino6.hip eavsr_amd/csrc/capi.hip -o eavsr_amd/lib/libwino4_$name.so 2>/dev/null &
 done
 wait
