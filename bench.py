@@ -49,12 +49,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=4, help="clips per GPU (configs[1]: 4)")
-    ap.add_argument("--frames", type=int, default=7)
-    ap.add_argument("--height", type=int, default=180)
-    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 4],
+                    help="BASELINE.json configs[i]: 1 (default, the headline) = eavsrp x4, 4 clips x 7 x 3 x 180 x 320 fp32; "
+                         "2 = eavsrpx2 (x2 RealVSR path), 8 clips x 7 x 3 x 256 x 256, bf16; 4 = eavsrp x4, 1 clip x 15 x 3 x 540 x 960, "
+                         "fp16 (long-sequence stress).  2 and 4 are reported under their own metric names, with the PSNR of the "
+                         "16-bit output against the fp32 forward of the same clips.  (configs[3] is --mode train.)")
+    ap.add_argument("--clips", type=int, default=None, help="clips per GPU (default: the config's: 4 / 8 / 1)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--preset", default="trained_like", choices=["default", "trained_like"])
-    ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16", "fp16"],
+    ap.add_argument("--backbone-dtype", default=None, choices=["fp32", "bf16", "fp16"],
                     help="fp32 (default, the BASELINE headline: exact fp32 everywhere) or a 16-bit NHWC residual backbone "
                          "(BASELINE.json configs[2] / [4]); the 16-bit runs are reported under their own metric name")
     ap.add_argument("--conv-mode", default="winograd4", choices=["winograd", "winograd4", "direct", "bf16x9"],
@@ -65,7 +70,7 @@ def parse():
                     help="DCNv2: il6 (default) = IL8-layout kernel fed by the paired warp and the predictor heads, fp32 operands "
                          "split into 3 bf16 terms, 6 partial products (dropped ones < 2^-23 relative); il9 = all 9 products "
                          "(exact); native / bf16x9 = round 1's NCHW kernels behind affine_offsets + two warps")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=None,
                     help="split the clips of a step into this many sub-batches, each replayed as its own HIP graph on its own "
                          "stream (eavsr_amd.graph.StreamedForward)")
     ap.add_argument("--graph", action="store_true",
@@ -86,14 +91,27 @@ def parse():
     ap.add_argument("--dry", action="store_true",
                     help="plumbing test without a GPU: the step is a sleep, ranks talk over gloo; the line is labelled "
                          "as such and is not a measurement")
-    return ap.parse_args()
+    args = ap.parse_args()
+    # the workload of the chosen BASELINE.json config: (clips, frames, h, w, scale, dtype the config names, sub-batches)
+    cfg = {1: (4, 7, 180, 320, 4, "fp32", 2), 2: (8, 7, 256, 256, 2, "bf16", 2), 4: (1, 15, 540, 960, 4, "fp16", 1)}[args.config]
+    args.clips = cfg[0] if args.clips is None else args.clips
+    args.frames = cfg[1] if args.frames is None else args.frames
+    args.height = cfg[2] if args.height is None else args.height
+    args.width = cfg[3] if args.width is None else args.width
+    args.scale = cfg[4]
+    args.backbone_dtype = cfg[5] if args.backbone_dtype is None else args.backbone_dtype
+    if args.streams is None:
+        args.streams = cfg[6]
+        if args.config == 4:
+            args.graph = True        # one clip cannot be split into sub-batches: the whole forward as ONE HIP graph
+    return args
 
 
-def build_model(device, preset):
+def build_model(device, preset, scale=4):
     from argparse import Namespace
     from eavsr_amd.eavsrp_model import EAVSRP
     from eavsr_amd.utils.synthetic import fill_state_dict, shapes_of
-    net = EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale=4), None)
+    net = EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale=scale), None)
     sd0 = net.state_dict()
     sd = fill_state_dict(shapes_of(sd0), preset, fixed=sd0)
     net.load_state_dict(sd, strict=True)
@@ -354,7 +372,7 @@ def main():
     from eavsr_amd.utils.synthetic import synthetic_clip
     if args.mode == "train":
         return train_bench(args, rank, world, device)
-    net, sd = build_model(device, args.preset)
+    net, sd = build_model(device, args.preset, args.scale)
     if args.backbone_dtype != "fp32":
         from eavsr_amd import networks as _nw
         _nw.set_backbone_dtype(args.backbone_dtype)
@@ -408,6 +426,22 @@ def main():
         timed_vs_eager = float((timed_first - eager_first).abs().max().item())
         timed_equal = bool(torch.equal(timed_first, eager_first))
         timed_finite = bool(torch.isfinite(timed_first).all().item())
+        psnr_vs_fp32 = None
+        if args.backbone_dtype != "fp32":
+            # reduced precision is judged by PSNR against the exact path (BASELINE.json: "PSNR vs CPU ref"; the fp32 HIP forward
+            # is pinned to the CPU oracle within 1e-3 by tests/test_hip_configs.py): the same clips once more in fp32, eagerly
+            import math
+            from eavsr_amd import networks as _nw2
+            _nw2.set_backbone_dtype(None)
+            exact_first = net(clips[:sub])
+            _nw2.set_backbone_dtype(args.backbone_dtype)
+            q = lambda z: (z.clamp(0, 1) * 255).round()          # util/util.py:302-320 on base_model.py:145-150 images
+            mse = float(((q(timed_first) - q(exact_first)) / 255).pow(2).mean().item())
+            psnr_vs_fp32 = {"psnr_db": None if mse == 0 else -10 * math.log10(mse), "identical_8bit_images": mse == 0,
+                            "max_abs": float((timed_first - exact_first).abs().max().item()),
+                            "what": f"clips 0..{sub - 1} of the last timed step ({args.backbone_dtype} mode) vs the fp32 forward of the same clips, "
+                                    "on clamp*255*round images"}
+            del exact_first
         del timed_first, eager_first
     on_dev = world > 1 and torch.distributed.get_backend() == "nccl"
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
@@ -419,8 +453,13 @@ def main():
     med_ms = shard.max_over_ranks(statistics.median(step_ms), device=device if on_dev else None)
 
     line = {
-        "metric": "SR frames/sec at 4x 7-frame 180x320->720x1280" +
-                  ("" if args.backbone_dtype == "fp32" else f" [{args.backbone_dtype} residual backbone, not the fp32 headline]") +
+        "metric": ({1: "SR frames/sec at 4x 7-frame 180x320->720x1280",
+                    2: f"SR frames/sec, eavsrpx2 2x RealVSR path, {n} clips x {t} x 3 x {h} x {w} -> {2 * h}x{2 * w} (BASELINE.json configs[2])",
+                    4: f"SR frames/sec, eavsrp 4x long-sequence propagation, {n} clip x {t} frames x 3 x {h} x {w} -> {4 * h}x{4 * w} "
+                       "(BASELINE.json configs[4])"}[args.config]) +
+                  ("" if args.backbone_dtype == "fp32" else
+                   f" [{args.backbone_dtype}: 16-bit residual backbone, warp -> DCNv2 and predictor heads; fp32 elsewhere" +
+                   ("; not the fp32 headline]" if args.config == 1 else "]")) +
                   ("" if args.conv_mode != "bf16x9" and args.dcn_mode != "bf16x9" else " [fp32 via exact bf16x9 split products, opt-in mode]"),
         "value": value,
         "unit": "frames/s",
@@ -444,9 +483,9 @@ def main():
         "timed_output_max_abs_vs_eager": timed_vs_eager,
         "timed_output_check": {"what": f"clips 0..{n // args.streams - 1} of the last timed step vs one eager forward of the same clips after the "
                                        "timed region (max over ranks)", "bit_identical": timed_equal, "finite": timed_finite, "bound": 1e-5},
-        "config": {"workload": f"eavsrp x4 inference, {n} clips/GPU x {t} frames x 3 x {h} x {w} fp32 "
-                               f"(BASELINE.json configs[1]), weights: seeded '{args.preset}' init",
-                   "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "scale": 4, "sharding": "clips across ranks, no collective",
+        "config": {"workload": f"{'eavsrpx2 x2' if args.scale == 2 else 'eavsrp x4'} inference, {n} clips/GPU x {t} frames x 3 x {h} x {w} "
+                               f"{args.backbone_dtype} (BASELINE.json configs[{args.config}]), weights: seeded '{args.preset}' init",
+                   "clips_per_gpu": n, "frames": t, "lr_size": [h, w], "scale": args.scale, "sharding": "clips across ranks, no collective",
                    "conv3x3": {"winograd": "Winograd F(2x2,3x3), fp32 MFMA (direct fp32 kernel for the shapes it does not cover)",
                                "winograd4": "Winograd F(4x4,3x3), fp32 MFMA (F(2x2,3x3) / direct fp32 kernels for the shapes it does not cover)",
                                "direct": "direct sum, fp32 MFMA", "bf16x9": "direct sum, exact bf16x9 split"}[args.conv_mode],
@@ -551,6 +590,8 @@ def main():
 
     if degraded is not None:
         line["degraded"] = degraded
+    if psnr_vs_fp32 is not None:
+        line["psnr_vs_fp32"] = psnr_vs_fp32
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -24,7 +24,8 @@ d.src[0] = x.data_ptr(); d.src_c[0] = 64; d.n_src = 1; d.ksize = 3
 d.bias = b.data_ptr(); d.out = out.data_ptr()
 d.n, d.h, d.w, d.cin, d.cout = n, h, w, 64, 64
 d.act = 1
-names = ["top", "own DMA landed", "barrier released", "early DMA issued", "transform done", "GEMM half", "late DMA issued", "GEMM done"]
+names_lock = ["top", "own DMA landed", "barrier released", "early DMA issued", "transform done", "GEMM half", "late DMA issued", "GEMM done"]
+names_pp = ["top", "B: barrier", "GEMM done", "own DMA landed", "barrier", "service done", "bottom (A: barrier)", "-"]
 for path in sorted(glob.glob(os.path.join(ROOT, "eavsr_amd", "lib", "libwino4_itstamp*.so"))):
     lib = C.CDLL(path)
     lib.eavsr_conv3x3_wino4_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -42,11 +43,14 @@ for path in sorted(glob.glob(os.path.join(ROOT, "eavsr_amd", "lib", "libwino4_it
     lib.eavsr_debug_w4_itstamps(buf)
     nwg = min(256, n * 23 * 5)
     a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 4, 8, 8)[:nwg].astype(np.int64)   # [wg][iteration 8..11][wave][point]
+    pp = "_pp" in os.path.basename(path)
+    names = names_pp if pp else names_lock
+    ref = 0 if pp else 2
     for itx in range(4):
-        rel = a[:, itx] - a[:, itx, :, 2].min(axis=1)[:, None, None]     # cycles after the first wave left the barrier
-        nxt = (a[:, itx + 1, :, 2].min(axis=1) - a[:, itx, :, 2].min(axis=1)) if itx < 3 else None
-        print(f"  iteration {8 + itx} (duty pair: waves {2 * (itx & 3)}, {2 * (itx & 3) + 1})"
-              + (f": {int(np.median(nxt))} cycles to the next iteration's barrier release" if nxt is not None else ""))
+        rel = a[:, itx] - a[:, itx, :4, ref].min(axis=1)[:, None, None]     # cycles after the first wave of group A was at the reference point
+        nxt = (a[:, itx + 1, :4, ref].min(axis=1) - a[:, itx, :4, ref].min(axis=1)) if itx < 3 else None
+        print(f"  iteration {8 + itx}" + ("" if pp else f" (duty pair: waves {2 * (itx & 3)}, {2 * (itx & 3) + 1})")
+              + (f": {int(np.median(nxt))} cycles to the same point of the next iteration" if nxt is not None else ""))
         print("    wave  " + "  ".join(f"{nm:>17s}" for nm in names))
         for wv in range(8):
             print(f"    {wv:4d}  " + "  ".join(f"{int(np.median(rel[:, wv, i])):17d}" for i in range(8)))
