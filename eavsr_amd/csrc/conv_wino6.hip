@@ -34,6 +34,16 @@
 #ifdef EAVSR_W4_REG_WEIGHTS
 #define EAVSR_W4_UREGS 1
 #endif
+// Round 3 (per-wave stamps, tools/gpu_wino4_itstamp.py): the pair on duty has the longest path of an iteration -- its DMA pieces
+// (every wave that requests pieces at the same time as others is held ~1,100-1,250 cycles: the CU moves one 1-KiB piece per
+// ~45 cycles whoever issues it), then the transform (1,300 cycles with the SIMD's priority, 2,950 without), then its 36 MFMAs.
+// EAVSR_W4_DUTY_NO_U: it requests no weight pieces (the other six waves take six each) and its patch pieces behind the
+// transform; EAVSR_W4_DUTYPRIO: it runs the transform at priority 3.  46.8 -> 40.6 us per 2 x 64 x 180 x 320 launch together
+// with the re-paired positions (w6_slot) and the branch-free activation.  -DEAVSR_W4_ROUND2_DUTY builds the A/B reference.
+#ifndef EAVSR_W4_ROUND2_DUTY
+#define EAVSR_W4_DUTY_NO_U 1
+#define EAVSR_W4_DUTYPRIO 1
+#endif
 
 #include <mutex>
 #include <cstdlib>
@@ -71,6 +81,17 @@ constexpr int U_ELEMS = NPOS * CK * 64;               // 9216 floats = 36 KB: on
 constexpr int U_SEGS = U_ELEMS / 256;                 // 36
 constexpr int U_IT = (U_SEGS + NW - 1) / NW;          // 5
 constexpr int V_ELEMS = NPOS * CK * 32;               // 4608 floats = 18 KB
+
+// Transform-domain position (row i, column q) of the 6 x 6 block -> its slot in U, V and the accumulators.  Slots are consumed in
+// PAIRS (one ds_read_b64 per operand and two positions); a row's pairs are the columns (1, 2), (3, 4), (0, 5) -- the pairs the
+// row pass of the input transform produces as packed fp32 registers: (x3, x4) - 4 (x1, x2) = (b, a) and (x3, x4) - (x1, x2) =
+// (e, c) are ONE packed instruction each and (a + b, a - b), (c + 2 e, c - 2 e) come out as adjacent registers, ready for their
+// 8-byte LDS store (with the natural pairing (0, 1), (2, 3), (4, 5) the row pass was 14 scalar instructions + moves per row).
+__host__ __device__ constexpr int w6_pair_of(int q) { return (q == 1 || q == 2) ? 0 : (q == 3 || q == 4) ? 1 : 2; }
+__host__ __device__ constexpr int w6_half_of(int q) { return (q == 1 || q == 3 || q == 0) ? 0 : 1; }
+__host__ __device__ constexpr int w6_slot(int i, int q) { return 2 * (3 * i + w6_pair_of(q)) + w6_half_of(q); }
+// inverse: column of (pair within the row, half)
+__host__ __device__ constexpr int w6_col_of(int pp, int half) { return pp == 0 ? 1 + half : pp == 1 ? 3 + half : (half ? 5 : 0); }
 
 // R = 3: F(4x4, 3x3), output tile 8 x 64 px.  R = 5: F(2x2, 5x5) - the same 6 x 6 input tiles, points and B^T, 2 x 2
 // outputs per tile (2.78x fewer multiplications than the direct 5x5 sum), output tile 4 x 32 px: the predictor's
@@ -419,14 +440,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       in1d(d, t34);   // columns 4, 5
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {   // row pass (.) B; positions are stored in pairs
-      const float d3[6] = {t05[i].x, t12[i].x, t12[i].y, t34[i].x, t34[i].y, t05[i].y};
-      const float d5[6] = {t05[i].x, t05[i].y, t12[i].x, t12[i].y, t34[i].x, t34[i].y};
-      const float (&d)[6] = R == 3 ? d3 : d5;
-      float o[6];
-      in1d(d, o);
-#pragma unroll
-      for (int j = 0; j < 6; j += 2) *reinterpret_cast<f32x2*>(vd + (i * 3 + j / 2) * (CK * 64)) = f32x2{o[j], o[j + 1]};
+    for (int i = 0; i < 6; ++i) {   // row pass (.) B; a row's positions are stored as the pairs (1, 2), (3, 4), (0, 5): w6_slot
+      f32x2 o12, o34, o05;
+      if (R == 3) {
+        // the column pass left exactly these pairs in packed registers: x1,x2 = t12[i], x3,x4 = t34[i], x0,x5 = t05[i]
+        const f32x2 ba = t34[i] - 4.f * t12[i];          // (b, a) = (x3 - 4 x1, x4 - 4 x2)
+        const f32x2 ec = t34[i] - t12[i];                // (e, c) = (x3 - x1, x4 - x2)
+        // (a + b, a - b) and (c + 2 e, c - 2 e): one packed instruction each with half selects / a negated half (the compiler
+        // builds (b, -b) with a move and an xor instead)
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(o12) : "v"(ba));
+        asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(o34) : "v"(ec));
+        o05 = f32x2{4.f * t05[i].x + (t34[i].y - 5.f * t12[i].y), 4.f * t12[i].x + (t05[i].y - 5.f * t34[i].x)};
+      } else {
+        const float d5[6] = {t05[i].x, t05[i].y, t12[i].x, t12[i].y, t34[i].x, t34[i].y};
+        float o[6];
+        in1d(d5, o);
+        o12 = f32x2{o[1], o[2]};
+        o34 = f32x2{o[3], o[4]};
+        o05 = f32x2{o[0], o[5]};
+      }
+      *reinterpret_cast<f32x2*>(vd + (i * 3 + 0) * (CK * 64)) = o12;
+      *reinterpret_cast<f32x2*>(vd + (i * 3 + 1) * (CK * 64)) = o34;
+      *reinterpret_cast<f32x2*>(vd + (i * 3 + 2) * (CK * 64)) = o05;
     }
 #endif
   };
@@ -508,7 +543,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     // the two waves of a SIMD (w and w + 4) issue their DMA pieces at different points of the iteration
     const bool dma_late = wave >= 4;
 #ifndef EAVSR_W4_SPREAD
+#ifdef EAVSR_W4_DUTY_NO_U
+    if (!dma_late && !on_duty) issue_dma();    // the pair on duty requests its (patch) pieces behind its transform
+#else
     if (!dma_late) issue_dma();
+#endif
 #endif
     // the pair on duty transforms the next chunk before its GEMM steps
     W4_IT(3);
@@ -530,6 +569,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     };
 #ifndef EAVSR_W4_UREGS
     duty_transform();
+#if defined(EAVSR_W4_DUTY_NO_U) && !defined(EAVSR_W4_SPREAD)
+    if (!dma_late && on_duty) issue_dma();
+#endif
 #endif
     // ---- the 36 GEMM steps of this wave: M_xi[co, t] += sum over the chunk's 4 channels U_xi[co, c] V_xi[c, t]
     // U and V hold the positions in PAIRS ([xi / 2][c][column][xi & 1], column ^ 16 (c & 1)): one ds_read_b64 per operand
@@ -565,12 +607,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     for (int i = 0; i < NSTEP; ++i) {
 #ifdef EAVSR_W4_SPREAD
       // one DMA piece per GEMM step, in the steps' matrix-pipe shadow (FUSE keeps the burst: its patch has two parts)
-      if (!FUSE && i < U_IT + IN_IT) {
+#ifndef EAVSR_W4_SPREAD_STRIDE
+#define EAVSR_W4_SPREAD_STRIDE 1
+#endif
+      constexpr int SS = EAVSR_W4_SPREAD_STRIDE;
+      if (!FUSE && i % SS == SS - 1 && i / SS < U_IT + IN_IT) {
+        constexpr int dummy_ = 0; (void)dummy_;
+        const int k = i / SS;
         __builtin_amdgcn_sched_barrier(0);
-        if (i < U_IT) { if (it + 1 < total_iters) issue_u_piece(i, chunk_n, (it + 1) & 1); }
+        if (k < U_IT) { if (it + 1 < total_iters) issue_u_piece(k, chunk_n, (it + 1) & 1); }
         else if (it + 2 < total_iters) {
-          issue_patch_piece(i - U_IT, it & 1);
-          if (i == U_IT + IN_IT - 1) patch_advance();
+          issue_patch_piece(k - U_IT, it & 1);
+          if (k == U_IT + IN_IT - 1) patch_advance();
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -662,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
             for (int q = 0; q < 6; ++q) {      // row dy of A^T m, column q of the 6 x 6 block
               f32x2 m[6];
 #pragma unroll
-              for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[i * 6 + q][2 * rp], acc[i * 6 + q][2 * rp + 1]};
+              for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[w6_slot(i, q)][2 * rp], acc[w6_slot(i, q)][2 * rp + 1]};
               if (dy == 0) s[q] = m[0] + (m[1] + m[2]) + (m[3] + m[4]);
               else if (dy == 1) s[q] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
               else if (dy == 2) s[q] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
@@ -727,8 +775,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
           float s[2][6];
 #pragma unroll
           for (int q = 0; q < 6; ++q) {
-            const float m0 = acc[0 * 6 + q][r], m1 = acc[1 * 6 + q][r], m2 = acc[2 * 6 + q][r], m3 = acc[3 * 6 + q][r],
-                        m4 = acc[4 * 6 + q][r], m5 = acc[5 * 6 + q][r];
+            const float m0 = acc[w6_slot(0, q)][r], m1 = acc[w6_slot(1, q)][r], m2 = acc[w6_slot(2, q)][r], m3 = acc[w6_slot(3, q)][r],
+                        m4 = acc[w6_slot(4, q)][r], m5 = acc[w6_slot(5, q)][r];
             s[0][q] = m0 + (m1 + m2) + (m3 + m4);
             s[1][q] = ((m1 - m2) + 2.f * (m3 - m4)) + m5;
           }
@@ -793,1009 +841,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Ping-pong schedule (round 3, the default; conv_wino6_kernel above stays for the fused channel-attention prologue and as the
-// A/B reference: EAVSR_WINO6_SCHED=lockstep).
-//
-// What the per-wave stamps of the lock-step kernel showed (tools/gpu_wino4_itstamp.py, 2 x 64 x 180 x 320, cycles after the
-// iteration's barrier): every wave issues its 5-7 LDS-DMA pieces in 1,000-1,250 cycles (the CU moves one 1-KiB piece per ~48
-// cycles whoever issues it: 48 pieces = a whole iteration's matrix-pipe time), the pair on duty then runs the input transform as
-// one 1,800-2,100-cycle dependent chain and only then its 36 MFMAs: 4,950 cycles on the duty waves while the other six are
-// done after 2,900-3,900 and wait at the barrier.  Same program in all waves = every wave stalls on the same queues at the
-// same time, and the matrix pipe (2,304 cycles of work per SIMD and iteration) idles behind them.
-//
-// Here the two waves of a SIMD (w, w + 4) never do the same thing at the same time.  An iteration (one chunk of 4 input
-// channels) is two half-phases, two workgroup barriers:
-//   half 0:  waves 0-3 (group A): the 36 MFMAs of chunk `it`                waves 4,5: input transform of chunk it + 1 -> V
-//                                                                            waves 6,7: weight slab U(it + 1) by LDS-DMA (36 pieces)
-//   half 1:  waves 4-7 (group B): the 36 MFMAs of chunk `it`                waves 0-3: input patch of chunk it + 3 (12 pieces);
-//                                                                                       on a tile's last chunk their epilogue
-// so a service wave's queue stalls and dependent chains run beside its SIMD partner's MFMAs.  Three patch stages (requested three
-// chunks ahead), two U stages, two V stages: 144.5 KB of LDS.  Group B's epilogue runs in half 0 of the next tile's first chunk
-// (behind its service work), i.e. at the end of the kernel when a workgroup has one tile.
-template <int R>
-struct WPCfg {
-  using C = WCfg<R>;
-  static constexpr int NST_P = 3;                                   // patch stages
-  static constexpr int P_IT = (C::IN_SEGS + 3) / 4;                 // patch pieces per wave of group A: 3 | 2
-  static constexpr int OFF_U = NST_P * C::IN_PAD;
-  static constexpr int OFF_V = OFF_U + 2 * U_ELEMS;
-  static constexpr int LDS_MAIN = OFF_V + 2 * V_ELEMS;
-#ifdef EAVSR_W4_ITSTAMP
-  static constexpr int LDS_FLOATS = LDS_MAIN + 256 + 512;           // + 256 shader-clock stamps (diagnostic build)
-#else
-  static constexpr int LDS_FLOATS = LDS_MAIN + 256;                 // + two sets of per-tile channel sums
-#endif
-  static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-};
-
-#ifndef EAVSR_W6P_PRIO_SVC
-#define EAVSR_W6P_PRIO_SVC 2
-#endif
-#ifndef EAVSR_W6P_PRIO_GEMM
-#define EAVSR_W6P_PRIO_GEMM 0
-#endif
-
-template <int R>
-__global__ __launch_bounds__(512, 2) void conv_wino6p_kernel(W4Args a) {
-  using C = WCfg<R>;
-  using P = WPCfg<R>;
-  constexpr int M = C::M, PADR = C::PADR, TOH = C::TOH, TOW = C::TOW, IH = C::IH, IW = C::IW, IN_ELEMS = C::IN_ELEMS;
-  constexpr int IN_SEGS = C::IN_SEGS, IN_PAD = C::IN_PAD, P_IT = P::P_IT, OFF_U = P::OFF_U, OFF_V = P::OFF_V;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_v = smem + OFF_V;
-  float* s_red = smem + P::LDS_MAIN;
-#ifdef EAVSR_W4_ITSTAMP
-  unsigned long long* s_its = reinterpret_cast<unsigned long long*>(smem + P::LDS_MAIN + 256);
-#endif
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool grp_a = wave < 4;
-  const unsigned lane16 = lane * 16u;
-  // the first weight slab does not depend on the tile: requested before the set-up arithmetic, by all eight waves
-  const float* const wu_base = a.wu + (size_t)blockIdx.y * (a.cin / CK) * U_ELEMS;
-  {
-    const char* usrc0 = reinterpret_cast<const char*>(wu_base) + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < U_IT; ++i) {
-      const int seg = i * NW + wave;
-      if (seg < U_SEGS)
-        __builtin_amdgcn_global_load_lds((gptr_t)(usrc0 + i * (NW * 1024) + lane16), (lptr_t)(smem + OFF_U + seg * 256), 16, 0, 0);
-    }
-  }
-
-  const int cot = blockIdx.y;
-  const int h = a.h, w = a.w;
-  const size_t plane = (size_t)h * w;
-  const int total_tiles = a.tiles_x * a.tiles_y * a.n;
-  const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  auto tile_coords = [&](int k, int& bn_, int& y0_, int& x0_, int& lin_) __attribute__((always_inline)) {
-    int t = eavsr_xcd_remap((int)blockIdx.x + k * (int)gridDim.x, total_tiles);
-    const int tx_ = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty_ = t % a.tiles_y;
-    bn_ = t / a.tiles_y;
-    y0_ = ty_ * TOH;
-    x0_ = tx_ * TOW;
-    lin_ = ty_ * a.tiles_x + tx_;
-  };
-
-  const int l15 = lane & 15, kq = lane >> 4;
-  const int cb = wave >> 1, tg = wave & 1;
-  float bias_r[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = cot * 64 + cb * 16 + 4 * kq + r;
-    bias_r[r] = (co < a.cout && a.bias != nullptr) ? a.bias[co] : 0.f;
-  }
-  const float act_s = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope;   // max(t, t s), as above
-  f32x4 acc[NPOS];
-#pragma unroll
-  for (int x = 0; x < NPOS; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  int total_chunks = 0;
-  for (int s = 0; s < a.n_src; ++s) total_chunks += a.src_c[s] / CK;
-  const int total_iters = my_tiles * total_chunks;
-
-  // ---- patch stream of group A (three chunks ahead of the compute stream, across tile boundaries) ----
-  int p_k = 0, p_cs = 0, p_cc0 = 0, p_bn = 0, p_y0 = 0, p_x0 = 0, p_lin = 0;
-  unsigned voff[P_IT];
-  auto p_setup_tile = [&]() __attribute__((always_inline)) {
-    tile_coords(p_k, p_bn, p_y0, p_x0, p_lin);
-#pragma unroll
-    for (int i = 0; i < P_IT; ++i) {
-      const int seg = i * 4 + wave;
-      const int e4 = seg * 64 + lane;
-      const int ci = e4 / (IH * (IW / 4));
-      const int rem = e4 - ci * (IH * (IW / 4));
-      const int r = rem / (IW / 4);
-      const int c4 = rem - r * (IW / 4);
-      const int gy = p_y0 - PADR + r, gx = p_x0 - MARG + 4 * c4;
-      const bool ok = e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
-      voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
-    }
-  };
-  int bn = 0, y0 = 0, x0 = 0, tile_lin = 0;
-  tile_coords(0, bn, y0, x0, tile_lin);
-  const float* const sp0 = a.src[0]; const float* const sp1 = a.src[1]; const float* const sp2 = a.src[2];
-  const float* const sp3 = a.src[3]; const float* const sp4 = a.src[4];
-  const int sc0 = a.src_c[0], sc1 = a.src_c[1], sc2 = a.src_c[2], sc3 = a.src_c[3], sc4 = a.src_c[4];
-  auto src_of = [&](int i) __attribute__((always_inline)) { return i == 0 ? sp0 : i == 1 ? sp1 : i == 2 ? sp2 : i == 3 ? sp3 : sp4; };
-  auto src_c_of = [&](int i) __attribute__((always_inline)) { return i == 0 ? sc0 : i == 1 ? sc1 : i == 2 ? sc2 : i == 3 ? sc3 : sc4; };
-  const char* zero_src = reinterpret_cast<const char*>(g_wino4_zero);
-  asm volatile("" : "+s"(zero_src));
-  const int n_src = a.n_src;
-  auto issue_patch = [&](int stage) {
-    float* s_in = smem + stage * IN_PAD;
-    const int sc = src_c_of(p_cs);
-    const char* sp = reinterpret_cast<const char*>(src_of(p_cs) + ((size_t)p_bn * sc + p_cc0) * plane);
-    const char* zp = zero_src;
-#pragma unroll
-    for (int i = 0; i < P_IT; ++i) {
-      const int seg = i * 4 + wave;
-      if (seg < IN_SEGS) {   // wave-uniform
-        const bool ok = voff[i] != 0xFFFFFFFFu;
-        __builtin_amdgcn_global_load_lds((gptr_t)(ok ? sp + voff[i] : zp), (lptr_t)(s_in + seg * 256), 16, 0, 0);
-      }
-    }
-    p_cc0 += CK;
-    if (p_cc0 >= sc) {
-      ++p_cs;
-      p_cc0 = 0;
-      if (p_cs >= n_src) {
-        p_cs = 0;
-        ++p_k;
-        if (p_k < my_tiles) p_setup_tile();
-      }
-    }
-  };
-  // the weight slab of chunk g -> U stage, by waves 6 and 7 (18 one-KiB pieces each)
-  auto issue_u67 = [&](int g, int stage) {
-    float* s_u = smem + OFF_U + stage * U_ELEMS;
-    const char* usrc = reinterpret_cast<const char*>(wu_base + (size_t)g * U_ELEMS) + (wave - 6) * 1024;
-#pragma unroll
-    for (int i = 0; i < U_SEGS / 2; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * 2048 + lane16), (lptr_t)(s_u + (i * 2 + (wave - 6)) * 256), 16, 0, 0);
-  };
-
-  // input transform of one chunk by waves 4 and 5: lane (kq, l15) of wave 4 + u: channel kq, tile (row u, column l15)
-  auto transform = [&](int ps, int vs) __attribute__((always_inline)) {
-    float* vd = s_v + vs * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));   // + (xi / 2) * 256 + (xi & 1)
-    f32x2 t12[6], t34[6], t05[6];
-    if (R == 3) {
-      const float* pp = smem + ps * IN_PAD + kq * (IH * IW) + (M * tg) * IW + 4 * l15;
-      {
-        f32x4 q[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) q[r] = *reinterpret_cast<const f32x4*>(pp + r * IW + 4);
-        f32x2 d[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][0], q[r][1]};
-        in1d(d, t12);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) d[r] = f32x2{q[r][2], q[r][3]};
-        in1d(d, t34);
-      }
-      {
-        f32x2 d[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW + 3], pp[r * IW + 8]};
-        in1d(d, t05);
-      }
-    } else {
-      const float* pp = smem + ps * IN_PAD + kq * (IH * IW) + (M * tg) * IW + (MARG - PADR) + 2 * l15;
-      f32x2 d[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(pp + r * IW);
-      in1d(d, t05);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(pp + r * IW + 2);
-      in1d(d, t12);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x2*>(pp + r * IW + 4);
-      in1d(d, t34);
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const float d3[6] = {t05[i].x, t12[i].x, t12[i].y, t34[i].x, t34[i].y, t05[i].y};
-      const float d5[6] = {t05[i].x, t05[i].y, t12[i].x, t12[i].y, t34[i].x, t34[i].y};
-      const float (&d)[6] = R == 3 ? d3 : d5;
-      float o[6];
-      in1d(d, o);
-#pragma unroll
-      for (int j = 0; j < 6; j += 2) *reinterpret_cast<f32x2*>(vd + (i * 3 + j / 2) * (CK * 64)) = f32x2{o[j], o[j + 1]};
-    }
-  };
-
-  // the 36 GEMM steps of this wave on stage st: M_xi[co, t] += sum over the chunk's 4 channels U_xi[co, c] V_xi[c, t]
-  auto gemm = [&](int st) __attribute__((always_inline)) {
-    const float* ua = smem + OFF_U + st * U_ELEMS + kq * 128 + 2 * ((cb * 16 + l15) ^ ((kq & 1) << 4));
-    const float* vb = s_v + st * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));
-    constexpr int AHEAD = 3, NSTEP = NPOS / 2;
-    f32x2 av[AHEAD + 1], bv[AHEAD + 1];
-#pragma unroll
-    for (int i = 0; i < AHEAD; ++i) {
-      av[i] = *reinterpret_cast<const f32x2*>(ua + i * (CK * 128));
-      bv[i] = *reinterpret_cast<const f32x2*>(vb + i * (CK * 64));
-    }
-#pragma unroll
-    for (int i = 0; i < NSTEP; ++i) {
-      if (i + AHEAD < NSTEP) {
-        av[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(ua + (i + AHEAD) * (CK * 128));
-        bv[(i + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(vb + (i + AHEAD) * (CK * 64));
-      }
-      const int cur = i % (AHEAD + 1);
-      acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur].x, bv[cur].x, acc[2 * i], 0, 0, 0);
-      acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur].y, bv[cur].y, acc[2 * i + 1], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the 2 reads of step i + AHEAD
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // the 2 MFMAs of step i
-    }
-  };
-
-  // the same steps without their own scheduling directives (the hosted transform's block brings its own pipeline)
-  auto gemm_plain = [&](int st) __attribute__((always_inline)) {
-    const float* ua = smem + OFF_U + st * U_ELEMS + kq * 128 + 2 * ((cb * 16 + l15) ^ ((kq & 1) << 4));
-    const float* vb = s_v + st * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));
-#pragma unroll
-    for (int i = 0; i < NPOS / 2; ++i) {
-      const f32x2 av = *reinterpret_cast<const f32x2*>(ua + i * (CK * 128));
-      const f32x2 bv = *reinterpret_cast<const f32x2*>(vb + i * (CK * 64));
-      acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[2 * i], 0, 0, 0);
-      acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[2 * i + 1], 0, 0, 0);
-    }
-  };
-
-  // epilogue of this wave's block of tile (e_bn, e_y0, e_x0), all in registers; leaves its per-channel sums in s_red set `rs`
-  auto epilogue = [&](int e_bn, int e_y0, int e_x0, int rs) __attribute__((always_inline)) {
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (R == 3) {
-      const int gx = e_x0 + 4 * l15;
-#pragma unroll
-      for (int rp = 0; rp < 2; ++rp) {
-        const int co0 = cot * 64 + cb * 16 + 4 * kq + 2 * rp;
-#pragma unroll
-        for (int dy = 0; dy < 4; ++dy) {
-          __builtin_amdgcn_sched_barrier(0);
-          const int gy = e_y0 + 4 * tg + dy;
-          const bool pok = gy < h && gx < w;
-          f32x4 rr[2];
-#pragma unroll
-          for (int ch = 0; ch < 2; ++ch) {
-            rr[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.residual != nullptr && co0 + ch < a.cout && pok)
-              rr[ch] = *reinterpret_cast<const f32x4*>(a.residual + ((size_t)e_bn * a.cout + co0 + ch) * plane + (size_t)gy * w + gx);
-          }
-          f32x2 s[6];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            f32x2 m[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[i * 6 + q][2 * rp], acc[i * 6 + q][2 * rp + 1]};
-            if (dy == 0) s[q] = m[0] + (m[1] + m[2]) + (m[3] + m[4]);
-            else if (dy == 1) s[q] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
-            else if (dy == 2) s[q] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
-            else s[q] = ((m[1] - m[2]) + 8.f * (m[3] - m[4])) + m[5];
-          }
-          const f32x2 p1 = s[1] + s[2], p2 = s[1] - s[2], p3 = s[3] + s[4], p4 = s[3] - s[4];
-          f32x2 y[4];
-          y[0] = s[0] + p1 + p3;
-          y[1] = p2 + 2.f * p4;
-          y[2] = p1 + 4.f * p3;
-          y[3] = (p2 + 8.f * p4) + s[5];
-          float vv[2][4];
-#pragma unroll
-          for (int ch = 0; ch < 2; ++ch) {
-            const int r = 2 * rp + ch;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float t = (ch == 0 ? y[j].x : y[j].y) + bias_r[r];
-              vv[ch][j] = fmaxf(t, t * act_s);
-            }
-          }
-          if (a.out_shuffle == 2) {
-            if (co0 + 1 < a.cout && pok) {
-              float* o = a.out + ((size_t)e_bn * (a.cout >> 2) + (co0 >> 2)) * (4 * plane) + (size_t)(2 * gy + rp) * (2 * w) + 2 * gx;
-              *reinterpret_cast<f32x4*>(o) = f32x4{vv[0][0], vv[1][0], vv[0][1], vv[1][1]};
-              *reinterpret_cast<f32x4*>(o + 4) = f32x4{vv[0][2], vv[1][2], vv[0][3], vv[1][3]};
-            }
-          } else {
-#pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
-              const int r = 2 * rp + ch, co = co0 + ch;
-              if (co < a.cout && pok) {
-                csum[r] += (vv[ch][0] + vv[ch][1]) + (vv[ch][2] + vv[ch][3]);
-                *reinterpret_cast<f32x4*>(a.out + ((size_t)e_bn * a.cout + co) * plane + (size_t)gy * w + gx) =
-                    f32x4{vv[ch][0] + rr[ch][0], vv[ch][1] + rr[ch][1], vv[ch][2] + rr[ch][2], vv[ch][3] + rr[ch][3]};
-              }
-            }
-          }
-        }
-      }
-    } else {
-      const int gx = e_x0 + 2 * l15;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = cot * 64 + cb * 16 + 4 * kq + r;
-        const bool cok = co < a.cout;
-        const float bb = bias_r[r];
-        __builtin_amdgcn_sched_barrier(0);
-        f32x2 rr[2];
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-          const int gy = e_y0 + 2 * tg + dy;
-          rr[dy] = f32x2{0.f, 0.f};
-          if (a.residual != nullptr && cok && gy < h && gx < w)
-            rr[dy] = *reinterpret_cast<const f32x2*>(a.residual + ((size_t)e_bn * a.cout + co) * plane + (size_t)gy * w + gx);
-        }
-        float s[2][6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          const float m0 = acc[0 * 6 + q][r], m1 = acc[1 * 6 + q][r], m2 = acc[2 * 6 + q][r], m3 = acc[3 * 6 + q][r],
-                      m4 = acc[4 * 6 + q][r], m5 = acc[5 * 6 + q][r];
-          s[0][q] = m0 + (m1 + m2) + (m3 + m4);
-          s[1][q] = ((m1 - m2) + 2.f * (m3 - m4)) + m5;
-        }
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-          float y[2];
-          y[0] = s[dy][0] + (s[dy][1] + s[dy][2]) + (s[dy][3] + s[dy][4]);
-          y[1] = ((s[dy][1] - s[dy][2]) + 2.f * (s[dy][3] - s[dy][4])) + s[dy][5];
-          const int gy = e_y0 + 2 * tg + dy;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            y[j] += bb;
-            y[j] = fmaxf(y[j], y[j] * act_s);
-          }
-          if (cok && gy < h && gx < w) {
-            csum[r] += y[0] + y[1];
-            *reinterpret_cast<f32x2*>(a.out + ((size_t)e_bn * a.cout + co) * plane + (size_t)gy * w + gx) =
-                f32x2{y[0] + rr[dy].x, y[1] + rr[dy].y};
-          }
-        }
-      }
-    }
-    if (a.chan_partial) {
-      // per output channel: 16 lanes (tiles) here and the same again in wave ^ 1 (summed in a fixed order by the writer below)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = csum[r];
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 1);
-        if (l15 == 0) s_red[rs * 128 + tg * 64 + cb * 16 + 4 * kq + r] = v;
-      }
-    }
-#pragma unroll
-    for (int x = 0; x < NPOS; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  auto write_partial = [&](int w_bn, int w_lin, int rs) __attribute__((always_inline)) {   // one wave, after a barrier behind both groups' sums
-    const int co = cot * 64 + lane;
-    if (co < a.cout)
-      a.chan_partial[((size_t)w_bn * (a.tiles_x * a.tiles_y) + w_lin) * a.cout + co] = s_red[rs * 128 + lane] + s_red[rs * 128 + 64 + lane];
-  };
-
-  // ---- prologue: patches of chunks 0, 1, 2 (group A), U(0) (requested at entry), transform of chunk 0 (waves 4, 5) ----
-  if (grp_a) {
-    p_setup_tile();
-    issue_patch(0);
-    if (total_iters > 1) issue_patch(1);
-    if (total_iters > 2) issue_patch(2);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (!grp_a && wave < 6) transform(0, 0);
-  __syncthreads();
-
-  // Group B's service for iteration j (its half 0): V(j + 1) by waves 4, 5; U(j + 1) by waves 6, 7
-  int u_next = total_chunks > 1 ? 1 : 0;   // chunk (within the tile) of the next weight slab to request
-#ifdef EAVSR_W6P_HOST
-  // hosted transform: waves 4, 5 run the input transform of chunk j + 1 INSIDE their own 36 GEMM steps of chunk j (one basic
-  // block, interleaved by the scheduling pipeline below): its dependent chain -- two LDS round trips, ~150 vector instructions,
-  // nine LDS stores; 1,800-2,500 cycles as a block of its own -- hides under the wave's own MFMAs.  U(j + 1) is requested by
-  // all four waves of group B in their service half (9 pieces each).
-  auto issue_u_b = [&](int g, int stage) {
-    float* s_u = smem + OFF_U + stage * U_ELEMS;
-    const char* usrc = reinterpret_cast<const char*>(wu_base + (size_t)g * U_ELEMS) + (wave - 4) * 1024;
-#pragma unroll
-    for (int i = 0; i < U_SEGS / 4; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * 4096 + lane16), (lptr_t)(s_u + (i * 4 + (wave - 4)) * 256), 16, 0, 0);
-  };
-  auto service_b = [&](int j) __attribute__((always_inline)) {
-    if (j + 1 < total_iters) {
-      issue_u_b(u_next, (j + 1) & 1);
-      u_next = u_next + 1 == total_chunks ? 0 : u_next + 1;
-    }
-  };
-#else
-  auto service_b = [&](int j) __attribute__((always_inline)) {
-    if (j + 1 < total_iters) {
-      if (wave < 6) transform((j + 1) % 3, (j + 1) & 1);
-      else {
-        issue_u67(u_next, (j + 1) & 1);
-        u_next = u_next + 1 == total_chunks ? 0 : u_next + 1;
-      }
-    }
-  };
-#endif
-  if (!grp_a) {
-    __builtin_amdgcn_s_setprio(EAVSR_W6P_PRIO_SVC);
-    service_b(0);
-  }
-
-  // One loop body for both groups -- one GEMM site, one epilogue site (two inlined copies of either make the register allocator
-  // copy the 144 accumulators) -- group B runs it half an iteration behind group A:
-  //   A:  [MFMAs it] b [patch it + 3, channel sums, epilogue] b [MFMAs it + 1] ...
-  //   B:  [V / U it + 1] b [MFMAs it] b [V / U it + 2, epilogue] b ...
-  int chunk = 0, tile_k = 0;
-  bool part_pending = false;              // the channel sums of the previous tile are complete in s_red after group A's next barrier
-  int w_bn = 0, w_lin = 0, w_rs = 0;
-  for (int it = 0; it < total_iters; ++it) {
-    const bool last = chunk + 1 == total_chunks;
-    W4_IT(0);
-    if (!grp_a) __syncthreads();                            // B: end of its service half
-    W4_IT(1);
-    __builtin_amdgcn_s_setprio(EAVSR_W6P_PRIO_GEMM);
-#ifdef EAVSR_W6P_HOST
-    if (!grp_a && wave < 6 && it + 1 < total_iters) {
-      __builtin_amdgcn_sched_barrier(0);
-      transform((it + 1) % 3, (it + 1) & 1);
-      gemm_plain(it & 1);
-      // the pipeline of this block: per GEMM step 2 operand reads (+ the patch reads while they last), 2 MFMAs, a slice of the
-      // transform's vector work, and its LDS stores as they become ready
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-      }
-#pragma unroll
-      for (int i = 6; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-      }
-#pragma unroll
-      for (int i = 8; i < NPOS / 2; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      gemm(it & 1);
-    }
-#else
-    gemm(it & 1);
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    W4_IT(2);
-    // A: its pieces of the patch of chunk it + 2 (requested in its last service half); B: U(it + 1), the epilogue's stores
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    W4_IT(3);
-    __syncthreads();                                        // A: end of half 0; B: end of half 1
-    W4_IT(4);
-    __builtin_amdgcn_s_setprio(EAVSR_W6P_PRIO_SVC);
-    if (grp_a) {
-      if (it + 3 < total_iters) issue_patch(it % 3);        // chunk it + 3 -> the stage the transform of chunk it has read
-      if (part_pending && wave == 0) write_partial(w_bn, w_lin, w_rs);
-    } else {
-      service_b(it + 1);
-    }
-    W4_IT(5);
-    part_pending = false;
-    if (last) {
-      epilogue(bn, y0, x0, tile_k & 1);
-      part_pending = a.chan_partial != nullptr; w_bn = bn; w_lin = tile_lin; w_rs = tile_k & 1;
-      ++tile_k;
-      if (it + 1 < total_iters) tile_coords(tile_k, bn, y0, x0, tile_lin);
-    }
-    if (grp_a) __syncthreads();                             // A: end of half 1
-    W4_IT(6);
-    chunk = last ? 0 : chunk + 1;
-  }
-  if (part_pending) {
-    __syncthreads();
-    if (wave == 0) write_partial(w_bn, w_lin, w_rs);
-  }
-#ifdef EAVSR_W4_ITSTAMP
-  __syncthreads();
-  if (tid < 256) g_w4_it[(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid] = s_its[tid];
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Quarter-job schedule (round 3): every wave the same program again, but nobody is "on duty".
-//
-// The per-wave stamps of the kernels above (tools/gpu_wino4_itstamp.py) put the input transform on the critical path: as one
-// wave's job it is a 1,800-2,500-cycle dependent chain (two LDS round trips, ~150 vector instructions, nine wide LDS stores) in
-// front of that wave's 36 MFMAs, while the other waves wait at the barrier.  Here the 6 x 6 transform of a (channel, tile) job is
-// cut into four quarter jobs -- output rows {0,1,2} | {3,4,5} x output columns {0,1,2} | {3,4,5} -- and lane (kq, l15) of wave
-// (cb, tg) computes quarter cb of job (channel kq, tile (tg, l15)): 9 of the 36 positions, 18 packed + ~36 plain vector
-// instructions, three 8-byte and three 4-byte LDS stores.  All eight waves carry the same small slice, and it sits in the SAME
-// basic block as the wave's 36 MFMAs of the current chunk, interleaved by the scheduling pipeline at the end of the block: its
-// LDS latencies and dependent chains run under the wave's own matrix work.
-//   B^T rows 1,2 = (d4 - 4 d2) +- (d3 - 4 d1), rows 3,4 = (d4 - d2) +- 2 (d3 - d1): one formula A +- beta B with
-//   A = d4 - alpha d2, B = d3 - alpha d1, (alpha, beta) = (4, 1) | (1, 2); rows 0 / 5 = 4 s0 - 5 s1 + s2 on input rows
-//   (0, 2, 4) | (1, 3, 5).  The same split applies to the columns.  The row half is a matter of LDS addresses (the three
-//   source rows of the single output are read separately), the column half of a few selects: no branch in the block.
-template <int R>
-__global__ __launch_bounds__(512, 2) void conv_wino6q_kernel(W4Args a) {
-  using C = WCfg<R>;
-  constexpr int M = C::M, PADR = C::PADR, TOH = C::TOH, TOW = C::TOW, IH = C::IH, IW = C::IW, IN_ELEMS = C::IN_ELEMS;
-  constexpr int IN_SEGS = C::IN_SEGS, IN_PAD = C::IN_PAD, IN_IT = C::IN_IT, OFF_U = C::OFF_U, OFF_V = C::OFF_V;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_v = smem + OFF_V;
-  float* s_red = smem + C::LDS_MAIN;
-#ifdef EAVSR_W4_ITSTAMP
-  unsigned long long* s_its = reinterpret_cast<unsigned long long*>(smem + C::LDS_MAIN + 128);
-#endif
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned lane16 = lane * 16u;
-  const float* const wu_base = a.wu + (size_t)blockIdx.y * (a.cin / CK) * U_ELEMS;
-  auto issue_u = [&](int g, int stage) {
-    float* s_u = smem + OFF_U + stage * U_ELEMS;
-    const char* usrc = reinterpret_cast<const char*>(wu_base + (size_t)g * U_ELEMS) + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < U_IT; ++i) {
-      const int seg = i * NW + wave;
-      if (seg < U_SEGS)
-        __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * (NW * 1024) + lane16), (lptr_t)(s_u + seg * 256), 16, 0, 0);
-    }
-  };
-  issue_u(0, 0);   // the first weight slab does not depend on the tile: requested before the set-up arithmetic
-
-  const int cot = blockIdx.y;
-  const int h = a.h, w = a.w;
-  const size_t plane = (size_t)h * w;
-  const int total_tiles = a.tiles_x * a.tiles_y * a.n;
-  const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  auto tile_coords = [&](int k, int& bn_, int& y0_, int& x0_, int& lin_) __attribute__((always_inline)) {
-    int t = eavsr_xcd_remap((int)blockIdx.x + k * (int)gridDim.x, total_tiles);
-    const int tx_ = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty_ = t % a.tiles_y;
-    bn_ = t / a.tiles_y;
-    y0_ = ty_ * TOH;
-    x0_ = tx_ * TOW;
-    lin_ = ty_ * a.tiles_x + tx_;
-  };
-
-  const int l15 = lane & 15, kq = lane >> 4;
-  const int cb = wave >> 1, tg = wave & 1;
-  eavsr_stagger_priority(wave);
-  float bias_r[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = cot * 64 + cb * 16 + 4 * kq + r;
-    bias_r[r] = (co < a.cout && a.bias != nullptr) ? a.bias[co] : 0.f;
-  }
-  const float act_s = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope;
-  f32x4 acc[NPOS];
-#pragma unroll
-  for (int x = 0; x < NPOS; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  int total_chunks = 0;
-  for (int s = 0; s < a.n_src; ++s) total_chunks += a.src_c[s] / CK;
-  const int total_iters = my_tiles * total_chunks;
-
-  // ---- patch stream (two chunks ahead of the compute stream, across tile boundaries) ----
-  int p_k = 0, p_cs = 0, p_cc0 = 0, p_bn = 0, p_y0 = 0, p_x0 = 0, p_lin = 0;
-  unsigned voff[IN_IT];
-  auto p_setup_tile = [&]() __attribute__((always_inline)) {
-    tile_coords(p_k, p_bn, p_y0, p_x0, p_lin);
-#pragma unroll
-    for (int i = 0; i < IN_IT; ++i) {
-      const int seg = i * NW + wave;
-      const int e4 = seg * 64 + lane;
-      const int ci = e4 / (IH * (IW / 4));
-      const int rem = e4 - ci * (IH * (IW / 4));
-      const int r = rem / (IW / 4);
-      const int c4 = rem - r * (IW / 4);
-      const int gy = p_y0 - PADR + r, gx = p_x0 - MARG + 4 * c4;
-      const bool ok = e4 < IN_ELEMS / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;
-      voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
-    }
-  };
-  p_setup_tile();
-  int bn = 0, y0 = 0, x0 = 0, tile_lin = 0;
-  tile_coords(0, bn, y0, x0, tile_lin);
-  const float* const sp0 = a.src[0]; const float* const sp1 = a.src[1]; const float* const sp2 = a.src[2];
-  const float* const sp3 = a.src[3]; const float* const sp4 = a.src[4];
-  const int sc0 = a.src_c[0], sc1 = a.src_c[1], sc2 = a.src_c[2], sc3 = a.src_c[3], sc4 = a.src_c[4];
-  auto src_of = [&](int i) __attribute__((always_inline)) { return i == 0 ? sp0 : i == 1 ? sp1 : i == 2 ? sp2 : i == 3 ? sp3 : sp4; };
-  auto src_c_of = [&](int i) __attribute__((always_inline)) { return i == 0 ? sc0 : i == 1 ? sc1 : i == 2 ? sc2 : i == 3 ? sc3 : sc4; };
-  const char* zero_src = reinterpret_cast<const char*>(g_wino4_zero);
-  asm volatile("" : "+s"(zero_src));
-  const int n_src = a.n_src;
-  auto issue_patch = [&](int stage) {
-    float* s_in = smem + stage * IN_PAD;
-    const int sc = src_c_of(p_cs);
-    const char* sp = reinterpret_cast<const char*>(src_of(p_cs) + ((size_t)p_bn * sc + p_cc0) * plane);
-    const char* zp = zero_src;
-#pragma unroll
-    for (int i = 0; i < IN_IT; ++i) {
-      const int seg = i * NW + wave;
-      if (seg < IN_SEGS) {   // wave-uniform
-        const bool ok = voff[i] != 0xFFFFFFFFu;
-        __builtin_amdgcn_global_load_lds((gptr_t)(ok ? sp + voff[i] : zp), (lptr_t)(s_in + seg * 256), 16, 0, 0);
-      }
-    }
-    p_cc0 += CK;
-    if (p_cc0 >= sc) {
-      ++p_cs;
-      p_cc0 = 0;
-      if (p_cs >= n_src) {
-        p_cs = 0;
-        ++p_k;
-        if (p_k < my_tiles) p_setup_tile();
-      }
-    }
-  };
-
-  // ---- quarter-job constants of this wave ----
-  const int rh = cb >> 1, ch = cb & 1;                       // output-row half, output-column half
-  const float al_r = rh ? 1.f : 4.f, be_r = rh ? 2.f : 1.f;  // rows 1,2 | 3,4
-  const float al_c = ch ? 1.f : 4.f, be_c = ch ? 2.f : 1.f;  // columns 1,2 | 3,4
-  const bool chb = ch != 0;
-  // LDS float offsets: patch row of this lane's tile (R = 3: the 6 x 6 patch of tile column l15 starts at column 3 + 4 l15)
-  const int p_lane = kq * (IH * IW) + (M * tg) * IW + (R == 3 ? 4 * l15 : (MARG - PADR) + 2 * l15);
-  // V destination of this lane: + pair * (CK * 64) + (xi & 1); the three output rows of this quarter are 3 rh + {0, 1, 2} in
-  // the order (single, plus, minus) = rows (0, 1, 2) | (5, 3, 4)
-  const int v_lane = kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));
-  const int row_s = rh ? 5 : 0, row_p = rh ? 3 : 1, row_m = rh ? 4 : 2;
-  // per output row: the 8-byte store goes to pair 3 row + 2 ch, the 4-byte store to pair 3 row + 1, half ch
-  const int vo_s = (3 * row_s) * (CK * 64), vo_p = (3 * row_p) * (CK * 64), vo_m = (3 * row_m) * (CK * 64);
-  const int vq64 = 2 * ch * (CK * 64), vq32 = (CK * 64) + ch;
-
-  unsigned tok = 0;   // orders the inline-assembly V stores among themselves (transform_gemm)
-  // quarter transform of chunk patch stage ps -> V stage vs, and the 36 GEMM steps on stage st: ONE basic block
-  auto transform_gemm = [&](int ps, int vs, int st) __attribute__((always_inline)) {
-    const float* pp = smem + ps * IN_PAD + p_lane;
-    float* vd = s_v + vs * V_ELEMS + v_lane;
-    // column pass on packed column pairs: rows d1..d4 (common) and the three source rows of the single output
-    f32x2 c12[4], c34[4], c05[4], s12[3], s34[3], s05[3];
-    if (R == 3) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(pp + (r + 1) * IW + 4);
-        c12[r] = f32x2{q[0], q[1]};
-        c34[r] = f32x2{q[2], q[3]};
-        c05[r] = f32x2{pp[(r + 1) * IW + 3], pp[(r + 1) * IW + 8]};
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float* ps_ = pp + (2 * r + rh) * IW;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(ps_ + 4);
-        s12[r] = f32x2{q[0], q[1]};
-        s34[r] = f32x2{q[2], q[3]};
-        s05[r] = f32x2{ps_[3], ps_[8]};
-      }
-    } else {
-      // 5x5: pairs (c0, c1), (c2, c3), (c4, c5) as three aligned 8-byte reads per row; renamed so that both sizes share the passes
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x2 q0 = *reinterpret_cast<const f32x2*>(pp + (r + 1) * IW), q1 = *reinterpret_cast<const f32x2*>(pp + (r + 1) * IW + 2),
-                    q2 = *reinterpret_cast<const f32x2*>(pp + (r + 1) * IW + 4);
-        c05[r] = f32x2{q0.x, q2.y};
-        c12[r] = f32x2{q0.y, q1.x};
-        c34[r] = f32x2{q1.y, q2.x};
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float* ps_ = pp + (2 * r + rh) * IW;
-        const f32x2 q0 = *reinterpret_cast<const f32x2*>(ps_), q1 = *reinterpret_cast<const f32x2*>(ps_ + 2), q2 = *reinterpret_cast<const f32x2*>(ps_ + 4);
-        s05[r] = f32x2{q0.x, q2.y};
-        s12[r] = f32x2{q0.y, q1.x};
-        s34[r] = f32x2{q1.y, q2.x};
-      }
-    }
-    // c..[0..3] = input rows d1..d4; t_s / t_p / t_m: the three output rows of this half for column pairs (1,2), (3,4), (0,5)
-    auto col3 = [&](const f32x2 (&c)[4], const f32x2 (&sr)[3], f32x2& ts, f32x2& tp, f32x2& tm) __attribute__((always_inline)) {
-      const f32x2 A = c[3] - al_r * c[1];
-      const f32x2 B = c[2] - al_r * c[0];
-      tp = A + be_r * B;
-      tm = A - be_r * B;
-      ts = 4.f * sr[0] + (sr[2] - 5.f * sr[1]);
-    };
-    f32x2 ts12, tp12, tm12, ts34, tp34, tm34, ts05, tp05, tm05;
-    col3(c12, s12, ts12, tp12, tm12);
-    col3(c34, s34, ts34, tp34, tm34);
-    col3(c05, s05, ts05, tp05, tm05);
-    // row pass of one output row: x0..x5 = (t05.x, t12.x, t12.y, t34.x, t34.y, t05.y); outputs of this column half
-    // The V stores are inline assembly WITHOUT a memory clobber: as ordinary stores they may alias the GEMM's V reads below (same
-    // array, run-time stage index) and the scheduler would finish the whole transform before the first operand read -- the
-    // serial chain this kernel exists to remove.  They write stage vs, the GEMM reads stage st != vs; the loop's barrier (behind
-    // an explicit lgkmcnt(0)) publishes them.  `tok` chains them so that none is dropped.
-    const unsigned vbase = (unsigned)(uintptr_t)(lptr_t)vd;
-    auto row3 = [&](const f32x2& t05, const f32x2& t12, const f32x2& t34, int vo) __attribute__((always_inline)) {
-      const float A = t34.y - al_c * t12.y;
-      const float B = t34.x - al_c * t12.x;
-      const float op = A + be_c * B;
-      const float om = A - be_c * B;
-      const float u0 = chb ? t12.x : t05.x, u1 = chb ? t34.x : t12.y, u2 = chb ? t05.y : t34.y;
-      const float os = 4.f * u0 + (u2 - 5.f * u1);
-      // columns (0, 1 | 2) of half 0: (os, op | om); columns (3 | 4, 5) of half 1: (op | om, os)
-      const f32x2 w64 = chb ? f32x2{om, os} : f32x2{os, op};
-      const float w32 = chb ? op : om;
-      const unsigned a64 = vbase + 4u * (unsigned)(vo + vq64), a32 = vbase + 4u * (unsigned)(vo + vq32);
-      asm("ds_write_b64 %1, %2" : "+v"(tok) : "v"(a64), "v"(w64));
-      asm("ds_write_b32 %1, %2" : "+v"(tok) : "v"(a32), "v"(w32));
-    };
-    row3(ts05, ts12, ts34, vo_s);
-    row3(tp05, tp12, tp34, vo_p);
-    row3(tm05, tm12, tm34, vo_m);
-
-    const float* ua = smem + OFF_U + st * U_ELEMS + kq * 128 + 2 * ((cb * 16 + l15) ^ ((kq & 1) << 4));
-    const float* vb = s_v + st * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));
-#pragma unroll
-    for (int i = 0; i < NPOS / 2; ++i) {
-      const f32x2 av = *reinterpret_cast<const f32x2*>(ua + i * (CK * 128));
-      const f32x2 bv = *reinterpret_cast<const f32x2*>(vb + i * (CK * 64));
-      acc[2 * i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[2 * i], 0, 0, 0);
-      acc[2 * i + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[2 * i + 1], 0, 0, 0);
-    }
-    // the block's pipeline: per GEMM step its operand reads (the patch reads ride along while they last), 2 MFMAs, a slice of
-    // the transform's vector work, and its LDS stores once their values exist
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    }
-#pragma unroll
-    for (int i = 7; i < 12; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-    }
-#pragma unroll
-    for (int i = 12; i < NPOS / 2; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    }
-  };
-  // the transform alone (chunk 0, before the loop)
-  auto transform_only = [&](int ps, int vs) __attribute__((always_inline)) {
-    const float* pp = smem + ps * IN_PAD + p_lane;
-    float* vd = s_v + vs * V_ELEMS + v_lane;
-    f32x2 c12[4], c34[4], c05[4], s12[3], s34[3], s05[3];
-    if (R == 3) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(pp + (r + 1) * IW + 4);
-        c12[r] = f32x2{q[0], q[1]};
-        c34[r] = f32x2{q[2], q[3]};
-        c05[r] = f32x2{pp[(r + 1) * IW + 3], pp[(r + 1) * IW + 8]};
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float* ps_ = pp + (2 * r + rh) * IW;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(ps_ + 4);
-        s12[r] = f32x2{q[0], q[1]};
-        s34[r] = f32x2{q[2], q[3]};
-        s05[r] = f32x2{ps_[3], ps_[8]};
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x2 q0 = *reinterpret_cast<const f32x2*>(pp + (r + 1) * IW), q1 = *reinterpret_cast<const f32x2*>(pp + (r + 1) * IW + 2),
-                    q2 = *reinterpret_cast<const f32x2*>(pp + (r + 1) * IW + 4);
-        c05[r] = f32x2{q0.x, q2.y};
-        c12[r] = f32x2{q0.y, q1.x};
-        c34[r] = f32x2{q1.y, q2.x};
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float* ps_ = pp + (2 * r + rh) * IW;
-        const f32x2 q0 = *reinterpret_cast<const f32x2*>(ps_), q1 = *reinterpret_cast<const f32x2*>(ps_ + 2), q2 = *reinterpret_cast<const f32x2*>(ps_ + 4);
-        s05[r] = f32x2{q0.x, q2.y};
-        s12[r] = f32x2{q0.y, q1.x};
-        s34[r] = f32x2{q1.y, q2.x};
-      }
-    }
-    auto col3 = [&](const f32x2 (&c)[4], const f32x2 (&sr)[3], f32x2& ts, f32x2& tp, f32x2& tm) __attribute__((always_inline)) {
-      const f32x2 A = c[3] - al_r * c[1];
-      const f32x2 B = c[2] - al_r * c[0];
-      tp = A + be_r * B;
-      tm = A - be_r * B;
-      ts = 4.f * sr[0] + (sr[2] - 5.f * sr[1]);
-    };
-    f32x2 ts12, tp12, tm12, ts34, tp34, tm34, ts05, tp05, tm05;
-    col3(c12, s12, ts12, tp12, tm12);
-    col3(c34, s34, ts34, tp34, tm34);
-    col3(c05, s05, ts05, tp05, tm05);
-    auto row3 = [&](const f32x2& t05, const f32x2& t12, const f32x2& t34, int vo) __attribute__((always_inline)) {
-      const float A = t34.y - al_c * t12.y;
-      const float B = t34.x - al_c * t12.x;
-      const float op = A + be_c * B;
-      const float om = A - be_c * B;
-      const float u0 = chb ? t12.x : t05.x, u1 = chb ? t34.x : t12.y, u2 = chb ? t05.y : t34.y;
-      const float os = 4.f * u0 + (u2 - 5.f * u1);
-      const f32x2 w64 = chb ? f32x2{om, os} : f32x2{os, op};
-      const float w32 = chb ? op : om;
-      *reinterpret_cast<f32x2*>(vd + vo + vq64) = w64;
-      vd[vo + vq32] = w32;
-    };
-    row3(ts05, ts12, ts34, vo_s);
-    row3(tp05, tp12, tp34, vo_p);
-    row3(tm05, tm12, tm34, vo_m);
-  };
-
-  // ---- prologue ----
-  issue_patch(0);
-  if (total_iters > 1) issue_patch(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  transform_only(0, 0);
-
-  int chunk = 0;
-  for (int it = 0; it < total_iters; ++it) {
-    W4_IT(0);
-    // U(it) and the patch of chunk it + 1 (requested during iteration it - 1) have landed; V(it) is complete (its stores are
-    // inline assembly: the explicit lgkmcnt(0)); every wave is done with the stages of iteration it - 1
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(tok) : "memory");
-    W4_IT(1);
-    __syncthreads();
-    W4_IT(2);
-    const int chunk_n = chunk + 1 == total_chunks ? 0 : chunk + 1;
-    if (it + 1 < total_iters) issue_u(chunk_n, (it + 1) & 1);
-    if (it + 2 < total_iters) issue_patch(it & 1);
-    W4_IT(3);
-    __builtin_amdgcn_sched_barrier(0);
-    // (after the last chunk the transform reads a stale patch stage into a V stage nobody reads: no branch in the block)
-    transform_gemm((it + 1) & 1, (it + 1) & 1, it & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    W4_IT(7);
-    chunk = chunk_n;
-    if (chunk != 0) continue;   // the tile is not finished yet
-
-    // ---- epilogue, all in registers (as conv_wino6_kernel) ----
-    {
-      float csum[4] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (R == 3) {
-        const int gx = x0 + 4 * l15;
-#pragma unroll
-        for (int rp = 0; rp < 2; ++rp) {
-          const int co0 = cot * 64 + cb * 16 + 4 * kq + 2 * rp;
-#pragma unroll
-          for (int dy = 0; dy < 4; ++dy) {
-            __builtin_amdgcn_sched_barrier(0);
-            const int gy = y0 + 4 * tg + dy;
-            const bool pok = gy < h && gx < w;
-            f32x4 rr[2];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-              rr[c2] = f32x4{0.f, 0.f, 0.f, 0.f};
-              if (a.residual != nullptr && co0 + c2 < a.cout && pok)
-                rr[c2] = *reinterpret_cast<const f32x4*>(a.residual + ((size_t)bn * a.cout + co0 + c2) * plane + (size_t)gy * w + gx);
-            }
-            f32x2 s[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-              f32x2 m[6];
-#pragma unroll
-              for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[i * 6 + q][2 * rp], acc[i * 6 + q][2 * rp + 1]};
-              if (dy == 0) s[q] = m[0] + (m[1] + m[2]) + (m[3] + m[4]);
-              else if (dy == 1) s[q] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
-              else if (dy == 2) s[q] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
-              else s[q] = ((m[1] - m[2]) + 8.f * (m[3] - m[4])) + m[5];
-            }
-            const f32x2 p1 = s[1] + s[2], p2 = s[1] - s[2], p3 = s[3] + s[4], p4 = s[3] - s[4];
-            f32x2 y[4];
-            y[0] = s[0] + p1 + p3;
-            y[1] = p2 + 2.f * p4;
-            y[2] = p1 + 4.f * p3;
-            y[3] = (p2 + 8.f * p4) + s[5];
-            float vv[2][4];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-              const int r = 2 * rp + c2;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                float t = (c2 == 0 ? y[j].x : y[j].y) + bias_r[r];
-                vv[c2][j] = fmaxf(t, t * act_s);
-              }
-            }
-            if (a.out_shuffle == 2) {
-              if (co0 + 1 < a.cout && pok) {
-                float* o = a.out + ((size_t)bn * (a.cout >> 2) + (co0 >> 2)) * (4 * plane) + (size_t)(2 * gy + rp) * (2 * w) + 2 * gx;
-                *reinterpret_cast<f32x4*>(o) = f32x4{vv[0][0], vv[1][0], vv[0][1], vv[1][1]};
-                *reinterpret_cast<f32x4*>(o + 4) = f32x4{vv[0][2], vv[1][2], vv[0][3], vv[1][3]};
-              }
-            } else {
-#pragma unroll
-              for (int c2 = 0; c2 < 2; ++c2) {
-                const int r = 2 * rp + c2, co = co0 + c2;
-                if (co < a.cout && pok) {
-                  csum[r] += (vv[c2][0] + vv[c2][1]) + (vv[c2][2] + vv[c2][3]);
-                  *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
-                      f32x4{vv[c2][0] + rr[c2][0], vv[c2][1] + rr[c2][1], vv[c2][2] + rr[c2][2], vv[c2][3] + rr[c2][3]};
-                }
-              }
-            }
-          }
-        }
-      } else {
-        const int gx = x0 + 2 * l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = cot * 64 + cb * 16 + 4 * kq + r;
-          const bool cok = co < a.cout;
-          const float bb = bias_r[r];
-          __builtin_amdgcn_sched_barrier(0);
-          f32x2 rr[2];
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy) {
-            const int gy = y0 + 2 * tg + dy;
-            rr[dy] = f32x2{0.f, 0.f};
-            if (a.residual != nullptr && cok && gy < h && gx < w)
-              rr[dy] = *reinterpret_cast<const f32x2*>(a.residual + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx);
-          }
-          float s[2][6];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) {
-            const float m0 = acc[0 * 6 + q][r], m1 = acc[1 * 6 + q][r], m2 = acc[2 * 6 + q][r], m3 = acc[3 * 6 + q][r],
-                        m4 = acc[4 * 6 + q][r], m5 = acc[5 * 6 + q][r];
-            s[0][q] = m0 + (m1 + m2) + (m3 + m4);
-            s[1][q] = ((m1 - m2) + 2.f * (m3 - m4)) + m5;
-          }
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy) {
-            float y[2];
-            y[0] = s[dy][0] + (s[dy][1] + s[dy][2]) + (s[dy][3] + s[dy][4]);
-            y[1] = ((s[dy][1] - s[dy][2]) + 2.f * (s[dy][3] - s[dy][4])) + s[dy][5];
-            const int gy = y0 + 2 * tg + dy;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              y[j] += bb;
-              y[j] = fmaxf(y[j], y[j] * act_s);
-            }
-            if (cok && gy < h && gx < w) {
-              csum[r] += y[0] + y[1];
-              *reinterpret_cast<f32x2*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
-                  f32x2{y[0] + rr[dy].x, y[1] + rr[dy].y};
-            }
-          }
-        }
-      }
-      if (a.chan_partial) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = csum[r];
-          v += __shfl_xor(v, 8);
-          v += __shfl_xor(v, 4);
-          v += __shfl_xor(v, 2);
-          v += __shfl_xor(v, 1);
-          if (l15 == 0) s_red[tg * 64 + cb * 16 + 4 * kq + r] = v;
-        }
-        __syncthreads();
-        if (tid < 64) {
-          const int co = cot * 64 + tid;
-          if (co < a.cout)
-            a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + tile_lin) * a.cout + co] = s_red[tid] + s_red[64 + tid];
-        }
-      }
-#pragma unroll
-      for (int x = 0; x < NPOS; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (it + 1 < total_iters) tile_coords((it + 1) / total_chunks, bn, y0, x0, tile_lin);
-    }
-  }
-#ifdef EAVSR_W4_ITSTAMP
-  __syncthreads();
-  if (tid < 256) g_w4_it[(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid] = s_its[tid];
-#endif
-}
-
 // weight (cout, cin, R, R) -> U = G g G^T laid out [cot][cin / 4][xi / 2][c][co ^ 16 (c & 1)][xi & 1] (zero for
 // co >= cout); evaluated in double and rounded once.  G[p] = scale_p * (1, p, p^2, ..) for the points 0, 1, -1, 2, -2
 // (scales 1/4, -1/6, -1/6, 1/24, 1/24) and the unit vector of the highest power for the point at infinity.
@@ -1808,7 +853,8 @@ __global__ void pack_wino6_kernel(const float* __restrict__ wt, float* __restric
   const int colsw = (int)((e >> 1) & 63);
   long u = e >> 7;
   const int c = (int)(u % CK); u /= CK;
-  const int xi = 2 * (int)(u % (NPOS / 2)) + lo; u /= NPOS / 2;
+  const int pair = (int)(u % (NPOS / 2)); u /= NPOS / 2;
+  const int xi = 6 * (pair / 3) + w6_col_of(pair % 3, lo);   // the position this slot holds (w6_slot)
   const int col = colsw ^ ((c & 1) << 4);
   const int nchunks = cin / CK;
   const int chunk = (int)(u % nchunks);
@@ -1949,12 +995,6 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
     if (R == 3 && attr_err == hipSuccess)
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WCfg<3>::LDS_BYTES + 2 * WCfg<3>::IN_PAD * sizeof(float)));
-    if (attr_err == hipSuccess)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6p_kernel<R>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)WPCfg<R>::LDS_BYTES);
-    if (attr_err == hipSuccess)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6q_kernel<R>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv_wino6: hipFuncSetAttribute(%zu B of LDS): %s", C::LDS_BYTES, hipGetErrorString(attr_err));
@@ -1964,31 +1004,11 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   const long per_cot = blocks < 256 ? blocks : 256;
   dim3 grid((unsigned)per_cot, eavsr::cdiv(d->cout, 64));
   // EAVSR_WINO6_SCHED=lockstep: round 2's schedule (every wave the same program), the A/B reference of the ping-pong kernel
-  // EAVSR_WINO6_SCHED = lockstep (default) | pingpong | quarter: round 3 built two other schedules of the same arithmetic
-  // (bit-identical outputs); both are SLOWER than the lock-step kernel (44.3 / 49.1 / 52.4 us per 2 x 64 x 180 x 320 launch) and
-  // stay as measured experiments behind this switch
-#if defined(EAVSR_W6_FORCE_LOCKSTEP)
-  static const int sched = 0;
-#elif defined(EAVSR_W6_FORCE_PINGPONG)
-  static const int sched = 1;
-#elif defined(EAVSR_W6_FORCE_QUARTER)
-  static const int sched = 2;
-#else
-  static const int sched = [] {
-    const char* e = getenv("EAVSR_WINO6_SCHED");
-    return e == nullptr ? 0 : strcmp(e, "quarter") == 0 ? 2 : strcmp(e, "pingpong") == 0 ? 1 : 0;
-  }();
-#endif
-  const bool lockstep = sched == 0;
   if (fuse) {
     if constexpr (R == 3)
       hipLaunchKernelGGL((conv_wino6_kernel<3, true>), grid, dim3(64 * NW), LDS_FUSE, eavsr::as_stream(stream), a);
-  } else if (lockstep) {
-    hipLaunchKernelGGL((conv_wino6_kernel<R, false>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
-  } else if (sched == 1) {
-    hipLaunchKernelGGL((conv_wino6p_kernel<R>), grid, dim3(64 * NW), WPCfg<R>::LDS_BYTES, eavsr::as_stream(stream), a);
   } else {
-    hipLaunchKernelGGL((conv_wino6q_kernel<R>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
+    hipLaunchKernelGGL((conv_wino6_kernel<R, false>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
   }
   return eavsr::launch_status("conv_wino6");
 }
