@@ -92,6 +92,10 @@ SIGNATURES = {
     "eavsr_resize_bilinear_ac_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_pyramid_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_add_f32": (C.c_int, [vp, vp, vp, vp, i64, vp]),
+    "eavsr_normalize_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "eavsr_avg_pool2_f32": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "eavsr_resize_bilinear_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp]),
+    "eavsr_concat3_f32": (C.c_int, [vp, i32, vp, i32, vp, i32, vp, i32, i32, vp]),
     # backward entry points
     "eavsr_act_bwd_f32": (C.c_int, [vp, vp, vp, i64, i32, f32, vp]),
     "eavsr_plane_sum_f32": (C.c_int, [vp, vp, vp, i32, i32, f32, vp]),

@@ -172,8 +172,7 @@ __global__ __launch_bounds__(256 * KZ) void conv3x3_smallco_kernel(SmallArgs a) 
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
           float v = acc[co][p] + (a.bias ? a.bias[co] : 0.f);
-          if (a.act == EAVSR_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (a.act == EAVSR_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+          v = fmaxf(v, v * (a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope));   // branch-free: max(v, v s), 0 <= s <= 1
           const size_t o = ((size_t)bn * COUT + co) * plane + (size_t)gy * w + gx;
           if (a.residual) v += a.residual[o];
           a.out[o] = v;
@@ -193,6 +192,8 @@ extern "C" int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, co
   EAVSR_REQUIRE(cout == 2 || cout == 3 || cout == 4 || cout == 6, -2,
                 "conv3x3_smallco: %d output channels unsupported (2, 3, 4, 6); use eavsr_conv2d_f32", cout);
   EAVSR_REQUIRE(act >= 0 && act <= 2, -1, "conv3x3_smallco: act %d", act);
+  EAVSR_REQUIRE(act != EAVSR_ACT_LRELU || (slope >= 0.f && slope <= 1.f), -2,
+                "conv3x3_smallco: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)slope);
   if (n == 0) return 0;
   SmallArgs a;
   a.x = x; a.wt = weight; a.bias = bias; a.residual = residual; a.out = out;

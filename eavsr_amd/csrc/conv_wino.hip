@@ -362,8 +362,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
         for (int dy = 0; dy < 2; ++dy) {
           const int gy = y0 + 2 * (tb0 + b) + dy;
           float v0 = y[dy][0] + bb, v1 = y[dy][1] + bb;
-          if (a.act == EAVSR_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          else if (a.act == EAVSR_ACT_LRELU) { v0 = v0 > 0.f ? v0 : v0 * a.slope; v1 = v1 > 0.f ? v1 : v1 * a.slope; }
+          { const float as_ = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope; v0 = fmaxf(v0, v0 * as_); v1 = fmaxf(v1, v1 * as_); }   // branch-free: max(v, v s)
           if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
             const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
             csum[r] += v0 + v1;
@@ -462,6 +461,8 @@ extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* w
   EAVSR_REQUIRE(d->out_shuffle == 0, -2, "conv3x3_wino: the pixel-shuffle epilogue exists in eavsr_conv3x3_wino4_f32 only");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv3x3_wino: bad dims");
   EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv3x3_wino: act %d", d->act);
+  EAVSR_REQUIRE(d->act != EAVSR_ACT_LRELU || (d->slope >= 0.f && d->slope <= 1.f), -2,
+                "conv3x3_wino: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)d->slope);
   const bool fuse = d->ca_scale != nullptr;
   if (fuse) {
     EAVSR_REQUIRE(d->ca_x != nullptr, -1, "conv3x3_wino: ca_scale without ca_x");

@@ -270,8 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x9_kernel(CxArgs a) {
       for (int t = 0; t < NT; ++t) {
         const int gy = y0 + wave * NT + t;
         float v = acc[m][t][r] + b;
-        if (a.act == EAVSR_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (a.act == EAVSR_ACT_LRELU) v = v > 0.f ? v : v * a.slope;
+        v = fmaxf(v, v * (a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope));   // branch-free: max(v, v s), 0 <= s <= 1
         if (cok && xok && gy < h) {
           const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
           sum += v;
@@ -319,6 +318,8 @@ extern "C" int eavsr_conv3x3_f32x9(const eavsr_conv2d_desc* d, const void* weigh
   EAVSR_REQUIRE(d->out_shuffle == 0, -2, "conv3x3_f32x9: the pixel-shuffle epilogue exists in eavsr_conv3x3_wino4_f32 only");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv3x3_f32x9: bad dims");
   EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv3x3_f32x9: act %d", d->act);
+  EAVSR_REQUIRE(d->act != EAVSR_ACT_LRELU || (d->slope >= 0.f && d->slope <= 1.f), -2,
+                "conv3x3_f32x9: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)d->slope);
   EAVSR_REQUIRE(d->ca_scale == nullptr && d->ca_x == nullptr && d->ca_out == nullptr, -2,
                 "conv3x3_f32x9: no fused channel-attention prologue");
   EAVSR_REQUIRE(d->w % 4 == 0, -2, "conv3x3_f32x9: w %% 4 != 0 (use eavsr_conv2d_f32)");

@@ -124,11 +124,11 @@ class SPyNet(nn.Module):
     def compute_flow(self, ref, supp):
         """eavsrp_model.py:433-488"""
         n, _, h, w = ref.size()
-        ref = [(ref - self.mean) / self.std]
-        supp = [(supp - self.mean) / self.std]
+        ref = [ops.normalize(ref, self.mean, self.std)]
+        supp = [ops.normalize(supp, self.mean, self.std)]
         for _ in range(5):
-            ref.append(F.avg_pool2d(ref[-1], kernel_size=2, stride=2, count_include_pad=False))
-            supp.append(F.avg_pool2d(supp[-1], kernel_size=2, stride=2, count_include_pad=False))
+            ref.append(ops.avg_pool2(ref[-1]))
+            supp.append(ops.avg_pool2(supp[-1]))
         ref, supp = ref[::-1], supp[::-1]
         flow = ref[0].new_zeros(n, 2, h // 32, w // 32)
         for level in range(len(ref)):
@@ -137,7 +137,7 @@ class SPyNet(nn.Module):
             else:
                 flow_up = ops.resize_bilinear_ac(flow, (flow.shape[2] * 2, flow.shape[3] * 2), 2.0)
             warped = ops.flow_warp(supp[level], flow_up, padding_mode="border")
-            res = self.basic_module[level](torch.cat([ref[level], warped, flow_up], 1))
+            res = self.basic_module[level](ops.concat3(ref[level], warped, flow_up))
             flow = ops.add(flow_up, res)
         return flow
 
@@ -146,11 +146,14 @@ class SPyNet(nn.Module):
         h, w = ref.shape[2:4]
         w_up = w if (w % 32) == 0 else 32 * (w // 32 + 1)
         h_up = h if (h % 32) == 0 else 32 * (h // 32 + 1)
-        ref = F.interpolate(ref, size=(h_up, w_up), mode="bilinear", align_corners=False)
-        supp = F.interpolate(supp, size=(h_up, w_up), mode="bilinear", align_corners=False)
-        flow = F.interpolate(self.compute_flow(ref, supp), size=(h, w), mode="bilinear", align_corners=False)
-        flow[:, 0, :, :] *= float(w) / float(w_up)
-        flow[:, 1, :, :] *= float(h) / float(h_up)
+        # F.interpolate(.., size, 'bilinear', align_corners=False) both ways and the flow rescaling, as HIP kernels; a resize to
+        # the same size is the identity (source coordinate = destination coordinate, weights 1 / 0) and is skipped
+        if (h_up, w_up) != (h, w):
+            ref = ops.resize_bilinear(ref, (h_up, w_up))
+            supp = ops.resize_bilinear(supp, (h_up, w_up))
+        flow = self.compute_flow(ref, supp)
+        if (h_up, w_up) != (h, w):
+            flow = ops.resize_bilinear(flow, (h, w), channel_mul=(float(w) / float(w_up), float(h) / float(h_up)))
         return flow
 
 
@@ -199,15 +202,18 @@ class EAVSRP(nn.Module):
         self.lrelu = N._Act("lrelu", 0.1)
 
     # -- flows -----------------------------------------------------------------------------
-    def compute_flow(self, lrs):
+    def compute_flow(self, lrs, lr_tm=None):
         """eavsrp_model.py:179-200.  Both directions go through SPyNet as one batch."""
         n, t, c, h, w = lrs.shape
-        lrs_1 = lrs[:, :-1].reshape(-1, c, h, w)
-        lrs_2 = lrs[:, 1:].reshape(-1, c, h, w)
-        both = self.spynet(torch.cat([lrs_1, lrs_2], 0), torch.cat([lrs_2, lrs_1], 0))
+        # frame-major pairs (pair (frame i, clip b) -> row i n + b): the two frame runs are contiguous views of the frame-major
+        # input, and a time step's flow `flows[:, i]` of the (n, t-1, 2, h, w) VIEWS returned here is contiguous, so that
+        # `propagate` copies nothing (44 strided copies per forward in round 2)
+        lr_tm = lrs.transpose(0, 1).reshape(t * n, c, h, w) if lr_tm is None else lr_tm
         m = n * (t - 1)
-        flows_backward = both[:m].view(n, t - 1, 2, h, w)
-        flows_forward = both[m:].view(n, t - 1, 2, h, w)
+        lrs_1, lrs_2 = lr_tm[:m], lr_tm[n:]
+        both = self.spynet(torch.cat([lrs_1, lrs_2], 0), torch.cat([lrs_2, lrs_1], 0))
+        flows_backward = both[:m].view(t - 1, n, 2, h, w).transpose(0, 1)
+        flows_forward = both[m:].view(t - 1, n, 2, h, w).transpose(0, 1)
         return flows_forward, flows_backward
 
     # -- forward ---------------------------------------------------------------------------
@@ -219,11 +225,11 @@ class EAVSRP(nn.Module):
         if not lrs.is_cuda:
             raise RuntimeError("eavsr_amd.EAVSRP runs on the GPU only (no CPU path); for a CPU reference use "
                                "the original repository with --gpu_ids -1")
-        with torch.no_grad():
-            flows_forward, flows_backward = self.compute_flow(lrs)
-
-        # frame-major feature tensors so every per-frame slice is contiguous
+        # frame-major input so that every per-frame slice (of the input, the features, the flows) is contiguous
         lr_tm = lrs.transpose(0, 1).reshape(t * n, c, h, w)
+        with torch.no_grad():
+            flows_forward, flows_backward = self.compute_flow(lrs, lr_tm)
+
         f1 = self.encoder(lr_tm)                                   # :216
         f2, f4 = AG.pyramid(f1)                                    # :218-220
         feats: Dict[str, List[Tensor]] = {
@@ -237,7 +243,7 @@ class EAVSRP(nn.Module):
                 feats[module] = []
                 flows = flows_backward if direction == "backward" else flows_forward
                 feats = self.propagate(feats, flows, module)
-        return self.upsample(lrs, feats)
+        return self.upsample(lrs, feats, lr_tm)
 
     def propagate(self, feats, flows, module_name):
         """eavsrp_model.py:242-329."""
@@ -290,7 +296,7 @@ class EAVSRP(nn.Module):
         feats[module_name] = _FrameList(feats[module_name], stacked)
         return feats
 
-    def upsample(self, lqs, feats):
+    def upsample(self, lqs, feats, lq_tm=None):
         """eavsrp_model.py:331-364, all t frames as one batch."""
         n, t = lqs.shape[:2]
         branches = [k for k in feats if k not in _PYR]
@@ -302,8 +308,11 @@ class EAVSRP(nn.Module):
         if self.scale == 4:
             hr = self.upsample2[0](hr, act="lrelu", slope=0.1, pixel_shuffle2=True)
         hr = self.conv_hr(hr, act="lrelu", slope=0.1)
-        lq_tm = lqs.transpose(0, 1).reshape(t * n, *lqs.shape[2:])
-        skip = self.img_upsample(lq_tm)
+        if lq_tm is None:
+            lq_tm = lqs.transpose(0, 1).reshape(t * n, *lqs.shape[2:])
+        # nn.Upsample(scale_factor, 'bilinear', align_corners=False) (:158,359): source coordinate (dst + 0.5) / s - 0.5
+        skip = (self.img_upsample(lq_tm) if lq_tm.requires_grad else
+                ops.resize_bilinear(lq_tm, (self.scale * lq_tm.shape[2], self.scale * lq_tm.shape[3])))
         out = self.conv_last(hr, residual=skip)                                      # :359-360
         return out.view(t, n, *out.shape[1:]).transpose(0, 1).contiguous()
 

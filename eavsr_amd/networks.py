@@ -483,7 +483,7 @@ class ContrasExtractorLayer(nn.Module):
         self.register_buffer("std", torch.Tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1))
 
     def forward(self, batch):
-        batch = (batch - self.mean) / self.std
+        batch = (batch - self.mean) / self.std if batch.requires_grad else ops.normalize(batch, self.mean, self.std)
         return self.tail(_run_fused(self.model, batch))
 
 

@@ -903,6 +903,62 @@ def add(a: Tensor, b: Tensor, c: Optional[Tensor] = None, out: Optional[Tensor] 
     return out
 
 
+def normalize(x: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    """(x - mean) / std per channel (models/eavsrp_model.py:436-437, networks.py:550); mean / std: c floats on the device"""
+    x = _chk(x, "x")
+    n, c, h, w = x.shape
+    mean, std = _chk(mean.reshape(-1), "mean"), _chk(std.reshape(-1), "std")
+    if mean.numel() != c or std.numel() != c:
+        raise ValueError("normalize: one mean / std per channel")
+    out = torch.empty_like(x)
+    st = _stream(x)
+    _launch("normalize", 2.0 * x.numel(), 8.0 * x.numel(), x,
+            lambda: lib().eavsr_normalize_f32(_p(x), _p(mean), _p(std), _p(out), n, c, h * w, st), "normalize")
+    return out
+
+
+def avg_pool2(x: Tensor) -> Tensor:
+    """F.avg_pool2d(x, 2, 2, count_include_pad=False) for even h, w (models/eavsrp_model.py:450-462)"""
+    x = _chk(x, "x")
+    n, c, h, w = x.shape
+    if h % 2 or w % 2:
+        raise ValueError(f"avg_pool2: h={h}, w={w} must be even")
+    out = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    _launch("avg_pool2", 4.0 * out.numel(), 4.0 * (x.numel() + out.numel()), x,
+            lambda: lib().eavsr_avg_pool2_f32(_p(x), _p(out), n * c, h, w, st), "avg_pool2")
+    return out
+
+
+def resize_bilinear(x: Tensor, size: Tuple[int, int], channel_mul: Optional[Tuple[float, float]] = None) -> Tensor:
+    """F.interpolate(x, size, mode='bilinear', align_corners=False); `channel_mul` = (m0, m1) multiplies channels 0 / 1 of the
+    result (the flow rescaling of models/eavsrp_model.py:519-521)"""
+    x = _chk(x, "x")
+    n, c, hin, win = x.shape
+    hout, wout = int(size[0]), int(size[1])
+    out = torch.empty((n, c, hout, wout), device=x.device, dtype=torch.float32)
+    m0, m1 = (1.0, 1.0) if channel_mul is None else (float(channel_mul[0]), float(channel_mul[1]))
+    st = _stream(x)
+    _launch("resize_bilinear", 8.0 * out.numel(), 4.0 * (x.numel() + out.numel()), x,
+            lambda: lib().eavsr_resize_bilinear_f32(_p(x), _p(out), n, c, hin, win, hout, wout, 0 if channel_mul is None else c,
+                                                    m0, m1, st), "resize_bilinear")
+    return out
+
+
+def concat3(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
+    """torch.cat([a, b, c], 1) (models/eavsrp_model.py:486)"""
+    a, b, c = _chk(a, "a"), _chk(b, "b"), _chk(c, "c")
+    n, ca, h, w = a.shape
+    if b.shape[0] != n or c.shape[0] != n or b.shape[2:] != a.shape[2:] or c.shape[2:] != a.shape[2:]:
+        raise ValueError("concat3: shape mismatch")
+    cb, cc = b.shape[1], c.shape[1]
+    out = torch.empty((n, ca + cb + cc, h, w), device=a.device, dtype=torch.float32)
+    st = _stream(a)
+    _launch("concat3", 0.0, 8.0 * out.numel(), a,
+            lambda: lib().eavsr_concat3_f32(_p(a), ca, _p(b), cb, _p(c), cc, _p(out), n, h * w, st), "concat3")
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # channel attention
 # ------------------------------------------------------------------------------------------

@@ -300,6 +300,22 @@ int eavsr_pyramid_f32(const float* in, float* down2, float* down4,
 int eavsr_add_f32(const float* a, const float* b, const float* c, float* out, int64_t count,
                   void* stream);
 
+/* ---- f1 / f2 glue either side of the path (round 3: the ATen kernels that were left inside the forward) -----------
+ * out = (in - mean[c]) / std[c]: SPyNet.compute_flow models/eavsrp_model.py:436-437, ContrasExtractorLayer.forward
+ * models/networks.py:550 (mean / std: c device floats). */
+int eavsr_normalize_f32(const float* in, const float* mean, const float* std, float* out,
+                        int32_t n, int32_t c, int32_t hw, void* stream);
+/* F.avg_pool2d(x, kernel_size=2, stride=2, count_include_pad=False), models/eavsrp_model.py:450-462; h, w even. */
+int eavsr_avg_pool2_f32(const float* in, float* out, int32_t nc, int32_t h, int32_t w, void* stream);
+/* F.interpolate(x, size=(hout, wout), mode='bilinear', align_corners=False): models/eavsrp_model.py:499-509 (SPyNet's
+ * resize to a multiple of 32 and back) and nn.Upsample(scale_factor, 'bilinear') at :158,359 (the LR skip).  cmul = c
+ * multiplies channel 0 by m0 and channel 1 by m1 afterwards (the flow rescaling of :519-521); cmul = 0: no scaling. */
+int eavsr_resize_bilinear_f32(const float* in, float* out, int32_t n, int32_t c, int32_t hin, int32_t win,
+                              int32_t hout, int32_t wout, int32_t cmul, float m0, float m1, void* stream);
+/* torch.cat([a, b, c], dim=1) of (n, ca | cb | cc, h, w): the 8-channel input of a SPyNet level, models/eavsrp_model.py:486 */
+int eavsr_concat3_f32(const float* a, int32_t ca, const float* b, int32_t cb, const float* c, int32_t cc, float* out,
+                      int32_t n, int32_t hw, void* stream);
+
 /* ============================================================================================
  * Backward entry points (training step).  They replace the ATen / cuDNN / mmcv
  * backward kernels autograd runs for the same modules in the reference's loss.backward()

@@ -831,6 +831,32 @@ def test_pyramid_matches_interpolate(ops, cuda):
         ops.pyramid(torch.zeros(1, 2, 10, 12, device=cuda))
 
 
+def test_glue_either_side_of_the_path_matches_aten(ops, cuda):
+    """round 3: the ATen kernels that were left inside the forward (SPyNet's normalisation, 2x2 average-pool pyramid, resize to a
+    multiple of 32 and back, 8-channel concat; the encoder's normalisation; the tail's bilinear LR skip) as HIP kernels,
+    against the torch CPU ops the reference calls (models/eavsrp_model.py:436-437,450-462,486,499-521,158,359)."""
+    x = cases.randn(5, 4, 3, 60, 100) * 0.3 + 0.5
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    assert H.maxabs(ops.normalize(g(x, cuda), g(mean, cuda), g(std, cuda)).cpu(), (x - mean) / std) <= 1e-6
+    assert H.maxabs(ops.avg_pool2(g(x, cuda)).cpu(), F.avg_pool2d(x, 2, 2, count_include_pad=False)) <= 1e-6
+    with pytest.raises(ValueError):
+        ops.avg_pool2(torch.zeros(1, 1, 5, 4, device=cuda))
+    for size in ((64, 128), (60, 100), (240, 400), (37, 51)):       # up to /32 multiples, identity, x4, an odd shrink
+        got = ops.resize_bilinear(g(x, cuda), size).cpu()
+        want = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+        assert H.maxabs(got, want) <= 2e-6, size
+    want4 = torch.nn.Upsample(scale_factor=4, mode="bilinear", align_corners=False)(x)
+    assert H.maxabs(ops.resize_bilinear(g(x, cuda), (240, 400)).cpu(), want4) <= 2e-6
+    fl = cases.randn(6, 3, 2, 64, 128) * 3
+    got = ops.resize_bilinear(g(fl, cuda), (60, 100), channel_mul=(100 / 128, 60 / 64)).cpu()
+    want = F.interpolate(fl, size=(60, 100), mode="bilinear", align_corners=False)
+    want[:, 0] *= float(100) / float(128)
+    want[:, 1] *= float(60) / float(64)
+    assert H.maxabs(got, want) <= 2e-6
+    a, b, c = cases.randn(7, 3, 3, 12, 20), cases.randn(8, 3, 3, 12, 20), cases.randn(9, 3, 2, 12, 20)
+    assert torch.equal(ops.concat3(g(a, cuda), g(b, cuda), g(c, cuda)).cpu(), torch.cat([a, b, c], 1))
+
+
 def test_add(ops, cuda):
     a, b, c = (cases.randn(i, 3, 2, 17, 19) for i in range(3))
     assert torch.equal(ops.add(g(a, cuda), g(b, cuda)).cpu(), a + b)
