@@ -204,8 +204,11 @@ extern "C" int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, co
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_smallco: too many tiles");
   hipStream_t st = eavsr::as_stream(stream);
   dim3 grid((unsigned)blocks);
-  // less than two workgroups per CU: split the channel loop over two thread groups (one more wave per SIMD to hide LDS latency)
-  const bool split = blocks < 512 && cin >= 16;
+  // few workgroups per CU: split the channel loop over two thread groups (one more wave per SIMD to hide LDS latency).  The two
+  // groups sum the channels in another order than the single group, so the choice depends on the IMAGE size only, never on the
+  // batch: a clip's output bits must not depend on how many clips share its launch (256 tiles per sample = two sub-batch clips
+  // of 180 x 320 stay below two workgroups per CU)
+  const bool split = (long)a.tiles_x * a.tiles_y < 256 && cin >= 16;
 #define EAVSR_SMALLCO(CO)                                                                                  \
   if (split) hipLaunchKernelGGL((conv3x3_smallco_kernel<CO, 2>), grid, dim3(512), 0, st, a);               \
   else hipLaunchKernelGGL((conv3x3_smallco_kernel<CO, 1>), grid, dim3(256), 0, st, a)

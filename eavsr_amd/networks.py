@@ -256,6 +256,7 @@ class MultiAdSTN(ModulatedDeformConv2d):
                 and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
                 and self.dilation == (1, 1) and self.groups == 1 and self.in_channels % 8 == 0
                 and (self.in_channels // self.deform_groups) % 8 == 0 and self.adastn.D == self.deform_groups
+                and ((self.in_channels // self.deform_groups) // 8) & ((self.in_channels // self.deform_groups) // 8 - 1) == 0
                 and nbr.shape == feat_prop.shape)
 
     def forward(self, nbr_feat_l, ref_feat_l, feat_prop, offset, flag=False):

@@ -508,7 +508,8 @@ def modulated_deform_conv2d(input: Tensor, offset: Tensor, mask: Tensor, weight:
     st = _stream(x)
     px = float(n) * h * w
     flops, nbytes = 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * deform_groups + cout)
-    if DCN_MODE in ("il6", "il9"):
+    octets = (cin // deform_groups) // 8
+    if DCN_MODE in ("il6", "il9") and octets & (octets - 1) == 0:     # the IL8 kernel wants a power-of-two number of octets per group
         # generic callers hold an NCHW tensor: one conversion pass to the IL8 layout, then the hot-path kernel (inside
         # MultiAdSTN the warp before the call writes IL8 itself and the predictor heads are passed instead of offset / mask)
         return dcnv2_il(to_il8(x), offset, mask, weight, b, deform_groups, nprod=int(DCN_MODE[2]), heads=False)

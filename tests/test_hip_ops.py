@@ -216,8 +216,9 @@ def _dcn_inputs(n, c, h, w, cout, dg, sigma, seed=0):
 
 @pytest.mark.parametrize("sigma", [0.0, 0.5, 2.0, 8.0])
 @pytest.mark.parametrize("shape", [(1, 64, 24, 40, 64, 8), (2, 64, 13, 37, 64, 8), (1, 64, 10, 12, 64, 1),
-                                   (1, 16, 9, 33, 32, 2), (1, 64, 7, 5, 40, 8)])
-def test_dcnv2_vs_oracle(ops, cuda, shape, sigma):
+                                   (1, 16, 9, 33, 32, 2), (1, 64, 7, 5, 40, 8),
+                                   (1, 48, 12, 20, 32, 2), (1, 96, 8, 16, 16, 4)])     # 24 channels per group: 3 octets, not a
+def test_dcnv2_vs_oracle(ops, cuda, shape, sigma):                                     # power of two -> the NCHW kernel
     n, c, h, w, cout, dg = shape
     x, off, mask, wt, b = _dcn_inputs(n, c, h, w, cout, dg, sigma)
     ref = O.dcnv2(x, off, mask, wt, b, 1, 1, 1, 1, dg)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B build of the whole library with extra compiler flags: tools/build_ab_lib.sh NAME "-DFLAG ..." -> eavsr_amd/lib/libeavsr_NAME.so
+# (selected at run time with EAVSR_LIB_PATH; same ABI as the default build)
+set -e
+cd "$(dirname "$0")/.."
+NAME=$1; FLAGS=$2
+F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -ffp-contract=fast -Wno-unused-function"
+mkdir -p eavsr_amd/lib/obj_$NAME
+for f in eavsr_amd/csrc/*.hip; do
+  ( /opt/rocm/bin/hipcc $F $FLAGS -c $f -o eavsr_amd/lib/obj_$NAME/$(basename ${f%.hip}).o 2>/dev/null ) &
+  while [ $(jobs -r | wc -l) -ge 6 ]; do sleep 0.2; done
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o eavsr_amd/lib/libeavsr_$NAME.so eavsr_amd/lib/obj_$NAME/*.o
+rm -rf eavsr_amd/lib/obj_$NAME
+ls -la eavsr_amd/lib/libeavsr_$NAME.so
