@@ -565,7 +565,18 @@ def main():
         dcn_name = {"il6": "dcnv2_il_heads", "il9": "dcnv2_il_heads", "native": "dcnv2", "bf16x9": "dcnv2_x9"}[args.dcn_mode]
         if args.backbone_dtype != "fp32" and args.dcn_mode in ("il6", "il9"):
             dcn_name = "dcnv2_il16_heads"
-        line["kernels"] = [e for e in (entry(dcn_name, "hbm"), entry("flow_warp_pair", "hbm"), entry("flow_warp", "hbm"),
+        dcn_entry = entry(dcn_name, "hbm")
+        if dcn_entry is not None and dcn_name.endswith("_heads"):
+            # heads mode: `achieved` / `frac` price the kernel on SURVEY 8d's algorithmic 344 e B/px of the DCNv2 op (what the
+            # reference's op moves at least: input, 18 D offsets, 9 D masks, output); the fused kernel itself reads the 15 D head
+            # channels instead of 27 D offset / mask channels -- both figures, so that neither is mistaken for the other
+            moved_px = (64 * 2 + 15 * 8 * 4 + 64 * 4) if dcn_name.startswith("dcnv2_il16") else (64 + 15 * 8 + 64) * 4
+            alg_px = 344 * (2 if dcn_name.startswith("dcnv2_il16") else 4)
+            dcn_entry["bytes_per_px"] = {"algorithmic": alg_px, "moved_by_this_kernel": moved_px}
+            dcn_entry["moved"] = {"achieved": dcn_entry["achieved"] * moved_px / alg_px, "unit": "GB/s",
+                                  "frac": dcn_entry["frac"] * moved_px / alg_px,
+                                  "note": "bytes the fused (heads-mode) kernel itself moves / time / 8 TB/s"}
+        line["kernels"] = [e for e in (dcn_entry, entry("flow_warp_pair", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),
                                        entry("conv5x5_64to120", "mfma")) if e]
