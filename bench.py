@@ -260,7 +260,7 @@ def train_bench(args, rank, world, device):
     shard.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    on_dev = world > 1 and torch.distributed.get_backend() == "nccl"
+    on_dev = world > 1 and not shard.host_collectives()      # only a pure-RCCL group needs device tensors for the MAX
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
     if rank == 0:
         print(json.dumps({
@@ -443,7 +443,7 @@ def main():
                                     "on clamp*255*round images"}
             del exact_first
         del timed_first, eager_first
-    on_dev = world > 1 and torch.distributed.get_backend() == "nccl"
+    on_dev = world > 1 and not shard.host_collectives()      # only a pure-RCCL group needs device tensors for the MAX
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
     timed_vs_eager = shard.max_over_ranks(timed_vs_eager, device=device if on_dev else None)
     frames_total = world * n * t * args.steps
@@ -474,7 +474,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "world_size": torch.distributed.get_world_size() if world > 1 else 1,
-        "backend": (torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else ""))
+        "backend": (str(torch.distributed.get_backend()) + (" (nccl = RCCL; inference has no data-path collective, the barrier and "
+                                                              "the MAX over ranks are host scalars)" if "nccl" in str(torch.distributed.get_backend()) else ""))
                    if world > 1 else "none (one process)",
         "dtype": ("f32" if args.backbone_dtype == "fp32" else f"{args.backbone_dtype} backbone + f32") +
                  ("" if args.conv_mode != "bf16x9" and args.dcn_mode != "bf16x9"

@@ -5,7 +5,8 @@ scatter `lrs` on dim 0, replicate the parameters every forward, gather the outpu
 independent units, so the MI355X-native form has NO data-path collective for
 inference: rank r owns clips r, r+G, r+2G, ... and keeps its own resident copy of the weights.  The
 only communication is control-plane (a barrier and a MAX over per-rank wall times for
-measurement), which runs over RCCL when the process group is 'nccl' and over gloo in the CPU tests.
+measurement): a few host scalars, which go over gloo -- the default process group on GPUs is 'cpu:gloo,cuda:nccl', so that a
+barrier never enqueues a kernel on the device it brackets and RCCL carries only device tensors (the training step's gradients).
 Training is plain data parallelism: every rank holds the full model, runs
 forward + backward on its own clips, and the ONLY data-path communication is one all-reduce(sum) of the
 loss gradients of the 12.28 M trainable parameters (49.1 MB fp32) per step -- `GradientAllReducer`
@@ -56,8 +57,12 @@ def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            # RCCL ("nccl") on GPUs; EAVSR_DIST_BACKEND=gloo lets several ranks share one GPU in tests
-            backend = os.environ.get("EAVSR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # On GPUs: RCCL ("nccl") for device tensors -- the gradient all-reduce of the training step, the path's only
+            # data-path collective -- and gloo for host tensors: the control plane of a measurement (barrier, MAX over the
+            # per-rank wall times) is a few host scalars, and keeping it off the GPU means a barrier never enqueues a kernel
+            # on the device it brackets (and that inference, which has no collective, never opens a RCCL communicator).
+            # EAVSR_DIST_BACKEND=gloo lets several ranks share one GPU in tests; =nccl forces everything onto RCCL.
+            backend = os.environ.get("EAVSR_DIST_BACKEND") or ("cpu:gloo,cuda:nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             # one process per GPU: bind this process to its device BEFORE the communicator exists, so that RCCL's
             # collectives (and barrier) never have to guess the device from the rank
@@ -66,9 +71,16 @@ def init_process_group(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, local_rank, world
 
 
+def host_collectives() -> bool:
+    """True when host tensors have a backend of their own (gloo): barrier / MAX then run on the CPU"""
+    return dist.is_initialized() and "gloo" in str(dist.get_backend())
+
+
 def barrier():
     if dist.is_initialized():
-        if dist.get_backend() == "nccl":
+        if host_collectives():
+            dist.all_reduce(torch.zeros(1))                       # a host all-reduce IS a barrier; never touches the GPU
+        elif "nccl" in str(dist.get_backend()):
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
             dist.barrier()
@@ -114,10 +126,13 @@ def gather_outputs(local: torch.Tensor, n_clips: int, rank: int, world: int) -> 
 
 
 class GradientAllReducer:
-    """Bucketed all-reduce of `.grad` (the one collective of the training step).  Buckets whose parameters all get their
-    gradient through autograd hooks are launched during backward; the rest (every bucket with a grad_sink'd convolution
-    parameter, i.e. most of them) in finish().  Bucket layouts are fixed at construction and identical on every rank:
-    a parameter without a gradient on this rank contributes zeros, never a shorter buffer."""
+    """Bucketed all-reduce of `.grad` (the one collective of the training step).  In the training step as it is run
+    (`autograd.grad_sink`: convolution weight / bias gradients reach `.grad` only when backward ends, and nearly every ~8 MB bucket
+    holds such a parameter) the 49 MB are reduced in `finish()`, AFTER backward -- there is no overlap worth the name, and none
+    is needed: ~0.6 ms at the per-link xGMI bound against a 0.4 s step.  A bucket whose parameters ALL receive their gradient
+    through ordinary autograd accumulation is still launched from the post-accumulate-grad hook as soon as it is complete.
+    Bucket layouts are fixed at construction and identical on every rank: a parameter without a gradient on this rank
+    contributes zeros, never a shorter buffer."""
 
     def __init__(self, params, bucket_bytes: int = 8 << 20):
         self.params = [p for p in params if p.requires_grad]
