@@ -225,15 +225,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   const size_t plane = (size_t)h * w;
   const int total_tiles = a.tiles_x * a.tiles_y * a.n;
   const int my_tiles = (total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  // (unsigned divisions: the set-up in front of the first request is ~500 executed scalar instructions, a third of them the
+  // sign handling and fix-ups of signed divisions)
+  const unsigned u_tx = (unsigned)a.tiles_x, u_ty = (unsigned)a.tiles_y;
   auto tile_coords = [&](int k, int& bn_, int& y0_, int& x0_, int& lin_) __attribute__((always_inline)) {
-    int t = eavsr_xcd_remap((int)blockIdx.x + k * (int)gridDim.x, total_tiles);
-    const int tx_ = t % a.tiles_x;
-    t /= a.tiles_x;
-    const int ty_ = t % a.tiles_y;
-    bn_ = t / a.tiles_y;
-    y0_ = ty_ * TOH;
-    x0_ = tx_ * TOW;
-    lin_ = ty_ * a.tiles_x + tx_;
+    unsigned t = (unsigned)eavsr_xcd_remap((int)blockIdx.x + k * (int)gridDim.x, total_tiles);
+    const unsigned q1 = t / u_tx;
+    const unsigned tx_ = t - q1 * u_tx;
+    const unsigned q2 = q1 / u_ty;
+    const unsigned ty_ = q1 - q2 * u_ty;
+    bn_ = (int)q2;
+    y0_ = (int)ty_ * TOH;
+    x0_ = (int)tx_ * TOW;
+    lin_ = (int)(ty_ * u_tx + tx_);
   };
 
   // acc[xi]: M_xi of output channels 16 cb + 4 kq + r, Winograd tile (row tg, column l15)
@@ -265,8 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   // ---- prefetch stream (runs up to two chunks ahead of the compute stream, across tile boundaries) -------------
   int p_k = 0, p_cs = 0, p_cc0 = 0, p_bn = 0, p_y0 = 0, p_x0 = 0, p_lin = 0;
   unsigned voff[IN_IT];   // per-lane byte offsets of this wave's patch pieces; 0xFFFFFFFF: zero padding
-  auto p_setup_tile = [&]() __attribute__((always_inline)) {
-    tile_coords(p_k, p_bn, p_y0, p_x0, p_lin);
+  auto p_setup_lanes = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < IN_IT; ++i) {
       const int seg = i * NW + wave;
@@ -280,9 +283,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       voff[i] = ok ? (unsigned)(((size_t)ci * plane + (size_t)gy * w + gx) * 4) : 0xFFFFFFFFu;
     }
   };
-  p_setup_tile();
+  auto p_setup_tile = [&]() __attribute__((always_inline)) {
+    tile_coords(p_k, p_bn, p_y0, p_x0, p_lin);
+    p_setup_lanes();
+  };
   int bn = 0, y0 = 0, x0 = 0, tile_lin = 0;
   tile_coords(0, bn, y0, x0, tile_lin);
+  p_bn = bn; p_y0 = y0; p_x0 = x0; p_lin = tile_lin;   // the prefetch stream starts on the same tile: its coordinates once
+  p_setup_lanes();
 
   // The source table is read from the kernel arguments ONCE, into scalar registers, and indexed by select chains (no
   // scalar loads inside the loop: they share the lgkmcnt counter with the LDS reads and return out of order).

@@ -47,11 +47,35 @@ for n in [int(v) for v in os.environ.get("NS", "2,4").split(",")]:
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 20 * 1000)
-        note = ""
+        # "in-step-like": 48 weight sets and 6 inputs in rotation (28 MB of weights + 177 MB of activations between two uses
+        # of the same bytes: nothing is L2-resident, everything memory-side-cache resident, as in the forward)
+        if n == 2:
+            if "wus" not in globals():
+                globals()["wus"] = [ops._packed_wino([torch.randn(64, 64, 3, 3, device=dev) * 0.05], four=True) for _ in range(48)]
+                globals()["xs"] = [torch.randn(n, 64, h, w, device=dev) for _ in range(6)]
+            wus, xs = globals()["wus"], globals()["xs"]
+            def call_rot(i):
+                d.src[0] = xs[i % 6].data_ptr()
+                return lib.eavsr_conv3x3_wino4_f32(C.byref(d), C.c_void_p(wus[i % 48].data_ptr()), None)
+            for i in range(48):
+                call_rot(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(96):
+                call_rot(i)
+            e1.record()
+            torch.cuda.synchronize()
+            cold = e0.elapsed_time(e1) / 96 * 1000
+            d.src[0] = x.data_ptr()
+            call(); torch.cuda.synchronize()
+        else:
+            cold = float("nan")
+        note = f"   rotating weights / inputs {cold:6.1f} us"
         if ref_out is None and "base" in path:
             ref_out = out.clone()
         elif ref_out is not None:
-            note = f"   max |out - base| = {(out - ref_out).abs().max().item():.3e}"
+            note += f"   max |out - base| = {(out - ref_out).abs().max().item():.3e}"
         print(f"{os.path.basename(path):36s} {min(ts):7.1f} us (median {sorted(ts)[2]:.1f}){note}")
         if hasattr(lib, "eavsr_debug_w4_timeline"):
             buf = (C.c_ulonglong * (512 * 16))()
