@@ -84,47 +84,33 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const float* __rest
   }
 }
 
-// The whole RCAB tail in ONE launch (round 2): out = r * sigmoid(MLP(mean_hw(r))) + x, from the conv's per-tile channel sums.
-// Every workgroup finishes the mean + the MLP for its sample itself -- the same fixed-order reduction as ca_scale_kernel, so all
-// workgroups of a sample get the identical scale -- and then streams its slice of the sample: pixels [p0, p1) of EVERY channel.
-// The loads of r and x do not depend on the scale and are issued first, so the reduction's round trips (the partial sums are
-// 57 KB per sample, L2-resident, re-read by each of the 128 workgroups of the sample) overlap the streaming latency.
-// Replaces ca_scale (one 1024-thread workgroup per sample, ~5-7 us of pure latency) + scale_residual (15 us) per block.
-constexpr int CT_THREADS = 1024, CT_PIECES = 8;      // up to 8 float4 per thread and stream: slices of <= 8192 float4
+// The whole RCAB tail in ONE launch: out = r * sigmoid(MLP(mean_hw(r))) + x, from the conv's per-tile channel sums.
+// Round 2's version (1024-thread workgroups, eight 16-byte pieces per thread in registers) was bit-identical and 3 ms less kernel
+// time per forward, and made the two-stream step SLOWER (261 -> 274 ms): its workgroups filled every CU and evicted the other
+// stream's convolution workgroups.  This is the version shaped to run BESIDE a resident Winograd workgroup (which leaves 48 vector
+// registers per lane and 28 KB of LDS on its CU): 256 threads, < 32 registers, 4.6 KB of LDS, one pair of 16-byte loads in flight
+// per thread.  Every workgroup finishes the mean + the MLP of its sample itself -- the fixed-order reduction of ca_scale_kernel
+// replayed by 256 threads (each takes the role of four of its 1024), so every workgroup of a sample gets the identical scale and
+// the result equals ca_scale + scale_residual bit for bit -- and then streams its slice: float4 columns [p0, p0 + len) of EVERY
+// channel.  The partial sums are 29 KB per sample, L2-resident, re-read by each workgroup of the sample.
+constexpr int CT_THREADS = 256;
 __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __restrict__ r, const float* __restrict__ partial,
                                                             int tiles, float inv_hw, const float* __restrict__ w1,
                                                             const float* __restrict__ b1, const float* __restrict__ w2,
                                                             const float* __restrict__ b2, const float* __restrict__ x,
                                                             float* __restrict__ out, int c, int cr, int hw4, int slice) {
   extern __shared__ float sm[];  // part[Q*c] then mean[c] then hidden[cr] then scale[c]
-  const int Q = CT_THREADS / c;
+  const int Q = CA_THREADS / c;  // the grouping of ca_scale_kernel (1024 logical threads), whatever this kernel's width
   float* part = sm;
   float* mean = sm + Q * c;
   float* hid = mean + c;
   float* s_scale = hid + cr;
   const int bn = blockIdx.y;
   const int tid = threadIdx.x;
-  const int p0 = blockIdx.x * slice, len = min(slice, hw4 - p0);          // this workgroup's float4 columns of every channel
-  const int total = len * c;                                               // flat (channel, column) pieces
-  const f32x4* r4 = reinterpret_cast<const f32x4*>(r) + (size_t)bn * c * hw4 + p0;
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + (size_t)bn * c * hw4 + p0;
-  f32x4* o4 = reinterpret_cast<f32x4*>(out) + (size_t)bn * c * hw4 + p0;
-  // 1. the streams' loads (flat piece f -> channel f / len, column f % len)
-  f32x4 ra[CT_PIECES], xa[CT_PIECES];
-  int chs[CT_PIECES];
-#pragma unroll
-  for (int k = 0; k < CT_PIECES; ++k) {
-    const int f = min(tid + k * CT_THREADS, total - 1);
-    const int ch = f / len, col = f - ch * len;
-    chs[k] = ch;
-    const size_t o = (size_t)ch * hw4 + col;
-    ra[k] = r4[o];
-    xa[k] = x4[o];
-  }
-  // 2. mean + MLP (as ca_scale_kernel)
-  const int q = tid / c, chn = tid - q * c;
-  if (q < Q) {
-    const float* p = partial + (size_t)bn * tiles * c + chn;
+  // 1. mean + MLP (ca_scale_kernel's arithmetic, one logical thread at a time)
+  for (int lt = tid; lt < Q * c; lt += CT_THREADS) {
+    const int q = lt / c, ch = lt - q * c;
+    const float* p = partial + (size_t)bn * tiles * c + ch;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int t = q;
     for (; t + 3 * Q < tiles; t += 4 * Q) {
@@ -133,13 +119,13 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
       s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
     for (; t < tiles; t += Q) s0 += p[(size_t)t * c];
-    part[q * c + chn] = (s0 + s1) + (s2 + s3);
+    part[q * c + ch] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
-  if (tid < c) {
+  for (int ch = tid; ch < c; ch += CT_THREADS) {
     float s = 0.f;
-    for (int k = 0; k < Q; ++k) s += part[k * c + tid];
-    mean[tid] = s * inv_hw;
+    for (int k = 0; k < Q; ++k) s += part[k * c + ch];
+    mean[ch] = s * inv_hw;
   }
   __syncthreads();
   if (tid < cr) {
@@ -148,23 +134,29 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
     hid[tid] = fmaxf(v, 0.f);
   }
   __syncthreads();
-  if (tid < c) {
-    float v = b2[tid];
-    for (int j = 0; j < cr; ++j) v += w2[tid * cr + j] * hid[j];
-    s_scale[tid] = 1.f / (1.f + expf(-v));
+  for (int ch = tid; ch < c; ch += CT_THREADS) {
+    float v = b2[ch];
+    for (int j = 0; j < cr; ++j) v += w2[ch * cr + j] * hid[j];
+    s_scale[ch] = 1.f / (1.f + expf(-v));
   }
   __syncthreads();
-  // 3. out = r * scale + x
-#pragma unroll
-  for (int k = 0; k < CT_PIECES; ++k) {
-    const int f = tid + k * CT_THREADS;
-    if (f < total) {
-      const float s = s_scale[chs[k]];
-      const int ch = chs[k], col = f - ch * len;
-      f32x4 o;
-      o[0] = ra[k][0] * s + xa[k][0]; o[1] = ra[k][1] * s + xa[k][1]; o[2] = ra[k][2] * s + xa[k][2]; o[3] = ra[k][3] * s + xa[k][3];
-      o4[(size_t)ch * hw4 + col] = o;
-    }
+  // 2. out = r * scale + x over the slice: flat piece f -> channel f / len, column f % len (kept incrementally)
+  const int p0 = blockIdx.x * slice, len = min(slice, hw4 - p0);
+  const int total = len * c;
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(r) + (size_t)bn * c * hw4 + p0;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + (size_t)bn * c * hw4 + p0;
+  f32x4* o4 = reinterpret_cast<f32x4*>(out) + (size_t)bn * c * hw4 + p0;
+  int ch = tid / len, col = tid - ch * len;
+  const int dch = CT_THREADS / len, dcol = CT_THREADS - dch * len;
+  for (int f = tid; f < total; f += CT_THREADS) {
+    const size_t o = (size_t)ch * hw4 + col;
+    const f32x4 a = r4[o], b = x4[o];
+    const float s = s_scale[ch];
+    f32x4 v;
+    v[0] = a[0] * s + b[0]; v[1] = a[1] * s + b[1]; v[2] = a[2] * s + b[2]; v[3] = a[3] * s + b[3];
+    o4[o] = v;
+    ch += dch; col += dcol;
+    if (col >= len) { col -= len; ++ch; }
   }
 }
 
@@ -211,15 +203,12 @@ extern "C" int eavsr_ca_tail_f32(const float* r, const float* chan_partial, int3
                 "ca_tail: hw %% 4 == 0 and 16-byte aligned tensors (otherwise eavsr_ca_scale_f32 + eavsr_scale_residual_f32)");
   if (n == 0) return 0;
   const int hw4 = hw / 4;
-  // slices of at most CT_THREADS * CT_PIECES / c float4 columns (every thread holds its pieces in registers), at least
-  // ~128 workgroups per sample when the plane allows
-  const int max_slice = CT_THREADS * CT_PIECES / c;
-  EAVSR_REQUIRE(max_slice >= 1, -2, "ca_tail: too many channels");
-  int slice = eavsr::cdiv(hw4, 128);
-  if (slice > max_slice) slice = max_slice;
-  if (slice < 1) slice = 1;
+  // ~256 workgroups per sample (each re-reduces the sample's per-tile sums: 29 KB of L2 reads at c = 64, 115 tiles), at
+  // least 32 float4 columns per workgroup
+  int slice = eavsr::cdiv(hw4, 256);
+  if (slice < 32) slice = 32;
   const int bx = eavsr::cdiv(hw4, slice);
-  const int Q = CT_THREADS / c;
+  const int Q = CA_THREADS / c;
   hipLaunchKernelGGL(ca_tail_kernel, dim3(bx, n), dim3(CT_THREADS), (size_t)(Q * c + c + cr + c) * sizeof(float),
                      eavsr::as_stream(stream), r, chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, x, out, c, cr, hw4, slice);
   return eavsr::launch_status("ca_tail");

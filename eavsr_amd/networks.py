@@ -353,10 +353,11 @@ class RCABlock(nn.Module):
 # side output) against the 27 us scale_residual launch it removes - 314 ms vs 311 ms per step - so it is off by default.
 import os as _os
 # The RCAB tail (mean -> MLP -> sigmoid -> res * y + x, networks.py:444-447,463-464) as ONE launch (eavsr_ca_tail_f32) instead of
-# ca_scale + scale_residual: EAVSR_FUSE_CA_TAIL=1.  OFF by default: bit-identical and 3 ms less kernel time per 2-clip forward
-# (18.1 against 14.7 + 6.2 ms), but the two-stream step gets SLOWER, 261.4 -> 273.8 ms (A/B on one box): its 256 workgroups of 1024
-# threads fill every CU for ~20 us and push the other stream's convolution workgroups out, where scale_residual's small
-# workgroups run beside them and ca_scale's two workgroups leave the GPU to the other stream.
+# ca_scale + scale_residual: EAVSR_FUSE_CA_TAIL=1.  OFF by default.  Round 3's kernel is shaped to run beside a resident
+# convolution workgroup (256 threads, 27 registers, 4.6 KB of LDS), is bit-identical and 7.6 us shorter back to back (22.3 against
+# 29.9 us per block) -- and the two-stream step is still SLOWER with it, 241.6 -> 249.8 ms (A/B on one box): three 16-register
+# scale_residual waves fit per SIMD beside a convolution but one 32-register wave of the fused kernel, each holding its slot through a
+# latency-bound MLP prologue, while ca_scale's two workgroups leave the GPU to the other stream.
 FUSE_CA_TAIL = _os.environ.get("EAVSR_FUSE_CA_TAIL", "0") == "1"
 FUSE_CA_INTO_CONV = _os.environ.get("EAVSR_FUSE_CA", "0") == "1"
 # One kernel per pyramid level of the residual-flow refinement (eavsr_flow_level_f32: front end + 64 -> 6 heads + affine +

@@ -985,9 +985,7 @@ def ca_tail(r: Tensor, partial: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: 
     if x.shape != r.shape or partial.shape[0] != n or partial.shape[2] != c:
         raise ValueError("ca_tail: shape mismatch")
     hw = h * w
-    # every workgroup of the fused kernel re-reduces its sample's per-tile sums: pays while a sample is <= ~256 workgroups
-    # (128 float4 columns x c channels each); larger planes keep the two launches
-    if hw % 4 or (r.data_ptr() | x.data_ptr()) % 16 or c > 256 or hw // 4 > 256 * (8192 // c):
+    if hw % 4 or (r.data_ptr() | x.data_ptr()) % 16 or c > 256:
         return scale_residual(r, ca_scale(partial, hw, w1, b1, w2, b2), x)
     tiles = int(partial.shape[1])
     cr = int(w1.shape[0])

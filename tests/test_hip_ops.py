@@ -909,7 +909,7 @@ def test_ca_tail_one_launch_equals_ca_scale_plus_scale_residual(ops, cuda, shape
     cr = max(c // 16, 1)
     w1, b1 = cases.randn(72, cr, c, 1, 1, scale=0.2), cases.randn(73, cr, scale=0.1)
     w2, b2 = cases.randn(74, c, cr, 1, 1, scale=0.5), cases.randn(75, c, scale=0.1)
-    tiles = 7
+    tiles = 115 if h == 180 else 67 if h == 45 else 7      # 115: the bench shape's tile count (both loops of the fixed-order reduction)
     # per-tile channel sums that add up to the true sums (what the conv epilogue hands over)
     sums = r.sum(dim=(2, 3))
     frac = torch.softmax(cases.randn(76, n, tiles, c), dim=1)
