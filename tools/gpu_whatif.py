@@ -63,4 +63,22 @@ ops.dcnv2_il = lambda x, oh, m, w, b, dg, nprod=6, heads=False: cache.setdefault
     ("dcn", tuple(oh.shape)), torch.zeros(oh.shape[0], w.shape[0], oh.shape[2], oh.shape[3], device=oh.device))
 measure("no DCNv2 kernel")
 ops.dcnv2_il = orig_dcn
+# (5) the small-cout vector-ALU convolutions (64 -> 6 heads and 18 -> 2 of every pyramid level, conv_last): 112-184 registers per
+#     lane, so they cannot run beside a resident Winograd workgroup -- how much of their time is on the step's critical path?
+orig_small = ops._conv3x3_smallco
+ops._conv3x3_smallco = lambda x, weights, biases, act, slope, residual: cache.setdefault(
+    ("sc", tuple(x.shape), sum(int(w_.shape[0]) for w_ in weights)),
+    torch.zeros(x.shape[0], sum(int(w_.shape[0]) for w_ in weights), x.shape[2], x.shape[3], device=x.device))
+measure("no small-cout convolutions")
+ops._conv3x3_smallco = orig_small
+
+# (6) the predictor front end (co-resident: 46 registers, 21 KB of LDS)
+orig_fe = ops.adapt_frontend
+ops.adapt_frontend = lambda x, h_hr, *a_, **k_: cache.setdefault(("fe", tuple(x.shape)), torch.zeros(
+    x.shape[0], x.shape[1], x.shape[2], x.shape[3], device=x.device))
+try:
+    measure("no adapt_frontend")
+except Exception as e:  # noqa: BLE001
+    print("no adapt_frontend: skipped", type(e).__name__, e)
+ops.adapt_frontend = orig_fe
 measure("base again")
