@@ -182,6 +182,144 @@ __global__ __launch_bounds__(256 * KZ) void conv3x3_smallco_kernel(SmallArgs a) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same convolution shaped to run BESIDE a resident Winograd workgroup of the other stream (round 3).
+//
+// The what-if timings of the two-stream step (tools/gpu_whatif.py) put the small-cout convolutions at -9.2 ms of 240 when they
+// are removed: with 112-184 registers per lane they cannot share a CU with a conv_wino6 workgroup (which leaves 48 registers per
+// lane and 28 KB of LDS), so every launch waits for convolution-free CUs and then displaces the other stream's convolutions.  This
+// variant is built for the leftover: 256 threads (one wave per SIMD), 23 KB of LDS, and as few vector registers as the compiler
+// can be talked into:
+//   * the input slabs go global -> LDS by LDS-DMA (no staging registers): 4 channels x 10 rows x 72 columns per stage, the patch
+//     starting 4 columns left of the tile so that a row is eighteen aligned 16-byte units (lanes outside the image copy zeros),
+//     two stages, the next slab requested right behind the barrier that retires its stage;
+//   * the weights never touch a vector register or LDS: packed [ci][kx][ky][co] (eavsr_pack_smallco_weight), they are wave-uniform
+//     scalar loads and enter the FMAs as scalar operands;
+//   * the 3 x 3 window of a channel is read column by column (4 values live instead of 12).
+// Same products as conv3x3_smallco_kernel, channels in order; a channel's nine taps are summed column by column (the other kernel
+// goes row by row), so the two agree to rounding, not bit for bit.  Which one runs depends on the image (w % 4, alignment) and
+// on EAVSR_SMALLCO, never on the batch.
+typedef const __attribute__((address_space(1))) void* sl_gptr_t;
+typedef __attribute__((address_space(3))) void* sl_lptr_t;
+__device__ __attribute__((aligned(16))) float g_smallco_zero[4];
+
+constexpr int SL_C = 4, SL_W = ST_W + 8, SL_H = ST_H + 2;          // channels per stage; 72-column patch rows; 10 rows
+constexpr int SL_STAGE = SL_C * SL_H * SL_W;                       // 2880 floats
+constexpr int SL_SEGS = (SL_STAGE / 4 + 63) / 64;                  // 12 one-KiB pieces (the last one a quarter used)
+constexpr int SL_PAD = SL_SEGS * 256;                              // 3072 floats per stage
+constexpr int SL_IT = SL_SEGS / 4;                                 // 3 pieces per wave
+__host__ __device__ constexpr int sl_colblock(int cout) { return cout <= 2 ? 8 : cout <= 4 ? 16 : 32; }   // floats per (ci, kx)
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_smallco_lite_kernel(SmallArgs a) {
+  constexpr int CB = sl_colblock(COUT);
+  __shared__ __attribute__((aligned(16))) float s_in[2][SL_PAD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned bid = (unsigned)eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned q1 = bid / (unsigned)a.tiles_x, tx = bid - q1 * (unsigned)a.tiles_x;
+  const unsigned bn = q1 / (unsigned)a.tiles_y, ty = q1 - bn * (unsigned)a.tiles_y;
+  const int y0 = (int)ty * ST_H, x0 = (int)tx * ST_W;
+  const int h = a.h, w = a.w, cin = a.cin;
+  const unsigned plane4 = (unsigned)(h * w) * 4u;                   // bytes per channel plane (the launcher checks < 2^31)
+
+  // this wave's three pieces of a stage: 16-byte unit e4 -> (channel, row, unit of the row): byte offset inside the 4-channel
+  // block, 0xFFFFFFFF = zero padding (rows / columns outside the image, the unused tail of the last piece)
+  unsigned voff[SL_IT];
+#pragma unroll
+  for (int i = 0; i < SL_IT; ++i) {
+    const int e4 = (i * 4 + wave) * 64 + lane;
+    const int ci = e4 / (SL_H * (SL_W / 4));
+    const int rem = e4 - ci * (SL_H * (SL_W / 4));
+    const int r = rem / (SL_W / 4), c4 = rem - r * (SL_W / 4);
+    const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * c4;
+    const bool ok = e4 < SL_STAGE / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;      // w % 4 == 0: a unit is inside or outside as a whole
+    voff[i] = ok ? (unsigned)ci * plane4 + (unsigned)(gy * w + gx) * 4u : 0xFFFFFFFFu;
+  }
+  const char* const zero_src = reinterpret_cast<const char*>(g_smallco_zero);
+  const char* const xb = reinterpret_cast<const char*>(a.x) + (size_t)bn * cin * plane4;      // wave-uniform
+  const unsigned total4 = (unsigned)cin * plane4;
+  auto issue = [&](int c0, int stage) __attribute__((always_inline)) {
+    const unsigned cbase = (unsigned)c0 * plane4;
+#pragma unroll
+    for (int i = 0; i < SL_IT; ++i) {
+      const unsigned off = cbase + voff[i];
+      const bool ok = voff[i] != 0xFFFFFFFFu && off < total4;      // channels past cin (the last stage of 18 -> 2) read zeros
+      const char* src = ok ? xb + off : zero_src;
+      __builtin_amdgcn_global_load_lds((sl_gptr_t)src, (sl_lptr_t)(&s_in[stage][(i * 4 + wave) * 256]), 16, 0, 0);
+    }
+  };
+
+  float acc[COUT][2];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co][0] = acc[co][1] = 0.f;
+  const int lx = lane, ly = wave;
+  // packed [ci][kx][CB] ([ky][co] in the first 3 COUT floats), read through the CONSTANT address space: a wave-uniform address
+  // there is a scalar load (through the global pointer the compiler must assume the kernel's own stores may alias the weights and
+  // uses vector loads: 13 x 16 bytes per lane and channel, and the registers to hold them)
+  typedef const __attribute__((address_space(4))) float* sl_cptr_t;
+  const sl_cptr_t wpk = (sl_cptr_t)(uintptr_t)a.wt;
+
+  issue(0, 0);
+  for (int c0 = 0, stage = 0; c0 < cin; c0 += SL_C, stage ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();     // this stage's patch is complete; every wave is done with the other stage
+    if (c0 + SL_C < cin) issue(c0 + SL_C, stage ^ 1);
+    const int nci = min(SL_C, cin - c0);
+    for (int ci = 0; ci < nci; ++ci) {
+      const float* pin = &s_in[stage][(ci * SL_H + 2 * ly) * SL_W + lx + 3];
+      const sl_cptr_t wc = wpk + (size_t)(c0 + ci) * 3 * CB;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = pin[r * SL_W + kx];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) {
+            const float wv = wc[kx * CB + ky * COUT + co];            // wave-uniform: a scalar load, a scalar operand
+            acc[co][0] += wv * v[ky];
+            acc[co][1] += wv * v[ky + 1];
+          }
+      }
+    }
+  }
+  const int gx = x0 + lx;
+  if (gx < w) {
+    const float act_s = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int gy = y0 + 2 * ly + p;
+      if (gy < h) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          float v = acc[co][p] + (a.bias ? a.bias[co] : 0.f);
+          v = fmaxf(v, v * act_s);
+          const size_t o = ((size_t)bn * COUT + co) * (plane4 / 4) + (size_t)gy * w + gx;
+          if (a.residual) v += a.residual[o];
+          a.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// (cout, cin, 3, 3) -> [ci][kx][CB]: element ky * cout + co of a column block is w[co][ci][ky][kx]; the rest zero
+__global__ void pack_smallco_kernel(const float* __restrict__ wt, float* __restrict__ out, int cout, int cin, int cb) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= cin * 3 * cb) return;
+  const int j = e % cb, kx = (e / cb) % 3, ci = e / (3 * cb);
+  float v = 0.f;
+  if (j < 3 * cout) {
+    const int ky = j / cout, co = j - ky * cout;
+    v = wt[((size_t)co * cin + ci) * 9 + ky * 3 + kx];
+  }
+  out[e] = v;
+}
+
 }  // namespace
 
 extern "C" int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, const float* bias,
@@ -220,4 +358,53 @@ extern "C" int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, co
   }
 #undef EAVSR_SMALLCO
   return eavsr::launch_status("conv3x3_smallco");
+}
+
+extern "C" int64_t eavsr_smallco_packed_elems(int32_t cout, int32_t cin) {
+  if (cout < 1 || cout > 6 || cin < 1) return 0;
+  return (int64_t)cin * 3 * sl_colblock(cout == 5 ? 6 : cout);
+}
+
+extern "C" int eavsr_pack_smallco_weight(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_smallco_weight: NULL pointer");
+  EAVSR_REQUIRE(cout >= 1 && cout <= 6 && cin >= 1, -1, "pack_smallco_weight: cout %d (1..6), cin %d", cout, cin);
+  const int kc = cout == 1 ? 2 : cout == 5 ? 6 : cout;      // the kernel instances: 2, 3, 4, 6 outputs
+  const int cb = sl_colblock(kc);
+  const int total = cin * 3 * cb;
+  // the column blocks are laid out for the kernel's output count kc: ky * kc + co
+  hipLaunchKernelGGL(pack_smallco_kernel, dim3((total + 255) / 256), dim3(256), 0, eavsr::as_stream(stream), weight, packed,
+                     kc == cout ? cout : kc, cin, cb);
+  return eavsr::launch_status("pack_smallco_weight");
+}
+
+// The co-resident variant (see conv3x3_smallco_lite_kernel): `weight_packed` from eavsr_pack_smallco_weight; cout in {2, 3, 4, 6};
+// w % 4 == 0, x 16-byte aligned, h * w * cin * 4 < 2^32.  Other shapes: eavsr_conv3x3_smallco_f32.
+extern "C" int eavsr_conv3x3_smallco_lite_f32(const float* x, const float* weight_packed, const float* bias, const float* residual,
+                                              float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t act,
+                                              float slope, void* stream) {
+  EAVSR_REQUIRE(x && weight_packed && out, -1, "conv3x3_smallco_lite: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && cin > 0 && h > 0 && w > 0, -1, "conv3x3_smallco_lite: bad dims");
+  EAVSR_REQUIRE(cout == 2 || cout == 3 || cout == 4 || cout == 6, -2, "conv3x3_smallco_lite: cout %d (2, 3, 4 or 6)", cout);
+  EAVSR_REQUIRE(act >= 0 && act <= 2, -1, "conv3x3_smallco_lite: act %d", act);
+  EAVSR_REQUIRE(act != EAVSR_ACT_LRELU || (slope >= 0.f && slope <= 1.f), -2, "conv3x3_smallco_lite: leaky-ReLU slope %g outside [0, 1]",
+                (double)slope);
+  EAVSR_REQUIRE(w % 4 == 0 && (((uintptr_t)x) & 15) == 0, -2, "conv3x3_smallco_lite: w %% 4 == 0 and a 16-byte aligned input");
+  EAVSR_REQUIRE((long)h * w * 4 * cin < (1L << 32), -2, "conv3x3_smallco_lite: sample too large for 32-bit byte offsets");
+  if (n == 0) return 0;
+  SmallArgs a;
+  a.x = x; a.wt = weight_packed; a.bias = bias; a.residual = residual; a.out = out;
+  a.n = n; a.cin = cin; a.h = h; a.w = w; a.act = act; a.slope = slope;
+  a.tiles_x = eavsr::cdiv(w, ST_W);
+  a.tiles_y = eavsr::cdiv(h, ST_H);
+  const long blocks = (long)a.tiles_x * a.tiles_y * n;
+  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_smallco_lite: too many tiles");
+  hipStream_t st = eavsr::as_stream(stream);
+  dim3 grid((unsigned)blocks);
+  switch (cout) {
+    case 2: hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<2>), grid, dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<3>), grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<4>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<6>), grid, dim3(256), 0, st, a); break;
+  }
+  return eavsr::launch_status("conv3x3_smallco_lite");
 }

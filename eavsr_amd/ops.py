@@ -281,6 +281,38 @@ def _cat_weights(weights: Sequence[Tensor]) -> Tensor:
     return cat
 
 
+# Small-cout 3x3 convolutions: launches of >= SMALLCO_LITE_MIN_TILES workgroups (conv_last at 4x resolution: 25,200) run
+# eavsr_conv3x3_smallco_lite_f32 -- 32-39 registers, weights as scalar operands, six workgroups per CU: 850 us against 1,723 us
+# for the 184-register kernel at 14 x 64 x 720 x 1280 -> 3.  Launches of a few hundred workgroups (the 64 -> 6 / 18 -> 2 heads of the
+# pyramid levels: 230) keep round 2's kernels, whose two thread groups per tile hide more latency when there is less than one
+# workgroup per CU (28.9 against 36.3 us).  The variant was built to run BESIDE a resident Winograd workgroup of the other stream
+# (it fits the 48 registers / 28 KB such a CU has left); with it on every launch the step moved 239.9 -> 239.5 ms: the what-if gain of
+# removing these convolutions is their arithmetic and their place in the dependency chain, not their footprint (DESIGN.md 4k).
+# EAVSR_SMALLCO=classic | lite forces one kind for every launch the shape allows.
+SMALLCO_LITE = os.environ.get("EAVSR_SMALLCO", "auto") != "classic"
+SMALLCO_LITE_MIN_TILES = 0 if os.environ.get("EAVSR_SMALLCO") == "lite" else 1024
+_smallco_pack_cache = {}
+
+
+def _packed_smallco(weights: Sequence[Tensor]) -> Tensor:
+    """[ci][kx][block] form of a small-cout 3x3 weight (eavsr_pack_smallco_weight); cached per weight objects and versions"""
+    key = tuple((id(w), w._version) for w in weights)
+    hit = _smallco_pack_cache.get(key)
+    if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
+        return hit[1]
+    w = _chk(_cat_weights(weights).detach(), "weight")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    packed = torch.empty(lib().eavsr_smallco_packed_elems(cout, cin), device=w.device, dtype=torch.float32)
+    with _DeviceOf(w):
+        N.check(lib().eavsr_pack_smallco_weight(_p(w), _p(packed), cout, cin, _stream(w)), "pack_smallco_weight")
+    ids = {id(x) for x in weights}
+    for k in [k for k in _smallco_pack_cache if any(i in ids for i, _ in k)]:
+        _smallco_pack_cache.pop(k, None)
+    refs = tuple(weakref.ref(x, lambda _r, k=key: _smallco_pack_cache.pop(k, None)) for x in weights)
+    _smallco_pack_cache[key] = (refs, packed)
+    return packed
+
+
 def _conv3x3_smallco(x: Tensor, weights, biases, act, slope, residual):
     n, cin, h, w = x.shape
     wt = _cat_weights(weights)
@@ -293,6 +325,13 @@ def _conv3x3_smallco(x: Tensor, weights, biases, act, slope, residual):
             raise ValueError("residual shape mismatch")
     st = _stream(x)
     px = float(n) * h * w
+    if (SMALLCO_LITE and cout in (2, 3, 4, 6) and w % 4 == 0 and x.data_ptr() % 16 == 0 and h * w * cin * 4 < 2 ** 32
+            and n * ((h + 7) // 8) * ((w + 63) // 64) >= SMALLCO_LITE_MIN_TILES):
+        wp = _packed_smallco(list(weights))
+        _launch(f"conv3x3_{cin}to{cout}", 2.0 * cin * cout * 9 * px, 4.0 * px * (cin + cout + (cout if residual is not None else 0)), x,
+                lambda: lib().eavsr_conv3x3_smallco_lite_f32(_p(x), _p(wp), _p(b), _p(residual), _p(out), n, cin, h, w, cout,
+                                                             ACT[act], float(slope), st), "conv3x3_smallco_lite")
+        return out
     _launch(f"conv3x3_{cin}to{cout}", 2.0 * cin * cout * 9 * px, 4.0 * px * (cin + cout + (cout if residual is not None else 0)), x,
             lambda: lib().eavsr_conv3x3_smallco_f32(_p(x), _p(wt), _p(b), _p(residual), _p(out), n, cin, h, w, cout,
                                                     ACT[act], float(slope), st), "conv3x3_smallco")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 19
+#define EAVSR_ABI_VERSION 20
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -254,6 +254,16 @@ int eavsr_pack_conv_weight_f32(const float* weight, float* packed, int32_t cout,
 int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, const float* bias, const float* residual,
                               float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t act,
                               float slope, void* stream);
+
+/* The same convolution (cout in {2, 3, 4, 6}) shaped to run beside a resident Winograd workgroup of another stream: 256 threads,
+ * <= 40 vector registers, 24 KB of LDS, weights as scalar operands from the packed form [ci][kx][block] made by
+ * eavsr_pack_smallco_weight (eavsr_smallco_packed_elems floats).  w % 4 == 0, 16-byte aligned input; same reference call sites as
+ * eavsr_conv3x3_smallco_f32 (models/networks.py:330-331,568, models/eavsrp_model.py:156). */
+int64_t eavsr_smallco_packed_elems(int32_t cout, int32_t cin);
+int eavsr_pack_smallco_weight(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream);
+int eavsr_conv3x3_smallco_lite_f32(const float* x, const float* weight_packed, const float* bias, const float* residual,
+                                   float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t act,
+                                   float slope, void* stream);
 
 /* ---- a11: channel attention -----------------------------------------------------------------
  * CALayer (models/networks.py:432-447): scale[n,c] = sigmoid(W2 . relu(W1 . mean_hw(r) + b1) + b2)

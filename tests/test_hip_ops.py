@@ -148,6 +148,40 @@ def test_conv2d_vs_torch_cpu(ops, cuda, case, direct_conv):
     assert H.maxabs(out.cpu(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [([64], 6, 2, 45, 80, "lrelu", False), ([18], 2, 2, 24, 32, None, False), ([64], 3, 1, 33, 64, None, True),
+                                  ([64], 4, 1, 10, 72, "relu", False), ([18], 2, 3, 180, 320, None, False),
+                                  ([20], 3, 1, 9, 136, None, True)])
+def test_conv3x3_small_cout_co_resident_variant(ops, cuda, case):
+    """round 3: conv3x3_smallco_lite (256 threads, <= 40 registers, scalar weights from the packed form; the variant that fits beside
+    a resident Winograd workgroup) against torch CPU and against the classic kernel, incl. a ragged last stage (18 and 20 input
+    channels over 4-channel stages), tiles cut by the image, several sources, residual."""
+    chans, cout, n, h, w, act, use_res = case
+    cin = sum(chans)
+    srcs = [cases.randn(30 + i, n, c, h, w) for i, c in enumerate(chans)]
+    wt = cases.randn(40, cout, cin, 3, 3, scale=1.0 / (cin * 9) ** 0.5)
+    b = cases.randn(41, cout, scale=0.1)
+    res = cases.randn(42, n, cout, h, w) if use_res else None
+    ref = F.conv2d(torch.cat(srcs, 1), wt, b, 1, 1)
+    ref = F.relu(ref) if act == "relu" else F.leaky_relu(ref, 0.1) if act == "lrelu" else ref
+    if use_res:
+        ref = ref + res
+    outs = {}
+    was = ops.SMALLCO_LITE, ops.SMALLCO_LITE_MIN_TILES
+    try:
+        ops.SMALLCO_LITE_MIN_TILES = 0          # (the default sends only launches of >= 1024 workgroups to the variant)
+        for lite in (True, False):
+            ops.SMALLCO_LITE = lite
+            with ops.profile() as prof:
+                outs[lite] = ops.conv2d([g(s_, cuda) for s_ in srcs], g(wt, cuda), g(b, cuda), act=act, slope=0.1,
+                                        residual=None if res is None else g(res, cuda)).cpu()
+            assert list(prof.summary()) == [f"conv3x3_{cin}to{cout}"]
+    finally:
+        ops.SMALLCO_LITE, ops.SMALLCO_LITE_MIN_TILES = was
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert H.maxabs(outs[True], ref) <= tol and H.maxabs(outs[False], ref) <= tol
+    assert H.maxabs(outs[True], outs[False]) <= tol
+
+
 def test_conv2d_multi_head_weights(ops, cuda):
     x = cases.randn(1, 1, 64, 14, 18)
     ws = [cases.randn(2 + i, co, 64, 3, 3, scale=0.05) for i, co in enumerate((4, 2))]
