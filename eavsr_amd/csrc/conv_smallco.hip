@@ -204,38 +204,44 @@ typedef const __attribute__((address_space(1))) void* sl_gptr_t;
 typedef __attribute__((address_space(3))) void* sl_lptr_t;
 __device__ __attribute__((aligned(16))) float g_smallco_zero[4];
 
-constexpr int SL_C = 4, SL_W = ST_W + 8, SL_H = ST_H + 2;          // channels per stage; 72-column patch rows; 10 rows
-constexpr int SL_STAGE = SL_C * SL_H * SL_W;                       // 2880 floats
-constexpr int SL_SEGS = (SL_STAGE / 4 + 63) / 64;                  // 12 one-KiB pieces (the last one a quarter used)
-constexpr int SL_PAD = SL_SEGS * 256;                              // 3072 floats per stage
-constexpr int SL_IT = SL_SEGS / 4;                                 // 3 pieces per wave
+constexpr int SL_C = 4;                                            // channels per stage
 __host__ __device__ constexpr int sl_colblock(int cout) { return cout <= 2 ? 8 : cout <= 4 ? 16 : 32; }   // floats per (ci, kx)
 
-template <int COUT>
-__global__ __launch_bounds__(256) void conv3x3_smallco_lite_kernel(SmallArgs a) {
+// TH x TW output pixels per workgroup, PXR vertically adjacent pixels per thread: 8 x 64 x 2 (256 threads) for launches of many
+// workgroups, 4 x 32 x 1 (128 threads, four times the workgroups) for the pyramid-level heads, whose 230 tiles of 8 x 64 would be
+// less than one workgroup per CU with nothing to hide a slab's round trip behind.
+template <int COUT, int TH, int TW, int PXR>
+__global__ __launch_bounds__((TH / PXR) * TW) void conv3x3_smallco_lite_kernel(SmallArgs a) {
+  constexpr int NT = (TH / PXR) * TW, NWV = NT / 64;
+  constexpr int PW = TW + 8, PH = TH + 2;                          // patch: 4 columns left of the tile (16-byte units), 1 row above
+  constexpr int STAGE = SL_C * PH * PW;                            // floats
+  constexpr int SEGS = (STAGE / 4 + 63) / 64;                      // one-KiB pieces
+  constexpr int PAD = SEGS * 256;
+  constexpr int P_IT = (SEGS + NWV - 1) / NWV;                     // pieces per wave
   constexpr int CB = sl_colblock(COUT);
-  __shared__ __attribute__((aligned(16))) float s_in[2][SL_PAD];
+  static_assert(TW % 4 == 0 && NT % 64 == 0 && (TW == 32 || TW == 64), "tile shape");
+  __shared__ __attribute__((aligned(16))) float s_in[2][PAD];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned bid = (unsigned)eavsr_xcd_remap(blockIdx.x, gridDim.x);
   const unsigned q1 = bid / (unsigned)a.tiles_x, tx = bid - q1 * (unsigned)a.tiles_x;
   const unsigned bn = q1 / (unsigned)a.tiles_y, ty = q1 - bn * (unsigned)a.tiles_y;
-  const int y0 = (int)ty * ST_H, x0 = (int)tx * ST_W;
+  const int y0 = (int)ty * TH, x0 = (int)tx * TW;
   const int h = a.h, w = a.w, cin = a.cin;
-  const unsigned plane4 = (unsigned)(h * w) * 4u;                   // bytes per channel plane (the launcher checks < 2^31)
+  const unsigned plane4 = (unsigned)(h * w) * 4u;                   // bytes per channel plane (the launcher checks the range)
 
-  // this wave's three pieces of a stage: 16-byte unit e4 -> (channel, row, unit of the row): byte offset inside the 4-channel
-  // block, 0xFFFFFFFF = zero padding (rows / columns outside the image, the unused tail of the last piece)
-  unsigned voff[SL_IT];
+  // this wave's pieces of a stage: 16-byte unit e4 -> (channel, row, unit of the row): byte offset inside the 4-channel block,
+  // 0xFFFFFFFF = zero padding (rows / columns outside the image, the unused tail of the last piece)
+  unsigned voff[P_IT];
 #pragma unroll
-  for (int i = 0; i < SL_IT; ++i) {
-    const int e4 = (i * 4 + wave) * 64 + lane;
-    const int ci = e4 / (SL_H * (SL_W / 4));
-    const int rem = e4 - ci * (SL_H * (SL_W / 4));
-    const int r = rem / (SL_W / 4), c4 = rem - r * (SL_W / 4);
+  for (int i = 0; i < P_IT; ++i) {
+    const int e4 = (i * NWV + wave) * 64 + lane;
+    const int ci = e4 / (PH * (PW / 4));
+    const int rem = e4 - ci * (PH * (PW / 4));
+    const int r = rem / (PW / 4), c4 = rem - r * (PW / 4);
     const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * c4;
-    const bool ok = e4 < SL_STAGE / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;      // w % 4 == 0: a unit is inside or outside as a whole
+    const bool ok = e4 < STAGE / 4 && gy >= 0 && gy < h && gx >= 0 && gx < w;      // w % 4 == 0: a unit is inside or outside as a whole
     voff[i] = ok ? (unsigned)ci * plane4 + (unsigned)(gy * w + gx) * 4u : 0xFFFFFFFFu;
   }
   const char* const zero_src = reinterpret_cast<const char*>(g_smallco_zero);
@@ -244,18 +250,22 @@ __global__ __launch_bounds__(256) void conv3x3_smallco_lite_kernel(SmallArgs a) 
   auto issue = [&](int c0, int stage) __attribute__((always_inline)) {
     const unsigned cbase = (unsigned)c0 * plane4;
 #pragma unroll
-    for (int i = 0; i < SL_IT; ++i) {
-      const unsigned off = cbase + voff[i];
-      const bool ok = voff[i] != 0xFFFFFFFFu && off < total4;      // channels past cin (the last stage of 18 -> 2) read zeros
-      const char* src = ok ? xb + off : zero_src;
-      __builtin_amdgcn_global_load_lds((sl_gptr_t)src, (sl_lptr_t)(&s_in[stage][(i * 4 + wave) * 256]), 16, 0, 0);
+    for (int i = 0; i < P_IT; ++i) {
+      if (i * NWV + wave < SEGS) {     // wave-uniform
+        const unsigned off = cbase + voff[i];
+        const bool ok = voff[i] != 0xFFFFFFFFu && off < total4;      // channels past cin (the last stage of 18 -> 2) read zeros
+        const char* src = ok ? xb + off : zero_src;
+        __builtin_amdgcn_global_load_lds((sl_gptr_t)src, (sl_lptr_t)(&s_in[stage][(i * NWV + wave) * 256]), 16, 0, 0);
+      }
     }
   };
 
-  float acc[COUT][2];
+  float acc[COUT][PXR];
 #pragma unroll
-  for (int co = 0; co < COUT; ++co) acc[co][0] = acc[co][1] = 0.f;
-  const int lx = lane, ly = wave;
+  for (int co = 0; co < COUT; ++co)
+#pragma unroll
+    for (int p = 0; p < PXR; ++p) acc[co][p] = 0.f;
+  const int lx = tid % TW, ly = tid / TW;
   // packed [ci][kx][CB] ([ky][co] in the first 3 COUT floats), read through the CONSTANT address space: a wave-uniform address
   // there is a scalar load (through the global pointer the compiler must assume the kernel's own stores may alias the weights and
   // uses vector loads: 13 x 16 bytes per lane and channel, and the registers to hold them)
@@ -269,20 +279,20 @@ __global__ __launch_bounds__(256) void conv3x3_smallco_lite_kernel(SmallArgs a) 
     if (c0 + SL_C < cin) issue(c0 + SL_C, stage ^ 1);
     const int nci = min(SL_C, cin - c0);
     for (int ci = 0; ci < nci; ++ci) {
-      const float* pin = &s_in[stage][(ci * SL_H + 2 * ly) * SL_W + lx + 3];
+      const float* pin = &s_in[stage][(ci * PH + PXR * ly) * PW + lx + 3];
       const sl_cptr_t wc = wpk + (size_t)(c0 + ci) * 3 * CB;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        float v[4];
+        float v[PXR + 2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = pin[r * SL_W + kx];
+        for (int r = 0; r < PXR + 2; ++r) v[r] = pin[r * PW + kx];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int co = 0; co < COUT; ++co) {
             const float wv = wc[kx * CB + ky * COUT + co];            // wave-uniform: a scalar load, a scalar operand
-            acc[co][0] += wv * v[ky];
-            acc[co][1] += wv * v[ky + 1];
+#pragma unroll
+            for (int p = 0; p < PXR; ++p) acc[co][p] += wv * v[ky + p];
           }
       }
     }
@@ -291,8 +301,8 @@ __global__ __launch_bounds__(256) void conv3x3_smallco_lite_kernel(SmallArgs a) 
   if (gx < w) {
     const float act_s = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int gy = y0 + 2 * ly + p;
+    for (int p = 0; p < PXR; ++p) {
+      const int gy = y0 + PXR * ly + p;
       if (gy < h) {
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
@@ -394,17 +404,30 @@ extern "C" int eavsr_conv3x3_smallco_lite_f32(const float* x, const float* weigh
   SmallArgs a;
   a.x = x; a.wt = weight_packed; a.bias = bias; a.residual = residual; a.out = out;
   a.n = n; a.cin = cin; a.h = h; a.w = w; a.act = act; a.slope = slope;
-  a.tiles_x = eavsr::cdiv(w, ST_W);
-  a.tiles_y = eavsr::cdiv(h, ST_H);
+  // 8 x 64 tiles while they give every CU several workgroups; 4 x 32 tiles (a quarter of the pixels, 128 threads) below that:
+  // the choice depends on the image size only (a clip's bits never depend on the batch -- and here not on the tile either: a
+  // pixel's sum is the same sequence of operations in both shapes)
+  const bool small_tiles = (long)eavsr::cdiv(w, ST_W) * eavsr::cdiv(h, ST_H) < 1024;
+#ifndef EAVSR_SL_TH
+#define EAVSR_SL_TH 4
+#define EAVSR_SL_TW 32
+#endif
+  const int th = small_tiles ? EAVSR_SL_TH : ST_H, tw = small_tiles ? EAVSR_SL_TW : ST_W;
+  a.tiles_x = eavsr::cdiv(w, tw);
+  a.tiles_y = eavsr::cdiv(h, th);
   const long blocks = (long)a.tiles_x * a.tiles_y * n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_smallco_lite: too many tiles");
   hipStream_t st = eavsr::as_stream(stream);
   dim3 grid((unsigned)blocks);
+#define EAVSR_SMALLCO_LITE(CO)                                                                                         \
+  if (small_tiles) hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<CO, EAVSR_SL_TH, EAVSR_SL_TW, 1>), grid, dim3(EAVSR_SL_TH * EAVSR_SL_TW), 0, st, a); \
+  else hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<CO, ST_H, ST_W, 2>), grid, dim3(256), 0, st, a)
   switch (cout) {
-    case 2: hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<2>), grid, dim3(256), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<3>), grid, dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<4>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((conv3x3_smallco_lite_kernel<6>), grid, dim3(256), 0, st, a); break;
+    case 2: EAVSR_SMALLCO_LITE(2); break;
+    case 3: EAVSR_SMALLCO_LITE(3); break;
+    case 4: EAVSR_SMALLCO_LITE(4); break;
+    default: EAVSR_SMALLCO_LITE(6); break;
   }
+#undef EAVSR_SMALLCO_LITE
   return eavsr::launch_status("conv3x3_smallco_lite");
 }

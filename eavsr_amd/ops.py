@@ -281,16 +281,12 @@ def _cat_weights(weights: Sequence[Tensor]) -> Tensor:
     return cat
 
 
-# Small-cout 3x3 convolutions: launches of >= SMALLCO_LITE_MIN_TILES workgroups (conv_last at 4x resolution: 25,200) run
-# eavsr_conv3x3_smallco_lite_f32 -- 32-39 registers, weights as scalar operands, six workgroups per CU: 850 us against 1,723 us
-# for the 184-register kernel at 14 x 64 x 720 x 1280 -> 3.  Launches of a few hundred workgroups (the 64 -> 6 / 18 -> 2 heads of the
-# pyramid levels: 230) keep round 2's kernels, whose two thread groups per tile hide more latency when there is less than one
-# workgroup per CU (28.9 against 36.3 us).  The variant was built to run BESIDE a resident Winograd workgroup of the other stream
-# (it fits the 48 registers / 28 KB such a CU has left); with it on every launch the step moved 239.9 -> 239.5 ms: the what-if gain of
-# removing these convolutions is their arithmetic and their place in the dependency chain, not their footprint.
-# EAVSR_SMALLCO=classic | lite forces one kind for every launch the shape allows.
-SMALLCO_LITE = os.environ.get("EAVSR_SMALLCO", "auto") != "classic"
-SMALLCO_LITE_MIN_TILES = 0 if os.environ.get("EAVSR_SMALLCO") == "lite" else 1024
+# Small-cout 3x3 convolutions (64 -> 6 / 18 -> 2 heads of the pyramid levels, conv_last): eavsr_conv3x3_smallco_lite_f32 wherever the
+# shape allows -- 30-39 registers, weights as scalar operands, so that its waves fit beside a resident Winograd workgroup of the other
+# stream (48 registers / 28 KB are left on such a CU): conv_last 1,723 -> 850 us, and with 4 x 32-pixel tiles on the small launches
+# the step 240.0 -> 236.8 ms.  EAVSR_SMALLCO=classic: round 2's 112-184-register kernels (the A/B reference).
+SMALLCO_LITE = os.environ.get("EAVSR_SMALLCO", "lite") != "classic"
+SMALLCO_LITE_MIN_TILES = 0
 _smallco_pack_cache = {}
 
 
