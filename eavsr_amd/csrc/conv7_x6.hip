@@ -1,0 +1,364 @@
+// 7x7 stride-1 "same" convolution, fp32 in / fp32 out, the contraction on the bf16 matrix pipe with exact operand splits
+// ("bf16x6"): the five layers of SPyNet's basic module (8 -> 32 -> 64 -> 32 -> 16 -> 2 at six pyramid levels; reference
+// eavsrp_model.py:398-431, called from compute_flow eavsrp_model.py:433-488), which conv2d_mfma_kernel<7, ..> ran on the fp32
+// MFMA at 0.43 of its peak (28 ms of the 236 ms bench step).
+//
+// Arithmetic (as dcnv2_il.hip, NPROD = 6): every fp32 operand is split EXACTLY into three bf16 terms (hi = trunc_bf16(x),
+// mid = trunc_bf16(x - hi), lo = x - hi - mid; hi + mid + lo == x bit for bit), products of bf16 numbers are exact in fp32, the
+// six partial products down to 2^-16 of the result are accumulated in fp32 and the three below 2^-23 (mid*lo, lo*mid, lo*lo)
+// are dropped: at most 2 * 2^-24 relative per product -- one fp32 rounding.  No operand is rounded to 16 bits.
+// v_mfma_f32_32x32x16_bf16 does 16 k in 32 cycles where v_mfma_f32_32x32x2_f32 does 2 k in 64: six of them are 2.67x the fp32 rate.
+//
+// Unlike conv_x9.hip (3x3, split in registers per use) the input is split ONCE per value, on its way into LDS: a 7x7 tap window
+// reuses every input value 49 times.  Per workgroup (512 threads, 16 rows x 32 pixels, 32 MT output channels) and per chunk of
+// 8 input channels:
+//   * patch: (16+6) x 40 pixels x 8 channels, read from the NCHW image by plain coalesced loads one chunk ahead (16 values per
+//     thread in flight), split in registers, stored channel-interleaved as three bf16 planes [plane][row][col][8 ch] (16 bytes
+//     per pixel and plane): the MFMA B operand of lane (n = lane & 31, g = lane >> 5) for k-step s -- the 8 channels of pixel
+//     n shifted by ITS tap 2 s + g -- is one ds_read_b128 per plane, consecutive lanes 16 bytes apart (no bank conflicts);
+//   * weights: pre-split and pre-arranged by eavsr_pack_conv7_weight_x6 in MFMA A-operand order, streamed by 16-byte LDS-DMA
+//     in slabs of 5 k-steps (10 taps; 25 k-steps = 49 taps + one zero tap per chunk: 2 % padding) into two stages; the slab
+//     barrier sits one k-step before the slab changes, so that the next slab's first A operands are prefetched like any other.
+// The main loop is LDS reads and MFMAs only: 6 + 3 MT reads of 16 bytes per 12 MT MFMAs and wave, operands read one k-step ahead.
+#include "common.h"
+
+#include <mutex>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int S_NW = 8, S_NT = 2, S_TH = S_NW * S_NT, S_TW = 32, S_PAD = 3;
+constexpr int S_IH = S_TH + 6, S_IW = 40;                     // patch rows y0-3 .. y0+18, columns x0-3 .. x0+36 (38 used + the zero tap's overread)
+constexpr int S_NPIX = S_IH * S_IW;                           // 880 pixels
+constexpr int S_PLANE_B = S_NPIX * 16;                        // bytes of one bf16 plane of the patch (8 channels per pixel)
+constexpr int S_PATCH_B = 3 * S_PLANE_B;                      // 42,240
+constexpr int S_KSTEPS = 25, S_SLAB = 5, S_NSLAB = S_KSTEPS / S_SLAB;
+template <int MT> struct C7 {
+  static constexpr int SLAB_U4 = S_SLAB * 3 * MT * 64;         // 16-byte elements of one weight slab (5 k-steps)
+  static constexpr int SLAB_SEGS = SLAB_U4 / 64;               // one-KiB DMA pieces: 15 MT
+  static constexpr int W_IT = (SLAB_SEGS + S_NW - 1) / S_NW;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)S_PATCH_B + 2 * (size_t)SLAB_U4 * 16;   // 145,920 (MT = 2), 115,200 (MT = 1)
+};
+
+struct C7Args {
+  const float* x;        // (n, cin, h, w)
+  const u32x4* wsplit;   // [cot][chunk][k-step][plane][mt][lane] 16-byte elements
+  const float* bias;
+  float* out;            // (n, cout, h, w)
+  int n, cin, cout, h, w, tiles_x, tiles_y;
+  int act;
+  float slope;
+};
+
+// exact three-way split of two fp32 values into packed bf16 pairs (low half = first value)
+__device__ __forceinline__ void s_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
+  const unsigned uma = __float_as_uint(ra), umb = __float_as_uint(rb);
+  const float la = ra - __uint_as_float(uma & 0xFFFF0000u), lb = rb - __uint_as_float(umb & 0xFFFF0000u);
+  hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+  mid = __builtin_amdgcn_perm(umb, uma, 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+}
+
+__device__ __forceinline__ f32x16 s_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int MT>
+__global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
+  using K = C7<MT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
+  unsigned char* s_patch = smem7;                                            // [2][3 planes][22][40][16 B]
+  u32x4* s_w = reinterpret_cast<u32x4*>(smem7 + 2 * S_PATCH_B);              // [2][SLAB_U4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kg = lane >> 5;
+
+  int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int bn = bid / a.tiles_y;
+  const int cot = blockIdx.y;
+  const int y0 = ty * S_TH, x0 = tx * S_TW;
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+  const int nch = a.cin >> 3;
+
+  // ---- patch producer: thread t owns patch pixels t and t + 512 --------------------------------------------------
+  bool pok[2];
+  unsigned pgo[2], plo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + i * 512;
+    const int r = p / S_IW, c = p - r * S_IW;
+    const int gy = y0 - S_PAD + r, gx = x0 - S_PAD + c;
+    // columns 38, 39 are never a tap of anybody: kept zero (the zero tap of the last k-step reads column 39, below)
+    pok[i] = p < S_NPIX && c < S_TW + 6 && gy >= 0 && gy < h && gx >= 0 && gx < w;
+    pgo[i] = pok[i] ? (unsigned)(gy * w + gx) : 0u;
+    plo[i] = (unsigned)p * 16u;
+  }
+  const bool second = tid + 512 < S_NPIX;    // 368 threads own a second pixel
+  float pv[2][8];
+  auto load_patch = [&](int ch) __attribute__((always_inline)) {
+    const float* sp = a.x + ((size_t)bn * a.cin + (size_t)ch * 8) * plane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[i][j] = pok[i] ? sp[(size_t)j * plane + pgo[i]] : 0.f;
+  };
+  auto store_patch = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && !second) break;
+      u32x4 pl[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned h2, m2, l2;
+        s_split2(pv[i][2 * c], pv[i][2 * c + 1], h2, m2, l2);
+        pl[0][c] = h2; pl[1][c] = m2; pl[2][c] = l2;
+      }
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3)
+        *reinterpret_cast<u32x4*>(s_patch + stage * S_PATCH_B + p3 * S_PLANE_B + plo[i]) = pl[p3];
+    }
+  };
+  // ---- weight slabs: global slab index gs = chunk * 5 + slab, LDS stage gs & 1 -------------------------------------
+  const int nslabs = nch * S_NSLAB;
+  auto issue_slab = [&](int gs) __attribute__((always_inline)) {
+    const char* wsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)cot * nslabs + gs) * K::SLAB_U4);
+    u32x4* dst = s_w + (gs & 1) * K::SLAB_U4;
+#pragma unroll
+    for (int i = 0; i < K::W_IT; ++i) {
+      const int seg = i * S_NW + wave;
+      if (seg < K::SLAB_SEGS)  // wave-uniform
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (unsigned)(seg * 64 + lane) * 16u), (lptr_t)(dst + seg * 64), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MT][S_NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int t = 0; t < S_NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+  // B operand address of this lane: pixel (wave * 2 + row + ky, l31 + kx) of the patch, tap (ky, kx) = 2 s + kg.  The tap pair
+  // of a k-step is (kx, kx + 1) of one kernel row, or (6 of row ky, 0 of row ky + 1): two lane bases, everything else immediate.
+  // The last k-step pairs tap 48 with a tap that does not exist: its weights are zero and its lanes read the always-zero column
+  // 39 of patch row 0 / 1 (0 x 0, whatever the image holds next to the window).
+  const int bbase = ((wave * S_NT) * S_IW + l31) * 16;
+  const int b_same = bbase + (kg ? 16 : 0);
+  const int b_wrap = bbase + (kg ? (S_IW - 6) * 16 : 0);
+  const int b_last = kg ? (S_IW - 1) * 16 - (6 * S_IW + 6) * 16 : bbase;
+  auto read_b = [&](int stage, int s, u32x4 (&b)[S_NT][3]) __attribute__((always_inline)) {
+    const int tap0 = 2 * s, ky = tap0 / 7, kx = tap0 - 7 * ky;
+    const unsigned char* base = s_patch + stage * S_PATCH_B + ((s == S_KSTEPS - 1 ? b_last : kx == 6 ? b_wrap : b_same) + (ky * S_IW + kx) * 16);
+#pragma unroll
+    for (int t = 0; t < S_NT; ++t)
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) b[t][p3] = *reinterpret_cast<const u32x4*>(base + t * S_IW * 16 + p3 * S_PLANE_B);
+  };
+  auto read_a = [&](int gs, int sl, u32x4 (&av)[3][MT]) __attribute__((always_inline)) {
+    const u32x4* ws = s_w + (gs & 1) * K::SLAB_U4 + sl * (3 * MT * 64) + lane;
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[p3][m] = ws[(p3 * MT + m) * 64];
+  };
+
+  // ---- prologue --------------------------------------------------------------------------------------------------
+  issue_slab(0);
+  load_patch(0);
+  store_patch(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nslabs > 1) issue_slab(1);
+  u32x4 acur[3][MT], bcur[S_NT][3];
+  read_a(0, 0, acur);
+  read_b(0, 0, bcur);
+
+  for (int ch = 0; ch < nch; ++ch) {
+    const int pst = ch & 1;
+    const bool more = ch + 1 < nch;
+    if (more) load_patch(ch + 1);
+#pragma unroll
+    for (int ks = 0; ks < S_KSTEPS; ++ks) {
+      const int gs = ch * S_NSLAB + ks / S_SLAB;
+      const int sl = ks % S_SLAB;
+      if (sl == S_SLAB - 1) {
+        // the slab barrier, one k-step early: slab gs + 1 has landed (requested a slab ago), every wave has read the last A
+        // operands of slab gs (they were prefetched in the previous k-step), so its stage takes slab gs + 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (gs + 2 < nslabs) issue_slab(gs + 2);
+      }
+      if (ks == 11 && more) store_patch(pst ^ 1);      // published by the barriers at k-steps 14, 19, 24
+      // operands of the next k-step
+      u32x4 anext[3][MT], bnext[S_NT][3];
+      const bool last = ks == S_KSTEPS - 1;
+      if (!last) {
+        read_a(sl == S_SLAB - 1 ? gs + 1 : gs, (sl + 1) % S_SLAB, anext);
+        read_b(pst, ks + 1, bnext);
+      } else if (more) {
+        read_a(gs + 1, 0, anext);
+        read_b(pst ^ 1, 0, bnext);
+      }
+      // the six partial products, smallest first: (A plane, B plane) = (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+#pragma unroll
+      for (int t = 0; t < S_NT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x16 c_ = acc[m][t];
+          c_ = s_mfma(acur[2][m], bcur[t][0], c_);
+          c_ = s_mfma(acur[0][m], bcur[t][2], c_);
+          c_ = s_mfma(acur[1][m], bcur[t][1], c_);
+          c_ = s_mfma(acur[1][m], bcur[t][0], c_);
+          c_ = s_mfma(acur[0][m], bcur[t][1], c_);
+          c_ = s_mfma(acur[0][m], bcur[t][0], c_);
+          acc[m][t] = c_;
+        }
+      // issue order: the next k-step's reads go out between the first MFMAs of this one (one MFMA, one read, ..), the rest of
+      // the MFMAs cover their latency; nothing crosses the end of the k-step (the scheduler otherwise sinks every read to just
+      // in front of its first use, behind an s_waitcnt lgkmcnt(0))
+      {
+        constexpr int NRD = 3 * MT + 3 * S_NT, NMF = 6 * MT * S_NT;
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // (the MFMA first: its wait for the operands read during the
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      //  previous k-step then does not cover a read issued just now)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!last || more) {
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acur[p3][m] = anext[p3][m];
+#pragma unroll
+          for (int t = 0; t < S_NT; ++t) bcur[t][p3] = bnext[t][p3];
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, activation, NCHW stores (lanes 0-31 / 32-63: 32 consecutive pixels of two channels 4 apart) ----
+  const int gx = x0 + l31;
+  const bool xok = gx < w;
+  const float act_s = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cot * 32 * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const bool cok = co < a.cout;
+      const float b = (cok && a.bias) ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int t = 0; t < S_NT; ++t) {
+        const int gy = y0 + wave * S_NT + t;
+        float v = acc[m][t][r] + b;
+        v = fmaxf(v, v * act_s);      // branch-free: max(v, v s), 0 <= s <= 1
+        if (cok && xok && gy < h) a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = v;
+      }
+    }
+}
+
+// (cout, cin, 7, 7) fp32 -> [cot][chunk][k-step][plane][mt][lane] 16-byte elements: lane (r = lane & 31, g = lane >> 5) holds
+// A[row r][k = 8 g + j] = W[cot * 32 MT + mt * 32 + r][chunk * 8 + j][tap 2 s + g], j = 0..7, plane 0 / 1 / 2 = hi / mid / lo
+__global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p, int cout, int cin, int mt_n, long total) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  long q = e;
+  const int lane = (int)(q % 64); q /= 64;
+  const int mt = (int)(q % mt_n); q /= mt_n;
+  const int pl = (int)(q % 3); q /= 3;
+  const int s = (int)(q % S_KSTEPS); q /= S_KSTEPS;
+  const int nch = cin / 8;
+  const int ch = (int)(q % nch);
+  const int cot = (int)(q / nch);
+  const int co = cot * 32 * mt_n + mt * 32 + (lane & 31);
+  const int tap = 2 * s + (lane >> 5);
+  u32x4 o;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ci = ch * 8 + 2 * c + u;
+      v[u] = (co < cout && tap < 49) ? wt[((size_t)co * cin + ci) * 49 + tap] : 0.f;
+    }
+    unsigned h2, m2, l2;
+    s_split2(v[0], v[1], h2, m2, l2);
+    o[c] = pl == 0 ? h2 : pl == 1 ? m2 : l2;
+  }
+  p[e] = o;
+}
+
+int mt_of(int cout) { return cout > 32 ? 2 : 1; }
+
+template <int MT>
+int launch7(const C7Args& a, void* stream) {
+  using K = C7<MT>;
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once_pd.flag[dev_], [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv7x7_x6_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)K::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("conv7x7_f32x6: hipFuncSetAttribute(%zu B of LDS): %s", K::LDS_BYTES, hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  const long blocks = (long)a.tiles_x * a.tiles_y * a.n;
+  dim3 grid((unsigned)blocks, eavsr::cdiv(a.cout, 32 * MT));
+  hipLaunchKernelGGL(conv7x7_x6_kernel<MT>, grid, dim3(64 * S_NW), K::LDS_BYTES, eavsr::as_stream(stream), a);
+  return eavsr::launch_status("conv7x7_f32x6");
+}
+
+}  // namespace
+
+extern "C" size_t eavsr_conv7_weight_x6_bytes(int32_t cout, int32_t cin) {
+  if (cout <= 0 || cin <= 0 || cin % 8) return 0;
+  const int mt = mt_of(cout);
+  return (size_t)eavsr::cdiv(cout, 32 * mt) * (cin / 8) * S_KSTEPS * 3 * mt * 64 * 16;
+}
+
+extern "C" int eavsr_pack_conv7_weight_x6(const float* weight, void* packed, int32_t cout, int32_t cin, void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_conv7_weight_x6: NULL pointer");
+  EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % 8 == 0, -1, "pack_conv7_weight_x6: cin %d must be a multiple of 8", cin);
+  const long total = (long)(eavsr_conv7_weight_x6_bytes(cout, cin) / 16);
+  hipLaunchKernelGGL(pack7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
+                     reinterpret_cast<u32x4*>(packed), cout, cin, mt_of(cout), total);
+  return eavsr::launch_status("pack_conv7_weight_x6");
+}
+
+extern "C" int eavsr_conv7x7_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,
+                                   int32_t cout, int32_t h, int32_t w, int32_t act, float slope, void* stream) {
+  EAVSR_REQUIRE(x && weight_x6 && out, -1, "conv7x7_f32x6: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && cin > 0 && cout > 0 && h > 0 && w > 0, -1, "conv7x7_f32x6: bad dims");
+  EAVSR_REQUIRE(cin % 8 == 0, -2, "conv7x7_f32x6: cin %d must be a multiple of 8 (use eavsr_conv2d_f32)", cin);
+  EAVSR_REQUIRE(act >= 0 && act <= 2, -1, "conv7x7_f32x6: act %d", act);
+  EAVSR_REQUIRE(act != EAVSR_ACT_LRELU || (slope >= 0.f && slope <= 1.f), -2,
+                "conv7x7_f32x6: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)slope);
+  EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "conv7x7_f32x6: image plane too large for 32-bit pixel offsets");
+  if (n == 0) return 0;
+  C7Args a;
+  a.x = x; a.wsplit = reinterpret_cast<const u32x4*>(weight_x6); a.bias = bias; a.out = out;
+  a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.w = w;
+  a.tiles_x = eavsr::cdiv(w, S_TW);
+  a.tiles_y = eavsr::cdiv(h, S_TH);
+  a.act = act; a.slope = slope;
+  EAVSR_REQUIRE((long)a.tiles_x * a.tiles_y * n < (1L << 31), -1, "conv7x7_f32x6: too many tiles");
+  return mt_of(cout) == 2 ? launch7<2>(a, stream) : launch7<1>(a, stream);
+}

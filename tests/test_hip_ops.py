@@ -182,6 +182,50 @@ def test_conv3x3_small_cout_co_resident_variant(ops, cuda, case):
     assert H.maxabs(outs[True], outs[False]) <= tol
 
 
+@pytest.mark.parametrize("case", [(8, 32, 2, 24, 40, "relu"), (32, 64, 1, 48, 80, "relu"), (64, 32, 2, 16, 32, "relu"), (32, 16, 3, 6, 10, "relu"),
+                                  (16, 2, 2, 12, 20, None), (64, 64, 1, 37, 70, "lrelu"), (8, 70, 1, 19, 33, None), (24, 32, 1, 96, 160, "relu")])
+def test_conv7x7_bf16x6_matches_fp64_and_the_fp32_kernel(ops, cuda, case):
+    """round 3: eavsr_conv7x7_f32x6 (SPyNet's basic module, eavsrp_model.py:398-431: the contraction on the bf16 matrix pipe, both
+    operands split exactly into three bf16 terms) at every layer shape of the module, tiles cut by the image in both directions, a
+    cout that is not a multiple of 32, three input chunks, against an fp64 evaluation (as accurate as the fp32-MFMA kernel, whose
+    error is measured beside it) and against torch's fp32 CPU convolution."""
+    cin, cout, n, h, w, act = case
+    x = cases.randn(50, n, cin, h, w)
+    wt = cases.randn(51, cout, cin, 7, 7, scale=1.0 / (cin * 49) ** 0.5)
+    b = cases.randn(52, cout, scale=0.1)
+    ref64 = F.conv2d(x.double(), wt.double(), b.double(), 1, 3)
+    ref64 = F.relu(ref64) if act == "relu" else F.leaky_relu(ref64, 0.1) if act == "lrelu" else ref64
+    outs = {}
+    was = ops.CONV7_MODE
+    try:
+        for mode in ("bf16x6", "fp32"):
+            ops.CONV7_MODE = mode
+            with ops.profile() as prof:
+                outs[mode] = ops.conv2d(g(x, cuda), g(wt, cuda), g(b, cuda), act=act, slope=0.1).cpu()
+            assert list(prof.summary()) == [f"conv7x7_{cin}to{cout}_x6" if mode == "bf16x6" else f"conv7x7_{cin}to{cout}"]
+    finally:
+        ops.CONV7_MODE = was
+    scale = max(1.0, ref64.abs().max().item())
+    e6 = (outs["bf16x6"].double() - ref64).abs().max().item() / scale
+    e32 = (outs["fp32"].double() - ref64).abs().max().item() / scale
+    assert e6 <= 3e-6 and e6 <= 2.0 * e32 + 2e-7, (e6, e32)
+    ref = ref64.float()
+    assert H.maxabs(outs["bf16x6"], ref) <= 2e-5 * scale
+
+
+def test_conv7x7_bf16x6_zero_tap_reads_no_neighbour(ops, cuda):
+    """the 50th tap of a chunk has zero weights and reads the always-zero patch column: a NaN / Inf next to the receptive field of a
+    pixel must not reach it (0 x NaN), and one inside must."""
+    x = cases.randn(53, 1, 8, 20, 48)
+    x[0, 3, 9, 30] = float("inf")
+    wt = cases.randn(54, 32, 8, 7, 7, scale=0.05)
+    out = ops.conv2d(g(x, cuda), g(wt, cuda), None).cpu()
+    ref = F.conv2d(x, wt, None, 1, 3)
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(out), fin)
+    assert H.maxabs(out[fin], ref[fin]) <= 2e-5 * max(1.0, ref[fin].abs().max().item())
+
+
 def test_conv2d_multi_head_weights(ops, cuda):
     x = cases.randn(1, 1, 64, 14, 18)
     ws = [cases.randn(2 + i, co, 64, 3, 3, scale=0.05) for i, co in enumerate((4, 2))]
