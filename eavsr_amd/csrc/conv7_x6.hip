@@ -31,17 +31,21 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int S_NW = 8, S_NT = 2, S_TH = S_NW * S_NT, S_TW = 32, S_PAD = 3;
-constexpr int S_IH = S_TH + 6, S_IW = 40;                     // patch rows y0-3 .. y0+18, columns x0-3 .. x0+36 (38 used + the zero tap's overread)
-constexpr int S_NPIX = S_IH * S_IW;                           // 880 pixels
-constexpr int S_PLANE_B = S_NPIX * 16;                        // bytes of one bf16 plane of the patch (8 channels per pixel)
-constexpr int S_PATCH_B = 3 * S_PLANE_B;                      // 42,240
+constexpr int S_NW = 8, S_TW = 32, S_PAD = 3;
+constexpr int S_IW = 40;                                      // patch columns x0-3 .. x0+36 (38 used; 39 stays zero for the zero tap)
 constexpr int S_KSTEPS = 25, S_SLAB = 5, S_NSLAB = S_KSTEPS / S_SLAB;
-template <int MT> struct C7 {
+// MT: 32-channel output tiles per workgroup; NT: image rows per wave (tile = 8 NT rows x 32 pixels).  NT = 1 and MT = 1 exist for
+// the coarse pyramid levels, where a launch is a handful of workgroups and its time is ONE workgroup's chain of k-steps.
+template <int MT, int NT> struct C7 {
+  static constexpr int TH = S_NW * NT;
+  static constexpr int IH = TH + 6;                            // patch rows y0-3 .. y0+TH+2
+  static constexpr int NPIX = IH * S_IW;                       // 880 (NT = 2), 560 (NT = 1) pixels
+  static constexpr int PLANE_B = NPIX * 16;                    // bytes of one bf16 plane of the patch (8 channels per pixel)
+  static constexpr int PATCH_B = 3 * PLANE_B;                  // 42,240 / 26,880
   static constexpr int SLAB_U4 = S_SLAB * 3 * MT * 64;         // 16-byte elements of one weight slab (5 k-steps)
   static constexpr int SLAB_SEGS = SLAB_U4 / 64;               // one-KiB DMA pieces: 15 MT
   static constexpr int W_IT = (SLAB_SEGS + S_NW - 1) / S_NW;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)S_PATCH_B + 2 * (size_t)SLAB_U4 * 16;   // 145,920 (MT = 2), 115,200 (MT = 1)
+  static constexpr size_t LDS_BYTES = 2 * (size_t)PATCH_B + 2 * (size_t)SLAB_U4 * 16 + 64 * 4;   // 146,176 at MT = NT = 2 (+ the bias)
 };
 
 struct C7Args {
@@ -69,12 +73,31 @@ __device__ __forceinline__ f32x16 s_mfma(const u32x4& a, const u32x4& b, const f
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int MT>
+#ifdef EAVSR_C7_STAMPS
+// diagnostic build only (tools/build_c7_diag.sh): shader cycles per phase, summed over wave 0 of every workgroup
+__device__ unsigned long long g_c7_stamps[8];
+#define C7_STAMP(i)                                                   \
+  do {                                                                \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();       \
+    st_acc[i] += t_ - st_last;                                        \
+    st_last = t_;                                                     \
+  } while (0)
+#else
+#define C7_STAMP(i) do { } while (0)
+#endif
+
+template <int MT, int NT, int WMT>
 __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
-  using K = C7<MT>;
+  using K = C7<MT, NT>;
+  constexpr int S_NT = NT, S_TH = K::TH, S_NPIX = K::NPIX, S_PLANE_B = K::PLANE_B, S_PATCH_B = K::PATCH_B;
+#ifdef EAVSR_C7_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem7[];
   unsigned char* s_patch = smem7;                                            // [2][3 planes][22][40][16 B]
   u32x4* s_w = reinterpret_cast<u32x4*>(smem7 + 2 * S_PATCH_B);              // [2][SLAB_U4]
+  float* s_bias = reinterpret_cast<float*>(smem7 + 2 * S_PATCH_B + 2 * K::SLAB_U4 * 16);   // [32 MT]: the accumulators start from it
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -105,7 +128,7 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
     pgo[i] = pok[i] ? (unsigned)(gy * w + gx) : 0u;
     plo[i] = (unsigned)p * 16u;
   }
-  const bool second = tid + 512 < S_NPIX;    // 368 threads own a second pixel
+  const bool second = tid + 512 < S_NPIX;    // 368 (NT = 2) / 48 (NT = 1) threads own a second pixel
   float pv[2][8];
   auto load_patch = [&](int ch) __attribute__((always_inline)) {
     const float* sp = a.x + ((size_t)bn * a.cin + (size_t)ch * 8) * plane;
@@ -132,24 +155,24 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
   };
   // ---- weight slabs: global slab index gs = chunk * 5 + slab, LDS stage gs & 1 -------------------------------------
   const int nslabs = nch * S_NSLAB;
+  // (the packed weight holds WMT >= MT 32-channel tiles per `cot`, one-KiB pieces in [k-step][plane][tile] order: a workgroup of
+  //  fewer tiles picks its pieces out of the slab)
+  constexpr int wsplit_n = WMT / MT;                        // workgroups per packed cot
+  const int wcot = cot / wsplit_n, wsub = (cot - wcot * wsplit_n) * MT;
   auto issue_slab = [&](int gs) __attribute__((always_inline)) {
-    const char* wsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)cot * nslabs + gs) * K::SLAB_U4);
+    const char* wsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)wcot * nslabs + gs) * (K::SLAB_U4 * wsplit_n));
     u32x4* dst = s_w + (gs & 1) * K::SLAB_U4;
 #pragma unroll
     for (int i = 0; i < K::W_IT; ++i) {
-      const int seg = i * S_NW + wave;
-      if (seg < K::SLAB_SEGS)  // wave-uniform
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (unsigned)(seg * 64 + lane) * 16u), (lptr_t)(dst + seg * 64), 16, 0, 0);
+      const int seg = i * S_NW + wave;                      // piece (k-step, plane, tile m) = seg / MT, seg % MT of this workgroup
+      if (seg < K::SLAB_SEGS) {  // wave-uniform
+        const int sp = MT == 1 ? seg * WMT + wsub : (seg >> 1) * WMT + wsub + (seg & 1);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (unsigned)(sp * 64 + lane) * 16u), (lptr_t)(dst + seg * 64), 16, 0, 0);
+      }
     }
   };
 
   f32x16 acc[MT][S_NT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int t = 0; t < S_NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
 
   // B operand address of this lane: pixel (wave * 2 + row + ky, l31 + kx) of the patch, tap (ky, kx) = 2 s + kg.  The tap pair
   // of a k-step is (kx, kx + 1) of one kernel row, or (6 of row ky, 0 of row ky + 1): two lane bases, everything else immediate.
@@ -178,13 +201,27 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
   // ---- prologue --------------------------------------------------------------------------------------------------
   issue_slab(0);
   load_patch(0);
+  if (tid < 32 * MT) {
+    const int co = cot * 32 * MT + tid;
+    s_bias[tid] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+  }
   store_patch(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // the bias is the accumulators' initial value (32 dependent global loads in the epilogue were 10 % of a workgroup's time)
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float bv = s_bias[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
+#pragma unroll
+      for (int t = 0; t < S_NT; ++t) acc[m][t][r] = bv;
+    }
   if (nslabs > 1) issue_slab(1);
   u32x4 acur[3][MT], bcur[S_NT][3];
   read_a(0, 0, acur);
   read_b(0, 0, bcur);
+  C7_STAMP(0);      // prologue
 
   for (int ch = 0; ch < nch; ++ch) {
     const int pst = ch & 1;
@@ -197,9 +234,13 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
       if (sl == S_SLAB - 1) {
         // the slab barrier, one k-step early: slab gs + 1 has landed (requested a slab ago), every wave has read the last A
         // operands of slab gs (they were prefetched in the previous k-step), so its stage takes slab gs + 2
+        C7_STAMP(1);  // k-steps
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C7_STAMP(2);  // own DMA / loads outstanding
         __syncthreads();
+        C7_STAMP(3);  // barrier
         if (gs + 2 < nslabs) issue_slab(gs + 2);
+        C7_STAMP(4);  // DMA issue
       }
       if (ks == 11 && more) store_patch(pst ^ 1);      // published by the barriers at k-steps 14, 19, 24
       // operands of the next k-step
@@ -251,25 +292,36 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
     }
   }
 
+  C7_STAMP(1);
   // ---- epilogue: bias, activation, NCHW stores (lanes 0-31 / 32-63: 32 consecutive pixels of two channels 4 apart) ----
-  const int gx = x0 + l31;
+  int gx = x0 + l31;
+  asm volatile("" : "+v"(gx));      // keeps the address arithmetic below here (hoisted above the loop its 64-bit results spill)
   const bool xok = gx < w;
   const float act_s = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope;
+  const int co0 = cot * 32 * MT + 4 * kg;
+  // lane part of the address once; the channel advances by one plane per register, five across a group of four
+  float* ob = a.out + ((size_t)bn * a.cout + co0) * plane + (size_t)(y0 + wave * S_NT) * w + gx;
+  const bool full = cot * 32 * MT + 32 * MT <= a.cout;      // wave-uniform
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = cot * 32 * MT + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      const bool cok = co < a.cout;
-      const float b = (cok && a.bias) ? a.bias[co] : 0.f;
+      const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
+      const bool cok = full || co0 + cu < a.cout;
 #pragma unroll
       for (int t = 0; t < S_NT; ++t) {
-        const int gy = y0 + wave * S_NT + t;
-        float v = acc[m][t][r] + b;
+        float v = acc[m][t][r];
         v = fmaxf(v, v * act_s);      // branch-free: max(v, v s), 0 <= s <= 1
-        if (cok && xok && gy < h) a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = v;
+        if (cok && xok && y0 + wave * S_NT + t < h) ob[(size_t)cu * plane + (size_t)t * w] = v;
       }
     }
+#ifdef EAVSR_C7_STAMPS
+  C7_STAMP(5);      // epilogue issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  C7_STAMP(6);      // stores acknowledged
+  if (tid == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_c7_stamps[i], st_acc[i]);
+#endif
 }
 
 // (cout, cin, 7, 7) fp32 -> [cot][chunk][k-step][plane][mt][lane] 16-byte elements: lane (r = lane & 31, g = lane >> 5) holds
@@ -305,28 +357,43 @@ __global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p
 
 int mt_of(int cout) { return cout > 32 ? 2 : 1; }
 
-template <int MT>
+template <int MT, int NT, int WMT>
 int launch7(const C7Args& a, void* stream) {
-  using K = C7<MT>;
+  using K = C7<MT, NT>;
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
   static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
   hipError_t& attr_err = attr_err_pd[dev_];
   std::call_once(once_pd.flag[dev_], [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv7x7_x6_kernel<MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv7x7_x6_kernel<MT, NT, WMT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)K::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv7x7_f32x6: hipFuncSetAttribute(%zu B of LDS): %s", K::LDS_BYTES, hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  const long blocks = (long)a.tiles_x * a.tiles_y * a.n;
+  C7Args b = a;
+  b.tiles_y = eavsr::cdiv(a.h, K::TH);
+  const long blocks = (long)b.tiles_x * b.tiles_y * b.n;
+  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv7x7_f32x6: too many tiles");
   dim3 grid((unsigned)blocks, eavsr::cdiv(a.cout, 32 * MT));
-  hipLaunchKernelGGL(conv7x7_x6_kernel<MT>, grid, dim3(64 * S_NW), K::LDS_BYTES, eavsr::as_stream(stream), a);
+  hipLaunchKernelGGL((conv7x7_x6_kernel<MT, NT, WMT>), grid, dim3(64 * S_NW), K::LDS_BYTES, eavsr::as_stream(stream), b);
   return eavsr::launch_status("conv7x7_f32x6");
 }
 
 }  // namespace
+
+#ifdef EAVSR_C7_STAMPS
+extern "C" int eavsr_debug_c7_stamps(unsigned long long* host_out, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_c7_stamps), sizeof(unsigned long long) * 8);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_c7_stamps), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
 extern "C" size_t eavsr_conv7_weight_x6_bytes(int32_t cout, int32_t cin) {
   if (cout <= 0 || cin <= 0 || cin % 8) return 0;
@@ -357,8 +424,19 @@ extern "C" int eavsr_conv7x7_f32x6(const float* x, const void* weight_x6, const 
   a.x = x; a.wsplit = reinterpret_cast<const u32x4*>(weight_x6); a.bias = bias; a.out = out;
   a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.w = w;
   a.tiles_x = eavsr::cdiv(w, S_TW);
-  a.tiles_y = eavsr::cdiv(h, S_TH);
   a.act = act; a.slope = slope;
-  EAVSR_REQUIRE((long)a.tiles_x * a.tiles_y * n < (1L << 31), -1, "conv7x7_f32x6: too many tiles");
-  return mt_of(cout) == 2 ? launch7<2>(a, stream) : launch7<1>(a, stream);
+  a.tiles_y = 0;   // per tile height, in launch7
+  // Tile height and channel tiles per workgroup: the full 16-row, all-channel workgroup where that gives the GPU enough of
+  // them; otherwise 8-row tiles, then one 32-channel tile per workgroup -- a coarse pyramid level is a few dozen workgroups and
+  // takes as long as ONE of them.  Every output is the same sum in the same order whichever shape computes it.
+  const long wg2 = (long)a.tiles_x * eavsr::cdiv(h, 16) * n;
+  const long wg1 = (long)a.tiles_x * eavsr::cdiv(h, 8) * n;
+  EAVSR_REQUIRE(wg1 * 2 < (1L << 31), -1, "conv7x7_f32x6: too many tiles");
+  if (mt_of(cout) == 2) {     // (the packed weight has two 32-channel tiles per `cot`)
+    if (wg2 >= 128) return launch7<2, 2, 2>(a, stream);
+    if (wg1 >= 128) return launch7<2, 1, 2>(a, stream);
+    return launch7<1, 1, 2>(a, stream);
+  }
+  if (wg2 >= 128) return launch7<1, 2, 1>(a, stream);
+  return launch7<1, 1, 1>(a, stream);
 }

@@ -183,11 +183,14 @@ def test_conv3x3_small_cout_co_resident_variant(ops, cuda, case):
 
 
 @pytest.mark.parametrize("case", [(8, 32, 2, 24, 40, "relu"), (32, 64, 1, 48, 80, "relu"), (64, 32, 2, 16, 32, "relu"), (32, 16, 3, 6, 10, "relu"),
-                                  (16, 2, 2, 12, 20, None), (64, 64, 1, 37, 70, "lrelu"), (8, 70, 1, 19, 33, None), (24, 32, 1, 96, 160, "relu")])
+                                  (16, 2, 2, 12, 20, None), (64, 64, 1, 37, 70, "lrelu"), (8, 70, 1, 19, 33, None), (24, 32, 1, 96, 160, "relu"),
+                                  (8, 64, 24, 48, 80, "relu"), (8, 32, 24, 45, 80, "relu"), (8, 64, 24, 24, 40, "relu"), (16, 48, 13, 40, 70, None),
+                                  (8, 96, 4, 70, 100, "relu")])
 def test_conv7x7_bf16x6_matches_fp64_and_the_fp32_kernel(ops, cuda, case):
     """round 3: eavsr_conv7x7_f32x6 (SPyNet's basic module, eavsrp_model.py:398-431: the contraction on the bf16 matrix pipe, both
     operands split exactly into three bf16 terms) at every layer shape of the module, tiles cut by the image in both directions, a
-    cout that is not a multiple of 32, three input chunks, against an fp64 evaluation (as accurate as the fp32-MFMA kernel, whose
+    cout that is not a multiple of 32, three input chunks, launches of every workgroup shape the entry point chooses between (16- or
+    8-row tiles, one or two 32-channel tiles per workgroup, two workgroups per packed 64-channel block), against an fp64 evaluation (as accurate as the fp32-MFMA kernel, whose
     error is measured beside it) and against torch's fp32 CPU convolution."""
     cin, cout, n, h, w, act = case
     x = cases.randn(50, n, cin, h, w)
