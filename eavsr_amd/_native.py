@@ -86,9 +86,9 @@ SIGNATURES = {
     "eavsr_smallco_packed_elems": (C.c_int64, [i32, i32]),
     "eavsr_pack_smallco_weight": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_conv3x3_smallco_lite_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
-    "eavsr_conv7_weight_x6_bytes": (C.c_size_t, [i32, i32]),
-    "eavsr_pack_conv7_weight_x6": (C.c_int, [vp, vp, i32, i32, vp]),
-    "eavsr_conv7x7_f32x6": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "eavsr_conv_weight_x6_bytes": (C.c_size_t, [i32, i32, i32]),
+    "eavsr_pack_conv_weight_x6": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "eavsr_conv_f32x6": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_ca_scale_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_scale_residual_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_ca_tail_f32": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

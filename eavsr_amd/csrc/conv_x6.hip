@@ -1,7 +1,10 @@
-// 7x7 stride-1 "same" convolution, fp32 in / fp32 out, the contraction on the bf16 matrix pipe with exact operand splits
-// ("bf16x6"): the five layers of SPyNet's basic module (8 -> 32 -> 64 -> 32 -> 16 -> 2 at six pyramid levels; reference
-// eavsrp_model.py:398-431, called from compute_flow eavsrp_model.py:433-488), which conv2d_mfma_kernel<7, ..> ran on the fp32
-// MFMA at 0.43 of its peak (28 ms of the 236 ms bench step).
+// 7x7 and 5x5 stride-1 "same" convolutions, fp32 in / fp32 out, the contraction on the bf16 matrix pipe with exact operand
+// splits ("bf16x6"):
+//   * 7x7: the five layers of SPyNet's basic module (8 -> 32 -> 64 -> 32 -> 16 -> 2 at six pyramid levels; reference
+//     eavsrp_model.py:398-431, called from compute_flow eavsrp_model.py:433-488), which conv2d_mfma_kernel<7, ..> ran on the
+//     fp32 MFMA (0.85 of its peak at the finest level, launch-bound below it: 28 ms of the 236 ms bench step);
+//   * 5x5: the three heads of AdaptBlockOffset as one 64 -> 15 D launch (networks.py:289-315), which ran as F(2x2,5x5) on the
+//     fp32 MFMA (conv_wino6_kernel<5>).
 //
 // Arithmetic (as dcnv2_il.hip, NPROD = 6): every fp32 operand is split EXACTLY into three bf16 terms (hi = trunc_bf16(x),
 // mid = trunc_bf16(x - hi), lo = x - hi - mid; hi + mid + lo == x bit for bit), products of bf16 numbers are exact in fp32, the
@@ -11,14 +14,15 @@
 //
 // Unlike conv_x9.hip (3x3, split in registers per use) the input is split ONCE per value, on its way into LDS: a 7x7 tap window
 // reuses every input value 49 times.  Per workgroup (512 threads, 16 rows x 32 pixels, 32 MT output channels) and per chunk of
-// 8 input channels:
-//   * patch: (16+6) x 40 pixels x 8 channels, read from the NCHW image by plain coalesced loads one chunk ahead (16 values per
+// 8 input channels (written for KS = 7; 5x5 in brackets):
+//   * patch: (16+6) x 40 [(16+4) x 37] pixels x 8 channels, read from the NCHW image by plain coalesced loads one chunk ahead (16 values per
 //     thread in flight), split in registers, stored channel-interleaved as three bf16 planes [plane][row][col][8 ch] (16 bytes
 //     per pixel and plane): the MFMA B operand of lane (n = lane & 31, g = lane >> 5) for k-step s -- the 8 channels of pixel
 //     n shifted by ITS tap 2 s + g -- is one ds_read_b128 per plane, consecutive lanes 16 bytes apart (no bank conflicts);
 //   * weights: pre-split and pre-arranged by eavsr_pack_conv7_weight_x6 in MFMA A-operand order, streamed by 16-byte LDS-DMA
-//     in slabs of 5 k-steps (10 taps; 25 k-steps = 49 taps + one zero tap per chunk: 2 % padding) into two stages; the slab
-//     barrier sits one k-step before the slab changes, so that the next slab's first A operands are prefetched like any other.
+//     in slabs of 5 k-steps (10 taps; 25 k-steps = 49 taps + one zero tap per chunk: 2 % padding) [7 + 6 k-steps = 25 taps + one
+//     zero tap: 4 %] into two stages; the slab barrier sits one k-step before the slab changes, so that the next slab's first A
+//     operands are prefetched like any other.
 // The main loop is LDS reads and MFMAs only: 6 + 3 MT reads of 16 bytes per 12 MT MFMAs and wave, operands read one k-step ahead.
 #include "common.h"
 
@@ -31,21 +35,26 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int S_NW = 8, S_TW = 32, S_PAD = 3;
-constexpr int S_IW = 40;                                      // patch columns x0-3 .. x0+36 (38 used; 39 stays zero for the zero tap)
-constexpr int S_KSTEPS = 25, S_SLAB = 5, S_NSLAB = S_KSTEPS / S_SLAB;
-// MT: 32-channel output tiles per workgroup; NT: image rows per wave (tile = 8 NT rows x 32 pixels).  NT = 1 and MT = 1 exist for
-// the coarse pyramid levels, where a launch is a handful of workgroups and its time is ONE workgroup's chain of k-steps.
-template <int MT, int NT> struct C7 {
+constexpr int S_NW = 8, S_TW = 32;
+// KS: kernel size (7, 5); MT: 32-channel output tiles per workgroup; NT: image rows per wave (tile = 8 NT rows x 32 pixels).
+// NT = 1 and MT = 1 exist for the coarse pyramid levels, where a launch is a handful of workgroups and its time is ONE
+// workgroup's chain of k-steps.
+template <int KS, int MT, int NT> struct C7 {
+  static constexpr int PAD = KS / 2, KK = KS * KS;
+  static constexpr int KSTEPS = (KK + 1) / 2;                  // tap pairs per chunk: 25 (49 taps + a zero tap), 13 (25 + one)
+  static constexpr int SLAB = KS == 7 ? 5 : 7;                 // k-steps per weight slab (the last slab of a 5x5 chunk has 6)
+  static constexpr int NSLAB = (KSTEPS + SLAB - 1) / SLAB;     // 5, 2
   static constexpr int TH = S_NW * NT;
-  static constexpr int IH = TH + 6;                            // patch rows y0-3 .. y0+TH+2
-  static constexpr int NPIX = IH * S_IW;                       // 880 (NT = 2), 560 (NT = 1) pixels
+  static constexpr int IH = TH + KS - 1;                       // patch rows y0-PAD .. y0+TH+PAD-1
+  static constexpr int IW = S_TW + KS;                         // columns x0-PAD .. x0+32+PAD-1, and one that stays zero (the zero tap)
+  static constexpr int NPIX = IH * IW;
   static constexpr int PLANE_B = NPIX * 16;                    // bytes of one bf16 plane of the patch (8 channels per pixel)
-  static constexpr int PATCH_B = 3 * PLANE_B;                  // 42,240 / 26,880
-  static constexpr int SLAB_U4 = S_SLAB * 3 * MT * 64;         // 16-byte elements of one weight slab (5 k-steps)
-  static constexpr int SLAB_SEGS = SLAB_U4 / 64;               // one-KiB DMA pieces: 15 MT
-  static constexpr int W_IT = (SLAB_SEGS + S_NW - 1) / S_NW;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)PATCH_B + 2 * (size_t)SLAB_U4 * 16 + 64 * 4;   // 146,176 at MT = NT = 2 (+ the bias)
+  static constexpr int PATCH_B = 3 * PLANE_B;                  // 7x7: 41,184 (NT = 2); 5x5: 35,520
+  static constexpr int KS_U4 = 3 * MT * 64;                    // 16-byte elements of one k-step's A operands
+  static constexpr int SLAB_U4 = SLAB * KS_U4;                 // of a (full) weight slab
+  static constexpr size_t LDS_BYTES = 2 * (size_t)PATCH_B + 2 * (size_t)SLAB_U4 * 16 + 64 * 4;   // 7x7: 144,064, 5x5: 157,312 at MT = NT = 2
+  static_assert(NPIX <= 1024, "two patch pixels per thread");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 struct C7Args {
@@ -86,10 +95,11 @@ __device__ unsigned long long g_c7_stamps[8];
 #define C7_STAMP(i) do { } while (0)
 #endif
 
-template <int MT, int NT, int WMT>
-__global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
-  using K = C7<MT, NT>;
+template <int KS, int MT, int NT, int WMT>
+__global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
+  using K = C7<KS, MT, NT>;
   constexpr int S_NT = NT, S_TH = K::TH, S_NPIX = K::NPIX, S_PLANE_B = K::PLANE_B, S_PATCH_B = K::PATCH_B;
+  constexpr int S_PAD = K::PAD, S_IW = K::IW, S_KSTEPS = K::KSTEPS, S_SLAB = K::SLAB, S_NSLAB = K::NSLAB;
 #ifdef EAVSR_C7_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -123,12 +133,12 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
     const int p = tid + i * 512;
     const int r = p / S_IW, c = p - r * S_IW;
     const int gy = y0 - S_PAD + r, gx = x0 - S_PAD + c;
-    // columns 38, 39 are never a tap of anybody: kept zero (the zero tap of the last k-step reads column 39, below)
-    pok[i] = p < S_NPIX && c < S_TW + 6 && gy >= 0 && gy < h && gx >= 0 && gx < w;
+    // the last column is never a tap of anybody: kept zero (the zero tap of the last k-step reads it, below)
+    pok[i] = p < S_NPIX && c < S_IW - 1 && gy >= 0 && gy < h && gx >= 0 && gx < w;
     pgo[i] = pok[i] ? (unsigned)(gy * w + gx) : 0u;
     plo[i] = (unsigned)p * 16u;
   }
-  const bool second = tid + 512 < S_NPIX;    // 368 (NT = 2) / 48 (NT = 1) threads own a second pixel
+  const bool second = tid + 512 < S_NPIX;    // 7x7: 346 (NT = 2) / 34 (NT = 1) threads own a second pixel
   float pv[2][8];
   auto load_patch = [&](int ch) __attribute__((always_inline)) {
     const float* sp = a.x + ((size_t)bn * a.cin + (size_t)ch * 8) * plane;
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
   auto store_patch = [&](int stage) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (i == 1 && !second) break;
+      if (i == 0 ? tid >= S_NPIX : !second) break;          // (5x5 on 8-row tiles: 444 patch pixels)
       u32x4 pl[3];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -153,19 +163,21 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
         *reinterpret_cast<u32x4*>(s_patch + stage * S_PATCH_B + p3 * S_PLANE_B + plo[i]) = pl[p3];
     }
   };
-  // ---- weight slabs: global slab index gs = chunk * 5 + slab, LDS stage gs & 1 -------------------------------------
-  const int nslabs = nch * S_NSLAB;
+  // ---- weight slabs: global slab index gs = chunk * NSLAB + si, LDS stage gs & 1 --------------------------------------
   // (the packed weight holds WMT >= MT 32-channel tiles per `cot`, one-KiB pieces in [k-step][plane][tile] order: a workgroup of
   //  fewer tiles picks its pieces out of the slab)
+  const int nslabs = nch * S_NSLAB;
   constexpr int wsplit_n = WMT / MT;                        // workgroups per packed cot
   const int wcot = cot / wsplit_n, wsub = (cot - wcot * wsplit_n) * MT;
-  auto issue_slab = [&](int gs) __attribute__((always_inline)) {
-    const char* wsrc = reinterpret_cast<const char*>(a.wsplit + ((size_t)wcot * nslabs + gs) * (K::SLAB_U4 * wsplit_n));
+  auto issue_slab = [&](int gs, int ch, int si) __attribute__((always_inline)) {      // si (slab of its chunk) is a constant at every call
+    const int nks = (si + 1) * S_SLAB <= S_KSTEPS ? S_SLAB : S_KSTEPS - si * S_SLAB;   // k-steps of this slab
+    const int segs = nks * 3 * MT;
+    const char* wsrc = reinterpret_cast<const char*>(a.wsplit + (((size_t)wcot * nch + ch) * S_KSTEPS + si * S_SLAB) * (K::KS_U4 * wsplit_n));
     u32x4* dst = s_w + (gs & 1) * K::SLAB_U4;
 #pragma unroll
-    for (int i = 0; i < K::W_IT; ++i) {
+    for (int i = 0; i < (S_SLAB * 3 * MT + S_NW - 1) / S_NW; ++i) {
       const int seg = i * S_NW + wave;                      // piece (k-step, plane, tile m) = seg / MT, seg % MT of this workgroup
-      if (seg < K::SLAB_SEGS) {  // wave-uniform
+      if (seg < segs) {  // wave-uniform
         const int sp = MT == 1 ? seg * WMT + wsub : (seg >> 1) * WMT + wsub + (seg & 1);
         __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (unsigned)(sp * 64 + lane) * 16u), (lptr_t)(dst + seg * 64), 16, 0, 0);
       }
@@ -176,22 +188,22 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
 
   // B operand address of this lane: pixel (wave * 2 + row + ky, l31 + kx) of the patch, tap (ky, kx) = 2 s + kg.  The tap pair
   // of a k-step is (kx, kx + 1) of one kernel row, or (6 of row ky, 0 of row ky + 1): two lane bases, everything else immediate.
-  // The last k-step pairs tap 48 with a tap that does not exist: its weights are zero and its lanes read the always-zero column
-  // 39 of patch row 0 / 1 (0 x 0, whatever the image holds next to the window).
+  // The last k-step pairs the last tap with a tap that does not exist: its weights are zero and its lanes read the always-zero
+  // last column of patch row 0 / 1 (0 x 0, whatever the image holds next to the window).
   const int bbase = ((wave * S_NT) * S_IW + l31) * 16;
   const int b_same = bbase + (kg ? 16 : 0);
-  const int b_wrap = bbase + (kg ? (S_IW - 6) * 16 : 0);
-  const int b_last = kg ? (S_IW - 1) * 16 - (6 * S_IW + 6) * 16 : bbase;
+  const int b_wrap = bbase + (kg ? (S_IW - (KS - 1)) * 16 : 0);
+  const int b_last = kg ? (S_IW - 1) * 16 - ((KS - 1) * S_IW + KS - 1) * 16 : bbase;
   auto read_b = [&](int stage, int s, u32x4 (&b)[S_NT][3]) __attribute__((always_inline)) {
-    const int tap0 = 2 * s, ky = tap0 / 7, kx = tap0 - 7 * ky;
-    const unsigned char* base = s_patch + stage * S_PATCH_B + ((s == S_KSTEPS - 1 ? b_last : kx == 6 ? b_wrap : b_same) + (ky * S_IW + kx) * 16);
+    const int tap0 = 2 * s, ky = tap0 / KS, kx = tap0 - KS * ky;
+    const unsigned char* base = s_patch + stage * S_PATCH_B + ((s == S_KSTEPS - 1 ? b_last : kx == KS - 1 ? b_wrap : b_same) + (ky * S_IW + kx) * 16);
 #pragma unroll
     for (int t = 0; t < S_NT; ++t)
 #pragma unroll
       for (int p3 = 0; p3 < 3; ++p3) b[t][p3] = *reinterpret_cast<const u32x4*>(base + t * S_IW * 16 + p3 * S_PLANE_B);
   };
   auto read_a = [&](int gs, int sl, u32x4 (&av)[3][MT]) __attribute__((always_inline)) {
-    const u32x4* ws = s_w + (gs & 1) * K::SLAB_U4 + sl * (3 * MT * 64) + lane;
+    const u32x4* ws = s_w + (gs & 1) * K::SLAB_U4 + sl * K::KS_U4 + lane;
 #pragma unroll
     for (int p3 = 0; p3 < 3; ++p3)
 #pragma unroll
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
   };
 
   // ---- prologue --------------------------------------------------------------------------------------------------
-  issue_slab(0);
+  issue_slab(0, 0, 0);
   load_patch(0);
   if (tid < 32 * MT) {
     const int co = cot * 32 * MT + tid;
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
 #pragma unroll
       for (int t = 0; t < S_NT; ++t) acc[m][t][r] = bv;
     }
-  if (nslabs > 1) issue_slab(1);
+  if (nslabs > 1) issue_slab(1, S_NSLAB > 1 ? 0 : 1, S_NSLAB > 1 ? 1 : 0);
   u32x4 acur[3][MT], bcur[S_NT][3];
   read_a(0, 0, acur);
   read_b(0, 0, bcur);
@@ -229,9 +241,11 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
     if (more) load_patch(ch + 1);
 #pragma unroll
     for (int ks = 0; ks < S_KSTEPS; ++ks) {
-      const int gs = ch * S_NSLAB + ks / S_SLAB;
-      const int sl = ks % S_SLAB;
-      if (sl == S_SLAB - 1) {
+      constexpr int STORE_KS = KS == 7 ? 11 : 7;            // (behind a slab barrier: the chunk's loads have landed by its vmcnt(0))
+      const int si = ks / S_SLAB, sl = ks % S_SLAB;
+      const int gs = ch * S_NSLAB + si;
+      const bool slab_end = sl == S_SLAB - 1 || ks == S_KSTEPS - 1;
+      if (slab_end) {
         // the slab barrier, one k-step early: slab gs + 1 has landed (requested a slab ago), every wave has read the last A
         // operands of slab gs (they were prefetched in the previous k-step), so its stage takes slab gs + 2
         C7_STAMP(1);  // k-steps
@@ -239,15 +253,15 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
         C7_STAMP(2);  // own DMA / loads outstanding
         __syncthreads();
         C7_STAMP(3);  // barrier
-        if (gs + 2 < nslabs) issue_slab(gs + 2);
+        if (gs + 2 < nslabs) issue_slab(gs + 2, ch + (si + 2) / S_NSLAB, (si + 2) % S_NSLAB);
         C7_STAMP(4);  // DMA issue
       }
-      if (ks == 11 && more) store_patch(pst ^ 1);      // published by the barriers at k-steps 14, 19, 24
+      if (ks == STORE_KS && more) store_patch(pst ^ 1);     // published by the slab barriers behind it
       // operands of the next k-step
       u32x4 anext[3][MT], bnext[S_NT][3];
       const bool last = ks == S_KSTEPS - 1;
       if (!last) {
-        read_a(sl == S_SLAB - 1 ? gs + 1 : gs, (sl + 1) % S_SLAB, anext);
+        read_a(slab_end ? gs + 1 : gs, slab_end ? 0 : sl + 1, anext);
         read_b(pst, ks + 1, bnext);
       } else if (more) {
         read_a(gs + 1, 0, anext);
@@ -324,16 +338,17 @@ __global__ __launch_bounds__(512) void conv7x7_x6_kernel(C7Args a) {
 #endif
 }
 
-// (cout, cin, 7, 7) fp32 -> [cot][chunk][k-step][plane][mt][lane] 16-byte elements: lane (r = lane & 31, g = lane >> 5) holds
+// (cout, cin, KS, KS) fp32 -> [cot][chunk][k-step][plane][mt][lane] 16-byte elements: lane (r = lane & 31, g = lane >> 5) holds
 // A[row r][k = 8 g + j] = W[cot * 32 MT + mt * 32 + r][chunk * 8 + j][tap 2 s + g], j = 0..7, plane 0 / 1 / 2 = hi / mid / lo
-__global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p, int cout, int cin, int mt_n, long total) {
+__global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p, int cout, int cin, int kk, int mt_n, long total) {
+  const int ksteps = (kk + 1) / 2;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   long q = e;
   const int lane = (int)(q % 64); q /= 64;
   const int mt = (int)(q % mt_n); q /= mt_n;
   const int pl = (int)(q % 3); q /= 3;
-  const int s = (int)(q % S_KSTEPS); q /= S_KSTEPS;
+  const int s = (int)(q % ksteps); q /= ksteps;
   const int nch = cin / 8;
   const int ch = (int)(q % nch);
   const int cot = (int)(q / nch);
@@ -346,7 +361,7 @@ __global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int ci = ch * 8 + 2 * c + u;
-      v[u] = (co < cout && tap < 49) ? wt[((size_t)co * cin + ci) * 49 + tap] : 0.f;
+      v[u] = (co < cout && tap < kk) ? wt[((size_t)co * cin + ci) * kk + tap] : 0.f;
     }
     unsigned h2, m2, l2;
     s_split2(v[0], v[1], h2, m2, l2);
@@ -357,28 +372,45 @@ __global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p
 
 int mt_of(int cout) { return cout > 32 ? 2 : 1; }
 
-template <int MT, int NT, int WMT>
+template <int KS, int MT, int NT, int WMT>
 int launch7(const C7Args& a, void* stream) {
-  using K = C7<MT, NT>;
+  using K = C7<KS, MT, NT>;
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
   static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
   hipError_t& attr_err = attr_err_pd[dev_];
   std::call_once(once_pd.flag[dev_], [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv7x7_x6_kernel<MT, NT, WMT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)K::LDS_BYTES);
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<KS, MT, NT, WMT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
-    eavsr::set_error("conv7x7_f32x6: hipFuncSetAttribute(%zu B of LDS): %s", K::LDS_BYTES, hipGetErrorString(attr_err));
+    eavsr::set_error("conv_f32x6: hipFuncSetAttribute(%zu B of LDS): %s", K::LDS_BYTES, hipGetErrorString(attr_err));
     return (int)attr_err;
   }
   C7Args b = a;
   b.tiles_y = eavsr::cdiv(a.h, K::TH);
   const long blocks = (long)b.tiles_x * b.tiles_y * b.n;
-  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv7x7_f32x6: too many tiles");
+  EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv_f32x6: too many tiles");
   dim3 grid((unsigned)blocks, eavsr::cdiv(a.cout, 32 * MT));
-  hipLaunchKernelGGL((conv7x7_x6_kernel<MT, NT, WMT>), grid, dim3(64 * S_NW), K::LDS_BYTES, eavsr::as_stream(stream), b);
-  return eavsr::launch_status("conv7x7_f32x6");
+  hipLaunchKernelGGL((conv_x6_kernel<KS, MT, NT, WMT>), grid, dim3(64 * S_NW), K::LDS_BYTES, eavsr::as_stream(stream), b);
+  return eavsr::launch_status("conv_f32x6");
+}
+
+// Tile height and channel tiles per workgroup: the full 16-row, all-channel workgroup where that gives the GPU enough of them;
+// otherwise 8-row tiles, then one 32-channel tile per workgroup -- a coarse pyramid level is a few dozen workgroups and takes as
+// long as ONE of them.  Every output is the same sum in the same order whichever shape computes it.
+template <int KS>
+int dispatch7(const C7Args& a, void* stream) {
+  const long wg2 = (long)a.tiles_x * eavsr::cdiv(a.h, 16) * a.n;
+  const long wg1 = (long)a.tiles_x * eavsr::cdiv(a.h, 8) * a.n;
+  EAVSR_REQUIRE(wg1 * 2 < (1L << 31), -1, "conv_f32x6: too many tiles");
+  if (mt_of(a.cout) == 2) {     // (the packed weight has two 32-channel tiles per `cot`)
+    if (wg2 >= 128) return launch7<KS, 2, 2, 2>(a, stream);
+    if (wg1 >= 128) return launch7<KS, 2, 1, 2>(a, stream);
+    return launch7<KS, 1, 1, 2>(a, stream);
+  }
+  if (wg2 >= 128) return launch7<KS, 1, 2, 1>(a, stream);
+  return launch7<KS, 1, 1, 1>(a, stream);
 }
 
 }  // namespace
@@ -395,48 +427,38 @@ extern "C" int eavsr_debug_c7_stamps(unsigned long long* host_out, int reset) {
 }
 #endif
 
-extern "C" size_t eavsr_conv7_weight_x6_bytes(int32_t cout, int32_t cin) {
-  if (cout <= 0 || cin <= 0 || cin % 8) return 0;
+extern "C" size_t eavsr_conv_weight_x6_bytes(int32_t ksize, int32_t cout, int32_t cin) {
+  if ((ksize != 5 && ksize != 7) || cout <= 0 || cin <= 0 || cin % 8) return 0;
   const int mt = mt_of(cout);
-  return (size_t)eavsr::cdiv(cout, 32 * mt) * (cin / 8) * S_KSTEPS * 3 * mt * 64 * 16;
+  return (size_t)eavsr::cdiv(cout, 32 * mt) * (cin / 8) * ((ksize * ksize + 1) / 2) * 3 * mt * 64 * 16;
 }
 
-extern "C" int eavsr_pack_conv7_weight_x6(const float* weight, void* packed, int32_t cout, int32_t cin, void* stream) {
-  EAVSR_REQUIRE(weight && packed, -1, "pack_conv7_weight_x6: NULL pointer");
-  EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % 8 == 0, -1, "pack_conv7_weight_x6: cin %d must be a multiple of 8", cin);
-  const long total = (long)(eavsr_conv7_weight_x6_bytes(cout, cin) / 16);
+extern "C" int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight_x6: NULL pointer");
+  EAVSR_REQUIRE(ksize == 5 || ksize == 7, -2, "pack_conv_weight_x6: kernel size %d (5 and 7 only)", ksize);
+  EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % 8 == 0, -1, "pack_conv_weight_x6: cin %d must be a multiple of 8", cin);
+  const long total = (long)(eavsr_conv_weight_x6_bytes(ksize, cout, cin) / 16);
   hipLaunchKernelGGL(pack7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
-                     reinterpret_cast<u32x4*>(packed), cout, cin, mt_of(cout), total);
-  return eavsr::launch_status("pack_conv7_weight_x6");
+                     reinterpret_cast<u32x4*>(packed), cout, cin, ksize * ksize, mt_of(cout), total);
+  return eavsr::launch_status("pack_conv_weight_x6");
 }
 
-extern "C" int eavsr_conv7x7_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,
-                                   int32_t cout, int32_t h, int32_t w, int32_t act, float slope, void* stream) {
-  EAVSR_REQUIRE(x && weight_x6 && out, -1, "conv7x7_f32x6: NULL pointer");
-  EAVSR_REQUIRE(n >= 0 && cin > 0 && cout > 0 && h > 0 && w > 0, -1, "conv7x7_f32x6: bad dims");
-  EAVSR_REQUIRE(cin % 8 == 0, -2, "conv7x7_f32x6: cin %d must be a multiple of 8 (use eavsr_conv2d_f32)", cin);
-  EAVSR_REQUIRE(act >= 0 && act <= 2, -1, "conv7x7_f32x6: act %d", act);
+extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,
+                                int32_t cout, int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, void* stream) {
+  EAVSR_REQUIRE(x && weight_x6 && out, -1, "conv_f32x6: NULL pointer");
+  EAVSR_REQUIRE(ksize == 5 || ksize == 7, -2, "conv_f32x6: kernel size %d (5 and 7 only; 3x3 is eavsr_conv2d_f32 / eavsr_conv3x3_wino4_f32)", ksize);
+  EAVSR_REQUIRE(n >= 0 && cin > 0 && cout > 0 && h > 0 && w > 0, -1, "conv_f32x6: bad dims");
+  EAVSR_REQUIRE(cin % 8 == 0, -2, "conv_f32x6: cin %d must be a multiple of 8 (use eavsr_conv2d_f32)", cin);
+  EAVSR_REQUIRE(act >= 0 && act <= 2, -1, "conv_f32x6: act %d", act);
   EAVSR_REQUIRE(act != EAVSR_ACT_LRELU || (slope >= 0.f && slope <= 1.f), -2,
-                "conv7x7_f32x6: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)slope);
-  EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "conv7x7_f32x6: image plane too large for 32-bit pixel offsets");
+                "conv_f32x6: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)slope);
+  EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "conv_f32x6: image plane too large for 32-bit pixel offsets");
   if (n == 0) return 0;
   C7Args a;
   a.x = x; a.wsplit = reinterpret_cast<const u32x4*>(weight_x6); a.bias = bias; a.out = out;
   a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.w = w;
   a.tiles_x = eavsr::cdiv(w, S_TW);
-  a.act = act; a.slope = slope;
   a.tiles_y = 0;   // per tile height, in launch7
-  // Tile height and channel tiles per workgroup: the full 16-row, all-channel workgroup where that gives the GPU enough of
-  // them; otherwise 8-row tiles, then one 32-channel tile per workgroup -- a coarse pyramid level is a few dozen workgroups and
-  // takes as long as ONE of them.  Every output is the same sum in the same order whichever shape computes it.
-  const long wg2 = (long)a.tiles_x * eavsr::cdiv(h, 16) * n;
-  const long wg1 = (long)a.tiles_x * eavsr::cdiv(h, 8) * n;
-  EAVSR_REQUIRE(wg1 * 2 < (1L << 31), -1, "conv7x7_f32x6: too many tiles");
-  if (mt_of(cout) == 2) {     // (the packed weight has two 32-channel tiles per `cot`)
-    if (wg2 >= 128) return launch7<2, 2, 2>(a, stream);
-    if (wg1 >= 128) return launch7<2, 1, 2>(a, stream);
-    return launch7<1, 1, 2>(a, stream);
-  }
-  if (wg2 >= 128) return launch7<1, 2, 1>(a, stream);
-  return launch7<1, 1, 1>(a, stream);
+  a.act = act; a.slope = slope;
+  return ksize == 7 ? dispatch7<7>(a, stream) : dispatch7<5>(a, stream);
 }

@@ -309,42 +309,45 @@ def _packed_smallco(weights: Sequence[Tensor]) -> Tensor:
     return packed
 
 
-# 7x7 convolutions (SPyNet's basic module): "bf16x6" = eavsr_conv7x7_f32x6 (fp32 operands split exactly into bf16 terms, the
-# contraction on the bf16 matrix pipe), "fp32" = the fp32-MFMA implicit GEMM of eavsr_conv2d_f32 (A/B switch)
+# 7x7 convolutions (SPyNet's basic module) and the 5x5 heads of the predictor: "bf16x6" = eavsr_conv_f32x6 (fp32 operands split
+# exactly into bf16 terms, the contraction on the bf16 matrix pipe); otherwise the fp32-MFMA kernels (7x7: the implicit GEMM of
+# eavsr_conv2d_f32; 5x5: F(2x2,5x5)).  A/B switches.
 CONV7_MODE = os.environ.get("EAVSR_CONV7", "bf16x6")
+CONV5_MODE = os.environ.get("EAVSR_CONV5", "bf16x6")
 _conv7_pack_cache = {}
 
 
-def _packed_conv7(weights: Sequence[Tensor]) -> Tensor:
-    """A-operand form of a 7x7 weight (eavsr_pack_conv7_weight_x6); cached per weight objects and versions"""
+def _packed_conv_x6(weights: Sequence[Tensor]) -> Tensor:
+    """A-operand form of a 7x7 / 5x5 weight (eavsr_pack_conv_weight_x6); cached per weight objects and versions"""
     key = tuple((id(w), w._version) for w in weights)
     hit = _conv7_pack_cache.get(key)
     if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
         return hit[1]
     w = _chk(_cat_weights(weights).detach(), "weight")
-    cout, cin = int(w.shape[0]), int(w.shape[1])
-    packed = torch.empty(lib().eavsr_conv7_weight_x6_bytes(cout, cin), device=w.device, dtype=torch.uint8)
+    cout, cin, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[-1])
+    packed = torch.empty(lib().eavsr_conv_weight_x6_bytes(k, cout, cin), device=w.device, dtype=torch.uint8)
     with _DeviceOf(w):
-        N.check(lib().eavsr_pack_conv7_weight_x6(_p(w), _p(packed), cout, cin, _stream(w)), "pack_conv7_weight_x6")
+        N.check(lib().eavsr_pack_conv_weight_x6(_p(w), _p(packed), k, cout, cin, _stream(w)), "pack_conv_weight_x6")
     ids = {id(x) for x in weights}
-    for k in [k for k in _conv7_pack_cache if any(i in ids for i, _ in k)]:
-        _conv7_pack_cache.pop(k, None)
-    refs = tuple(weakref.ref(x, lambda _r, k=key: _conv7_pack_cache.pop(k, None)) for x in weights)
+    for k_ in [k_ for k_ in _conv7_pack_cache if any(i in ids for i, _ in k_)]:
+        _conv7_pack_cache.pop(k_, None)
+    refs = tuple(weakref.ref(x, lambda _r, k_=key: _conv7_pack_cache.pop(k_, None)) for x in weights)
     _conv7_pack_cache[key] = (refs, packed)
     return packed
 
 
-def _conv7x7_x6(x: Tensor, weights, biases, act, slope):
+def _conv_x6(x: Tensor, weights, biases, act, slope):
     n, cin, h, w = x.shape
     cout = sum(int(w_.shape[0]) for w_ in weights)
-    wp = _packed_conv7(weights)
+    k = int(weights[0].shape[-1])
+    wp = _packed_conv_x6(weights)
     b = _bias_of(biases)
     out = torch.empty((n, cout, h, w), device=x.device, dtype=torch.float32)
     st = _stream(x)
     px = float(n * h * w)
-    _launch(f"conv7x7_{cin}to{cout}_x6", 2.0 * cin * cout * 49 * px, 4.0 * px * (cin + cout), x,
-            lambda: lib().eavsr_conv7x7_f32x6(_p(x), _p(wp), _p(b), _p(out), n, cin, cout, h, w, ACT[act], float(slope), st),
-            "conv7x7_f32x6")
+    _launch(f"conv{k}x{k}_{cin}to{cout}_x6", 2.0 * cin * cout * k * k * px, 4.0 * px * (cin + cout), x,
+            lambda: lib().eavsr_conv_f32x6(_p(x), _p(wp), _p(b), _p(out), n, cin, cout, h, w, k, ACT[act], float(slope), st),
+            "conv_f32x6")
     return out
 
 
@@ -429,9 +432,9 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None:
         y = _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
         return torch.nn.functional.pixel_shuffle(y, 2) if pixel_shuffle2 else y
-    if (k == 7 and CONV7_MODE == "bf16x6" and len(srcs) == 1 and cin % 8 == 0 and residual is None and not chan_partial
-            and ca is None and not pixel_shuffle2):
-        return _conv7x7_x6(srcs[0], weights, biases, act, slope)
+    if (((k == 7 and CONV7_MODE == "bf16x6") or (k == 5 and CONV5_MODE == "bf16x6")) and len(srcs) == 1 and cin % 8 == 0
+            and residual is None and not chan_partial and ca is None and not pixel_shuffle2):
+        return _conv_x6(srcs[0], weights, biases, act, slope)
     ck = lib().eavsr_conv2d_ck(k)
     if any(int(s.shape[1]) % ck for s in srcs[:-1]):
         srcs = [torch.cat(srcs, 1)]  # ragged middle source: materialise (tiny SPyNet inputs only)

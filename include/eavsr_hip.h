@@ -265,16 +265,18 @@ int eavsr_conv3x3_smallco_lite_f32(const float* x, const float* weight_packed, c
                                    float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout, int32_t act,
                                    float slope, void* stream);
 
-/* 7x7 stride-1 "same" convolution of SPyNet's basic module (models/eavsrp_model.py:398-431: 8 -> 32 -> 64 -> 32 -> 16 -> 2, ReLU
- * between; called per pyramid level from compute_flow, models/eavsrp_model.py:433-488), fp32 in / out, the contraction on the bf16
- * matrix pipe with both operands split exactly into three bf16 terms and the six partial products >= 2^-16 of the result kept
- * ("bf16x6": <= 2 * 2^-24 relative per product, one fp32 rounding; no operand is rounded).  cin % 8 == 0; any cout.
- * `weight_x6`: eavsr_conv7_weight_x6_bytes(cout, cin) bytes written by eavsr_pack_conv7_weight_x6 from the (cout, cin, 7, 7)
- * weight.  act / slope as eavsr_conv2d_f32.                                                                                     */
-size_t eavsr_conv7_weight_x6_bytes(int32_t cout, int32_t cin);
-int eavsr_pack_conv7_weight_x6(const float* weight, void* packed, int32_t cout, int32_t cin, void* stream);
-int eavsr_conv7x7_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,
-                        int32_t cout, int32_t h, int32_t w, int32_t act, float slope, void* stream);
+/* 7x7 and 5x5 stride-1 "same" convolutions, fp32 in / out, the contraction on the bf16 matrix pipe with both operands split exactly
+ * into three bf16 terms and the six partial products >= 2^-16 of the result kept ("bf16x6": <= 2 * 2^-24 relative per product, one
+ * fp32 rounding; no operand is rounded):
+ *   ksize 7: SPyNet's basic module (models/eavsrp_model.py:398-431: 8 -> 32 -> 64 -> 32 -> 16 -> 2, ReLU between; called per
+ *            pyramid level from compute_flow, models/eavsrp_model.py:433-488);
+ *   ksize 5: AdaptBlockOffset's three heads as one 64 -> 15 D convolution (models/networks.py:289-315).
+ * cin % 8 == 0; any cout.  `weight_x6`: eavsr_conv_weight_x6_bytes(ksize, cout, cin) bytes written by eavsr_pack_conv_weight_x6
+ * from the (cout, cin, ksize, ksize) weight.  act / slope as eavsr_conv2d_f32.                                                  */
+size_t eavsr_conv_weight_x6_bytes(int32_t ksize, int32_t cout, int32_t cin);
+int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, void* stream);
+int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin, int32_t cout,
+                     int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, void* stream);
 
 /* ---- a11: channel attention -----------------------------------------------------------------
  * CALayer (models/networks.py:432-447): scale[n,c] = sigmoid(W2 . relu(W1 . mean_hw(r) + b1) + b2)

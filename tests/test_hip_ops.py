@@ -216,6 +216,32 @@ def test_conv7x7_bf16x6_matches_fp64_and_the_fp32_kernel(ops, cuda, case):
     assert H.maxabs(outs["bf16x6"], ref) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("case", [(64, (32, 16, 72), 2, 45, 80), (64, (32, 16, 72), 1, 180, 320), (64, (8, 4, 18), 3, 23, 40), (8, (40,), 24, 24, 40),
+                                  (16, (70,), 30, 30, 50)])
+def test_conv5x5_bf16x6_matches_fp64_and_winograd(ops, cuda, case):
+    """round 3: the predictor's 5x5 heads (networks.py:289-315, three weights in one launch) by eavsr_conv_f32x6 against an fp64
+    evaluation and the F(2x2,5x5) fp32 kernel it replaces; the last slab of a chunk has 6 k-steps, the zero tap is tap 25."""
+    cin, couts, n, h, w = case
+    x = cases.randn(60, n, cin, h, w)
+    ws = [cases.randn(61 + i, co, cin, 5, 5, scale=1.0 / (cin * 25) ** 0.5) for i, co in enumerate(couts)]
+    bs = [cases.randn(65 + i, co, scale=0.1) for i, co in enumerate(couts)]
+    ref64 = F.conv2d(x.double(), torch.cat(ws).double(), torch.cat(bs).double(), 1, 2)
+    outs = {}
+    was = ops.CONV5_MODE
+    try:
+        for mode in ("bf16x6", "wino"):
+            ops.CONV5_MODE = mode
+            with ops.profile() as prof:
+                outs[mode] = ops.conv2d(g(x, cuda), [g(w_, cuda) for w_ in ws], [g(b_, cuda) for b_ in bs]).cpu()
+            assert (list(prof.summary()) == [f"conv5x5_{cin}to{sum(couts)}_x6"]) == (mode == "bf16x6")
+    finally:
+        ops.CONV5_MODE = was
+    scale = max(1.0, ref64.abs().max().item())
+    e6 = (outs["bf16x6"].double() - ref64).abs().max().item() / scale
+    ew = (outs["wino"].double() - ref64).abs().max().item() / scale
+    assert e6 <= 3e-6 and e6 <= 2.0 * ew + 2e-7, (e6, ew)
+
+
 def test_conv7x7_bf16x6_zero_tap_reads_no_neighbour(ops, cuda):
     """the 50th tap of a chunk has zero weights and reads the always-zero patch column: a NaN / Inf next to the receptive field of a
     pixel must not reach it (0 x NaN), and one inside must."""
@@ -482,8 +508,11 @@ def test_conv3x3_winograd_error_against_fp64(ops, cuda):
 # ---- 3x3 conv by Winograd F(4x4, 3x3): same descriptor / tensors / epilogue, 8 x 64-pixel tiles -------------------
 @pytest.fixture()
 def conv_wino4(ops):
+    was5 = ops.CONV5_MODE
     ops.set_conv_mode("winograd4")
+    ops.CONV5_MODE = "wino"          # (the 5x5 heads default to eavsr_conv_f32x6; these tests are about F(2x2,5x5))
     yield ops
+    ops.CONV5_MODE = was5
     ops.set_conv_mode(DEFAULT_CONV_MODE)
 
 

@@ -18,7 +18,7 @@ paths.sort(key=lambda q: (not q.endswith("libc7_full.so"), q))
 ref = {}
 for path in paths:
     lib = C.CDLL(path)
-    lib.eavsr_conv7_weight_x6_bytes.restype = C.c_size_t
+    lib.eavsr_conv_weight_x6_bytes.restype = C.c_size_t
     name = os.path.basename(path)
     line = f"{name:24s}"
     for (h, w) in ((192, 320), (96, 160), (24, 40)):
@@ -27,10 +27,10 @@ for path in paths:
             x = torch.randn(N, cin, h, w, device=dev)
             wt = torch.randn(cout, cin, 7, 7, device=dev) * 0.02
             b = torch.randn(cout, device=dev) * 0.1
-            wp = torch.empty(lib.eavsr_conv7_weight_x6_bytes(cout, cin), device=dev, dtype=torch.uint8)
-            assert lib.eavsr_pack_conv7_weight_x6(p(wt), p(wp), cout, cin, None) == 0
+            wp = torch.empty(lib.eavsr_conv_weight_x6_bytes(7, cout, cin), device=dev, dtype=torch.uint8)
+            assert lib.eavsr_pack_conv_weight_x6(p(wt), p(wp), 7, cout, cin, None) == 0
             out = torch.zeros(N, cout, h, w, device=dev)
-            call = lambda: lib.eavsr_conv7x7_f32x6(p(x), p(wp), p(b), p(out), N, cin, cout, h, w, 1, C.c_float(0.0), None)
+            call = lambda: lib.eavsr_conv_f32x6(p(x), p(wp), p(b), p(out), N, cin, cout, h, w, 7, 1, C.c_float(0.0), None)
             for _ in range(2):
                 assert call() == 0
             torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""SPyNet's 7x7 layers (eavsrp_model.py:398-431) at the bench's pyramid shapes: eavsr_conv7x7_f32x6 against the fp32-MFMA kernel."""
+"""SPyNet 7x7 layers (eavsrp_model.py:398-431) at the pyramid shapes of the bench, and the 5x5 heads: eavsr_conv_f32x6 against the fp32-MFMA kernels."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,3 +36,22 @@ for lvl, (h, w) in enumerate([(6, 10), (12, 20), (24, 40), (48, 80), (96, 160), 
         print(f"level {lvl} {h:3d}x{w:3d} {cin:2d}->{cout:2d}: bf16x6 {res['bf16x6']:8.1f} us ({fl / res['bf16x6'] / 1e6:6.1f} TFLOP/s)   "
               f"fp32 {res['fp32']:8.1f} us ({fl / res['fp32'] / 1e6:6.1f} TFLOP/s)   max |diff| {d:.2e}", flush=True)
 print(f"sum over the pyramid: bf16x6 {tot['bf16x6'] / 1e3:.2f} ms   fp32 {tot['fp32'] / 1e3:.2f} ms")
+# the predictor's 5x5 heads (networks.py:289-315): one 64 -> 120 launch per frame step of a 2-clip sub-batch
+x = torch.randn(2, 64, 180, 320, device=dev)
+ws = [torch.randn(co, 64, 5, 5, device=dev) * 0.02 for co in (32, 16, 72)]
+bs = [torch.randn(co, device=dev) * 0.1 for co in (32, 16, 72)]
+res = {}
+for mode in ("bf16x6", "wino"):
+    ops.CONV5_MODE = mode
+    for _ in range(3):
+        y = ops.conv2d(x, ws, bs)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        y = ops.conv2d(x, ws, bs)
+    e1.record()
+    torch.cuda.synchronize()
+    res[mode] = (e0.elapsed_time(e1) / 20 * 1e3, y)
+print(f"5x5 heads 2 x 64 x 180 x 320 -> 120: bf16x6 {res['bf16x6'][0]:.1f} us   F(2x2,5x5) fp32 {res['wino'][0]:.1f} us   "
+      f"max |diff| {(res['bf16x6'][1] - res['wino'][1]).abs().max().item():.2e}")
