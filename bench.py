@@ -494,6 +494,9 @@ def main():
                                     "f32 accumulate; predictor heads + paired warp fused in",
                              "il9": "IL8 kernel, exact bf16x9 products, f32 accumulate; predictor heads + paired warp fused in",
                              "native": "fp32 MFMA, NCHW LDS-window kernel (round 1)", "bf16x9": "round-1 bf16x9 kernel"}[args.dcn_mode],
+                   "conv7x7_conv5x5": {"bf16x6": "eavsr_conv_f32x6: fp32 operands as 3 exact bf16 terms, 6 of 9 partial products (dropped < 2^-23 "
+                                                 "each), f32 accumulate, bf16 MFMA"}.get(ops.CONV7_MODE, "fp32 MFMA (implicit GEMM)") +
+                                      " | 5x5 heads: " + {"bf16x6": "the same kernel"}.get(ops.CONV5_MODE, "Winograd F(2x2,5x5), fp32 MFMA"),
                    "launch": (f"{args.streams} HIP graphs on {args.streams} streams per step" if args.streams > 1 else
                               "one HIP graph per step" if args.graph else "eager (one launch per kernel)")},
     }
@@ -514,6 +517,9 @@ def main():
                 return 100.0 / 36.0, "Winograd F(2x2,5x5): 36 products per 2x2 outputs instead of 100"
             if name.endswith("_wino") or name.endswith("_wino_ca"):
                 return 2.25, "Winograd F(2x2,3x3): 16 products per 2x2 outputs instead of 36"
+            if name.endswith("_x6"):
+                return 1.0 / 6.0, ("direct sum on the bf16 matrix pipe: every fp32 multiplication as 6 exact bf16 partial products "
+                                   "(operands split into 3 bf16 terms), f32 accumulate; priced against the bf16 MFMA peak")
             return 1.0, "direct sum"
 
         def entry(name, bound):
@@ -527,7 +533,7 @@ def main():
                 ach = alg / red
                 # `achieved` / `frac`: FLOP the matrix pipe actually performs per second against its fp32 peak (<= 1 by
                 # construction); the algorithmic-equivalent rate (SURVEY 8d's 2*cin*cout*k*k per pixel) is its own key
-                peak = PEAK_MFMA_16BIT_TFLOPS if name.endswith("_h16") else PEAK_MFMA_F32_TFLOPS
+                peak = PEAK_MFMA_16BIT_TFLOPS if name.endswith(("_h16", "_x6")) else PEAK_MFMA_F32_TFLOPS
                 return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
                         "share_of_step": v["ms"] / total_ms, "algorithm": how,
@@ -580,7 +586,9 @@ def main():
         line["kernels"] = [e for e in (dcn_entry, entry("flow_warp_pair", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),
-                                       entry("conv5x5_64to120", "mfma")) if e]
+                                       entry("conv5x5_64to120", "mfma"), entry("conv5x5_64to120_x6", "mfma"),
+                                       entry("conv7x7_32to64_x6", "mfma"), entry("conv7x7_64to32_x6", "mfma"),
+                                       entry("conv7x7_32to64", "mfma"), entry("conv7x7_64to32", "mfma")) if e]
         line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         line["step_device_ms_instrumented"] = total_ms * args.streams   # the sub-batches back to back, no overlap
         # HBM bytes per launch from the PMC passes of the last profiling visit (profiles/traffic.json:
