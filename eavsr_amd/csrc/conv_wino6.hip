@@ -184,9 +184,15 @@ __device__ unsigned long long g_w4_it[256 * 256];
 #define W4_IT(i) do { } while (0)
 #endif
 
-template <int R, bool FUSE = false>
+// GRP ("grouped", R = 3 without the fused prologue, an even number of 4-channel chunks): the input transform leaves the iterations.
+// The chunks are taken two at a time: a transform phase in which waves 0-3 -- one per SIMD, nothing beside them -- transform both
+// chunks (128 jobs each) while waves 4-7 request the second chunk's weight slab, then two pure GEMM iterations.  An fp32 MFMA
+// holds its SIMD's vector ALU for all of its 32 cycles (tools/ubench/mfma_fill.hip), so a transform beside MFMAs only ever adds
+// to ONE pair of SIMDs what the barrier then makes everybody wait for; as a phase of its own it costs every SIMD the same.
+template <int R, bool FUSE = false, bool GRP = false>
 __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
   static_assert(!FUSE || R == 3, "the fused channel-attention prologue exists for the 3x3 kernel");
+  static_assert(!GRP || (R == 3 && !FUSE), "the grouped schedule exists for the plain 3x3 kernel");
   using C = WCfg<R>;
   constexpr int M = C::M, PADR = C::PADR, TOH = C::TOH, TOW = C::TOW, IH = C::IH, IW = C::IW, IN_ELEMS = C::IN_ELEMS;
   constexpr int IN_SEGS = C::IN_SEGS, IN_PAD = C::IN_PAD, IN_IT = C::IN_IT;
@@ -504,10 +510,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
   if (total_iters > 1) issue_patch(1);
   W4_TL(1);   // set-up done, first DMA issued
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  W4_TL(2);   // first DMA landed for every wave
-  if ((wave >> 1) == 3) { sc_use = sc_first; transform(0, 0, bn, y0, x0, 0); }   // the pair on duty "before iteration 0"
+  if constexpr (!GRP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    W4_TL(2);   // first DMA landed for every wave
+    if ((wave >> 1) == 3) { sc_use = sc_first; transform(0, 0, bn, y0, x0, 0); }   // the pair on duty "before iteration 0"
+  }
   sc_use = sc_next;   // chunk 1's scale (loaded with patch 1), for the transform of iteration 0
   int chunk = 0;   // chunk of iteration `it` within its tile
   W4_STAMP(0);      // prologue: first DMA round trip, first transform
@@ -526,8 +534,45 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     W4_IT(2);
     W4_STAMP(2);    // waiting at the barrier
     const int chunk_n = chunk + 1 == total_chunks ? 0 : chunk + 1;
-    const bool on_duty = (wave >> 1) == (it & 3);
+    const bool on_duty = !GRP && (wave >> 1) == (it & 3);
+    if constexpr (GRP) {
+      if (it == 0) W4_TL(2);
+      if ((it & 1) == 0) {
+        // ---- transform phase of chunks it, it + 1 (patch 0 / 1 -> V 0 / 1): waves 0-3, one per SIMD; waves 4-7 request the weight
+        // slab of chunk it + 1 (stage 1: the GEMM of chunk it - 1 is behind the barrier above) and wait
+        if (wave < 4) {
+          transform(wave >> 1, wave >> 1, bn, y0, x0, chunk + (wave >> 1));
+        } else {
+#if !defined(EAVSR_WINO_EXP_NODMA) && !defined(EAVSR_WINO_EXP_NOUDMA)
+          const int rank = wave - 4;
+          float* s_u = smem + OFF_U + U_ELEMS;
+          const char* usrc = reinterpret_cast<const char*>(wu_base + (size_t)chunk_n * U_ELEMS) + rank * 1024;
+#pragma unroll
+          for (int i = 0; i < U_SEGS / 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * (4 * 1024) + lane16), (lptr_t)(s_u + (i * 4 + rank) * 256), 16, 0, 0);
+#endif
+        }
+        // V 0 / 1 published, the patches consumed.  A raw barrier behind the LDS stores only: __syncthreads() would also wait
+        // for the weight requests just made
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
     auto issue_dma = [&]() __attribute__((always_inline)) {
+      if constexpr (GRP) {
+#ifndef EAVSR_WINO_EXP_NODMA
+        // first GEMM of the pair: the patches of the next two chunks (both patch buffers are free behind the transform phase);
+        // second GEMM: the weight slab of the next pair's first chunk (stage 0: its last reader was the first GEMM)
+        if ((it & 1) == 0) {
+          if (it + 2 < total_iters) { issue_patch(0); issue_patch(1); }
+        } else {
+#ifndef EAVSR_WINO_EXP_NOUDMA
+          if (it + 1 < total_iters) issue_u(chunk_n, 0);
+#endif
+        }
+#endif
+        return;
+      }
 #ifndef EAVSR_WINO_EXP_NODMA
 #if !defined(EAVSR_WINO_EXP_NOUDMA) && !defined(EAVSR_W4_UREGS)
 #ifdef EAVSR_W4_DUTY_NO_U
@@ -1003,6 +1048,9 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
     if (R == 3 && attr_err == hipSuccess)
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WCfg<3>::LDS_BYTES + 2 * WCfg<3>::IN_PAD * sizeof(float)));
+    if (R == 3 && attr_err == hipSuccess)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, false, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)WCfg<3>::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv_wino6: hipFuncSetAttribute(%zu B of LDS): %s", C::LDS_BYTES, hipGetErrorString(attr_err));
@@ -1016,6 +1064,19 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
     if constexpr (R == 3)
       hipLaunchKernelGGL((conv_wino6_kernel<3, true>), grid, dim3(64 * NW), LDS_FUSE, eavsr::as_stream(stream), a);
   } else {
+    // the grouped schedule (transform phases of two chunks, pure GEMM iterations): 3x3, an even number of 4-channel chunks;
+    // EAVSR_W4_GRP=0 keeps the duty-pair schedule (A/B switch)
+#ifdef EAVSR_W4_NOGRP      // diagnostic builds (tools/build_wino4_diag.sh)
+    static const bool grp_on = false;
+#else
+    static const bool grp_on = [] { const char* e = getenv("EAVSR_W4_GRP"); return e == nullptr || atoi(e) != 0; }();
+#endif
+    if constexpr (R == 3) {
+      if (grp_on && (d->cin / CK) % 2 == 0) {
+        hipLaunchKernelGGL((conv_wino6_kernel<3, false, true>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
+        return eavsr::launch_status("conv_wino6");
+      }
+    }
     hipLaunchKernelGGL((conv_wino6_kernel<R, false>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
   }
   return eavsr::launch_status("conv_wino6");
