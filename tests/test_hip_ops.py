@@ -545,6 +545,36 @@ def test_conv3x3_winograd4_vs_torch_cpu(conv_wino4, cuda, case):
     assert H.maxabs(out.cpu(), ref) <= 6e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("chans", [[12], [4, 8, 8], [16, 24]])
+def test_conv3x3_winograd4_c_abi_odd_and_even_chunk_counts(conv_wino4, cuda, chans):
+    """eavsr_conv3x3_wino4_f32 straight through the C ABI with sources of 4-channel granularity: an odd number of chunks runs the
+    duty-pair schedule, an even number the grouped one (transform phases of two chunks) -- `ops.conv2d` only ever sends multiples of
+    8 channels, so the odd case is reachable from the boundary alone."""
+    from eavsr_amd import _native as Nn
+    ops = conv_wino4
+    n, h, w, cout = 3, 61, 132, 64
+    cin = sum(chans)
+    srcs = [g(cases.randn(70 + i, n, c, h, w), cuda) for i, c in enumerate(chans)]
+    wt = cases.randn(75, cout, cin, 3, 3, scale=1.0 / (cin * 9) ** 0.5)
+    b = cases.randn(76, cout, scale=0.1)
+    wu = ops._packed_wino([g(wt, cuda)], four=True)
+    bg = g(b, cuda)
+    out = torch.empty(n, cout, h, w, device=cuda)
+    d = Nn.ConvDesc()
+    for i, s_ in enumerate(srcs):
+        d.src[i] = s_.data_ptr(); d.src_c[i] = chans[i]
+    d.n_src = len(chans); d.ksize = 3
+    d.bias = bg.data_ptr(); d.out = out.data_ptr()
+    d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
+    d.act = 1
+    import ctypes as C
+    with torch.cuda.device(cuda):
+        code = ops.lib().eavsr_conv3x3_wino4_f32(C.byref(d), C.c_void_p(wu.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert code == 0, ops.lib().eavsr_last_error()
+    ref = F.relu(F.conv2d(torch.cat([s_.cpu() for s_ in srcs], 1), wt, b, 1, 1))
+    assert H.maxabs(out.cpu(), ref) <= 6e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("case", [(64, 256, "lrelu", 4, 100, 128, True), (64, 256, None, 2, 180, 320, True), (64, 40, "relu", 3, 97, 132, True),
                                   (16, 8, "lrelu", 1, 9, 12, False)],
                          ids=lambda c: f"c{c[0]}_o{c[1]}_{c[3]}x{c[4]}x{c[5]}")
