@@ -37,11 +37,11 @@ def _clip(n, t, h, w, seed):
 # ---------------------------------------------------------------------------------------------------------- configs[1]
 def test_config1_full_size_clip_matches_the_cpu_oracle(cuda):
     """BASELINE.json configs[1] / the north star's parity statement: one 7 x 3 x 180 x 320 clip, fp32, default kernel
-    mode (Winograd F(4x4,3x3) 3x3 convolutions, F(2x2,5x5) predictor heads, fused DCNv2), against the CPU oracle's
+    mode (Winograd F(4x4,3x3) 3x3 convolutions, bf16x6 predictor heads and SPyNet 7x7 layers, fused DCNv2), against the CPU oracle's
     `eavsrp_forward` (models/eavsrp_model.py:202-240) within 1e-3 max abs.  The 64 x 64 golden clip is too small for the
     Winograd kernels to engage; this is the size the bench times."""
     from eavsr_amd import ops
-    assert ops.CONV_MODE == "winograd4" and ops.DCN_MODE == "il6"
+    assert ops.CONV_MODE == "winograd4" and ops.DCN_MODE == "il6" and ops.CONV5_MODE == "bf16x6" and ops.CONV7_MODE == "bf16x6"
     net, sd = _net(cuda)
     clip = _clip(1, 7, 180, 320, seed=0)
     with torch.no_grad():
@@ -53,7 +53,7 @@ def test_config1_full_size_clip_matches_the_cpu_oracle(cuda):
         y2 = net(torch.cat([clip, _clip(1, 7, 180, 320, seed=1)], 0).to(cuda))[0:1].cpu()
         ref = O.eavsrp_forward(sd, clip, 4)
     assert tuple(y.shape) == (1, 7, 3, 720, 1280)
-    ran = {"conv3x3_64to64_wino4", "conv5x5_64to120_wino"}
+    ran = {"conv3x3_64to64_wino4", "conv5x5_64to120_x6", "conv7x7_32to64_x6", "conv7x7_64to32_x6", "conv7x7_8to32_x6", "conv7x7_16to2_x6"}
     assert ran <= names, names
     assert {"dcnv2_il_heads", "flow_warp_pair", "flow_warp"} <= names, names
     err = H.maxabs(y, ref)
