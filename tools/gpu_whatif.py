@@ -81,4 +81,18 @@ try:
 except Exception as e:  # noqa: BLE001
     print("no adapt_frontend: skipped", type(e).__name__, e)
 ops.adapt_frontend = orig_fe
+# (7) the bf16x6 convolutions: the predictor's 5x5 heads, SPyNet's 7x7 layers (CU-owning kernels, 144-157 KB of LDS)
+orig_x6 = ops._conv_x6
+def no_x6(k_skip):
+    def f(x, weights, biases, act, slope):
+        if int(weights[0].shape[-1]) != k_skip:
+            return orig_x6(x, weights, biases, act, slope)
+        co = sum(int(w_.shape[0]) for w_ in weights)
+        return cache.setdefault(("x6", k_skip, tuple(x.shape), co), torch.zeros(x.shape[0], co, x.shape[2], x.shape[3], device=x.device))
+    return f
+ops._conv_x6 = no_x6(5)
+measure("no 5x5 heads convolution")
+ops._conv_x6 = no_x6(7)
+measure("no SPyNet 7x7 convolutions")
+ops._conv_x6 = orig_x6
 measure("base again")
