@@ -445,15 +445,15 @@ extern "C" int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int3
 
 extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,
                                 int32_t cout, int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, void* stream) {
-  EAVSR_REQUIRE(x && weight_x6 && out, -1, "conv_f32x6: NULL pointer");
   EAVSR_REQUIRE(ksize == 5 || ksize == 7, -2, "conv_f32x6: kernel size %d (5 and 7 only; 3x3 is eavsr_conv2d_f32 / eavsr_conv3x3_wino4_f32)", ksize);
   EAVSR_REQUIRE(n >= 0 && cin > 0 && cout > 0 && h > 0 && w > 0, -1, "conv_f32x6: bad dims");
+  if (n == 0) return 0;      // (an empty batch has no buffers)
+  EAVSR_REQUIRE(x && weight_x6 && out, -1, "conv_f32x6: NULL pointer");
   EAVSR_REQUIRE(cin % 8 == 0, -2, "conv_f32x6: cin %d must be a multiple of 8 (use eavsr_conv2d_f32)", cin);
   EAVSR_REQUIRE(act >= 0 && act <= 2, -1, "conv_f32x6: act %d", act);
   EAVSR_REQUIRE(act != EAVSR_ACT_LRELU || (slope >= 0.f && slope <= 1.f), -2,
                 "conv_f32x6: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)slope);
   EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "conv_f32x6: image plane too large for 32-bit pixel offsets");
-  if (n == 0) return 0;
   C7Args a;
   a.x = x; a.wsplit = reinterpret_cast<const u32x4*>(weight_x6); a.bias = bias; a.out = out;
   a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.w = w;

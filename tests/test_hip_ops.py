@@ -242,6 +242,22 @@ def test_conv5x5_bf16x6_matches_fp64_and_winograd(ops, cuda, case):
     assert e6 <= 3e-6 and e6 <= 2.0 * ew + 2e-7, (e6, ew)
 
 
+@pytest.mark.parametrize("k", [5, 7])
+@pytest.mark.parametrize("shape", [(8, 1, 1, 1, 1), (8, 33, 2, 3, 2), (16, 64, 1, 5, 200), (8, 5, 3, 2, 37), (40, 3, 0, 9, 9)])
+def test_conv_bf16x6_degenerate_shapes(ops, cuda, k, shape):
+    """images smaller than the kernel window (every tap but the centre ones in the zero padding), a single pixel, one output channel,
+    an empty batch, a 200-pixel row of 5: eavsr_conv_f32x6 against torch's CPU convolution"""
+    cin, cout, n, h, w = shape
+    x = cases.randn(80, n, cin, h, w)
+    wt = cases.randn(81, cout, cin, k, k, scale=1.0 / (cin * k * k) ** 0.5)
+    b = cases.randn(82, cout, scale=0.1)
+    out = ops.conv2d(g(x, cuda), g(wt, cuda), g(b, cuda)).cpu()
+    ref = F.conv2d(x, wt, b, 1, k // 2)
+    assert out.shape == ref.shape
+    if n:
+        assert H.maxabs(out, ref) <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_conv7x7_bf16x6_zero_tap_reads_no_neighbour(ops, cuda):
     """the 50th tap of a chunk has zero weights and reads the always-zero patch column: a NaN / Inf next to the receptive field of a
     pixel must not reach it (0 x NaN), and one inside must."""
