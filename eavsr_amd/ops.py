@@ -304,7 +304,7 @@ def _packed_smallco(weights: Sequence[Tensor]) -> Tensor:
     ids = {id(x) for x in weights}
     for k in [k for k in _smallco_pack_cache if any(i in ids for i, _ in k)]:
         _smallco_pack_cache.pop(k, None)
-    refs = tuple(weakref.ref(x, lambda _r, k=key: _smallco_pack_cache.pop(k, None)) for x in weights)
+    refs = tuple(weakref.ref(x, lambda _r, k=key, c=_smallco_pack_cache: c.pop(k, None)) for x in weights)
     _smallco_pack_cache[key] = (refs, packed)
     return packed
 
@@ -331,7 +331,7 @@ def _packed_conv_x6(weights: Sequence[Tensor]) -> Tensor:
     ids = {id(x) for x in weights}
     for k_ in [k_ for k_ in _conv7_pack_cache if any(i in ids for i, _ in k_)]:
         _conv7_pack_cache.pop(k_, None)
-    refs = tuple(weakref.ref(x, lambda _r, k_=key: _conv7_pack_cache.pop(k_, None)) for x in weights)
+    refs = tuple(weakref.ref(x, lambda _r, k_=key, c=_conv7_pack_cache: c.pop(k_, None)) for x in weights)
     _conv7_pack_cache[key] = (refs, packed)
     return packed
 
