@@ -786,7 +786,7 @@ def _packed_x9(weights: Sequence[Tensor]) -> Tensor:
     ids = {id(x) for x in weights}
     for k in [k for k in _x9_pack_cache if any(i in ids for i, _ in k)]:
         _x9_pack_cache.pop(k, None)
-    refs = tuple(weakref.ref(x, lambda _r, k=key: _x9_pack_cache.pop(k, None)) for x in weights)
+    refs = tuple(weakref.ref(x, lambda _r, k=key, c=_x9_pack_cache: c.pop(k, None)) for x in weights)
     _x9_pack_cache[key] = (refs, packed)
     return packed
 
@@ -868,7 +868,7 @@ def _packed_wino(weights: Sequence[Tensor], four: bool = False, kind: Optional[s
     ids = {id(x) for x in weights}
     for k in [k for k in _wino_pack_cache if k[-1] == (kind, 0) and any(i in ids for i, _ in k[:-1])]:
         _wino_pack_cache.pop(k, None)
-    refs = tuple(weakref.ref(x, lambda _r, k=key: _wino_pack_cache.pop(k, None)) for x in weights)
+    refs = tuple(weakref.ref(x, lambda _r, k=key, c=_wino_pack_cache: c.pop(k, None)) for x in weights)
     _wino_pack_cache[key] = (refs, packed)
     return packed
 
