@@ -110,7 +110,7 @@ def _dgrad_weight(ws, c0: int, cs: int) -> Tensor:
     ids = {id(w) for w in ws}
     for k_ in [k_ for k_ in _dgrad_cache if k_[-2:] == (c0, cs) and any(i in ids for i, _ in k_[:-2])]:
         _dgrad_cache.pop(k_, None)
-    refs = tuple(weakref.ref(w, lambda _r, k_=key: _dgrad_cache.pop(k_, None)) for w in ws)
+    refs = tuple(weakref.ref(w, lambda _r, k_=key, c=_dgrad_cache: c.pop(k_, None)) for w in ws)
     _dgrad_cache[key] = (refs, wt)
     return wt
 

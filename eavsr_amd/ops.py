@@ -256,7 +256,7 @@ def _bias_of(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
     if hit is not None and all(r() is b for r, b in zip(hit[0], biases)):
         return hit[1]
     cat = _chk(_cat_bias(biases), "bias")
-    refs = tuple(weakref.ref(b, lambda _r, k=key: _bias_cache.pop(k, None)) for b in biases)
+    refs = tuple(weakref.ref(b, lambda _r, k=key, c=_bias_cache: c.pop(k, None)) for b in biases)
     _bias_cache[key] = (refs, cat)
     return cat
 
@@ -276,7 +276,7 @@ def _cat_weights(weights: Sequence[Tensor]) -> Tensor:
     ids = {id(w) for w in weights}
     for k_ in [k_ for k_ in _wcat_cache if any(i in ids for i, _ in k_)]:
         _wcat_cache.pop(k_, None)
-    refs = tuple(weakref.ref(w, lambda _r, k_=key: _wcat_cache.pop(k_, None)) for w in weights)
+    refs = tuple(weakref.ref(w, lambda _r, k_=key, c=_wcat_cache: c.pop(k_, None)) for w in weights)
     _wcat_cache[key] = (refs, cat)
     return cat
 
@@ -692,7 +692,7 @@ def _packed_il16(weight: Tensor, code: int) -> Tensor:
         N.check(lib().eavsr_pack_dcn_il16_weight(_p(w), _p(packed), cout, cin, code, _stream(w)), "pack_dcn_il16_weight")
     for k in [k for k in _il16_pack_cache if k[0] == id(weight)]:
         _il16_pack_cache.pop(k, None)
-    _il16_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key: _il16_pack_cache.pop(k, None)), packed)
+    _il16_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key, c=_il16_pack_cache: c.pop(k, None)), packed)
     return packed
 
 
@@ -1366,7 +1366,7 @@ def _packed_h16(weight: Tensor, code: int) -> Tensor:
         N.check(lib().eavsr_pack_conv3x3_c64_h16(_p(w), _p(packed), code, st), "pack_conv3x3_c64_h16")
     for k in [k for k in _h16_pack_cache if k[0] == id(weight)]:
         _h16_pack_cache.pop(k, None)
-    _h16_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key: _h16_pack_cache.pop(k, None)), packed)
+    _h16_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key, c=_h16_pack_cache: c.pop(k, None)), packed)
     return packed
 
 
@@ -1408,7 +1408,7 @@ def _packed5_h16(wcat: Tensor, code: int) -> Tensor:
         N.check(lib().eavsr_pack_conv5x5_c64_h16(_p(wcat), _p(packed), int(wcat.shape[0]), code, st), "pack_conv5x5_c64_h16")
     for k in [k for k in _h16_pack5_cache if k[0] == id(wcat)]:
         _h16_pack5_cache.pop(k, None)
-    _h16_pack5_cache[key] = (weakref.ref(wcat, lambda _r, k=key: _h16_pack5_cache.pop(k, None)), packed)
+    _h16_pack5_cache[key] = (weakref.ref(wcat, lambda _r, k=key, c=_h16_pack5_cache: c.pop(k, None)), packed)
     return packed
 
 
