@@ -30,6 +30,15 @@ __global__ __launch_bounds__(CA_THREADS) void ca_scale_kernel(const float* __res
     const float* p = partial + (size_t)bn * tiles * c + ch;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int t = q;
+    // sixteen loads in flight where the tiles allow it (configs[4]: 1020 tiles per sample, 64 per thread -- four dependent batches of
+    // four loads each were 22 us of pure latency per launch); every accumulator still receives its addends in the same order
+    for (; t + 15 * Q < tiles; t += 16 * Q) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(t + j * Q) * c];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+    }
     for (; t + 3 * Q < tiles; t += 4 * Q) {
       const float v0 = p[(size_t)t * c], v1 = p[(size_t)(t + Q) * c], v2 = p[(size_t)(t + 2 * Q) * c],
                   v3 = p[(size_t)(t + 3 * Q) * c];

@@ -1056,7 +1056,7 @@ def test_conv2d_fused_channel_attention_prologue(ops, cuda):
                    ca=(torch.zeros(1, 64, device=cuda), torch.zeros(1, 64, 8, 10, device=cuda)))
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 180, 320), (1, 64, 24, 40), (3, 64, 45, 80), (1, 32, 12, 16), (2, 64, 9, 13)])
+@pytest.mark.parametrize("shape", [(2, 64, 180, 320), (1, 64, 24, 40), (3, 64, 45, 80), (1, 32, 12, 16), (2, 64, 9, 13), (1, 64, 136, 240)])
 def test_ca_tail_one_launch_equals_ca_scale_plus_scale_residual(ops, cuda, shape):
     """eavsr_ca_tail_f32 (CALayer + `res * y + x`, networks.py:444-447,463-464, in one launch) against the two-launch form
     bit for bit (same fixed-order reduction, same fma) and against the CPU oracle's ca_layer arithmetic"""
@@ -1065,7 +1065,8 @@ def test_ca_tail_one_launch_equals_ca_scale_plus_scale_residual(ops, cuda, shape
     cr = max(c // 16, 1)
     w1, b1 = cases.randn(72, cr, c, 1, 1, scale=0.2), cases.randn(73, cr, scale=0.1)
     w2, b2 = cases.randn(74, c, cr, 1, 1, scale=0.5), cases.randn(75, c, scale=0.1)
-    tiles = 115 if h == 180 else 67 if h == 45 else 7      # 115: the bench shape's tile count (both loops of the fixed-order reduction)
+    # 115: the bench shape's tile count (both short loops of the fixed-order reduction); 1020: configs[4]'s (the sixteen-deep loop too)
+    tiles = 115 if h == 180 else 67 if h == 45 else 1020 if h == 136 else 7
     # per-tile channel sums that add up to the true sums (what the conv epilogue hands over)
     sums = r.sum(dim=(2, 3))
     frac = torch.softmax(cases.randn(76, n, tiles, c), dim=1)
