@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -60,6 +60,9 @@ SIGNATURES = {
     "eavsr_nchw_to_il8_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_il_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_ws_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_dcn_weight_il2_bytes": (C.c_int64, [i32, i32]),
+    "eavsr_pack_dcn_weight_il2": (C.c_int, [vp, vp, i32, i32, vp]),
+    "eavsr_dcnv2_il2_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcn_il16_weight_bytes": (C.c_int64, [i32, i32]),
     "eavsr_pack_dcn_il16_weight": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "eavsr_nchw_to_il8_h16": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -23,6 +23,12 @@ FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fno-gpu-rdc",
          "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
 
 
+# per-source additions.  dcnv2_il2.hip: the SLP vectorizer packs pairs of independent fp32 additions / multiplications of the
+# sampler's set-up into v_pk_add_f32 / v_pk_mul_f32, which are slower than the two plain instructions beside MFMAs
+# (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; measured 84-88 -> 77-78 us per 2 x 64 x 180 x 320 launch).
+PER_FILE_FLAGS = {"dcnv2_il2.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -35,7 +41,7 @@ def sources():
 
 
 def _digest() -> str:
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(PER_FILE_FLAGS.items()))).encode())
     files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     files.append(os.path.join(os.path.dirname(HERE), "include", "eavsr_hip.h"))
     for f in files:
@@ -55,7 +61,7 @@ def build_native(force: bool = False, verbose: bool = False, extra_flags=()) -> 
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []), *extra_flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

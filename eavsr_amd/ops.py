@@ -645,13 +645,16 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
         if tuple(oh.shape) != (n, 18 * D, h, w) or tuple(mask.shape) != (n, 9 * D, h, w):
             raise ValueError("dcnv2_il: offset / mask shape")
     b = None if bias is None else _chk(bias.detach(), "bias")
-    wx = _packed_dcn_x9(weight)
+    impl = DCN_IL_IMPL
+    if impl == "il2" and cin % 16:
+        impl = "il"           # the round-4 schedule contracts groups in pairs
+    wx = _packed_dcn_il2(weight) if impl == "il2" else _packed_dcn_x9(weight)
     out = torch.empty((n, cout, h, w), device=x_il8.device, dtype=torch.float32)
     st = _stream(out)
     px = float(n) * h * w
     # algorithmic bytes of the DCNv2 op as SURVEY 8d defines them (input + 27 D offset/mask + output); in heads mode the
     # kernel itself moves (cin + 15 D + cout) floats per pixel
-    fn = lib().eavsr_dcnv2_ws_f32 if DCN_IL_IMPL == "ws" else lib().eavsr_dcnv2_il_f32
+    fn = {"ws": lib().eavsr_dcnv2_ws_f32, "il": lib().eavsr_dcnv2_il_f32, "il2": lib().eavsr_dcnv2_il2_f32}[impl]
     _launch("dcnv2_il" + ("_heads" if heads else ""), 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * D + cout), out,
             lambda: fn(_p(x_il8), _p(oh), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout, D,
                        int(nprod), 1 if heads else 0, st), "dcnv2_il")
@@ -662,14 +665,40 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
 # contracts (default: faster at the alignment's offsets, |offset| of a few pixels); "ws" = eavsr_dcnv2_ws_f32, wave-specialised
 # samplers / contractors (csrc/dcnv2_ws.hip): ~18 % slower there, 8-15 % faster when many samples leave the LDS window
 # (sigma = 4 px), because its out-of-window samples are blended in line instead of in a second MFMA pass.  DESIGN.md 4b.
-DCN_IL_IMPL = os.environ.get("EAVSR_DCN_IL_IMPL", "il")
+# "il2" = eavsr_dcnv2_il2_f32 (csrc/dcnv2_il2.hip, round 4): the two groups of a pair as nine full k-steps in one software
+# pipeline across group / pair / tile boundaries (same operands and products; falls back to "il" when cin % 16 != 0).
+DCN_IL_IMPL = os.environ.get("EAVSR_DCN_IL_IMPL", "il2")
 
 
 def set_dcn_il_impl(impl: str) -> None:
     global DCN_IL_IMPL
-    if impl not in ("il", "ws"):
-        raise ValueError(f"dcn il impl {impl!r}: 'il' or 'ws'")
+    if impl not in ("il", "ws", "il2"):
+        raise ValueError(f"dcn il impl {impl!r}: 'il', 'il2' or 'ws'")
     DCN_IL_IMPL = impl
+
+
+_il2_pack_cache = {}
+
+
+def _packed_dcn_il2(weight: Tensor) -> Tensor:
+    """Pre-split (3 x bf16) weight slab of a 3x3 DCNv2 weight in the pair-step order of eavsr_dcnv2_il2_f32; cached per weight
+    object and version, verified by identity."""
+    key = (id(weight), weight._version)
+    hit = _il2_pack_cache.get(key)
+    if hit is not None and hit[0]() is weight:
+        return hit[1]
+    w = _chk(weight.detach(), "weight")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    nbytes = lib().eavsr_dcn_weight_il2_bytes(cout, cin)
+    if nbytes <= 0 or tuple(w.shape[2:]) != (3, 3):
+        raise NotImplementedError(f"il2 weight shape {tuple(w.shape)} unsupported")
+    packed = torch.empty(nbytes // 4, device=w.device, dtype=torch.int32)
+    with _DeviceOf(w):
+        N.check(lib().eavsr_pack_dcn_weight_il2(_p(w), _p(packed), cout, cin, _stream(w)), "pack_dcn_weight_il2")
+    for k in [k for k in _il2_pack_cache if k[0] == id(weight)]:
+        _il2_pack_cache.pop(k, None)
+    _il2_pack_cache[key] = (weakref.ref(weight, lambda _r, k=key, c=_il2_pack_cache: c.pop(k, None)), packed)
+    return packed
 
 
 _il16_pack_cache = {}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 21
+#define EAVSR_ABI_VERSION 22
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -133,6 +133,19 @@ int eavsr_dcnv2_il_f32(const float* x_il8, const float* offset_or_heads, const f
 int eavsr_dcnv2_ws_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
                        const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
                        int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
+
+/* Round-4 schedule of eavsr_dcnv2_il_f32 (csrc/dcnv2_il2.hip): same operation, arguments, operand splits and products;
+ * the two 8-channel groups of a pair are contracted as 18 taps = nine full k-steps (no padded tenth half k-step) in one
+ * software pipeline that runs across group, pair and tile boundaries.  Replaces the modulated_deform_conv2d call of
+ * models/networks.py:627-630 (heads = 1: together with networks.py:302-315).  weight_il2: eavsr_dcn_weight_il2_bytes(cout,
+ * cin) bytes written by eavsr_pack_dcn_weight_il2 from weight(cout,cin,3,3).  Requires cin % 16 == 0 in addition to the
+ * requirements of eavsr_dcnv2_il_f32 (-2 otherwise: call eavsr_dcnv2_il_f32).  Results equal eavsr_dcnv2_il_f32's up to
+ * the re-association of the k-steps (and, heads = 1, <= 1 ulp of the mask: the sigmoid's reciprocal is v_rcp_f32). */
+int64_t eavsr_dcn_weight_il2_bytes(int32_t cout, int32_t cin);
+int eavsr_pack_dcn_weight_il2(const float* weight, void* weight_il2, int32_t cout, int32_t cin, void* stream);
+int eavsr_dcnv2_il2_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_il2,
+                        const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                        int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
 
 /* 16-bit form of eavsr_dcnv2_il_f32 for the 16-bit mode (BASELINE.json configs[2] bf16 / configs[4] fp16; csrc/dcnv2_il16.hip):
  * x_il8_h16 is the IL8 layout in 16 bits ([n][cin/8][h][w][8] bf16 / fp16: eavsr_flow_warp_pair_f32 with outb_il8 = 2 | 3, or

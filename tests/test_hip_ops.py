@@ -865,9 +865,10 @@ def test_to_il8_layout(ops, cuda):
     assert torch.equal(il, x.view(2, 3, 8, 7, 9).permute(0, 1, 3, 4, 2))
 
 
-@pytest.fixture(params=["il", "ws"])
+@pytest.fixture(params=["il2", "il", "ws"])
 def il_impl(request, ops):
-    """both schedules of the IL8 DCNv2 kernel: eavsr_dcnv2_il_f32 (default) and the wave-specialised eavsr_dcnv2_ws_f32"""
+    """every schedule of the IL8 DCNv2 kernel: eavsr_dcnv2_il2_f32 (round 4, default), eavsr_dcnv2_il_f32 (round 2) and the
+    wave-specialised eavsr_dcnv2_ws_f32"""
     prev = ops.DCN_IL_IMPL
     ops.set_dcn_il_impl(request.param)
     yield request.param
