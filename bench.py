@@ -504,9 +504,18 @@ def main():
     if rank == 0 and not args.no_kernel_profile:
         # one extra untimed pass with HIP events around every launch (events on the launch stream), over one sub-batch:
         # the launch shapes of the timed region
+        # The launches are enqueued behind a device-side delay, so that the host is a whole forward ahead of the device and the
+        # kernels run back to back: an event pair then brackets its kernel alone.  (Enqueued live, the device outruns the host
+        # on the small kernels and each bracket also holds the host's launch latency: 5-6 us on a 70 us kernel -- the reason
+        # round 3's event figures sat 7 % above the rocprofv3 durations of the same kernels.)
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(0.45 * 2.0e9))
         with torch.no_grad(), ops.profile() as prof:
             net(clips[:n // args.streams])
         summ = prof.summary()
+        line["kernel_timing"] = ("HIP events around every launch of one eager forward over one sub-batch, on the launch stream, "
+                                 "enqueued behind a 0.2 s device-side delay (kernels back to back, no host launch latency "
+                                 "inside a bracket); agrees with profiles/*rocprof* kernel-trace durations")
         total_ms = sum(v["ms"] for v in summ.values())
 
         def mult_reduction(name):
@@ -592,6 +601,46 @@ def main():
             dcn_entry["moved"] = {"achieved": dcn_entry["achieved"] * moved_px / alg_px, "unit": "GB/s",
                                   "frac": dcn_entry["frac"] * moved_px / alg_px,
                                   "note": "bytes the fused (heads-mode) kernel itself moves / time / 8 TB/s"}
+        if dcn_entry is not None and dcn_name == "dcnv2_il_heads":
+            # what the sampler saw in THIS workload: the offsets the predictor heads imply, per call, and the
+            # same launch shape again on synthetic heads with sigma = 4 px offsets (where ~20 % of the samples leave the LDS window)
+            dcn_entry["schedule"] = ops.DCN_IL_IMPL
+            try:
+                with torch.no_grad(), ops.dcn_probe() as probe:
+                    net(clips[:n // args.streams])
+                torch.cuda.synchronize()
+                keys = probe[0].keys() if probe else ()
+                dcn_entry["offset_stats"] = {"calls": len(probe), **{k: (max(p[k] for p in probe) if k == "max_abs" else
+                                                                        sum(p[k] for p in probe) / len(probe)) for k in keys},
+                                             "worst_call_frac_outside_lds_window": max((p["frac_outside_lds_window"] for p in probe), default=None),
+                                             "note": "offsets (T.R - R + t of networks.py:304-311) over all heads-mode DCNv2 calls of one "
+                                                     "sub-batch forward; outside = a bilinear corner leaves the kernel's LDS window"}
+                sub_n = n // args.streams
+                g4 = torch.Generator(device=device).manual_seed(4)
+                rn = lambda *sh: torch.randn(*sh, device=device, generator=g4)
+                ident = torch.tensor([1.0, 0, 0, 1.0], device=device).repeat(8).view(1, 32, 1, 1)
+                res4 = {}
+                for sg in (0.5, 4.0):
+                    hd = torch.cat([rn(sub_n, 32, h, w) * 0.25 + ident, rn(sub_n, 16, h, w) * sg, rn(sub_n, 72, h, w)], 1)
+                    xil = ops.to_il8(rn(sub_n, 64, h, w))
+                    wt4, b4 = rn(64, 64, 3, 3) * 0.05, rn(64) * 0.1
+                    for _ in range(3):
+                        ops.dcnv2_il(xil, hd, None, wt4, b4, 8, heads=True)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(20):
+                        ops.dcnv2_il(xil, hd, None, wt4, b4, 8, heads=True)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / 20
+                    st4 = ops.dcn_offset_stats(hd, 8)
+                    res4[f"sigma_{sg}"] = {"avg_ms": ms, "frac": alg_px * sub_n * h * w / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                           "frac_outside_lds_window": st4["frac_outside_lds_window"], "mean_norm": st4["mean_norm"]}
+                dcn_entry["synthetic_offsets"] = {**res4, "note": "same launch shape, iid gaussian translations of sigma px on top of "
+                                                  "near-identity transforms; 20 back-to-back launches per figure"}
+            except Exception as ex:      # measurement garnish must not void the line
+                dcn_entry["offset_stats_error"] = repr(ex)
         line["kernels"] = [e for e in (dcn_entry, entry("flow_warp_pair", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),
@@ -606,6 +655,8 @@ def main():
         if os.path.exists(pmc):
             try:
                 tr = json.load(open(pmc))
+                line["traffic_source"] = ("profiles/traffic.json: HBM bytes per launch from separate rocprofv3 --pmc passes of an earlier "
+                                          f"visit ({tr.get('_taken', 'date not recorded')}); REPLAYED here, not measured in this run")
                 if "roofline" in line:
                     line["roofline"]["traffic"] = tr.get(dom_name)
                 for e in line["kernels"]:

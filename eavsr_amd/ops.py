@@ -645,6 +645,8 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
         if tuple(oh.shape) != (n, 18 * D, h, w) or tuple(mask.shape) != (n, 9 * D, h, w):
             raise ValueError("dcnv2_il: offset / mask shape")
     b = None if bias is None else _chk(bias.detach(), "bias")
+    if heads and _dcn_probe is not None:
+        _dcn_probe.append(dcn_offset_stats(oh, D))
     impl = DCN_IL_IMPL
     if impl == "il2" and cin % 16:
         impl = "il"           # the round-4 schedule contracts groups in pairs
@@ -659,6 +661,48 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
             lambda: fn(_p(x_il8), _p(oh), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout, D,
                        int(nprod), 1 if heads else 0, st), "dcnv2_il")
     return out
+
+
+_dcn_probe = None      # bench.py: a list that collects offset statistics of every heads-mode DCNv2 call inside `dcn_probe()`
+
+
+class dcn_probe:
+    """Collect, per heads-mode DCNv2 call inside the scope, what the sampler saw: the offsets implied by the predictor heads
+    (networks.py:302-315) and how many samples left the kernel's LDS window (served from global memory)."""
+
+    def __enter__(self):
+        global _dcn_probe
+        _dcn_probe = []
+        return _dcn_probe
+
+    def __exit__(self, *exc):
+        global _dcn_probe
+        _dcn_probe = None
+        return False
+
+
+def dcn_offset_stats(heads: Tensor, D: int, tile_h: int = 8, tile_w: int = 32, margin_up: int = 6, margin_left: int = 8,
+                     win_h: int = 20, win_w: int = 48) -> dict:
+    """Statistics of the 18 D offsets that AdaptBlockOffset's heads imply (offset = T.R - R + t per deformable group) and the
+    fraction of (pixel, tap) samples whose bilinear corners leave the DCNv2 kernel's LDS window (tile 8 x 32, window rows
+    y0-6 .. y0+13, columns x0-8 .. x0+39: csrc/dcnv2_il2.hip).  Plain torch on the tensor's device; measurement only."""
+    n, _, h, w = heads.shape
+    T = heads[:, :4 * D].view(n, D, 2, 2, h, w)
+    t = heads[:, 4 * D:6 * D].view(n, D, 2, 1, h, w)
+    ky = torch.tensor([-1., -1., -1., 0., 0., 0., 1., 1., 1.], device=heads.device)
+    kx = torch.tensor([-1., 0., 1., -1., 0., 1., -1., 0., 1.], device=heads.device)
+    R = torch.stack([ky, kx], 0).view(1, 1, 2, 9, 1, 1)
+    off = (T[:, :, :, 0:1] * R[:, :, 0:1] + T[:, :, :, 1:2] * R[:, :, 1:2]) - R + t      # (n, D, 2, 9, h, w): dy, dx per tap
+    dy, dx = off[:, :, 0], off[:, :, 1]
+    ys = torch.arange(h, device=heads.device).view(1, 1, 1, h, 1) % tile_h
+    xs = torch.arange(w, device=heads.device).view(1, 1, 1, 1, w) % tile_w
+    ry = margin_up + ys + ky.view(1, 1, 9, 1, 1) + torch.floor(dy)
+    rx = margin_left + xs + kx.view(1, 1, 9, 1, 1) + torch.floor(dx)
+    outside = (ry < 0) | (ry > win_h - 2) | (rx < 0) | (rx > win_w - 2)
+    mag = torch.sqrt(dy * dy + dx * dx)
+    return {"mean_abs_dy": float(dy.abs().mean()), "mean_abs_dx": float(dx.abs().mean()), "mean_norm": float(mag.mean()),
+            "sigma_dy": float(dy.std()), "sigma_dx": float(dx.std()), "max_abs": float(torch.maximum(dy.abs().max(), dx.abs().max())),
+            "frac_outside_lds_window": float(outside.float().mean())}
 
 
 # Schedule of the IL8 DCNv2 kernel (same arithmetic, same arguments): "il" = eavsr_dcnv2_il_f32, every wave samples and
