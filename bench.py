@@ -65,7 +65,8 @@ def parse():
     ap.add_argument("--conv-mode", default="winograd4", choices=["winograd", "winograd4", "direct", "bf16x9"],
                     help="large 3x3 convolutions (all fp32 in / out / accumulate): winograd = F(2x2,3x3) on the fp32 MFMA "
                          "(default); direct = direct sum on the fp32 MFMA; bf16x9 = direct sum, both operands split exactly "
-                         "into three bf16 terms, nine partial products on the bf16 MFMA")
+                         "into three bf16 terms, nine partial products on the bf16 MFMA.  The 5x5 predictor heads and SPyNet's 7x7 layers "
+                         "are chosen separately: EAVSR_CONV5 / EAVSR_CONV7 = bf16x6 (default) | fp32 (reported in config.conv5 / conv7)")
     ap.add_argument("--dcn-mode", default="il6", choices=["il6", "il9", "native", "bf16x9"],
                     help="DCNv2: il6 (default) = IL8-layout kernel fed by the paired warp and the predictor heads, fp32 operands "
                          "split into 3 bf16 terms, 6 partial products (dropped ones < 2^-23 relative); il9 = all 9 products "
@@ -73,6 +74,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=None,
                     help="split the clips of a step into this many sub-batches, each replayed as its own HIP graph on its own "
                          "stream (eavsr_amd.graph.StreamedForward)")
+    ap.add_argument("--no-train-graph", action="store_true", help="--mode train: run the step eagerly even when every rank owns a device")
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward as one captured HIP graph (eavsr_amd.graph.GraphedForward): ~1 ms of host time "
                          "per step instead of ~180 ms of Python / ctypes launches; same kernels, same device time")
@@ -241,7 +243,11 @@ def train_bench(args, rank, world, device):
     data = {"lr_seq": synthetic_clip(n, t, h, w, seed=rank), "hr_seq": synthetic_clip(n, t, 4 * h, 4 * w, seed=100 + rank),
             "fname": "synthetic"}
     model.set_input(data, epoch=0)
-    if args.graph:
+    # the graphed step (forward + backward captured once; all-reduce and Adam behind each replay when world > 1) whenever every
+    # rank has a device of its own; ranks that share a device (test launches) stay eager: their graphs would interleave badly
+    own_device = world <= torch.cuda.device_count()
+    use_graph = args.graph or (own_device and not args.no_train_graph)
+    if use_graph:
         from eavsr_amd.graph import GraphedTrainStep
         graphed = GraphedTrainStep(model, warmup=max(args.warmup, 1))
         step = graphed.step
@@ -257,13 +263,17 @@ def train_bench(args, rank, world, device):
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0
     shard.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     on_dev = world > 1 and not shard.host_collectives()      # only a pure-RCCL group needs device tensors for the MAX
+    per_rank_ms = shard.all_ranks(1e3 * own_elapsed / args.steps, device=device if on_dev else None)
+    per_rank_device = shard.all_ranks_str(f"cuda:{device.index} {torch.cuda.get_device_name(device)}")
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
     if rank == 0:
         print(json.dumps({
+            "per_rank_ms": per_rank_ms, "per_rank_device": per_rank_device,
             "metric": "training LR frames/sec, eavsrp x4 step (forward + backward + grad all-reduce + Adam)",
             "value": world * n * t * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -271,7 +281,8 @@ def train_bench(args, rank, world, device):
             "config": {"workload": f"eavsrp x4 training step, {n} clips/GPU x {t} x 3 x {h} x {w}, HR {4*h}x{4*w}, L1, "
                                    "Adam (1e-4 / 1e-5), DP with one bucketed RCCL all-reduce on 49.1 MB of gradients "
                                    "(BASELINE.json configs[3])",
-                       "launch": "one HIP graph per step" if args.graph else "eager (one launch per kernel)"},
+                       "launch": ("HIP graph per step (forward + backward" + (" + Adam)" if world == 1 else "; all-reduce + Adam behind the replay)"))
+                                 if use_graph else "eager (one launch per kernel)"},
             "loss": model.get_current_losses()}), flush=True)
     if world > 1:
         shard.barrier()
@@ -294,7 +305,11 @@ def self_launch(args) -> int:
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cores // args.gpus)))      # N ranks share the node's cores
     r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
     line = None
     for ln in r.stdout.splitlines():
@@ -325,16 +340,25 @@ def dry_bench(args):
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     n, t = args.clips, args.frames
+    if os.environ.get("EAVSR_DRY_DIE_RANK") == str(rank):      # tests: a rank that dies must take the job down, not hang it
+        print(f"[bench] rank {rank}: dying on request (EAVSR_DRY_DIE_RANK)", file=sys.stderr)
+        os._exit(7)
     for _ in range(args.warmup):
         time.sleep(0.01)
     shard.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.01 * (1 + rank))          # ranks differ on purpose: the line must carry the MAX
+    own = time.perf_counter() - t0             # this rank's own work, before it waits for the others
     shard.barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    mine = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(mine)
+    per_rank = shard.all_ranks(1e3 * own / max(args.steps, 1))
+    per_dev = shard.all_ranks_str(f"cpu:{rank}")
+    thread_cap = shard.cap_host_threads(world)
     if rank == 0:
         print(json.dumps({
+            "per_rank_ms": per_rank, "per_rank_device": per_dev, "host_threads_per_rank": thread_cap,
             "metric": "DRY RUN -- no kernels, no GPU: launch / barrier / max-over-ranks plumbing only (not a measurement)",
             "value": world * n * t * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -364,6 +388,7 @@ def main():
         sys.exit(2)
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    thread_cap = shard.cap_host_threads(world)
     ops.lib()  # fail loudly if the HIP extension is missing
     if world > 1:
         # the N ranks the line reports are N live RCCL ranks, one per GPU (or EAVSR_DIST_BACKEND=gloo in shared-GPU tests)
@@ -413,6 +438,7 @@ def main():
             out = run(clips)
             marks[i + 1].record()          # device-side step boundaries (no host sync inside the timed region)
         torch.cuda.synchronize()
+        own_elapsed = time.perf_counter() - t0      # this rank's own K steps, before it waits for the others
         shard.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -444,6 +470,8 @@ def main():
             del exact_first
         del timed_first, eager_first
     on_dev = world > 1 and not shard.host_collectives()      # only a pure-RCCL group needs device tensors for the MAX
+    per_rank_ms = shard.all_ranks(1e3 * own_elapsed / args.steps, device=device if on_dev else None)
+    per_rank_device = shard.all_ranks_str(f"cuda:{device.index} {torch.cuda.get_device_name(device)}")
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
     timed_vs_eager = shard.max_over_ranks(timed_vs_eager, device=device if on_dev else None)
     frames_total = world * n * t * args.steps
@@ -467,6 +495,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        # every rank's own time per step (the job is quoted on their MAX) and the device each one ran on
+        "per_rank_ms": per_rank_ms, "per_rank_device": per_rank_device, "host_threads_per_rank": thread_cap,
         # median over the timed steps (device-side step boundaries; max over ranks of the per-rank medians)
         "ms_per_step_median": med_ms,
         "value_median": world * n * t / (med_ms * 1e-3),
@@ -497,6 +527,10 @@ def main():
                    "conv7x7_conv5x5": {"bf16x6": "eavsr_conv_f32x6: fp32 operands as 3 exact bf16 terms, 6 of 9 partial products (dropped < 2^-23 "
                                                  "each), f32 accumulate, bf16 MFMA"}.get(ops.CONV7_MODE, "fp32 MFMA (implicit GEMM)") +
                                       " | 5x5 heads: " + {"bf16x6": "the same kernel"}.get(ops.CONV5_MODE, "Winograd F(2x2,5x5), fp32 MFMA"),
+                   "conv3x3_wino4_schedule": ("grouped (transform phases of two chunks, pure GEMM iterations)"
+                                              if ops.lib().eavsr_wino4_schedule() else "duty pair (EAVSR_W4_GRP=0)"),
+                   "dcnv2_schedule": {"il2": "eavsr_dcnv2_il2_f32 (round 4: taps of two groups paired, one pipeline across groups / tiles)",
+                                      "il": "eavsr_dcnv2_il_f32 (round 2)", "ws": "eavsr_dcnv2_ws_f32 (wave-specialised)"}[ops.DCN_IL_IMPL],
                    "launch": (f"{args.streams} HIP graphs on {args.streams} streams per step" if args.streams > 1 else
                               "one HIP graph per step" if args.graph else "eager (one launch per kernel)")},
     }

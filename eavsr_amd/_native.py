@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -67,6 +67,7 @@ SIGNATURES = {
     "eavsr_pack_dcn_il16_weight": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "eavsr_nchw_to_il8_h16": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_il16": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_wino4_schedule": (C.c_int, []),
     "eavsr_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "eavsr_conv3x3_f32x9": (C.c_int, [vp, vp, vp]),
     "eavsr_wino_weight_elems": (C.c_int64, [i32, i32]),

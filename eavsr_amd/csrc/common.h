@@ -73,6 +73,19 @@ __device__ __forceinline__ void eavsr_stagger_priority(int wave) {
 }
 #endif
 
+// Activation of the convolution epilogues, branch-free: max(v, v (*) s) with s = 1 (none), 0 (ReLU) or the leaky slope, where (*)
+// is v_mul_legacy_f32 (0 times anything, infinities and NaNs included, is +0).  With the plain product ReLU(-inf) was -inf
+// (-inf * 0 = NaN, and max returns its other operand) and ReLU of a negative value -0.0; with the legacy product both
+// are +0, as torch.relu gives, at the same two instructions per value.  Infinities pass through the leaky / identity forms.
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float eavsr_mul_legacy(float a, float b) {
+  float r;
+  asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+#endif
+
 // spatial tile of the implicit-GEMM conv kernels: (32, 16 or 8) rows x 32 columns per 512-thread workgroup,
 // wave w owns NT = 4, 2 or 1 consecutive rows, one 32-pixel MFMA N-tile per row.
 #define EAVSR_CONV_TW 32

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256 * KZ) void conv3x3_smallco_kernel(SmallArgs a) 
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
           float v = acc[co][p] + (a.bias ? a.bias[co] : 0.f);
-          v = fmaxf(v, v * (a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope));   // branch-free: max(v, v s), 0 <= s <= 1
+          v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope));   // branch-free: max(v, v s), 0 <= s <= 1
           const size_t o = ((size_t)bn * COUT + co) * plane + (size_t)gy * w + gx;
           if (a.residual) v += a.residual[o];
           a.out[o] = v;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__((TH / PXR) * TW) void conv3x3_smallco_lite_kernel(S
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
           float v = acc[co][p] + (a.bias ? a.bias[co] : 0.f);
-          v = fmaxf(v, v * act_s);
+          v = fmaxf(v, eavsr_mul_legacy(v, act_s));
           const size_t o = ((size_t)bn * COUT + co) * (plane4 / 4) + (size_t)gy * w + gx;
           if (a.residual) v += a.residual[o];
           a.out[o] = v;
@@ -371,19 +371,22 @@ extern "C" int eavsr_conv3x3_smallco_f32(const float* x, const float* weight, co
 }
 
 extern "C" int64_t eavsr_smallco_packed_elems(int32_t cout, int32_t cin) {
-  if (cout < 1 || cout > 6 || cin < 1) return 0;
-  return (int64_t)cin * 3 * sl_colblock(cout == 5 ? 6 : cout);
+  if (!(cout == 2 || cout == 3 || cout == 4 || cout == 6) || cin < 1) return 0;      // the kernel instances
+  return (int64_t)cin * 3 * sl_colblock(cout);
 }
 
 extern "C" int eavsr_pack_smallco_weight(const float* weight, float* packed, int32_t cout, int32_t cin, void* stream) {
   EAVSR_REQUIRE(weight && packed, -1, "pack_smallco_weight: NULL pointer");
-  EAVSR_REQUIRE(cout >= 1 && cout <= 6 && cin >= 1, -1, "pack_smallco_weight: cout %d (1..6), cin %d", cout, cin);
-  const int kc = cout == 1 ? 2 : cout == 5 ? 6 : cout;      // the kernel instances: 2, 3, 4, 6 outputs
+  // only the output counts the kernels are instantiated for: the packing kernel reads weight[co] for co < cout (cout
+  // 1 / 5 were packed as 2 / 6 and read one output channel past the weight)
+  EAVSR_REQUIRE((cout == 2 || cout == 3 || cout == 4 || cout == 6) && cin >= 1, -2, "pack_smallco_weight: cout %d (2, 3, 4 or 6), cin %d",
+                cout, cin);
+  const int kc = cout;
   const int cb = sl_colblock(kc);
   const int total = cin * 3 * cb;
   // the column blocks are laid out for the kernel's output count kc: ky * kc + co
   hipLaunchKernelGGL(pack_smallco_kernel, dim3((total + 255) / 256), dim3(256), 0, eavsr::as_stream(stream), weight, packed,
-                     kc == cout ? cout : kc, cin, cb);
+                     kc, cin, cb);
   return eavsr::launch_status("pack_smallco_weight");
 }
 

@@ -51,6 +51,16 @@
 
 namespace {
 
+// the grouped schedule is the default; EAVSR_W4_GRP=0 keeps the duty-pair schedule (A/B switch), read once
+static bool w6_grouped_schedule() {
+#ifdef EAVSR_W4_NOGRP      // diagnostic builds (tools/build_wino4_diag.sh)
+  return false;
+#else
+  static const bool on = [] { const char* e = getenv("EAVSR_W4_GRP"); return e == nullptr || atoi(e) != 0; }();
+  return on;
+#endif
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -782,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 float t = (ch == 0 ? y[j].x : y[j].y) + bias_r[r];
-                t = fmaxf(t, t * act_s);
+                t = fmaxf(t, eavsr_mul_legacy(t, act_s));
                 vv[ch][j] = t;
               }
             }
@@ -842,7 +852,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               y[j] += bb;
-              y[j] = fmaxf(y[j], y[j] * act_s);
+              y[j] = fmaxf(y[j], eavsr_mul_legacy(y[j], act_s));
             }
             if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
               csum[r] += y[0] + y[1];
@@ -1066,11 +1076,7 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   } else {
     // the grouped schedule (transform phases of two chunks, pure GEMM iterations): 3x3, an even number of 4-channel chunks;
     // EAVSR_W4_GRP=0 keeps the duty-pair schedule (A/B switch)
-#ifdef EAVSR_W4_NOGRP      // diagnostic builds (tools/build_wino4_diag.sh)
-    static const bool grp_on = false;
-#else
-    static const bool grp_on = [] { const char* e = getenv("EAVSR_W4_GRP"); return e == nullptr || atoi(e) != 0; }();
-#endif
+    const bool grp_on = w6_grouped_schedule();
     if constexpr (R == 3) {
       if (grp_on && (d->cin / CK) % 2 == 0) {
         hipLaunchKernelGGL((conv_wino6_kernel<3, false, true>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
@@ -1104,3 +1110,5 @@ extern "C" int eavsr_conv3x3_wino4_f32(const eavsr_conv2d_desc* d, const float* 
 extern "C" int eavsr_conv5x5_wino_f32(const eavsr_conv2d_desc* d, const float* weight_wino5x5, void* stream) {
   return launch_wino6<5>(d, weight_wino5x5, stream);
 }
+
+extern "C" int eavsr_wino4_schedule(void) { return w6_grouped_schedule() ? 1 : 0; }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
 #pragma unroll
       for (int t = 0; t < S_NT; ++t) {
         float v = acc[m][t][r];
-        v = fmaxf(v, v * act_s);      // branch-free: max(v, v s), 0 <= s <= 1
+        v = fmaxf(v, eavsr_mul_legacy(v, act_s));      // branch-free: max(v, v s), 0 <= s <= 1
         if (cok && xok && y0 + wave * S_NT + t < h) ob[(size_t)cu * plane + (size_t)t * w] = v;
       }
     }

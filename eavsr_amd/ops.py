@@ -429,6 +429,8 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError(f"weight expects {[int(x.shape[1]) for x in weights]} input channels, sources give {cin}")
     if pixel_shuffle2 and (cout % 4 or residual is not None or chan_partial or ca is not None):
         raise ValueError("pixel_shuffle2: cout % 4 == 0, no residual / channel sums / channel-attention prologue")
+    if ca_out and ca is None:      # before any early return (the bf16x6 route used to skip this check)
+        raise ValueError("ca_out needs ca")
     if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None:
         y = _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
         return torch.nn.functional.pixel_shuffle(y, 2) if pixel_shuffle2 else y

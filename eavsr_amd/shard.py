@@ -96,6 +96,45 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def all_ranks(value: float, device=None) -> List[float]:
+    """every rank's host scalar, in rank order (per-rank step times beside the MAX the job is quoted on)"""
+    if not dist.is_initialized():
+        return [float(value)]
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=device if device is not None else "cpu")
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
+def all_ranks_str(value: str) -> List[str]:
+    """every rank's short string, in rank order (device names; through a fixed-size byte tensor: works on any backend that has
+    all_reduce, which is all this module relies on)"""
+    if not dist.is_initialized():
+        return [value]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    raw = value.encode()[:96]
+    dev = torch.device("cuda", torch.cuda.current_device()) if (not host_collectives() and torch.cuda.is_available()) else "cpu"
+    t = torch.zeros(world, 96, dtype=torch.int32, device=dev)
+    t[rank, :len(raw)] = torch.tensor(list(raw), dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [bytes(int(b) for b in row if b).decode(errors="replace") for row in t.cpu().tolist()]
+
+
+def cap_host_threads(world: int) -> int:
+    """N ranks on one node share its cores: cap this rank's intra-op / OpenMP threads at cores // world (at least 1), so that
+    eight ranks do not start eight full-width thread pools.  Returns the cap."""
+    import os
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cap = max(1, cores // max(1, world))
+    if world > 1:
+        torch.set_num_threads(min(torch.get_num_threads(), cap))
+    return cap
+
+
 def sum_over_ranks(value: float, device=None) -> float:
     if not dist.is_initialized():
         return float(value)

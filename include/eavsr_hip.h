@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 22
+#define EAVSR_ABI_VERSION 23
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -285,11 +285,20 @@ int eavsr_conv3x3_smallco_lite_f32(const float* x, const float* weight_packed, c
  *            pyramid level from compute_flow, models/eavsrp_model.py:433-488);
  *   ksize 5: AdaptBlockOffset's three heads as one 64 -> 15 D convolution (models/networks.py:289-315).
  * cin % 8 == 0; any cout.  `weight_x6`: eavsr_conv_weight_x6_bytes(ksize, cout, cin) bytes written by eavsr_pack_conv_weight_x6
- * from the (cout, cin, ksize, ksize) weight.  act / slope as eavsr_conv2d_f32.                                                  */
+ * from the (cout, cin, ksize, ksize) weight.  act / slope as eavsr_conv2d_f32.
+ * FINITE INPUTS: the exact split forms residuals a - trunc_bf16(a); for a = +-inf that is inf - inf = NaN, so an infinity in
+ * x or the weights becomes NaN in every output of its receptive field (the fp32-MFMA and Winograd kernels and the reference give
+ * +-inf there); values below 2^-110 lose their mid / lo terms to bf16 denormals.  The same holds for every bf16-split kernel of
+ * this library (eavsr_dcnv2_f32x9, eavsr_dcnv2_il_f32, eavsr_dcnv2_il2_f32, eavsr_conv3x3_f32x9).                            */
 size_t eavsr_conv_weight_x6_bytes(int32_t ksize, int32_t cout, int32_t cin);
 int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, void* stream);
 int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin, int32_t cout,
                      int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, void* stream);
+
+/* Which schedule eavsr_conv3x3_wino4_f32 runs for plain 3x3 launches with an even number of 4-channel chunks: 1 = grouped
+ * (transform phases of two chunks, pure GEMM iterations; default), 0 = duty pair (EAVSR_W4_GRP=0).  Chosen once per process from
+ * the environment; reported so that recorded measurements state which variant ran.                               */
+int eavsr_wino4_schedule(void);
 
 /* ---- a11: channel attention -----------------------------------------------------------------
  * CALayer (models/networks.py:432-447): scale[n,c] = sigmoid(W2 . relu(W1 . mean_hw(r) + b1) + b2)

@@ -450,8 +450,9 @@ def feature_pyramid(lr_feature: Tensor):
     return d2, d4
 
 
-def eavsrp_forward(sd: SD, lrs: Tensor, scale: int = 4, D: int = 8, flows=None) -> Tensor:
-    """EAVSRP.forward eavsrp_model.py:202-240: (n,t,3,h,w) -> (n,t,3,s*h,s*w)."""
+def eavsrp_forward(sd: SD, lrs: Tensor, scale: int = 4, D: int = 8, flows=None, return_feats: bool = False):
+    """EAVSRP.forward eavsrp_model.py:202-240: (n,t,3,h,w) -> (n,t,3,s*h,s*w).  return_feats: also the propagated branch
+    features (the `feats` dict that eavsrp_model.py:229-240 hands to `upsample`), for tests that compare them directly."""
     n, t, c, h, w = lrs.shape
     assert h >= 64 and w >= 64
     with torch.no_grad():
@@ -469,7 +470,8 @@ def eavsrp_forward(sd: SD, lrs: Tensor, scale: int = 4, D: int = 8, flows=None) 
                 module = f"{direction}_{it}"
                 feats[module] = []
                 feats = propagate(sd, feats, fb if direction == "backward" else ff, module, D)
-        return upsample(sd, lrs, feats, scale)
+        out = upsample(sd, lrs, feats, scale)
+        return (out, feats) if return_feats else out
 
 
 # --------------------------------------------------------------------------------------

@@ -271,6 +271,57 @@ def test_conv7x7_bf16x6_zero_tap_reads_no_neighbour(ops, cuda):
     assert H.maxabs(out[fin], ref[fin]) <= 2e-5 * max(1.0, ref[fin].abs().max().item())
 
 
+@pytest.mark.parametrize("mode", ["winograd4", "winograd", "direct", "bf16x9"])
+def test_conv_epilogue_relu_of_minus_infinity_and_of_negatives_is_plus_zero(ops, cuda, mode):
+    """the branch-free activation max(v, v * s) gave ReLU(-inf) = -inf (-inf * 0 = NaN, max returns the other operand)
+    and ReLU(negative) = -0.0.  With the legacy product both are +0, as torch.relu gives; leaky / identity keep -inf."""
+    x = cases.randn(71, 2, 64, 96, 128)
+    wt = cases.randn(72, 64, 64, 3, 3, scale=0.05)
+    b = cases.randn(73, 64, scale=0.1)
+    b[5] = float("-inf")                                  # channel 5: -inf before the activation
+    ops.set_conv_mode(mode)
+    try:
+        y = ops.conv2d(g(x, cuda), g(wt, cuda), g(b, cuda), act="relu").cpu()
+        yl = ops.conv2d(g(x, cuda), g(wt, cuda), g(b, cuda), act="lrelu", slope=0.1).cpu()
+    finally:
+        ops.set_conv_mode(DEFAULT_CONV_MODE)
+    ref = F.relu(F.conv2d(x, wt, b, 1, 1))
+    assert torch.isfinite(y).all() and (y[:, 5] == 0).all()
+    assert not torch.signbit(y[y == 0]).any()              # no -0.0
+    assert H.maxabs(y, ref) <= 1e-4 * max(1.0, ref.abs().max().item())
+    assert torch.isinf(yl[:, 5]).all() and (yl[:, 5] < 0).all()
+    # the small-cout and the bf16x6 kernels share the epilogue form
+    w3 = cases.randn(74, 3, 64, 3, 3, scale=0.05)
+    b3 = torch.tensor([0.1, float("-inf"), -0.2])
+    y3 = ops.conv2d(g(x, cuda), g(w3, cuda), g(b3, cuda), act="relu").cpu()
+    assert (y3[:, 1] == 0).all() and not torch.signbit(y3[y3 == 0]).any()
+    w5 = cases.randn(75, 16, 64, 5, 5, scale=0.03)
+    b5 = cases.randn(76, 16, scale=0.1)
+    b5[2] = float("-inf")
+    y5 = ops.conv2d(g(x, cuda), g(w5, cuda), g(b5, cuda), act="relu").cpu()
+    assert (y5[:, 2] == 0).all() and not torch.signbit(y5[y5 == 0]).any()
+
+
+def test_conv2d_ca_out_without_ca_raises_on_every_route(ops, cuda):
+    """the bf16x6 route returned before the argument check"""
+    x = torch.zeros(1, 64, 16, 16, device=cuda)
+    for k in (3, 5, 7):
+        with pytest.raises(ValueError):
+            ops.conv2d(x, torch.zeros(64, 64, k, k, device=cuda), None, ca_out=True)
+
+
+def test_pack_smallco_weight_rejects_output_counts_without_a_kernel(ops, cuda):
+    """cout 1 / 5 were packed as 2 / 6 and the packing kernel read past the weight"""
+    import ctypes as C
+    lib = ops.lib()
+    for cout in (1, 5, 7):
+        assert lib.eavsr_smallco_packed_elems(cout, 64) == 0
+        wt = torch.zeros(cout, 64, 3, 3, device=cuda)
+        buf = torch.zeros(4096, device=cuda)
+        assert lib.eavsr_pack_smallco_weight(C.c_void_p(wt.data_ptr()), C.c_void_p(buf.data_ptr()), cout, 64, None) == -2
+    assert lib.eavsr_smallco_packed_elems(3, 64) > 0
+
+
 def test_conv2d_multi_head_weights(ops, cuda):
     x = cases.randn(1, 1, 64, 14, 18)
     ws = [cases.randn(2 + i, co, 64, 3, 3, scale=0.05) for i, co in enumerate((4, 2))]

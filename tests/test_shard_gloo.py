@@ -170,6 +170,64 @@ def test_bench_single_rank_line_is_unchanged_by_the_launcher_and_child_failures_
     assert r.returncode != 0 and not lines
 
 
+def _worker8(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    from eavsr_amd import shard
+    r, _, w = shard.init_process_group("gloo")
+    mine = shard.clip_indices(32, r, w)
+    cap = shard.cap_host_threads(w)
+    shard.barrier()
+    times = shard.all_ranks(10.0 + r)                 # per-rank step times, rank order, on every rank
+    names = shard.all_ranks_str(f"cpu:{r}")
+    total = shard.sum_over_ranks(float(len(mine)))
+    q.put((rank, mine, times, names, total, cap, torch.get_num_threads()))
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_ranks_partition_32_clips_and_report_per_rank():
+    """the node's shape (SURVEY 8e: one process per GPU, 8 per node): 32 clips over 8 ranks, 4 each, every clip exactly once;
+    per-rank times / device names arrive in rank order on every rank; the host-thread cap is cores // 8"""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owned = sorted(i for _, mine, *_ in res for i in mine)
+    assert owned == list(range(32)) and all(len(mine) == 4 for _, mine, *_ in res)
+    for rank, mine, times, names, total, cap, nthreads in res:
+        assert mine == list(range(rank, 32, 8))
+        assert times == [10.0 + r for r in range(8)] and names == [f"cpu:{r}" for r in range(8)]
+        assert total == 32.0 and cap >= 1 and nthreads <= cap
+
+
+def test_bench_a_rank_that_dies_takes_the_job_down_within_a_timeout():
+    """`bench.py --gpus 2` where rank 1 exits before the first barrier: the launcher tears the other rank down and the parent
+    returns a non-zero status with no JSON line -- it does not hang in the barrier"""
+    import time as _t
+    t0 = _t.time()
+    r, lines = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry", env={"EAVSR_DRY_DIE_RANK": "1"})
+    assert r.returncode != 0 and not lines, (r.returncode, r.stdout[-500:])
+    assert _t.time() - t0 < 240
+
+
+def test_bench_dry_line_carries_per_rank_fields():
+    r, lines = _run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry")
+    assert r.returncode == 0 and len(lines) == 1
+    line = lines[0]
+    assert len(line["per_rank_ms"]) == 2 and line["per_rank_ms"][1] > line["per_rank_ms"][0] >= 9.0      # rank r sleeps 10 (1 + r) ms
+    assert line["per_rank_device"] == ["cpu:0", "cpu:1"] and line["host_threads_per_rank"] >= 1
+    assert abs(max(line["per_rank_ms"]) - line["ms_per_step"]) < 5.0
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_over_rccl_when_two_devices_are_visible():
     """The real N > 1 path: `python bench.py --gpus 2` starts two ranks itself, one per GPU, over RCCL (backend 'nccl'); also
