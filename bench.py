@@ -607,15 +607,6 @@ def main():
         if dom is not None:
             line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_ms",
                                                     "share_of_step", "algorithm", "algorithmic_equivalent")}
-            if args.conv_mode == "winograd4":
-                # what actually bounds this kernel: the bytes every workgroup pulls from L2 / the memory-side cache into LDS
-                # -- per workgroup-iteration (32 Winograd tiles x 64 channels x 36 positions x 4 input channels = 589,824 FLOP) a 36 KB
-                # weight slab, re-streamed by every tile, and an 11.25 KB input patch: 12.2 performed FLOP per ingested byte
-                fpb = (32 * 64 * 36 * 4 * 2) / (36 * 1024 + 2880 * 4)
-                line["roofline"]["lds_fill"] = {
-                    "flop_per_byte": fpb, "achieved": dom["achieved"] / fpb, "unit": "TB/s",
-                    "note": "L2 / Infinity-Cache -> LDS traffic the launches sustain (performed FLOP/s / FLOP per ingested byte): the kernel's "
-                            "binding resource (DESIGN 4i), reported beside the MFMA fraction, not a peak-normalised figure"}
             line["roofline"]["kernel"] = {
                 "winograd": "conv3x3_wino_kernel (3x3 64->64, the residual backbone)",
                 "winograd4": "conv_wino6_kernel<3> (3x3 64->64, the residual backbone)",

@@ -357,7 +357,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #pragma unroll
     for (int i = 0; i < U_IT; ++i) {
       const int seg = i * NW + wave;
+#ifdef EAVSR_WINO_EXP_QUARTER_U      // timing only: a quarter of the weight pieces (what an in-kernel G g G^T expansion would request)
+      if (seg < U_SEGS && (seg & 3) == 0)
+#else
       if (seg < U_SEGS)
+#endif
         __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * (NW * 1024) + lane16), (lptr_t)(s_u + seg * 256), 16, 0, 0);
     }
   };
@@ -367,7 +371,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     float* s_u = smem + OFF_U + stage * U_ELEMS;
     const char* usrc = reinterpret_cast<const char*>(wu_base + (size_t)g * U_ELEMS) + wave * 1024;
     const int seg = i * NW + wave;
+#ifdef EAVSR_WINO_EXP_QUARTER_U
+    if (seg < U_SEGS && (seg & 3) == 0)
+#else
     if (seg < U_SEGS)
+#endif
       __builtin_amdgcn_global_load_lds((gptr_t)(usrc + i * (NW * 1024) + lane16), (lptr_t)(s_u + seg * 256), 16, 0, 0);
   };
   auto issue_patch_piece = [&](int i, int stage) __attribute__((always_inline)) {
