@@ -179,6 +179,9 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   constexpr int WIN_IT = (JWIN_SEGS + 7) / 8;   // 4
   int prc[WIN_IT];
   unsigned poff[WIN_IT];
+#ifdef EAVSR_IL2_EXP_CONTIG
+  unsigned poffc[WIN_IT];
+#endif
 #pragma unroll
   for (int i = 0; i < WIN_IT; ++i) {
     const int e = (i * 8 + wave) * 64 + lane;
@@ -187,17 +190,20 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     const int rr = rem / JPW;
     const int cc = rem - rr * JPW;
     prc[i] = (rr << 8) | cc;
-#ifdef EAVSR_IL2_EXP_CONTIG      // timing only: what a [half][h][w][4] image layout (contiguous window rows) would cost
-    poff[i] = (unsigned)((rr * w + cc) * 16 + hh * 16 * 64);
-#else
     poff[i] = (unsigned)((rr * w + cc) * 32 + hh * 16);
+#ifdef EAVSR_IL2_EXP_CONTIG      // timing only (results wrong), interior tiles only (so that every address stays inside the image):
+    poffc[i] = (unsigned)(rr * w * 32 + hh * 768 + cc * 16);      // the same bytes of the window row as two contiguous 768-byte runs
 #endif
   }
   auto issue_win = [&](int i, const char* xorg, int y0, int x0, bool interior, int wslot) __attribute__((always_inline)) {
     const int p = i * 8 + wave;  // wave-uniform
     if (p < JWIN_SEGS) {
       char* dst = smem + JL_WIN + wslot * JWIN_B + p * 1024;
+#ifdef EAVSR_IL2_EXP_CONTIG
+      const char* src = xorg + (interior ? poffc[i] : poff[i]);
+#else
       const char* src = xorg + poff[i];
+#endif
       if (!interior) {
         const int ylo = y0 - JPY0, xlo = x0 - JPX0;
         const bool ok = (unsigned)(ylo + (prc[i] >> 8)) < (unsigned)h && (unsigned)(xlo + (prc[i] & 255)) < (unsigned)w;
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     }
 #ifndef EAVSR_IL2_EXP_NO_FIXUP
     const unsigned long long sm = slowm[u % 3];
-    if (sm != 0) {      // wave-uniform, rare
+    if (__builtin_expect(sm != 0, 0)) {      // wave-uniform, rare: the block is laid out away from the pipeline
       const bool mine = (sm >> lane) & 1ull;
       f32x4 tq[4];
 #pragma unroll
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
 #endif
       char* ob = reinterpret_cast<char*>(a.out + ((size_t)st_bn * a.cout + (size_t)cot * 64) * plane);
       const unsigned voff = st_po + (kg ? 4u * upl4 : 0u);
-      if (cot * 64 + 64 <= a.cout) {      // wave-uniform
+      if (__builtin_expect(cot * 64 + 64 <= a.cout, 1)) {      // wave-uniform
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll

@@ -37,11 +37,13 @@ if "dcn" in which:
         xil = ops.to_il8(x64)
         heads = torch.cat([r(n, 32, h, w) * 0.25 + torch.tensor([1.0, 0, 0, 1.0], device=dev).repeat(8).view(1, 32, 1, 1),
                            r(n, 16, h, w) * float(os.environ.get("SIGMA", 1.5)), r(n, 72, h, w)], 1)
-        for nprod in (6, 9):
-            for _ in range(reps):
-                ops.dcnv2_il(xil, off, mask, w33, b, 8, nprod=nprod)
-            for _ in range(reps):
-                ops.dcnv2_il(xil, heads, None, w33, b, 8, nprod=nprod, heads=True)
+        for impl in ("il", "il2"):       # round 2's schedule and round 4's: the counters of both in one pass
+            ops.set_dcn_il_impl(impl)
+            for nprod in (6, 9):
+                for _ in range(reps):
+                    ops.dcnv2_il(xil, off, mask, w33, b, 8, nprod=nprod)
+                for _ in range(reps):
+                    ops.dcnv2_il(xil, heads, None, w33, b, 8, nprod=nprod, heads=True)
 if "warp" in which:
     flow = r(n, 2, h, w) * 2
     for _ in range(reps):
