@@ -137,7 +137,7 @@ from eavsr_amd.eavsrp_model import EAVSRP
 from eavsr_amd.utils.synthetic import fill_state_dict, shapes_of, synthetic_clip
 cores = {cores}
 torch.set_num_threads(cores)
-net = EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale=4), None)
+net = EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale={scale}), None)
 sd0 = net.state_dict()
 sd = fill_state_dict(shapes_of(sd0), {preset!r}, fixed=sd0)
 del net
@@ -149,15 +149,15 @@ with torch.no_grad():
         if i > 1 and time.time() - t_start + times[-1] > {budget}:
             break
         t0 = time.time()
-        O.eavsrp_forward(sd, clip, 4)
+        O.eavsrp_forward(sd, clip, {scale})
         times.append(time.time() - t0)
         print(json.dumps({{"run": i, "seconds": times[-1]}}), flush=True)
 """
 
 
-def _run_cpu_child(preset, frames, h, w, cores, runs, budget, timeout_s):
+def _run_cpu_child(preset, frames, h, w, cores, runs, budget, timeout_s, scale=4):
     import subprocess
-    code = _CPU_CHILD.format(root=ROOT, cores=cores, preset=preset, frames=frames, h=h, w=w, runs=runs, budget=budget)
+    code = _CPU_CHILD.format(root=ROOT, cores=cores, preset=preset, frames=frames, h=h, w=w, runs=runs, budget=budget, scale=scale)
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="",
                CUDA_VISIBLE_DEVICES="")
     p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
@@ -175,7 +175,7 @@ def _run_cpu_child(preset, frames, h, w, cores, runs, budget, timeout_s):
     return secs, err
 
 
-def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=420.0, threads=0):
+def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=420.0, threads=0, scale=4):
     """The oracle (a port of the reference's algorithm, oracle/eavsr_oracle.py) timed on the host cores the way the
     reference times its own forward (models/eavsrp_model.py:100-107: wall time around one forward of one clip, the
     first iteration discarded): ONE full-size clip, one warm-up run, then up to `runs` timed runs, median; no
@@ -192,7 +192,7 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
         cands = sorted({c for c in (8, 16, 32, 64, 128, usable) if c <= usable})
         best = None
         for c in cands:      # ascending; stop as soon as more threads are clearly slower (saves the slow candidates' minutes)
-            secs_p, _ = _run_cpu_child(preset, frames, crop_h, crop_w, c, 1, 40.0, timeout_s=60)
+            secs_p, _ = _run_cpu_child(preset, min(frames, 7), crop_h, crop_w, c, 1, 40.0, timeout_s=60, scale=scale)
             if len(secs_p) >= 2:
                 probe += f"{c}: {secs_p[-1]:.1f} s; "
                 if best is None or secs_p[-1] < best[1]:
@@ -207,7 +207,20 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
         cores = best[0] if best else min(usable, 32)
         probe = f" (thread count chosen by a probe on a {crop_h}x{crop_w} clip over {usable} usable cores -- {probe.rstrip('; ')})"
     base = {"unit": "frames/s", "cores": cores, "kind": "port"}
-    secs, err = _run_cpu_child(preset, frames, full_h, full_w, cores, runs, budget, timeout_s=budget + 60)
+    if frames * full_h * full_w > 2_500_000:
+        # a clip this large (configs[4]: 15 x 540 x 960) needs minutes per run on the host: a BOUNDED sample instead -- all frames
+        # (the recurrence depth is the workload) on a centre-size third of the frame, scaled by the pixel ratio, and labelled
+        sh, sw = max(64, full_h // 3 // 4 * 4), max(64, full_w // 3 // 4 * 4)
+        secs_b, err_b = _run_cpu_child(preset, frames, sh, sw, cores, 1, budget, timeout_s=budget + 60, scale=scale)
+        if len(secs_b) >= 2:
+            dt = secs_b[-1]
+            return dict(base, value=frames / dt * (sh * sw) / float(full_h * full_w),
+                        sample=f"BOUNDED SAMPLE: 1 clip x {frames} frames x 3 x {sh} x {sw} (all frames, a third of the frame each way) "
+                               f"in {dt:.1f} s after one warm-up run ({secs_b[0]:.1f} s), scaled by the pixel ratio "
+                               f"{sh * sw}/{full_h * full_w} to the {full_h}x{full_w} workload; oracle/eavsr_oracle.py eavsrp_forward, "
+                               f"torch {torch.__version__} CPU, {cores} threads" + probe)
+        return dict(base, value=None, sample=f"failed: {err_b[-300:]!r}")
+    secs, err = _run_cpu_child(preset, frames, full_h, full_w, cores, runs, budget, timeout_s=budget + 60, scale=scale)
     if len(secs) >= 2:
         timed = secs[1:]
         med = statistics.median(timed)
@@ -217,7 +230,7 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
                            f"1 warm-up run ({secs[0]:.1f} s, discarded) + {len(timed)} timed run(s) "
                            f"{[round(x, 1) for x in timed]} s, median {med:.1f} s; no extrapolation" + probe)
     # fallback: the full clip did not finish twice within the budget
-    secs_c, err_c = _run_cpu_child(preset, frames, crop_h, crop_w, cores, 1, 120.0, timeout_s=180)
+    secs_c, err_c = _run_cpu_child(preset, frames, crop_h, crop_w, cores, 1, 120.0, timeout_s=180, scale=scale)
     if len(secs_c) >= 2:
         dt = secs_c[-1]
         return dict(base, value=frames / dt * (crop_h * crop_w) / float(full_h * full_w),
@@ -672,7 +685,7 @@ def main():
                                        entry("conv5x5_64to120", "mfma"), entry("conv5x5_64to120_x6", "mfma"),
                                        entry("conv7x7_32to64_x6", "mfma"), entry("conv7x7_64to32_x6", "mfma"),
                                        entry("conv7x7_32to64", "mfma"), entry("conv7x7_64to32", "mfma")) if e]
-        line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        line["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("EAVSR_BREAKDOWN_N", "12"))]}
         line["step_device_ms_instrumented"] = total_ms * args.streams   # the sub-batches back to back, no overlap
         # HBM bytes per launch from the PMC passes of the last profiling visit (profiles/traffic.json:
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there)
@@ -691,7 +704,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.preset, t, h, w, args.cpu_crop[0], args.cpu_crop[1], runs=args.cpu_runs,
-                                            budget=args.cpu_budget, threads=args.cpu_threads)
+                                            budget=args.cpu_budget, threads=args.cpu_threads, scale=args.scale)
 
     if degraded is not None:
         line["degraded"] = degraded
