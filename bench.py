@@ -659,16 +659,18 @@ def main():
                 ident = torch.tensor([1.0, 0, 0, 1.0], device=device).repeat(8).view(1, 32, 1, 1)
                 res4 = {}
                 for sg in (0.5, 4.0):
-                    hd = torch.cat([rn(sub_n, 32, h, w) * 0.25 + ident, rn(sub_n, 16, h, w) * sg, rn(sub_n, 72, h, w)], 1)
+                    act_m = ops.heads_mask_activated(64)      # as the fused alignment calls it: masks activated by the heads' epilogue
+                    mk = rn(sub_n, 72, h, w)
+                    hd = torch.cat([rn(sub_n, 32, h, w) * 0.25 + ident, rn(sub_n, 16, h, w) * sg, torch.sigmoid(mk) if act_m else mk], 1)
                     xil = ops.to_il8(rn(sub_n, 64, h, w))
                     wt4, b4 = rn(64, 64, 3, 3) * 0.05, rn(64) * 0.1
                     for _ in range(3):
-                        ops.dcnv2_il(xil, hd, None, wt4, b4, 8, heads=True)
+                        ops.dcnv2_il(xil, hd, None, wt4, b4, 8, heads=True, mask_activated=act_m)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     torch.cuda.synchronize()
                     e0.record()
                     for _ in range(20):
-                        ops.dcnv2_il(xil, hd, None, wt4, b4, 8, heads=True)
+                        ops.dcnv2_il(xil, hd, None, wt4, b4, 8, heads=True, mask_activated=act_m)
                     e1.record()
                     torch.cuda.synchronize()
                     ms = e0.elapsed_time(e1) / 20

@@ -79,6 +79,10 @@ __device__ __forceinline__ void eavsr_stagger_priority(int wave) {
 // are +0, as torch.relu gives, at the same two instructions per value.  Infinities pass through the leaky / identity forms.
 
 #ifdef __HIPCC__
+// sigmoid as 1 / (1 + 2^(-x log2 e)) with v_exp_f32 and v_rcp_f32 (<= 1 ulp each): the mask activation of AdaptBlockOffset
+// (networks.py:314), evaluated by the same instructions wherever it runs (the DCNv2 sampler or the epilogue of the 5x5 heads)
+__device__ __forceinline__ float eavsr_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 __device__ __forceinline__ float eavsr_mul_legacy(float a, float b) {
   float r;
   asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

@@ -65,6 +65,7 @@ struct C7Args {
   int n, cin, cout, h, w, tiles_x, tiles_y;
   int act;
   float slope;
+  int sig_from;      // output channels >= sig_from (a multiple of 8; -1: none) get the sigmoid instead of `act`
 };
 
 // exact three-way split of two fp32 values into packed bf16 pairs (low half = first value)
@@ -322,10 +323,13 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
     for (int r = 0; r < 16; ++r) {
       const int cu = m * 32 + (r & 3) + 8 * (r >> 2);
       const bool cok = full || co0 + cu < a.cout;
+      // the mask logits of the predictor heads leave as masks (networks.py:314): wave-uniform per group of eight channels
+      const bool sg = a.sig_from >= 0 && cot * 32 * MT + m * 32 + 8 * (r >> 2) >= a.sig_from;
 #pragma unroll
       for (int t = 0; t < S_NT; ++t) {
         float v = acc[m][t][r];
-        v = fmaxf(v, eavsr_mul_legacy(v, act_s));      // branch-free: max(v, v s), 0 <= s <= 1
+        if (sg) v = eavsr_sigmoid_fast(v);
+        else v = fmaxf(v, eavsr_mul_legacy(v, act_s));      // branch-free: max(v, v s), 0 <= s <= 1
         if (cok && xok && y0 + wave * S_NT + t < h) ob[(size_t)cu * plane + (size_t)t * w] = v;
       }
     }
@@ -444,7 +448,8 @@ extern "C" int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int3
 }
 
 extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,
-                                int32_t cout, int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, void* stream) {
+                                int32_t cout, int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t sigmoid_from,
+                                void* stream) {
   EAVSR_REQUIRE(ksize == 5 || ksize == 7, -2, "conv_f32x6: kernel size %d (5 and 7 only; 3x3 is eavsr_conv2d_f32 / eavsr_conv3x3_wino4_f32)", ksize);
   EAVSR_REQUIRE(n >= 0 && cin > 0 && cout > 0 && h > 0 && w > 0, -1, "conv_f32x6: bad dims");
   if (n == 0) return 0;      // (an empty batch has no buffers)
@@ -454,11 +459,13 @@ extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const flo
   EAVSR_REQUIRE(act != EAVSR_ACT_LRELU || (slope >= 0.f && slope <= 1.f), -2,
                 "conv_f32x6: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)slope);
   EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "conv_f32x6: image plane too large for 32-bit pixel offsets");
+  EAVSR_REQUIRE(sigmoid_from < 0 || (sigmoid_from % 8 == 0 && sigmoid_from < cout), -2,
+                "conv_f32x6: sigmoid_from %d (a multiple of 8 below cout, or -1)", sigmoid_from);
   C7Args a;
   a.x = x; a.wsplit = reinterpret_cast<const u32x4*>(weight_x6); a.bias = bias; a.out = out;
   a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.w = w;
   a.tiles_x = eavsr::cdiv(w, S_TW);
   a.tiles_y = 0;   // per tile height, in launch7
-  a.act = act; a.slope = slope;
+  a.act = act; a.slope = slope; a.sig_from = sigmoid_from < 0 ? -1 : sigmoid_from;
   return ksize == 7 ? dispatch7<7>(a, stream) : dispatch7<5>(a, stream);
 }

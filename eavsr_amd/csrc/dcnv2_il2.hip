@@ -103,7 +103,7 @@ __device__ __forceinline__ f32x16 j_mfma(const u32x4& a, const u32x4& b, const f
 
 // sampling position of one (pixel, tap): the one place where it is computed (pipeline set-up and global fix-up must take
 // the same in-window decision, so the products and sums are spelled out: no contraction choice is left to the compiler)
-template <bool HEADS>
+template <int HEADS>
 __device__ __forceinline__ void j_position(const float (&t)[6], float dyx, float dxx, float ry, float rx, float fgy, float fgx,
                                            float& py, float& px) {
   float dy, dx;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void j_position(const float (&t)[6], float dyx, float
   px = (fgx + rx) + dx;
 }
 
-__device__ __forceinline__ float j_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float j_sigmoid(float x) { return eavsr_sigmoid_fast(x); }
 
 #ifdef EAVSR_IL2_STAMPS
 // diagnostic build only (tools/build_il2_diag.sh): shader cycles per phase, summed over wave 0 and wave 4 of every workgroup
@@ -133,7 +133,8 @@ __device__ unsigned long long g_il2_stamps[32];
 #define J_STAMP(i) do { } while (0)
 #endif
 
-template <int NPROD, bool HEADS>
+// HEADS: 0 explicit offsets / masks;  1 predictor heads (mask logits);  2 predictor heads whose masks already went through the sigmoid
+template <int NPROD, int HEADS>
 __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     for (int j = 0; j < 6; ++j) t[j] = !HEADS ? 0.f : (u < 4 ? tfA[j] : (u > 4 ? tfB[j] : (kg ? tfB[j] : tfA[j])));
     float py, px;
     j_position<HEADS>(t, pa[u], pb[u], ryk, rxk, c.fgy, c.fgx, py, px);
-    const float m = HEADS ? j_sigmoid(pm[u]) : pm[u];
+    const float m = HEADS == 1 ? j_sigmoid(pm[u]) : pm[u];
     const float fy0 = floorf(py), fx0 = floorf(px);
     const float lh = py - fy0, lw = px - fx0;
     const float hh = 1.f - lh, hw = 1.f - lw;
@@ -754,7 +755,7 @@ __global__ void pack_il2_kernel(const float* __restrict__ wt, unsigned* __restri
   out[e] = term == 0 ? hi : (term == 1 ? mid : lo);
 }
 
-template <int NPROD, bool HEADS>
+template <int NPROD, int HEADS>
 int launch_il2(const IL2Args& a, dim3 grid, hipStream_t st) {
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
@@ -844,6 +845,7 @@ extern "C" int eavsr_dcnv2_il2_f32(const float* x_il8, const float* offset_or_he
   }
   dim3 grid((unsigned)(tiles < cus ? tiles : cus), eavsr::cdiv(cout, 64));
   hipStream_t st = eavsr::as_stream(stream);
-  if (nprod == 9) return heads ? launch_il2<9, true>(a, grid, st) : launch_il2<9, false>(a, grid, st);
-  return heads ? launch_il2<6, true>(a, grid, st) : launch_il2<6, false>(a, grid, st);
+  EAVSR_REQUIRE(heads >= 0 && heads <= 2, -1, "dcnv2_il2: heads %d (0, 1 or 2)", heads);
+  if (nprod == 9) return heads == 2 ? launch_il2<9, 2>(a, grid, st) : heads ? launch_il2<9, 1>(a, grid, st) : launch_il2<9, 0>(a, grid, st);
+  return heads == 2 ? launch_il2<6, 2>(a, grid, st) : heads ? launch_il2<6, 1>(a, grid, st) : launch_il2<6, 0>(a, grid, st);
 }

@@ -191,9 +191,10 @@ class AdaptBlockOffset(_AdaptBase):
         self.mask_conv = Conv2d(inplanes, 9 * self.D, 5, 1, 2, bias=True)
         self.relu = _Act("lrelu", 0.2)  # unused by forward in the reference as well
 
-    def heads(self, x, h_hr):
+    def heads(self, x, h_hr, mask_activated=False):
         """the three 5x5 heads as one (n, 15 D, h, w) tensor: transform g*4+{0..3}, translation 4D + g*2+{0,1}, mask logits
-        6D + g*9+k -- what `forward` expands into (offset, mask) and what the fused DCNv2 kernel consumes directly"""
+        6D + g*9+k -- what `forward` expands into (offset, mask) and what the fused DCNv2 kernel consumes directly.
+        mask_activated: the 9 D mask channels leave as sigmoid(logit) (networks.py:313-314 applied in the convolution's epilogue)"""
         f = self._frontend(x, h_hr)
         ws = [self.transform_matrix_conv.weight, self.translation_conv.weight, self.mask_conv.weight]
         bs = [self.transform_matrix_conv.bias, self.translation_conv.bias, self.mask_conv.bias]
@@ -201,6 +202,8 @@ class AdaptBlockOffset(_AdaptBase):
                 and not AG.needs_grad(f, ws, bs)):
             # 16-bit modes (BASELINE configs[2] / [4]): operands rounded once to bf16 / fp16, fp32 accumulation, fp32 heads out
             return ops.conv5x5_c64_h16(ops.to_nhwc_h16(f, BACKBONE_DTYPE), ws, bs)
+        if mask_activated:
+            return ops.conv2d(f, ws, bs, sigmoid_from=6 * self.D)
         return AG.conv2d(f, ws, bs)
 
     def forward(self, x, h_hr):
@@ -289,9 +292,10 @@ class MultiAdSTN(ModulatedDeformConv2d):
                 heads = self.adastn.heads(nbr, ref_feat_l[0])
                 return ops.dcnv2_il16(feat_il, heads, None, self.weight, self.bias, self.deform_groups, heads=True)
             nbr, feat_il = ops.flow_warp_pair(nbr_feat_l[0], feat_prop, offset, b_il8=True)          # :621, :623
-            heads = self.adastn.heads(nbr, ref_feat_l[0])                                            # :625
+            act = ops.heads_mask_activated(int(self.weight.shape[1]))      # the mask sigmoid in the heads' epilogue (:313-314)
+            heads = self.adastn.heads(nbr, ref_feat_l[0], mask_activated=act)                        # :625
             return ops.dcnv2_il(feat_il, heads, None, self.weight, self.bias, self.deform_groups,
-                                nprod=int(ops.DCN_MODE[2]), heads=True)                              # :627-630
+                                nprod=int(ops.DCN_MODE[2]), heads=True, mask_activated=act)          # :627-630
         nbr = AG.flow_warp(nbr_feat_l[0], offset)                             # :621
         feat = AG.flow_warp(feat_prop, offset)                                # :623
         de_offset, mask = self.adastn(nbr, ref_feat_l[0])                      # :625

@@ -336,7 +336,7 @@ def _packed_conv_x6(weights: Sequence[Tensor]) -> Tensor:
     return packed
 
 
-def _conv_x6(x: Tensor, weights, biases, act, slope):
+def _conv_x6(x: Tensor, weights, biases, act, slope, sigmoid_from: int = -1):
     n, cin, h, w = x.shape
     cout = sum(int(w_.shape[0]) for w_ in weights)
     k = int(weights[0].shape[-1])
@@ -346,7 +346,8 @@ def _conv_x6(x: Tensor, weights, biases, act, slope):
     st = _stream(x)
     px = float(n * h * w)
     _launch(f"conv{k}x{k}_{cin}to{cout}_x6", 2.0 * cin * cout * k * k * px, 4.0 * px * (cin + cout), x,
-            lambda: lib().eavsr_conv_f32x6(_p(x), _p(wp), _p(b), _p(out), n, cin, cout, h, w, k, ACT[act], float(slope), st),
+            lambda: lib().eavsr_conv_f32x6(_p(x), _p(wp), _p(b), _p(out), n, cin, cout, h, w, k, ACT[act], float(slope),
+                                           int(sigmoid_from), st),
             "conv_f32x6")
     return out
 
@@ -402,9 +403,12 @@ FUSE_PIXEL_SHUFFLE = os.environ.get("EAVSR_FUSE_SHUFFLE", "1") == "1"
 def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence[Tensor]],
            bias: Union[None, Tensor, Sequence[Optional[Tensor]]] = None, act: Optional[str] = None,
            slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False,
-           ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False, pixel_shuffle2: bool = False):
+           ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False, pixel_shuffle2: bool = False,
+           sigmoid_from: Optional[int] = None):
     """conv over the virtual channel-concatenation of `srcs`; `weight` may be a list of weights
     that are concatenated along cout (several heads in one launch).
+    sigmoid_from=c: output channels >= c (a multiple of 8) leave through the sigmoid instead of `act` (the mask head of the
+    predictor, networks.py:313-314) -- in the epilogue of the bf16x6 5x5 / 7x7 kernel, by torch on every other route.
     pixel_shuffle2=True returns F.pixel_shuffle(out, 2) -- written by the F(4x4,3x3) kernel's epilogue itself where that kernel
     runs (the upsampling tail, eavsrp_model.py:343-347), by torch otherwise.
     ca=(scale (n,c), x (n,c,h,w)): the conv input is srcs * scale[n,c] + x (RCABlock tail fused into this
@@ -436,7 +440,13 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         return torch.nn.functional.pixel_shuffle(y, 2) if pixel_shuffle2 else y
     if (((k == 7 and CONV7_MODE == "bf16x6") or (k == 5 and CONV5_MODE == "bf16x6")) and len(srcs) == 1 and cin % 8 == 0
             and residual is None and not chan_partial and ca is None and not pixel_shuffle2):
-        return _conv_x6(srcs[0], weights, biases, act, slope)
+        return _conv_x6(srcs[0], weights, biases, act, slope, -1 if sigmoid_from is None else int(sigmoid_from))
+    if sigmoid_from is not None:
+        if residual is not None or chan_partial or ca is not None or pixel_shuffle2:
+            raise ValueError("sigmoid_from: plain convolutions only")
+        y = conv2d(srcs, weights, biases, act, slope)
+        y[:, sigmoid_from:] = torch.sigmoid(y[:, sigmoid_from:])
+        return y
     ck = lib().eavsr_conv2d_ck(k)
     if any(int(s.shape[1]) % ck for s in srcs[:-1]):
         srcs = [torch.cat(srcs, 1)]  # ragged middle source: materialise (tiny SPyNet inputs only)
@@ -623,7 +633,7 @@ def to_il8(x: Tensor) -> Tensor:
 
 
 def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], weight: Tensor, bias: Optional[Tensor],
-             deform_groups: int, nprod: int = 6, heads: bool = False) -> Tensor:
+             deform_groups: int, nprod: int = 6, heads: bool = False, mask_activated: bool = False) -> Tensor:
     """DCNv2 (3x3, stride 1, pad 1) on an IL8 input.  heads=False: `offset_or_heads` / `mask` as mmcv's offset (n,18D,h,w)
     and mask (n,9D,h,w).  heads=True: `offset_or_heads` is the (n,15D,h,w) output of AdaptBlockOffset's three 5x5 heads and
     the kernel applies networks.py:302-315 (affine -> offsets, sigmoid) itself.  nprod: 9 = exact bf16x9, 6 = the three
@@ -652,6 +662,8 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
     impl = DCN_IL_IMPL
     if impl == "il2" and cin % 16:
         impl = "il"           # the round-4 schedule contracts groups in pairs
+    if mask_activated and not (heads and impl == "il2"):
+        raise ValueError("mask_activated: heads mode of the 'il2' schedule only (see heads_mask_activated())")
     wx = _packed_dcn_il2(weight) if impl == "il2" else _packed_dcn_x9(weight)
     out = torch.empty((n, cout, h, w), device=x_il8.device, dtype=torch.float32)
     st = _stream(out)
@@ -661,8 +673,15 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
     fn = {"ws": lib().eavsr_dcnv2_ws_f32, "il": lib().eavsr_dcnv2_il_f32, "il2": lib().eavsr_dcnv2_il2_f32}[impl]
     _launch("dcnv2_il" + ("_heads" if heads else ""), 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * D + cout), out,
             lambda: fn(_p(x_il8), _p(oh), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout, D,
-                       int(nprod), 1 if heads else 0, st), "dcnv2_il")
+                       int(nprod), (2 if mask_activated else 1) if heads else 0, st), "dcnv2_il")
     return out
+
+
+def heads_mask_activated(cin: int) -> bool:
+    """True when the fused alignment should ask the predictor's heads convolution for MASKS (sigmoid in its epilogue,
+    networks.py:313-314) rather than mask logits: the round-4 DCNv2 schedule takes them as they are (heads = 2), which moves four
+    vector instructions per sample out of the kernel whose bound is vector issue."""
+    return DCN_IL_IMPL == "il2" and cin % 16 == 0 and CONV5_MODE == "bf16x6" and HEADS_MASK_ACTIVATED
 
 
 _dcn_probe = None      # bench.py: a list that collects offset statistics of every heads-mode DCNv2 call inside `dcn_probe()`
@@ -714,6 +733,7 @@ def dcn_offset_stats(heads: Tensor, D: int, tile_h: int = 8, tile_w: int = 32, m
 # "il2" = eavsr_dcnv2_il2_f32 (csrc/dcnv2_il2.hip, round 4): the two groups of a pair as nine full k-steps in one software
 # pipeline across group / pair / tile boundaries (same operands and products; falls back to "il" when cin % 16 != 0).
 DCN_IL_IMPL = os.environ.get("EAVSR_DCN_IL_IMPL", "il2")
+HEADS_MASK_ACTIVATED = os.environ.get("EAVSR_HEADS_SIGMOID", "1") != "0"      # A/B switch of heads_mask_activated()
 
 
 def set_dcn_il_impl(impl: str) -> None:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 23
+#define EAVSR_ABI_VERSION 24
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -117,6 +117,8 @@ int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask,
  *           per pixel): written directly by eavsr_flow_warp_pair_f32 (the warp of networks.py:623 that precedes the call)
  *           or by eavsr_nchw_to_il8_f32 from a plain NCHW tensor.
  *   heads   0: offset (n, dg*18, h, w) / mask (n, dg*9, h, w) exactly as mmcv's signature;
+ *           2 (eavsr_dcnv2_il2_f32 only): as 1, but the 9 dg mask channels already went through the sigmoid (eavsr_conv_f32x6 with
+ *              sigmoid_from = 6 dg);
  *           1: `offset_or_heads` is the (n, 15*dg, h, w) output of AdaptBlockOffset's three 5x5 convolutions
  *              (transform g*4+{0..3}, translation 4dg + g*2+{0,1}, mask logits 6dg + g*9+k) and the kernel applies
  *              networks.py:302-315 itself (offset = T.R - R + t, mask = sigmoid): de_offset / mask never exist in HBM.
@@ -293,7 +295,10 @@ int eavsr_conv3x3_smallco_lite_f32(const float* x, const float* weight_packed, c
 size_t eavsr_conv_weight_x6_bytes(int32_t ksize, int32_t cout, int32_t cin);
 int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, void* stream);
 int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin, int32_t cout,
-                     int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, void* stream);
+                     int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t sigmoid_from, void* stream);
+/* sigmoid_from: -1, or a multiple of 8: output channels >= sigmoid_from leave through the sigmoid instead of `act` -- the mask
+ * head of AdaptBlockOffset (mask = torch.sigmoid(mask_conv(..)), models/networks.py:313-314) when the three heads run as one
+ * convolution; eavsr_dcnv2_il2_f32 (heads = 2) then takes the masks as they are. */
 
 /* Which schedule eavsr_conv3x3_wino4_f32 runs for plain 3x3 launches with an even number of 4-channel chunks: 1 = grouped
  * (transform phases of two chunks, pure GEMM iterations; default), 0 = duty pair (EAVSR_W4_GRP=0).  Chosen once per process from

@@ -963,6 +963,48 @@ def test_dcnv2_il_heads_mode_applies_the_affine_expansion_and_the_sigmoid(ops, c
     assert H.maxabs(out.cpu(), out2.cpu()) <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_dcnv2_il2_takes_masks_activated_by_the_heads_convolution(ops, cuda):
+    """heads = 2 (round 4): the 5x5 heads convolution applies the mask sigmoid in its epilogue (networks.py:313-314, `sigmoid_from`)
+    and eavsr_dcnv2_il2_f32 takes the masks as they are -- the same instructions evaluate the sigmoid on either side, so the
+    outputs are bit-identical to heads = 1 on the logits"""
+    n, h, w, D = 2, 45, 80, 8
+    c = 8 * D
+    x = cases.randn(21, n, c, h, w)
+    f = cases.randn(22, n, 64, h, w, scale=0.5)
+    ws = [cases.randn(23, 4 * D, 64, 5, 5, scale=0.01), cases.randn(24, 2 * D, 64, 5, 5, scale=0.02), cases.randn(25, 9 * D, 64, 5, 5, scale=0.03)]
+    bs = [torch.tensor([1.0, 0, 0, 1.0]).repeat(D), cases.randn(26, 2 * D, scale=0.5), cases.randn(27, 9 * D, scale=0.5)]
+    wt = cases.randn(28, 64, c, 3, 3, scale=1.0 / (c * 9) ** 0.5)
+    b = cases.randn(29, 64, scale=0.1)
+    gw, gb = [g(t, cuda) for t in ws], [g(t, cuda) for t in bs]
+    prev = ops.DCN_IL_IMPL
+    ops.set_dcn_il_impl("il2")
+    try:
+        logits = ops.conv2d(g(f, cuda), gw, gb)
+        masks = ops.conv2d(g(f, cuda), gw, gb, sigmoid_from=6 * D)
+        assert torch.equal(logits[:, :6 * D], masks[:, :6 * D])
+        ref_m = torch.sigmoid(logits[:, 6 * D:].double()).float()
+        assert H.maxabs(masks[:, 6 * D:].cpu(), ref_m.cpu()) <= 3e-7
+        xil = ops.to_il8(g(x, cuda))
+        o1 = ops.dcnv2_il(xil, logits, None, g(wt, cuda), g(b, cuda), D, heads=True)
+        o2 = ops.dcnv2_il(xil, masks, None, g(wt, cuda), g(b, cuda), D, heads=True, mask_activated=True)
+        assert torch.equal(o1, o2)
+        # against the oracle through the explicit form
+        off = O.affine_offsets(logits[:, :4 * D].cpu(), logits[:, 4 * D:6 * D].cpu(), D)
+        ref = O.dcnv2(x, off, torch.sigmoid(logits[:, 6 * D:].cpu()), wt, b, 1, 1, 1, 1, D)
+        assert H.maxabs(o2.cpu(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+        ops.set_dcn_il_impl("il")
+        with pytest.raises(ValueError):
+            ops.dcnv2_il(xil, masks, None, g(wt, cuda), g(b, cuda), D, heads=True, mask_activated=True)
+    finally:
+        ops.set_dcn_il_impl(prev)
+    # every other route of conv2d applies the same sigmoid by torch
+    w3 = cases.randn(30, 16, 64, 3, 3, scale=0.05)
+    y3 = ops.conv2d(g(f, cuda), g(w3, cuda), None, sigmoid_from=8).cpu()
+    r3 = F.conv2d(f, w3, None, 1, 1)
+    r3[:, 8:] = torch.sigmoid(r3[:, 8:])
+    assert H.maxabs(y3, r3) <= 1e-4
+
+
 def test_dcnv2_il_error_against_fp64(ops, cuda):
     """x9 keeps every partial product (exact operands, fp32 accumulation); x6 drops the three products below 2^-23 of the
     result.  Against an fp64 evaluation both must be as accurate as the native fp32-MFMA kernel."""
