@@ -87,6 +87,63 @@ def test_config1_full_size_clip_matches_the_cpu_oracle(cuda):
           f"(inputs of reconstruction) worst max|hip - oracle| / scale = {worst:.3e}; 4-clip StreamedForward clip 3: {H.maxabs(y4, ref):.3e}")
 
 
+def test_config1_dcnv2_launch_shape_properties(cuda):
+    """The DCNv2 launch of configs[1] at full size (2 x 64 x 180 x 320, dg = 8; 460 tiles on 256 workgroups, both kernels of the
+    alignment's hot path) through size-independent properties: zero offsets + unit masks == conv2d; integer offsets shift the taps;
+    linearity in the sampled features; the round-4 schedule agrees with round 2's to re-association; heads mode == the explicit
+    form of the same offsets / masks."""
+    import torch.nn.functional as F
+    from eavsr_amd import ops
+    from tests.golden import cases
+    n, c, h, w, D = 2, 64, 180, 320, 8
+    x = cases.randn(301, n, c, h, w)
+    x2 = cases.randn(302, n, c, h, w)
+    wt = cases.randn(303, 64, c, 3, 3, scale=1.0 / (c * 9) ** 0.5)
+    b = cases.randn(304, 64, scale=0.1)
+    gx, gx2, gw, gb = x.to(cuda), x2.to(cuda), wt.to(cuda), b.to(cuda)
+    xil, xil2 = ops.to_il8(gx), ops.to_il8(gx2)
+    zero_off = torch.zeros(n, 18 * D, h, w, device=cuda)
+    ones = torch.ones(n, 9 * D, h, w, device=cuda)
+    prev = ops.DCN_IL_IMPL
+    try:
+        for impl in ("il2", "il"):
+            ops.set_dcn_il_impl(impl)
+            y0 = ops.dcnv2_il(xil, zero_off, ones, gw, gb, D).cpu()
+            assert H.maxabs(y0, F.conv2d(x, wt, b, 1, 1)) <= 3e-5, impl
+        ops.set_dcn_il_impl("il2")
+        # integer offsets (+1, -2) for every tap == the conv of the shifted, zero-extended image
+        off = zero_off.clone()
+        off[:, 0::2] = 1.0
+        off[:, 1::2] = -2.0
+        ys = ops.dcnv2_il(xil, off, ones, gw, gb, D).cpu()
+        xs = torch.zeros(n, c, h + 8, w + 8)
+        xs[:, :, 4:-4, 4:-4] = x
+        ref = F.conv2d(xs, wt, b, 1, 1)[:, :, 5:5 + h, 2:2 + w]
+        assert H.maxabs(ys, ref) <= 3e-5
+        # linearity in the sampled features (bias removed), with sub-pixel offsets and random masks
+        offr = (cases.randn(305, n, 18 * D, h, w, scale=0.8)).to(cuda)
+        mk = cases.rand(306, n, 9 * D, h, w).to(cuda)
+        ya = ops.dcnv2_il(xil, offr, mk, gw, None, D)
+        yb = ops.dcnv2_il(xil2, offr, mk, gw, None, D)
+        yab = ops.dcnv2_il(ops.to_il8(gx * 2.0 - gx2 * 0.5), offr, mk, gw, None, D)
+        sc = max(1.0, yab.abs().max().item())
+        assert H.maxabs(yab.cpu(), (2.0 * ya - 0.5 * yb).cpu()) <= 2e-5 * sc
+        # round 4 against round 2 on the same inputs
+        ops.set_dcn_il_impl("il")
+        ya_r2 = ops.dcnv2_il(xil, offr, mk, gw, None, D)
+        assert H.maxabs(ya.cpu(), ya_r2.cpu()) <= 1e-5 * sc
+        # heads mode (affine expansion + sigmoid inside) == explicit mode on the expanded offsets / masks
+        ops.set_dcn_il_impl("il2")
+        heads = torch.cat([cases.randn(307, n, 4 * D, h, w, scale=0.2) + torch.tensor([1.0, 0, 0, 1.0]).repeat(D).view(1, 4 * D, 1, 1),
+                           cases.randn(308, n, 2 * D, h, w, scale=0.8), cases.randn(309, n, 9 * D, h, w, scale=2.0)], 1)
+        offe = O.affine_offsets(heads[:, :4 * D], heads[:, 4 * D:6 * D], D)
+        yh = ops.dcnv2_il(xil, heads.to(cuda), None, gw, gb, D, heads=True)
+        ye = ops.dcnv2_il(xil, offe.to(cuda), torch.sigmoid(heads[:, 6 * D:]).to(cuda), gw, gb, D)
+        assert H.maxabs(yh.cpu(), ye.cpu()) <= 2e-5 * max(1.0, ye.abs().max().item())
+    finally:
+        ops.set_dcn_il_impl(prev)
+
+
 # ---------------------------------------------------------------------------------------------------------- configs[4]
 def test_config4_fifteen_frame_recurrence_matches_the_cpu_oracle_fp32_and_fp16(cuda):
     """t = 15 bidirectional propagation (configs[4]'s recurrence depth; eavsrp_model.py:242-329 index maps for t > n_frame)
