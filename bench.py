@@ -677,6 +677,26 @@ def main():
                     st4 = ops.dcn_offset_stats(hd, 8)
                     res4[f"sigma_{sg}"] = {"avg_ms": ms, "frac": alg_px * sub_n * h * w / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                            "frac_outside_lds_window": st4["frac_outside_lds_window"], "mean_norm": st4["mean_norm"]}
+                # SURVEY 8d names torch.rand clips; the timed clips are a drifting low-pass texture (white noise gives SPyNet no motion
+                # to find).  The same forward once on torch.rand clips of the same shape: the offsets DCNv2 sees there, and its time
+                from eavsr_amd.utils.synthetic import synthetic_clip as _sc
+                rclips = _sc(sub_n, t, h, w, seed=7, smooth=False).to(device)
+                torch.cuda.synchronize()
+                torch.cuda._sleep(int(0.45 * 2.0e9))
+                with torch.no_grad(), ops.profile() as prof_r:
+                    net(rclips)
+                with torch.no_grad(), ops.dcn_probe() as probe_r:
+                    net(rclips)
+                torch.cuda.synchronize()
+                vr = prof_r.summary().get(dcn_name)
+                if vr and probe_r:
+                    ms_r = vr["ms"] / vr["calls"]
+                    dcn_entry["on_torch_rand_clips"] = {
+                        "avg_ms": ms_r, "frac": alg_px * sub_n * h * w / (ms_r * 1e-3) / 1e9 / PEAK_HBM_GBS, "calls": vr["calls"],
+                        "mean_norm": sum(p["mean_norm"] for p in probe_r) / len(probe_r), "max_abs": max(p["max_abs"] for p in probe_r),
+                        "frac_outside_lds_window": sum(p["frac_outside_lds_window"] for p in probe_r) / len(probe_r),
+                        "note": "one eager forward of torch.rand clips (SURVEY 8d's literal workload) of the same shape, same event bracketing"}
+                del rclips
                 dcn_entry["synthetic_offsets"] = {**res4, "note": "same launch shape, iid gaussian translations of sigma px on top of "
                                                   "near-identity transforms; 20 back-to-back launches per figure"}
             except Exception as ex:      # measurement garnish must not void the line
