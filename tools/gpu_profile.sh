@@ -20,7 +20,7 @@ python3 - <<PY
 import json
 r = json.load(open('gpurun_out/prof/traffic.json'))
 g = lambda k: r.get(k, {}).get('total_bytes')
-out = {'conv3x3_64to64_wino4': g('conv_wino6_kernel<3, false'), 'conv5x5_64to120_wino': g('conv_wino6_kernel<5, false'), 'conv5x5_64to120_x6': g('conv_x6_kernel<5'), 'conv3x3_64to64_wino': g('conv3x3_wino_kernel'), 'conv3x3_64to64': g('conv2d_mfma_kernel'), 'dcnv2': g('dcnv2_grp_kernel'), 'dcnv2_il_heads': g('dcnv2_il2_kernel<6, true>') or g('dcnv2_il_kernel<6, true>'), 'dcnv2_il': g('dcnv2_il2_kernel<6, false>') or g('dcnv2_il_kernel<6, false>'), 'dcnv2_il_heads_round2_kernel': g('dcnv2_il_kernel<6, true>'), 'flow_warp': g('flow_warp_kernel'), 'flow_warp_pair': g('flow_warp_pair_kernel'),
+out = {'conv3x3_64to64_wino4': g('conv_wino6_kernel<3, false'), 'conv5x5_64to120_wino': g('conv_wino6_kernel<5, false'), 'conv5x5_64to120_x6': g('conv_x6_kernel<5'), 'conv3x3_64to64_wino': g('conv3x3_wino_kernel'), 'conv3x3_64to64': g('conv2d_mfma_kernel'), 'dcnv2': g('dcnv2_grp_kernel'), 'dcnv2_il_heads': g('dcnv2_il2_kernel<6, 1>') or g('dcnv2_il2_kernel<6, true>') or g('dcnv2_il_kernel<6, true>'), 'dcnv2_il': g('dcnv2_il2_kernel<6, 0>') or g('dcnv2_il2_kernel<6, false>') or g('dcnv2_il_kernel<6, false>'), 'dcnv2_il_heads_round2_kernel': g('dcnv2_il_kernel<6, true>'), 'flow_warp': g('flow_warp_kernel'), 'flow_warp_pair': g('flow_warp_pair_kernel'),
        '_taken': __import__('datetime').date.today().isoformat() + ' (' + '${TAG}' + ')',
        'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950; bytes per launch at 2x64x180x320 (one sub-batch of the default bench.py --streams 2)'}
 json.dump(out, open('profiles/traffic.json', 'w'), indent=1)

@@ -16,7 +16,7 @@ if stats:
     for r in rows[:16]:
         print(f"{float(r['Percentage']):6.2f}%  calls {int(r['Calls']):6d}  avg {float(r['AverageNs'])/1e3:10.1f} us  {r['Name'][:110]}")
 print()
-hot = ("conv_wino6_kernel<3, false", "conv_wino6_kernel<5, false", "conv_x6_kernel<5", "conv_x6_kernel<7", "conv3x3_wino_kernel", "conv2d_mfma_kernel", "dcnv2_grp_kernel", "dcnv2_il_kernel<6, true>", "dcnv2_il_kernel<6, false>", "dcnv2_il2_kernel<6, true>", "dcnv2_il2_kernel<6, false>", "flow_warp_kernel", "flow_warp_pair_kernel")
+hot = ("conv_wino6_kernel<3, false", "conv_wino6_kernel<5, false", "conv_x6_kernel<5", "conv_x6_kernel<7", "conv3x3_wino_kernel", "conv2d_mfma_kernel", "dcnv2_grp_kernel", "dcnv2_il_kernel<6, true>", "dcnv2_il_kernel<6, false>", "dcnv2_il2_kernel<6, 1>", "dcnv2_il2_kernel<6, 0>", "dcnv2_il2_kernel<6, 2>", "flow_warp_kernel", "flow_warp_pair_kernel")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(os.path.join(root, "pmc_*", "*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(d)):
