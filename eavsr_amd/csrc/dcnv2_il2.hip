@@ -602,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   bool stored_now = false;      // this pair step began with a tile store: its stores are still in flight at the first barrier
   for (int it = 0; it < total; ++it) {
     J_STAMP(0);      // loop bookkeeping (advance, slot rotation)
-    const bool more = it + 1 < total;
+    const int more_n = total - 1 - it;      // > 0: there is a next pair step (an integer: a bool carried across the body is copied through vector registers)
     const int q = it & 1;
     wpar = wA + (unsigned)(q * JKS_B);
     // window slots rotate by two per pair step: even group of the next pair step = slot after this pair's odd group
@@ -683,8 +683,8 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
           }
           // DMA: the next pair step's odd-group window + weights 4..7 all in k-step 8 (right behind the barrier that retired
           // their slots: 4 k-steps to land), its even-group window + weights 0..3, 8 over k-steps 3..6
-          if (u == 8 && more && dma_on) issue_ia(nn, sOn, 0);
-          if (u >= 3 && u <= 6 && more && dma_on) issue_win(u - 3, nn.xw + grp_b * (size_t)(2 * nn.P), nn.y0, nn.x0, nn.inter, sEn);
+          if (u == 8 && more_n > 0 && dma_on) issue_ia(nn, sOn, 0);
+          if (u >= 3 && u <= 6 && more_n > 0 && dma_on) issue_win(u - 3, nn.xw + grp_b * (size_t)(2 * nn.P), nn.y0, nn.x0, nn.inter, sEn);
         }
         if (k == 2 && blend_on) blend_pair(u1, 0);
         if (k == 3) {
@@ -693,15 +693,15 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
           load_a(u1, 0);
         }
         if (k == 4) {
-          if (u == 8 && more && dma_on) issue_ia(nn, sOn, 1);
-          if (u >= 3 && u <= 6 && more && dma_on) issue_wgt_ib(u - 3, nn.ws, q ^ 1);
+          if (u == 8 && more_n > 0 && dma_on) issue_ia(nn, sOn, 1);
+          if (u >= 3 && u <= 6 && more_n > 0 && dma_on) issue_wgt_ib(u - 3, nn.ws, q ^ 1);
         }
         if (k == 5) {
           if (blend_on) {
             blend_pair(u1, 2);
             blend_pair(u1, 3);
           }
-          if (u == 8 && more && dma_on) issue_ia(nn, sOn, 2);
+          if (u == 8 && more_n > 0 && dma_on) issue_ia(nn, sOn, 2);
         }
         (void)nx1;
         J_FENCE();

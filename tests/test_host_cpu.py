@@ -147,6 +147,71 @@ def test_committed_bench_line_follows_the_contract():
     assert "no extrapolation" in c["sample"] and "180 x 320" in c["sample"]      # one full-size clip, not a scaled crop
 
 
+def test_round4_bench_line_names_its_evidence():
+    """round 4's committed line: how the per-kernel figures were taken, that the PMC traffic is replayed, every rank's time and
+    device, and what the DCNv2 sampler saw"""
+    import json
+    path = os.path.join(ROOT, "profiles", "r04_bench_line.json")
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    assert "device-side delay" in line["kernel_timing"]
+    assert "REPLAYED" in line["traffic_source"] and "not measured in this run" in line["traffic_source"]
+    assert len(line["per_rank_ms"]) == line["n_gpus"] == len(line["per_rank_device"]) and line["host_threads_per_rank"] >= 1
+    assert abs(max(line["per_rank_ms"]) - line["ms_per_step"]) < 0.02 * line["ms_per_step"]
+    assert "lds_fill" not in line["roofline"]                     # the ingest-bound reading was withdrawn (DESIGN 4i)
+    dcn = line["kernels"][0]
+    assert dcn["kernel"] == "dcnv2_il_heads" and dcn["schedule"] == "il2" and 0.2 < dcn["frac"] < 1.0
+    st = dcn["offset_stats"]
+    assert st["calls"] > 0 and 0.0 <= st["frac_outside_lds_window"] <= 1.0 and st["max_abs"] >= st["mean_abs_dy"] >= 0.0
+    syn = dcn["synthetic_offsets"]
+    assert syn["sigma_4.0"]["frac_outside_lds_window"] > syn["sigma_0.5"]["frac_outside_lds_window"] >= 0.0
+    assert syn["sigma_4.0"]["avg_ms"] > syn["sigma_0.5"]["avg_ms"] > 0.0
+    assert dcn["on_torch_rand_clips"]["calls"] == dcn["calls"] and dcn["on_torch_rand_clips"]["avg_ms"] > 0.0
+    assert line["config"]["dcnv2_schedule"].startswith("eavsr_dcnv2_il2_f32") and "conv3x3_wino4_schedule" in line["config"]
+    for tag, frames in (("config2_bf16", 7), ("config4_fp16", 15)):
+        l2 = json.loads(open(os.path.join(ROOT, "profiles", f"r04_bench_line_{tag}.json")).read().strip().splitlines()[-1])
+        c = l2["cpu_baseline"]
+        assert c["value"] and c["kind"] == "port" and c["cores"] >= 1 and f"{frames} frames" in c["sample"].replace(" x ", " ").replace(f"x {frames} ", f"{frames} frames ")
+
+
+def test_dcn_offset_stats_expand_the_heads_as_the_reference_does():
+    """`ops.dcn_offset_stats` (measurement helper behind `kernels[0].offset_stats`) against the oracle's affine expansion
+    (networks.py:302-311) and a hand-count of samples outside the kernel's LDS window"""
+    from eavsr_amd import ops
+    from oracle import eavsr_oracle as O
+    D, n, h, w = 2, 1, 16, 64
+    g = torch.Generator().manual_seed(5)
+    heads = torch.cat([torch.randn(n, 4 * D, h, w, generator=g) * 0.3 + torch.tensor([1.0, 0, 0, 1.0]).repeat(D).view(1, 4 * D, 1, 1),
+                       torch.randn(n, 2 * D, h, w, generator=g) * 3.0, torch.randn(n, 9 * D, h, w, generator=g)], 1)
+    st = ops.dcn_offset_stats(heads, D)
+    off = O.affine_offsets(heads[:, :4 * D], heads[:, 4 * D:6 * D], D).view(n, D, 9, 2, h, w)      # (dy, dx) per tap
+    dy, dx = off[:, :, :, 0], off[:, :, :, 1]
+    assert abs(st["mean_abs_dy"] - dy.abs().mean().item()) < 1e-5 and abs(st["mean_abs_dx"] - dx.abs().mean().item()) < 1e-5
+    assert abs(st["max_abs"] - max(dy.abs().max().item(), dx.abs().max().item())) < 1e-5
+    ky = torch.tensor([-1., -1., -1., 0., 0., 0., 1., 1., 1.]).view(1, 1, 9, 1, 1)
+    kx = torch.tensor([-1., 0., 1., -1., 0., 1., -1., 0., 1.]).view(1, 1, 9, 1, 1)
+    ry = 6 + (torch.arange(h).view(1, 1, 1, h, 1) % 8) + ky + torch.floor(dy)
+    rx = 8 + (torch.arange(w).view(1, 1, 1, 1, w) % 32) + kx + torch.floor(dx)
+    outside = ((ry < 0) | (ry > 18) | (rx < 0) | (rx > 46)).float().mean().item()
+    assert outside > 0.0 and abs(st["frac_outside_lds_window"] - outside) < 1e-6
+
+
+def test_heads_mask_activation_is_chosen_only_where_the_kernel_takes_it():
+    from eavsr_amd import ops
+    prev = (ops.DCN_IL_IMPL, ops.HEADS_MASK_ACTIVATED)
+    try:
+        ops.set_dcn_il_impl("il2")
+        assert ops.heads_mask_activated(64) == (ops.CONV5_MODE == "bf16x6")
+        assert ops.heads_mask_activated(24) is False              # cin % 16 != 0: the round-2 kernel runs, which wants logits
+        ops.set_dcn_il_impl("il")
+        assert ops.heads_mask_activated(64) is False
+        ops.set_dcn_il_impl("il2")
+        ops.HEADS_MASK_ACTIVATED = False
+        assert ops.heads_mask_activated(64) is False
+    finally:
+        ops.set_dcn_il_impl(prev[0])
+        ops.HEADS_MASK_ACTIVATED = prev[1]
+
+
 # ---- optimizer files are interchangeable with the reference's (ADVICE r1) ------------------------------------------
 def test_optimizer_groups_follow_the_reference_grouping_and_state_dicts_round_trip():
     """models/eavsrp_model.py:45-59 builds Adam's groups from ALL parameters() (frozen SPyNet tensors included): group 0 =
