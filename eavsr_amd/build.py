@@ -19,14 +19,16 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libeavsr_hip.so")
 OBJDIR = os.path.join(LIBDIR, "obj")
 ARCH = "gfx950"
+# -fno-slp-vectorize: the SLP vectorizer packs pairs of independent fp32 additions / multiplications into v_pk_add_f32 /
+# v_pk_mul_f32, which beside MFMAs are slower than the two plain instructions (MI355X_MICROARCH.md, "price of one filler beside
+# MFMAs").  Measured: DCNv2 84-88 -> 77-78 us per 2 x 64 x 180 x 320 launch; the whole library 219.3 -> 217.7 ms per step
+# (tools/visits/r4_d.sh, r4_t.sh).  The packed instructions the kernels WANT are written as inline assembly (conv_wino6.hip).
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function", "-ffp-contract=fast"]
+         "-Wall", "-Wno-unused-function", "-ffp-contract=fast", "-fno-slp-vectorize"]
 
 
-# per-source additions.  dcnv2_il2.hip: the SLP vectorizer packs pairs of independent fp32 additions / multiplications of the
-# sampler's set-up into v_pk_add_f32 / v_pk_mul_f32, which are slower than the two plain instructions beside MFMAs
-# (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; measured 84-88 -> 77-78 us per 2 x 64 x 180 x 320 launch).
-PER_FILE_FLAGS = {"dcnv2_il2.hip": ["-fno-slp-vectorize"]}
+# per-source additions (none at present)
+PER_FILE_FLAGS = {}
 
 
 def _hipcc() -> str:

@@ -65,7 +65,9 @@ __device__ __forceinline__ int eavsr_xcd_remap(int bid, int nblk) {
 // matter: all within 1 us).  -DEAVSR_NO_WAVE_PRIO builds the A-B reference.
 #ifdef __HIPCC__
 __device__ __forceinline__ void eavsr_stagger_priority(int wave) {
-#ifndef EAVSR_NO_WAVE_PRIO
+#if defined(EAVSR_PRIO_LOW_HALF)      // A/B: the first-dispatched half instead (what the round-4 DCNv2 kernel prefers)
+  if (wave < 4) __builtin_amdgcn_s_setprio(3);
+#elif !defined(EAVSR_NO_WAVE_PRIO)
   if (wave >= 4) __builtin_amdgcn_s_setprio(3);
 #else
   (void)wave;

@@ -113,6 +113,11 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if defined(EAVSR_X6_PRIO) && EAVSR_X6_PRIO == 1      // A/B: static priority for one half of the workgroup (the two waves of a SIMD are w, w + 4)
+  if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#elif defined(EAVSR_X6_PRIO) && EAVSR_X6_PRIO == 2
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   const int l31 = lane & 31, kg = lane >> 5;
 
   int bid = eavsr_xcd_remap(blockIdx.x, gridDim.x);

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 NAME=$1; FLAGS=$2
-F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -ffp-contract=fast -Wno-unused-function"
+F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-gpu-rdc -ffp-contract=fast -fno-slp-vectorize -Wno-unused-function"
 mkdir -p eavsr_amd/lib/obj_$NAME
 for f in eavsr_amd/csrc/*.hip; do
   ( /opt/rocm/bin/hipcc $F $FLAGS -c $f -o eavsr_amd/lib/obj_$NAME/$(basename ${f%.hip}).o 2>/dev/null ) &
