@@ -602,7 +602,18 @@ def main():
                     "share_of_step": v["ms"] / total_ms}
 
         dom_name = {"winograd": "conv3x3_64to64_wino", "winograd4": "conv3x3_64to64_wino4", "direct": "conv3x3_64to64", "bf16x9": "conv3x3_64to64_x9"}[args.conv_mode]
+        fp32_dom = None
+        if args.backbone_dtype != "fp32" and "conv3x3_64to64_h16" in summ:
+            # 16-bit modes (configs[2] / [4]): the dominant kernel is the NHWC 16-bit residual-backbone convolution; it is priced on
+            # the 16-bit MFMA peak (its HBM fraction on the 16-bit activations it streams is reported beside it)
+            fp32_dom = entry(dom_name, "mfma")
+            dom_name = "conv3x3_64to64_h16"
         dom = entry(dom_name, "mfma")
+        if fp32_dom is not None and dom is not None:
+            hb = entry(dom_name, "hbm")
+            dom["algorithm"] = "direct sum, 16-bit operands, fp32 accumulation, 16-bit MFMA (csrc/conv_h16.hip)"
+            dom["hbm"] = {k: hb[k] for k in ("achieved", "peak", "unit", "frac")}
+            dom["fp32_kernel_of_the_same_shape_outside_the_groups"] = {k: fp32_dom[k] for k in ("kernel", "frac", "avg_ms", "share_of_step")}
         if args.backbone_dtype != "fp32":
             # which kernels of the step ran in 16 bits (the rest is fp32), with their share of the step's kernel time
             names16 = ("conv3x3_64to64_h16", "scale_residual_h16", "dcnv2_il16_heads", "dcnv2_il16", "nchw_f32_to_nhwc_h16",
@@ -619,12 +630,32 @@ def main():
             line["share_of_step_in_16bit"] = t16 / total_ms
         if dom is not None:
             line["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_ms",
-                                                    "share_of_step", "algorithm", "algorithmic_equivalent")}
+                                                    "share_of_step", "algorithm", "algorithmic_equivalent", "hbm",
+                                                    "fp32_kernel_of_the_same_shape_outside_the_groups") if k in dom}
+            # the same figure at ONE launch shape, so that it can be recomputed from profiles/ without the mix of shapes above:
+            # the sub-batch's full-resolution 64 -> 64 convolution (2 x 64 x 180 x 320 at configs[1])
+            try:
+                can_flops = 2.0 * 64 * 64 * 9 * (n // args.streams) * h * w
+                grp = prof.by_flops(dom_name).get(can_flops)
+                if grp:
+                    ms_c = grp[1] / grp[0]
+                    red_c, _ = mult_reduction(dom_name)
+                    ach_c = can_flops / red_c / (ms_c * 1e-3) / 1e12
+                    line["roofline"]["canonical_launch"] = {
+                        "shape": f"{n // args.streams} x 64 x {h} x {w} (3x3 64 -> 64)", "calls": grp[0], "avg_ms": ms_c, "achieved": ach_c,
+                        "frac": ach_c / (PEAK_MFMA_16BIT_TFLOPS if dom_name.endswith(("_h16", "_x6")) else PEAK_MFMA_F32_TFLOPS),
+                        "performed_flop_per_launch": can_flops / red_c,
+                        "note": "launches of this one shape only (the entry above averages every launch of the kernel name, incl. the "
+                                "half- and quarter-resolution pyramid levels)"}
+            except Exception as ex:
+                line["roofline"]["canonical_launch_error"] = repr(ex)
             line["roofline"]["kernel"] = {
                 "winograd": "conv3x3_wino_kernel (3x3 64->64, the residual backbone)",
                 "winograd4": "conv_wino6_kernel<3> (3x3 64->64, the residual backbone)",
                 "direct": "conv2d_mfma_kernel<3,2> (3x3 64->64, the residual backbone)",
                 "bf16x9": "conv3x3_x9_kernel (3x3 64->64, bf16x9; priced against the fp32 MFMA peak)"}[args.conv_mode]
+            if dom_name == "conv3x3_64to64_h16":
+                line["roofline"]["kernel"] = f"conv3x3_c64_h16_kernel<{args.backbone_dtype}> (3x3 64->64 NHWC 16-bit, the residual backbone)"
         dcn_name = {"il6": "dcnv2_il_heads", "il9": "dcnv2_il_heads", "native": "dcnv2", "bf16x9": "dcnv2_x9"}[args.dcn_mode]
         if args.backbone_dtype != "fp32" and args.dcn_mode in ("il6", "il9"):
             dcn_name = "dcnv2_il16_heads"

@@ -84,6 +84,16 @@ class Profile:
             d["bytes"] += nbytes
         return out
 
+    def by_flops(self, name: str):
+        """the launches of one kernel name grouped by their algorithmic FLOP count (= by launch shape): {flops: (calls, ms)}"""
+        torch.cuda.synchronize()
+        out = {}
+        for nm, flops, _nbytes, e0, e1 in self.records:
+            if nm == name:
+                c, ms = out.get(flops, (0, 0.0))
+                out[flops] = (c + 1, ms + e0.elapsed_time(e1))
+        return out
+
 
 _prof: Optional[Profile] = None
 
