@@ -21,7 +21,10 @@ Rank 0 prints ONE JSON line.  Besides the contract keys it carries
   kernels       the same for DCNv2 / flow_warp (HBM-bound) -- durations measured with HIP events on the
                 launch stream during one extra, untimed, instrumented pass over one sub-batch (the launch shapes of
                 the timed region, without the overlap),
-  cpu_baseline  the CPU oracle timed on this box's host cores on ONE full-size clip of the workload (no extrapolation).
+  cpu_baseline  the CPU oracle timed on this box's host cores on ONE full-size clip of the workload (no extrapolation),
+  other_configs (default run only: N = 1, --config 1) BASELINE.json configs[2] (x2 model, bf16), [3] (training step) and [4] (15 frames
+                at 540 x 960, fp16), each timed by a child `bench.py --config K` / `--mode train` process after the headline
+                measurement, a few steps each, under their own metric names (`--also ''` switches them off).
 `--dry` replaces the kernels by a sleep and the GPU by the CPU (gloo): it exists only so that the launch / barrier /
 max-over-ranks / JSON plumbing of `--gpus N` can be tested in a container without a GPU; its line says so.
 """
@@ -90,6 +93,11 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=300.0,
                     help="seconds the CPU baseline may take in total; further timed runs are skipped once it is spent")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every usable core)")
+    ap.add_argument("--also", default=os.environ.get("EAVSR_BENCH_ALSO", "2,3,4"),
+                    help="default run (N = 1, --config 1, inference) only: BASELINE.json configs that are timed as well, each in a child "
+                         "process behind the headline measurement, a few steps each, summarised under `other_configs` "
+                         "(3 = the training step); '' or 0 = none")
+    ap.add_argument("--also-budget", type=float, default=150.0, help="seconds the `other_configs` children may take in all")
     ap.add_argument("--dry", action="store_true",
                     help="plumbing test without a GPU: the step is a sleep, ranks talk over gloo; the line is labelled "
                          "as such and is not a measurement")
@@ -238,6 +246,44 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
                            f"{budget:.0f} s; finished runs: {[round(x, 1) for x in secs]}): 1 clip x {frames} x 3 x {crop_h} x "
                            f"{crop_w} crop in {dt:.1f} s, scaled by the pixel ratio; {cores} threads")
     return dict(base, value=None, sample=f"failed: {(err or err_c)[-300:]!r}")
+
+
+def other_configs(which, budget_s):
+    """BASELINE.json configs[2] / [3] / [4] under their own metric names, each by `bench.py --config K` (3: `--mode train`) in a child
+    process started after the headline measurement (this process keeps its GPU context; the child makes its own), a few steps
+    each and no CPU baseline, so that the lines of profiles/*bench_line_config*.json are re-measured by whoever runs the default
+    bench.  A child that fails or runs out of the time budget is reported as such; nothing here touches the headline figures."""
+    import subprocess
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "psnr_vs_fp32", "share_of_step_in_16bit",
+            "timed_output_check", "degraded", "loss")
+    out, t_end = [], time.perf_counter() + budget_s
+    for k in which:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--also", ""]
+        cmd += {2: ["--config", "2", "--steps", "4", "--warmup", "1"], 4: ["--config", "4", "--steps", "3", "--warmup", "1"],
+                3: ["--mode", "train", "--steps", "5", "--warmup", "2"]}[k]
+        left = t_end - time.perf_counter()
+        if left < 25:
+            out.append({"config": k, "skipped": "time budget of --also-budget spent"})
+            continue
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, env={**os.environ, "EAVSR_BREAKDOWN_N": "4"})
+            rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not rows:
+                out.append({"config": k, "error": f"exit {r.returncode}: {r.stderr.strip()[-300:]}"})
+                continue
+            ln = json.loads(rows[-1])
+            e = {"config": k, **{f: ln[f] for f in keep if f in ln}, "workload": ln["config"]["workload"], "launch": ln["config"].get("launch"),
+                 "child_wall_s": round(time.perf_counter() - t0, 1)}
+            if "roofline" in ln:
+                e["roofline"] = {f: ln["roofline"][f] for f in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "share_of_step", "hbm")
+                                 if f in ln["roofline"]}
+            out.append(e)
+        except subprocess.TimeoutExpired:
+            out.append({"config": k, "error": f"timed out after {left:.0f} s"})
+        except Exception as ex:
+            out.append({"config": k, "error": repr(ex)})
+    return out
 
 
 def train_bench(args, rank, world, device):
@@ -758,6 +804,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.preset, t, h, w, args.cpu_crop[0], args.cpu_crop[1], runs=args.cpu_runs,
                                             budget=args.cpu_budget, threads=args.cpu_threads, scale=args.scale)
+
+    also = [int(k) for k in str(args.also).replace(" ", "").split(",") if k and k != "0"]
+    if (rank == 0 and world == 1 and also and args.config == 1 and args.backbone_dtype == "fp32" and args.conv_mode == "winograd4"
+            and args.dcn_mode == "il6"):
+        # the other BASELINE.json configurations, each measured by a child process AFTER everything above (the headline is
+        # already in `line`); free what this process holds first: configs[4] wants ~71 GiB
+        del out, run, net, clips
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        line["other_configs"] = other_configs([k for k in also if k in (2, 3, 4)], args.also_budget)
 
     if degraded is not None:
         line["degraded"] = degraded

@@ -58,6 +58,17 @@ def med(call):
 
 res = {name: ([], []) for name, _ in cands}
 med(lambda: cands[1][1](1))      # burn the clock ramp
+# every build must give the product il2 kernel's bits (timing-only EXP builds excepted: they say so)
+for hm in (1, 0):
+    out.zero_()
+    cands[1][1](hm)
+    torch.cuda.synchronize()
+    want = out.clone()
+    for name, fn in cands[2:]:
+        out.zero_()
+        fn(hm)
+        torch.cuda.synchronize()
+        print(f"{name:28s} heads={hm} bits {'same' if torch.equal(out, want) else 'DIFFER max %.3g' % (out - want).abs().max().item()}")
 for r in range(rounds):
     for name, fn in cands:
         res[name][0].append(med(lambda: fn(1)))
