@@ -17,7 +17,8 @@
 //   swizzle is applied to the per-lane SOURCE address (slots outside the image are zero-filled by ds_write).
 //   Two patch stages, one per wave group.
 //   Epilogue: fp32 accumulators (+ bias, ReLU, optional per-tile channel sums in fp32) are rounded to
-//   16 bits and stored from the registers (8 bytes = 4 consecutive channels per lane and store).
+//   16 bits and stored from the registers (16 bytes = 8 consecutive channels per lane and store, after the two lanes of a
+//   pixel traded 4-channel runs by v_permlane32_swap).
 #include "common.h"
 
 #include <hip/hip_bf16.h>
@@ -161,6 +162,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
   for (int p = 0; p <= p_end; ++p) {
     const int q = p - grp;
     const int j = q >> 1;
+    // A memory phase issues its patch requests FIRST and its 8 output stores behind them: the counter is in order, so
+    // `vmcnt(8)` at the end of the phase waits for the patch and leaves the stores in flight (their acknowledgement from HBM
+    // is ~2 us that the phase used to end with).  Only when all 8 store instructions are known to have been issued: every
+    // pixel of the wave's two rows inside the image (wave-uniform).  The compute phase that follows ends with vmcnt(0).
+    bool stores_behind_dma = false;
     if (q >= 0 && (q & 1) == 0) {
       // ================================================================== memory phase =======================================
       if (j < cnt_g) {
@@ -210,6 +216,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         // 128-byte row (merged in L2).  No LDS staging: the patch stage is already being refilled.
         int bn, ty, tx;
         tile_at(j - 1, bn, ty, tx);
+#ifndef EAVSR_H16_EXP_WAIT_STORES
+        stores_behind_dma = ty * HT_H + 2 * w4 + 1 < h && tx * HT_W + 31 < w;
+#endif
         char* ob = reinterpret_cast<char*>(a.out) + (size_t)bn * h * w * 128;
         f32x4 bq4[2][4];     // this lane's 32 bias values: 4 consecutive channels per (m, qd)
 #pragma unroll
@@ -231,27 +240,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
           for (int r = 0; r < 2; ++r) {
             const int gy = ty * HT_H + 2 * w4 + r, gx = tx * HT_W + l31;
             const bool ok = gy < h && gx < w;
-            char* orow = ob + ((size_t)gy * w + gx) * 128 + 8 * half;
+            char* orow = ob + ((size_t)gy * w + gx) * 128;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-              for (int qd = 0; qd < 4; ++qd) {
-                // registers 4 qd .. 4 qd + 3 are 4 consecutive output channels co = m*32 + 8 qd + 4 half + (0..3)
-                unsigned short pk[4];
+              for (int qe = 0; qe < 4; qe += 2) {
+                // registers 4 qd .. 4 qd + 3 are 4 consecutive output channels co = m*32 + 8 qd + 4 half + (0..3): 8 bytes.  The
+                // lane pair (l31, half 0 | 1) trades runs by v_permlane32_swap -- half 0 keeps its run of qd = qe and takes its
+                // partner's, half 1 those of qd = qe + 1 -- so that a lane stores 16 contiguous bytes (channels 8 qd .. 8 qd + 7)
+                // and a store instruction writes 32 contiguous bytes per pixel: half as many store instructions, each touching
+                // the same 32 lines (the 8-byte form cost ~400 cycles of the memory pipe per instruction)
+                unsigned dw[2][2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  float v = acc[r][m][4 * qd + e] + bq4[m][qd][e];
-                  if (RELU) v = fmaxf(v, 0.f);
-                  pk[e] = to_h16<BF16>(v);
-                  if (SUMS) csum[m][4 * qd + e] += ok ? from_h16<BF16>(pk[e]) : 0.f;   // the 16-bit value the next layer reads
+                for (int q2 = 0; q2 < 2; ++q2) {
+                  const int qd = qe + q2;
+                  unsigned short pk[4];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    float v = acc[r][m][4 * qd + e] + bq4[m][qd][e];
+                    if (RELU) v = fmaxf(v, 0.f);
+                    pk[e] = to_h16<BF16>(v);
+                    if (SUMS) csum[m][4 * qd + e] += ok ? from_h16<BF16>(pk[e]) : 0.f;   // the 16-bit value the next layer reads
+                  }
+                  dw[q2][0] = (unsigned)pk[0] | ((unsigned)pk[1] << 16);
+                  dw[q2][1] = (unsigned)pk[2] | ((unsigned)pk[3] << 16);
                 }
+                const auto s0 = __builtin_amdgcn_permlane32_swap(dw[0][0], dw[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(dw[0][1], dw[1][1], false, false);
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t v4 = {s0[0], s1[0], s0[1], s1[1]};
 #ifdef EAVSR_H16_EXP_NO_STORE
-                if (pk[0] == 0x1234 && pk[1] == 0x4321)
+                if (v4[0] == 0x12344321u && v4[1] == 0x43211234u)
 #endif
-                if (ok)
-                  *reinterpret_cast<unsigned long long*>(orow + (m * 32 + 8 * qd) * 2) =
-                      (unsigned long long)pk[0] | ((unsigned long long)pk[1] << 16) | ((unsigned long long)pk[2] << 32) |
-                      ((unsigned long long)pk[3] << 48);
+                if (ok) *reinterpret_cast<u32x4_t*>(orow + (m * 32 + 8 * (qe + half)) * 2) = v4;
               }
           }
           H16_STAMP(5);     // bias / activation / rounding / output stores
@@ -303,58 +324,81 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
           for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][m][e] = 0.f;
-        // No LDS-DMA of THIS wave is in flight here (its pieces were waited for in front of the phase barrier); the operands of
-        // the next half tap (2 x (2 B + 2 A) fragments) are requested before the 8 MFMAs of this one.
+        // The 18 half taps (filter row ky, i = kx * 2 + pair of 16-channel blocks) as ONE software pipeline with hand-placed
+        // operand reads: the eight `ds_read_b128` of half tap s + 1 (order per 16-channel block: pixels row 0, weights m = 0,
+        // pixels row 1, weights m = 1) go one behind every MFMA of half tap s, and every MFMA that needs a new operand waits with
+        // `lgkmcnt(6)` -- the counter is in order, so "at most six younger reads outstanding" is exactly "mine has landed".  The
+        // reads are inline assembly because the compiler's own waits for them were `lgkmcnt(0)` behind a block of eight fresh
+        // reads (an exposed LDS round trip every other half tap; only one wave of a SIMD computes at a time, nobody fills it:
+        // 51 cycles per MFMA instead of 32 by the stamps).  No LDS-DMA of THIS wave is in flight here.
         f32x4 bq[2][4], aq[2][4];
-        // half a tap = two 16-channel blocks; i = kx * 2 + (block pair) within filter row ky.  The filter rows are a run-time
-        // loop (fully unrolled, the 27 hoisted operand addresses spilled the accumulators).
-        const unsigned char* prow = pst + (((2 * w4) * HP_W + l31) << 7);
-        const unsigned char* wrow = s_w + (((half * 64) + l31) << 4);
-        auto load_half = [&](const unsigned char* pr, const unsigned char* wr, int i, int set) __attribute__((always_inline)) {
-          const int kx = i >> 1;
-          const int swz = ((l31 + kx) >> 1) & 7;
+        const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)smem;
+        const unsigned lds_w = lds0 + (unsigned)(((half * 64) + l31) << 4), lds_w2 = lds_w + 2 * 24576;
+        unsigned ba[3][4];      // pixel-operand address of this lane for (kx, block cb), row 0 of the wave, filter row 0
 #pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) {
-            const int cb = (i & 1) * 2 + c2;
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
-              bq[set][c2 * 2 + r] = *reinterpret_cast<const f32x4*>(pr + ((r * HP_W + kx) << 7) + (((cb * 2 + half) ^ swz) << 4));
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-              aq[set][c2 * 2 + m] = *reinterpret_cast<const f32x4*>(wr + ((((kx * 4 + cb) * 2) * 64 + m * 32) << 4));
-          }
-        };
-        load_half(prow, wrow, 0, 0);
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-          const unsigned char* pr = prow + ky * (HP_W << 7);
-          const unsigned char* wr = wrow + ky * (3 * 4 * 2 * 64 * 16);
-#pragma unroll
-          for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_barrier(0);     // keep the requests of the next half tap in front of this one's MFMAs
-            if (i + 1 < 6) load_half(pr, wr, i + 1, (i + 1) & 1);
-            else if (ky + 1 < 3) load_half(pr + (HP_W << 7), wr + 3 * 4 * 2 * 64 * 16, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-              for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
+          for (int cb = 0; cb < 4; ++cb)
+            ba[kx][cb] = lds0 + (unsigned)(HW_BYTES + grp * (HP_SEGS * 1024) + (((2 * w4) * HP_W + l31 + kx) << 7) +
+                                           (((cb * 2 + half) ^ (((l31 + kx) >> 1) & 7)) << 4));
+#define H16_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+        // read K (0..7) of half tap (KY, I) into operand set SET
+#define H16_LOAD1(KY, I, SET, K)                                                                                          \
+  do {                                                                                                                    \
+    constexpr int kx_ = (I) >> 1, c2_ = (K) >> 2, j_ = (K) & 3, cb_ = ((I) & 1) * 2 + c2_;                                \
+    if constexpr ((j_ & 1) == 0) H16_DSR(bq[SET][c2_ * 2 + (j_ >> 1)], ba[kx_][cb_], (((j_ >> 1) + (KY)) * HP_W) << 7);   \
+    else if constexpr ((KY) < 2) H16_DSR(aq[SET][c2_ * 2 + (j_ >> 1)], lds_w,                                            \
+                                         (KY) * 24576 + (((kx_ * 4 + cb_) * 2 * 64 + (j_ >> 1) * 32) << 4));              \
+    else H16_DSR(aq[SET][c2_ * 2 + (j_ >> 1)], lds_w2, ((kx_ * 4 + cb_) * 2 * 64 + (j_ >> 1) * 32) << 4);                 \
+  } while (0)
+        // MFMA K of half tap (KY, I) on set SET (+ its wait), then read K of the next half tap (NKY, NI) into the other set
 #ifdef EAVSR_H16_EXP_NO_MFMA
-                  acc[r][m][c2] += aq[i & 1][c2 * 2 + m][0] + bq[i & 1][c2 * 2 + r][1];
+#define H16_MFMA(r_, m_, A_, B_) acc[r_][m_][0] += (A_)[0] + (B_)[1]
 #else
-                  acc[r][m] = mfma16<BF16>(aq[i & 1][c2 * 2 + m], bq[i & 1][c2 * 2 + r], acc[r][m]);
+#define H16_MFMA(r_, m_, A_, B_) acc[r_][m_] = mfma16<BF16>(A_, B_, acc[r_][m_])
 #endif
-                }
-          }
-        }
+#define H16_SLOT(SET, K, HASNEXT, NKY, NI)                                                                                \
+  do {                                                                                                                    \
+    constexpr int c2_ = (K) >> 2, m_ = ((K) >> 1) & 1, r_ = (K) & 1;                                                      \
+    constexpr int need_ = ((K) & 3) == 3 ? -1 : (K) + 1;      /* index of the youngest read this MFMA needs */            \
+    if constexpr (need_ >= 0)                                                                                             \
+      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(aq[SET][c2_ * 2 + m_]), "+v"(bq[SET][c2_ * 2 + r_])                    \
+                   : "n"(7 - need_ + ((HASNEXT) ? (K) : 0)));                                                             \
+    H16_MFMA(r_, m_, aq[SET][c2_ * 2 + m_], bq[SET][c2_ * 2 + r_]);                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    if constexpr (HASNEXT) {                                                                                              \
+      H16_LOAD1(NKY, NI, (SET) ^ 1, K);                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    }                                                                                                                     \
+  } while (0)
+#define H16_STEP(SET, HASNEXT, NKY, NI)                                                        \
+  H16_SLOT(SET, 0, HASNEXT, NKY, NI); H16_SLOT(SET, 1, HASNEXT, NKY, NI); H16_SLOT(SET, 2, HASNEXT, NKY, NI); \
+  H16_SLOT(SET, 3, HASNEXT, NKY, NI); H16_SLOT(SET, 4, HASNEXT, NKY, NI); H16_SLOT(SET, 5, HASNEXT, NKY, NI); \
+  H16_SLOT(SET, 6, HASNEXT, NKY, NI); H16_SLOT(SET, 7, HASNEXT, NKY, NI)
+        __builtin_amdgcn_sched_barrier(0);
+        H16_LOAD1(0, 0, 0, 0); H16_LOAD1(0, 0, 0, 1); H16_LOAD1(0, 0, 0, 2); H16_LOAD1(0, 0, 0, 3);
+        H16_LOAD1(0, 0, 0, 4); H16_LOAD1(0, 0, 0, 5); H16_LOAD1(0, 0, 0, 6); H16_LOAD1(0, 0, 0, 7);
+        __builtin_amdgcn_sched_barrier(0);
+        H16_STEP(0, true, 0, 1); H16_STEP(1, true, 0, 2); H16_STEP(0, true, 0, 3); H16_STEP(1, true, 0, 4); H16_STEP(0, true, 0, 5);
+        H16_STEP(1, true, 1, 0);
+        H16_STEP(0, true, 1, 1); H16_STEP(1, true, 1, 2); H16_STEP(0, true, 1, 3); H16_STEP(1, true, 1, 4); H16_STEP(0, true, 1, 5);
+        H16_STEP(1, true, 2, 0);
+        H16_STEP(0, true, 2, 1); H16_STEP(1, true, 2, 2); H16_STEP(0, true, 2, 3); H16_STEP(1, true, 2, 4); H16_STEP(0, true, 2, 5);
+        H16_STEP(1, false, 0, 0);
+#undef H16_STEP
+#undef H16_SLOT
+#undef H16_MFMA
+#undef H16_LOAD1
+#undef H16_DSR
         __builtin_amdgcn_sched_barrier(0);
         H16_STAMP(1);     // operand reads + MFMAs
       }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's DMA pieces, zero fills and sums have landed
-    __syncthreads();
+    // this wave's DMA pieces, zero fills and sums have landed (raw barrier: __syncthreads() would drain vmcnt again)
+    if (stores_behind_dma) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     H16_STAMP(0);         // waiting for the DMA and the barrier
   }
 #ifdef EAVSR_H16_STAMPS

@@ -10,12 +10,13 @@ import torch  # noqa: E402
 from eavsr_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-h, w = 180, 320
+h, w = int(os.environ.get("H", 180)), int(os.environ.get("W", 320))
+n_list = tuple(int(v) for v in os.environ.get("N", "2,4").split(","))
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 for path in sorted(glob.glob(os.path.join(ROOT, "eavsr_amd", "lib", "libh16_*.so"))):
     lib = C.CDLL(path)
     res = []
-    for n in (2, 4):
+    for n in n_list:
         x = torch.randn(n, 64, h, w, device=dev)
         xh = ops.to_nhwc_h16(x, "bf16")
         wt = torch.randn(64, 64, 3, 3, device=dev) * 0.04
@@ -33,7 +34,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "eavsr_amd", "lib", "libh16_*.so
         e1.record()
         torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / 20 * 1000)
-    print(f"{os.path.basename(path):24s} n=2 {res[0]:7.1f} us   n=4 {res[1]:7.1f} us", flush=True)
+    print(f"{os.path.basename(path):24s} " + "   ".join(f"n={n} {r:7.1f} us" for n, r in zip(n_list, res)), flush=True)
     if "stamps" in path:
         buf = (C.c_ulonglong * 8)()
         lib.eavsr_debug_h16_stamps(buf, 1)
@@ -41,4 +42,6 @@ for path in sorted(glob.glob(os.path.join(ROOT, "eavsr_amd", "lib", "libh16_*.so
         lib.eavsr_debug_h16_stamps(buf, 1)
         names = ["wait DMA + barrier", "reads + MFMAs", "border clear + DMA issue", "bias/round/stage", "channel sums", "stores"]
         tot = sum(buf[i] for i in range(6))
-        print("  wave 0 (n=4): " + "  ".join(f"{names[i]} {100.0 * buf[i] / max(tot, 1):.1f}%" for i in range(6)) + f"  (total {tot / 256:.0f} cycles per workgroup)")
+        print(f"  waves 0 + 4 (n={n_list[-1]}): " + "  ".join(f"{names[i]} {100.0 * buf[i] / max(tot, 1):.1f}%" for i in range(6)) + f"  (total {tot / 512:.0f} cycles per wave)")
+        tiles_g = ((h + 7) // 8) * ((w + 31) // 32) * n_list[-1] / 512.0      # tiles per wave group
+        print("    cycles per tile of a group: " + "  ".join(f"{names[i]} {buf[i] / 512 / tiles_g:.0f}" for i in range(6)) + f"  | sum {tot / 512 / tiles_g:.0f}")
