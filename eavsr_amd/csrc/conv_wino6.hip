@@ -46,6 +46,7 @@
 #endif
 
 #include <mutex>
+#include <type_traits>
 #include <cstdlib>
 #include <cstring>
 
@@ -657,6 +658,48 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #endif
     constexpr int AHEAD = EAVSR_W4_AHEAD, NSTEP = NPOS / 2;
     f32x2 av[AHEAD + 1], bv[AHEAD + 1];
+#if !defined(EAVSR_W4_COMPILER_READS) && !defined(EAVSR_W4_UREGS) && !defined(EAVSR_WINO_EXP_UREGS) && !defined(EAVSR_WINO_EXP_NOMFMA) && \
+    !defined(EAVSR_W4_SPREAD)
+    // The operand reads as inline assembly with hand-counted waits.  Left to the compiler every wait in this block is
+    // `lgkmcnt(0)` (with LDS-DMA in the kernel its wait-count pass never counts LDS reads): five of them per 18 steps, each
+    // right behind freshly issued reads of a LATER step, i.e. an LDS round trip exposed in front of the MFMAs it guards and the
+    // AHEAD-deep prefetch defeated.  The counter is in order: before the MFMAs of step i at most the 2 * min(AHEAD, NSTEP-1-i)
+    // reads of the later steps may be outstanding.
+    {
+      const unsigned ua_l = (unsigned)(unsigned long long)(lptr_t)ua, vb_l = (unsigned)(unsigned long long)(lptr_t)vb;
+      // (macros, not generic lambdas: clang rejects captured variables as asm operands inside one)
+#define W4_RD(I)                                                                                                     \
+  do {                                                                                                               \
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(av[(I) % (AHEAD + 1)]) : "v"(ua_l), "n"((I) * (CK * 128) * 4)); \
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bv[(I) % (AHEAD + 1)]) : "v"(vb_l), "n"((I) * (CK * 64) * 4));  \
+  } while (0)
+#define W4_S(I)                                                                                                      \
+  do {                                                                                                               \
+    constexpr int cur_ = (I) % (AHEAD + 1);                                                                          \
+    if constexpr ((I) == NSTEP / 2) {                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      W4_IT(5);                                                                                                      \
+      if (dma_late) issue_dma();                                                                                     \
+      W4_IT(6);                                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }                                                                                                                \
+    if constexpr ((I) + AHEAD < NSTEP) W4_RD(((I) + AHEAD < NSTEP ? (I) + AHEAD : 0));                               \
+    constexpr int later_ = NSTEP - 1 - (I) < AHEAD ? NSTEP - 1 - (I) : AHEAD;                                        \
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(av[cur_]), "+v"(bv[cur_]) : "n"(2 * later_));                        \
+    acc[2 * (I)] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur_].x, bv[cur_].x, acc[2 * (I)], 0, 0, 0);              \
+    acc[2 * (I) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur_].y, bv[cur_].y, acc[2 * (I) + 1], 0, 0, 0);      \
+    __builtin_amdgcn_sched_barrier(0);      /* the MFMAs stay between their wait and the next step's reads */        \
+  } while (0)
+      static_assert(AHEAD >= 1 && AHEAD <= 3 && NSTEP == 18, "the steps below are written out for 18 steps, up to 3 ahead");
+      W4_RD(0);
+      if constexpr (AHEAD > 1) W4_RD(1);
+      if constexpr (AHEAD > 2) W4_RD(2);
+      W4_S(0); W4_S(1); W4_S(2); W4_S(3); W4_S(4); W4_S(5); W4_S(6); W4_S(7); W4_S(8);
+      W4_S(9); W4_S(10); W4_S(11); W4_S(12); W4_S(13); W4_S(14); W4_S(15); W4_S(16); W4_S(17);
+#undef W4_S
+#undef W4_RD
+    }
+#else
 #ifdef EAVSR_W4_UREGS
     // the last iteration re-requests its own chunk (unconditional requests: a branch per step would cut the GEMM into 18 blocks)
     const int u_next = (it + 1 < total_iters ? chunk_n : chunk) * (U_ELEMS * 4);
@@ -741,6 +784,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     if (dma_late) issue_dma();
     acc[0][0] += av[0].x + bv[0].x;
 #endif
+#endif   // hand-counted reads | the compiler's
 #ifdef EAVSR_W4_UREGS
     // the pair on duty transforms the next chunk AFTER its GEMM steps: its last operand requests land under the transform
     __builtin_amdgcn_sched_barrier(0);

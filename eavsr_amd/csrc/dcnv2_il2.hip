@@ -196,6 +196,10 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     poffc[i] = (unsigned)(rr * w * 32 + hh * 768 + cc * 16);      // the same bytes of the window row as two contiguous 768-byte runs
 #endif
   }
+  // the address of the zero unit once, kept in scalar registers: rematerialised at its uses it is a scalar load (and an
+  // `lgkmcnt(0)` that also drains the LDS reads in flight) at every window request of a border tile
+  const char* zero_src = reinterpret_cast<const char*>(g_il2_zero);
+  asm volatile("" : "+s"(zero_src));
   auto issue_win = [&](int i, const char* xorg, int y0, int x0, bool interior, int wslot) __attribute__((always_inline)) {
     const int p = i * 8 + wave;  // wave-uniform
     if (p < JWIN_SEGS) {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
       if (!interior) {
         const int ylo = y0 - JPY0, xlo = x0 - JPX0;
         const bool ok = (unsigned)(ylo + (prc[i] >> 8)) < (unsigned)h && (unsigned)(xlo + (prc[i] & 255)) < (unsigned)w;
-        src = ok ? src : reinterpret_cast<const char*>(g_il2_zero);     // that IS the sampler's zero padding
+        src = ok ? src : zero_src;     // that IS the sampler's zero padding
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     }
