@@ -545,7 +545,7 @@ def main():
                     4: f"SR frames/sec, eavsrp 4x long-sequence propagation, {n} clip x {t} frames x 3 x {h} x {w} -> {4 * h}x{4 * w} "
                        "(BASELINE.json configs[4])"}[args.config]) +
                   ("" if args.backbone_dtype == "fp32" else
-                   f" [{args.backbone_dtype}: 16-bit residual backbone, warp -> DCNv2 and predictor heads; fp32 elsewhere" +
+                   f" [{args.backbone_dtype}: 16-bit residual backbone, warp -> DCNv2, predictor heads and upsampling tail; fp32 elsewhere" +
                    ("; not the fp32 headline]" if args.config == 1 else "]")) +
                   ("" if args.conv_mode != "bf16x9" and args.dcn_mode != "bf16x9" else " [fp32 via exact bf16x9 split products, opt-in mode]"),
         "value": value,
@@ -662,8 +662,8 @@ def main():
             dom["fp32_kernel_of_the_same_shape_outside_the_groups"] = {k: fp32_dom[k] for k in ("kernel", "frac", "avg_ms", "share_of_step")}
         if args.backbone_dtype != "fp32":
             # which kernels of the step ran in 16 bits (the rest is fp32), with their share of the step's kernel time
-            names16 = ("conv3x3_64to64_h16", "scale_residual_h16", "dcnv2_il16_heads", "dcnv2_il16", "nchw_f32_to_nhwc_h16",
-                       "nhwc_h16_to_nchw_f32")
+            names16 = ("conv3x3_64to64_h16", "conv3x3_64to256_h16_ps2", "conv3x3_64to3_h16", "scale_residual_h16", "dcnv2_il16_heads",
+                       "dcnv2_il16", "nchw_f32_to_nhwc_h16", "nhwc_h16_to_nchw_f32")
             heads16 = tuple(k for k in summ if k.startswith("conv5x5_") and k.endswith("_h16"))     # the predictor's 5x5 heads
             line["kernels_16bit"] = [e for e in (entry(k, "hbm") for k in names16) if e]
             line["kernels_16bit"] += [e for e in (entry(k, "mfma") for k in heads16) if e]

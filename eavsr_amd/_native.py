@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -129,6 +129,8 @@ SIGNATURES = {
     "eavsr_pack_conv5x5_c64_h16": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_conv5x5_c64_h16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_c64_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "eavsr_conv3x3_c64_h16_act": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
+    "eavsr_conv3x3_c64to3_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_nchw_f32_to_nhwc_h16": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_nhwc_h16_to_nchw_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_scale_residual_h16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

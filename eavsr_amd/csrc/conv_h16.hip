@@ -59,9 +59,13 @@ struct H16Args {
   const void* x;      // (n, h, w, 64) 16-bit
   const void* wp;     // packed weights [36 k-steps][2 halves][64 co][8] 16-bit
   const float* bias;  // fp32 [64] or NULL
-  void* out;          // (n, h, w, 64) 16-bit
+  void* out;          // (n, h, w, 64) 16-bit; ps: (n, 2 h, 2 w, 64)
   float* chan_partial;
-  int n, h, w, tiles_x, tiles_y, num_tiles, relu;
+  int n, h, w, tiles_x, tiles_y, num_tiles;
+  int act;            // 0 none, 1 ReLU, 2 LeakyReLU(slope)
+  float slope;
+  int ps;             // 1: conv 64 -> 256 + PixelShuffle(2) as four 64 -> 64 slices (blockIdx.y = 2 dy + dx): slice k holds the output
+                      // channels 4 c + k of the reference weight as its channel c, and its pixel (y, x) is output pixel (2 y + dy, 2 x + dx)
 };
 
 template <bool BF16> __device__ __forceinline__ unsigned short to_h16(float v);
@@ -122,11 +126,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
   const int h = a.h, w = a.w;
   unsigned char* pst = s_p + grp * (HP_SEGS * 1024);
 
-  if (tid < 64) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
+  const int slice = blockIdx.y;                     // 0 unless ps
+  const int oS = a.ps ? 2 : 1, o_dy = a.ps ? slice >> 1 : 0, o_dx = a.ps ? slice & 1 : 0;
+  if (tid < 64) s_bias[tid] = a.bias ? a.bias[slice * 64 + tid] : 0.f;
 #ifndef EAVSR_H16_EXP_NO_WDMA
 #pragma unroll 1
   for (int seg = wave; seg < HW_SEGS; seg += 8)
-    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.wp) + seg * 1024 + lane * 16),
+    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(a.wp) + (size_t)slice * HW_BYTES + seg * 1024 + lane * 16),
                                      (lptr_t)(s_w + seg * 1024), 16, 0, 0);
 #endif
 
@@ -219,7 +225,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
 #ifndef EAVSR_H16_EXP_WAIT_STORES
         stores_behind_dma = ty * HT_H + 2 * w4 + 1 < h && tx * HT_W + 31 < w;
 #endif
-        char* ob = reinterpret_cast<char*>(a.out) + (size_t)bn * h * w * 128;
+        const int ow = w * oS;      // output row length in pixels
+        char* ob = reinterpret_cast<char*>(a.out) + (size_t)bn * (h * oS) * ow * 128;
+        const float slope = a.slope;
         f32x4 bq4[2][4];     // this lane's 32 bias values: 4 consecutive channels per (m, qd)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -227,8 +235,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
           for (int qd = 0; qd < 4; ++qd) bq4[m][qd] = *reinterpret_cast<const f32x4*>(s_bias + m * 32 + 8 * qd + 4 * half);
         // the activation and the channel sums are launch constants: four straight-line variants (the sums alone are ~450 of the
         // ~900 vector instructions of a general epilogue, as many issue cycles as the tile's MFMAs)
-        auto epilogue = [&](auto sums_c, auto relu_c) __attribute__((always_inline)) {
-          constexpr bool SUMS = decltype(sums_c)::value, RELU = decltype(relu_c)::value;
+        auto epilogue = [&](auto sums_c, auto act_c) __attribute__((always_inline)) {
+          constexpr bool SUMS = decltype(sums_c)::value;
+          constexpr int ACT = decltype(act_c)::value;
           float csum[2][16];
           if (SUMS) {
 #pragma unroll
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
           for (int r = 0; r < 2; ++r) {
             const int gy = ty * HT_H + 2 * w4 + r, gx = tx * HT_W + l31;
             const bool ok = gy < h && gx < w;
-            char* orow = ob + ((size_t)gy * w + gx) * 128;
+            char* orow = ob + ((size_t)(gy * oS + o_dy) * ow + (gx * oS + o_dx)) * 128;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -258,7 +267,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
                     float v = acc[r][m][4 * qd + e] + bq4[m][qd][e];
-                    if (RELU) v = fmaxf(v, 0.f);
+                    if (ACT == 1) v = fmaxf(v, 0.f);
+                    if (ACT == 2) v = fmaxf(v, v * slope);
                     pk[e] = to_h16<BF16>(v);
                     if (SUMS) csum[m][4 * qd + e] += ok ? from_h16<BF16>(pk[e]) : 0.f;   // the 16-bit value the next layer reads
                   }
@@ -303,8 +313,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
-        if (a.chan_partial) { if (a.relu) epilogue(T_{}, T_{}); else epilogue(T_{}, F_{}); }
-        else { if (a.relu) epilogue(F_{}, T_{}); else epilogue(F_{}, F_{}); }
+        using A0 = std::integral_constant<int, 0>;
+        using A1 = std::integral_constant<int, 1>;
+        using A2 = std::integral_constant<int, 2>;
+        if (a.chan_partial) { if (a.act == 1) epilogue(T_{}, A1{}); else epilogue(T_{}, A0{}); }      // (the sums exist for the RCAB's second conv: no LeakyReLU form)
+        else { if (a.act == 1) epilogue(F_{}, A1{}); else if (a.act == 2) epilogue(F_{}, A2{}); else epilogue(F_{}, A0{}); }
         H16_STAMP(4);     // channel sums
       }
     } else if (q >= 1) {
@@ -409,6 +422,88 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
 
 
 // ---------------------------------------------------------------------------------------------
+// conv_last of the upsampling tail in the 16-bit modes (eavsrp_model.py:359-360): 3x3, 64 -> 3, 16-bit NHWC in, fp32 NCHW out
+// (+ the bilinear skip image).  5,184 FLOP per pixel against 128 bytes read: a streaming kernel.  One thread per output pixel,
+// the 10 x 34-pixel patch of an 8 x 32 tile in LDS (the XOR swizzle of the MFMA kernel's patch: 16 neighbouring pixels of a
+// ds_read_b128 hit 16 different bank quads), the 1,728 weights rounded to 16 bits into LDS by every workgroup (broadcast reads),
+// the contraction by v_dot2c_f32_{bf16,f16} (two channels per instruction, fp32 accumulate).
+// ---------------------------------------------------------------------------------------------
+struct L16Args {
+  const void* x;          // (n, h, w, 64) 16-bit
+  const float* weight;    // (3, 64, 3, 3) fp32
+  const float* bias;      // [3] or NULL
+  const float* residual;  // (n, 3, h, w) fp32 or NULL
+  float* out;             // (n, 3, h, w) fp32
+  int n, h, w, tiles_x, tiles_y;
+};
+
+template <bool BF16>
+__device__ __forceinline__ float dot2_h16(unsigned a, unsigned b, float c) {
+  if (BF16) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a), __builtin_bit_cast(bf2, b), c, false);
+  } else {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
+  }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void conv3x3_c64to3_h16_kernel(L16Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_patch[HP_BYTES];      // [row][col][8 x 16-byte blocks], blocks swizzled
+  __shared__ __attribute__((aligned(16))) unsigned short s_wt[9 * 8 * 3 * 8];   // [tap][block][co][8 channels]
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y, bn = t / a.tiles_y;
+  const int h = a.h, w = a.w;
+  const int y0 = ty * HT_H - 1, x0 = tx * HT_W - 1;
+  for (int e = tid; e < 9 * 8 * 3 * 8; e += 256) {
+    const int j = e & 7, co = (e >> 3) % 3, tb = e / 24, sb = tb & 7, tap = tb >> 3;
+    s_wt[e] = to_h16<BF16>(a.weight[((size_t)co * 64 + sb * 8 + j) * 9 + tap]);
+  }
+  const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)bn * h * w * 128;
+  for (int e = tid; e < HP_PIX * 8; e += 256) {
+    const int pp = e >> 3, sb = e & 7;
+    const int r = pp / HP_W, c = pp - r * HP_W;
+    const int gy = y0 + r, gx = x0 + c;
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = *reinterpret_cast<const u32x4_t*>(xb + ((size_t)gy * w + gx) * 128 + sb * 16);
+    *reinterpret_cast<u32x4_t*>(s_patch + pp * 128 + ((sb ^ ((c >> 1) & 7)) << 4)) = v;
+  }
+  __syncthreads();
+  const int r = tid >> 5, c = tid & 31;
+  float acc[3] = {a.bias ? a.bias[0] : 0.f, a.bias ? a.bias[1] : 0.f, a.bias ? a.bias[2] : 0.f};
+#pragma unroll 1      // (fully unrolled the 216 weight reads are hoisted and spill)
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll 1
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned char* px = s_patch + ((r + ky) * HP_W + c + kx) * 128;
+      const int swz = ((c + kx) >> 1) & 7;
+#pragma unroll
+      for (int sb = 0; sb < 8; ++sb) {
+        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(px + ((sb ^ swz) << 4));
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+          const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(s_wt + (((ky * 3 + kx) * 8 + sb) * 3 + co) * 8);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[co] = dot2_h16<BF16>(v[q], wv[q], acc[co]);
+        }
+      }
+    }
+  const int gy = ty * HT_H + r, gx = tx * HT_W + c;
+  if (gy < h && gx < w) {
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+      const size_t o = ((size_t)bn * 3 + co) * h * w + (size_t)gy * w + gx;
+      a.out[o] = acc[co] + (a.residual ? a.residual[o] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // layout / precision converters and the 16-bit RCAB tail
 // ---------------------------------------------------------------------------------------------
 template <bool BF16>
@@ -486,7 +581,7 @@ __global__ void pack_weight_h16_kernel(const float* __restrict__ w, unsigned sho
 }
 
 template <bool BF16>
-int launch_conv_h16(const H16Args& a, int blocks, hipStream_t st) {
+int launch_conv_h16(const H16Args& a, int blocks, int slices, hipStream_t st) {
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
   std::once_flag& once = once_pd.flag[dev_];
@@ -500,7 +595,7 @@ int launch_conv_h16(const H16Args& a, int blocks, hipStream_t st) {
     eavsr::set_error("conv3x3_c64_h16: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  hipLaunchKernelGGL(conv3x3_c64_h16_kernel<BF16>, dim3(blocks), dim3(512), H_LDS_BYTES, st, a);
+  hipLaunchKernelGGL(conv3x3_c64_h16_kernel<BF16>, dim3(blocks, slices), dim3(512), H_LDS_BYTES, st, a);
   return eavsr::launch_status("conv3x3_c64_h16");
 }
 
@@ -531,9 +626,25 @@ extern "C" int eavsr_pack_conv3x3_c64_h16(const float* weight, void* packed, int
   return eavsr::launch_status("pack_conv3x3_c64_h16");
 }
 
+static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, const float* bias, void* out, float* chan_partial,
+                                  int32_t n, int32_t h, int32_t w, int32_t act, float slope, int32_t ps, int32_t dtype, void* stream);
+
 extern "C" int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float* bias, void* out,
                                      float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t relu,
                                      int32_t dtype, void* stream) {
+  return conv3x3_c64_h16_launch(x, weight_packed, bias, out, chan_partial, n, h, w, relu ? 1 : 0, 0.f, 0, dtype, stream);
+}
+
+extern "C" int eavsr_conv3x3_c64_h16_act(const void* x, const void* weight_packed, const float* bias, void* out, int32_t n, int32_t h,
+                                         int32_t w, int32_t act, float slope, int32_t pixel_shuffle2, int32_t dtype, void* stream) {
+  EAVSR_REQUIRE(act == EAVSR_ACT_NONE || act == EAVSR_ACT_RELU || act == EAVSR_ACT_LRELU, -1, "conv3x3_c64_h16_act: act %d", act);
+  EAVSR_REQUIRE(pixel_shuffle2 == 0 || pixel_shuffle2 == 1, -1, "conv3x3_c64_h16_act: pixel_shuffle2 %d", pixel_shuffle2);
+  return conv3x3_c64_h16_launch(x, weight_packed, bias, out, nullptr, n, h, w, act == EAVSR_ACT_RELU ? 1 : act == EAVSR_ACT_LRELU ? 2 : 0,
+                                slope, pixel_shuffle2, dtype, stream);
+}
+
+static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, const float* bias, void* out, float* chan_partial,
+                                  int32_t n, int32_t h, int32_t w, int32_t act, float slope, int32_t ps, int32_t dtype, void* stream) {
   EAVSR_REQUIRE(x && weight_packed && out, -1, "conv3x3_c64_h16: NULL pointer");
   EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "conv3x3_c64_h16: dtype %d (1 = f16, 2 = bf16)", dtype);
   EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0, -1, "conv3x3_c64_h16: bad dims");
@@ -548,10 +659,32 @@ extern "C" int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, c
   const long tiles = (long)a.tiles_x * a.tiles_y * n;
   EAVSR_REQUIRE(tiles < (1L << 31), -1, "conv3x3_c64_h16: too many tiles");
   a.num_tiles = (int)tiles;
-  a.relu = relu;
-  const int blocks = tiles < 256 ? (int)tiles : 256;  // persistent: one workgroup per CU
-  return dtype == 2 ? launch_conv_h16<true>(a, blocks, eavsr::as_stream(stream))
-                    : launch_conv_h16<false>(a, blocks, eavsr::as_stream(stream));
+  a.act = act; a.slope = slope; a.ps = ps;
+  const int per = ps ? 64 : 256;                      // persistent: one workgroup per CU (four slices: 64 each)
+  const int blocks = tiles < per ? (int)tiles : per;
+  return dtype == 2 ? launch_conv_h16<true>(a, blocks, ps ? 4 : 1, eavsr::as_stream(stream))
+                    : launch_conv_h16<false>(a, blocks, ps ? 4 : 1, eavsr::as_stream(stream));
+}
+
+extern "C" int eavsr_conv3x3_c64to3_h16(const void* x, const float* weight, const float* bias, const float* residual, float* out,
+                                        int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream) {
+  EAVSR_REQUIRE(x && weight && out, -1, "conv3x3_c64to3_h16: NULL pointer");
+  EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "conv3x3_c64to3_h16: dtype %d (1 = f16, 2 = bf16)", dtype);
+  EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0, -1, "conv3x3_c64to3_h16: bad dims");
+  EAVSR_REQUIRE(((uintptr_t)x & 15) == 0, -1, "conv3x3_c64to3_h16: x must be 16-byte aligned");
+  if (n == 0) return 0;
+  L16Args a;
+  a.x = x; a.weight = weight; a.bias = bias; a.residual = residual; a.out = out;
+  a.n = n; a.h = h; a.w = w;
+  a.tiles_x = eavsr::cdiv(w, HT_W);
+  a.tiles_y = eavsr::cdiv(h, HT_H);
+  const long tiles = (long)a.tiles_x * a.tiles_y * n;
+  EAVSR_REQUIRE(tiles < (1L << 31), -1, "conv3x3_c64to3_h16: too many tiles");
+  if (dtype == 2)
+    hipLaunchKernelGGL(conv3x3_c64to3_h16_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, eavsr::as_stream(stream), a);
+  else
+    hipLaunchKernelGGL(conv3x3_c64to3_h16_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, eavsr::as_stream(stream), a);
+  return eavsr::launch_status("conv3x3_c64to3_h16");
 }
 
 extern "C" int eavsr_nchw_f32_to_nhwc_h16(const float* in, void* out, int32_t n, int32_t c, int32_t hw, int32_t dtype,

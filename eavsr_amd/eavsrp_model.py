@@ -23,6 +23,10 @@ from . import autograd as AG
 from . import networks as N
 from . import ops
 
+# In the 16-bit modes the upsampling tail (conv + PixelShuffle stages, conv_hr, conv_last) runs on the 16-bit kernels as well;
+# EAVSR_TAIL_16BIT=0 keeps it on the fp32 kernels (A/B switch).
+TAIL_IN_16BIT = os.environ.get("EAVSR_TAIL_16BIT", "1") == "1"
+
 Tensor = torch.Tensor
 
 
@@ -302,14 +306,31 @@ class EAVSRP(nn.Module):
         branches = [k for k in feats if k not in _PYR]
         srcs = [_frame_major(feats["spatial"])] + [_frame_major(feats[k]) for k in branches]
         hr = self.reconstruction(srcs)
+        if lq_tm is None:
+            lq_tm = lqs.transpose(0, 1).reshape(t * n, *lqs.shape[2:])
+        tail16 = (N.BACKBONE_DTYPE is not None and TAIL_IN_16BIT and self.n_feats == 64 and
+                  not AG.needs_grad(hr, lq_tm, list(self.upsample1.parameters()) + list(self.conv_hr.parameters()) +
+                                    list(self.conv_last.parameters()) + (list(self.upsample2.parameters()) if self.scale == 4 else [])))
+        if tail16:
+            # 16-bit modes (BASELINE configs[2] / [4]): the tail on the 16-bit backbone kernel -- every conv + PixelShuffle(2) stage as
+            # four 64 -> 64 slices whose store pattern is the shuffle, conv_hr as it is, conv_last by packed dot products; the
+            # activations between them 16-bit NHWC, the skip image and the result fp32
+            hr = ops.to_nhwc_h16(hr, N.BACKBONE_DTYPE)
+            u1 = self.upsample1[0]
+            hr = ops.conv3x3_c64_h16_act(hr, u1.weight, u1.bias, act="lrelu", slope=0.1, pixel_shuffle2=True)
+            if self.scale == 4:
+                u2 = self.upsample2[0]
+                hr = ops.conv3x3_c64_h16_act(hr, u2.weight, u2.bias, act="lrelu", slope=0.1, pixel_shuffle2=True)
+            hr = ops.conv3x3_c64_h16_act(hr, self.conv_hr.weight, self.conv_hr.bias, act="lrelu", slope=0.1)
+            skip = ops.resize_bilinear(lq_tm, (self.scale * lq_tm.shape[2], self.scale * lq_tm.shape[3]))
+            out = ops.conv3x3_c64to3_h16(hr, self.conv_last.weight, self.conv_last.bias, residual=skip)
+            return out.view(t, n, *out.shape[1:]).transpose(0, 1).contiguous()
         # conv -> PixelShuffle(2) -> LeakyReLU (:343-347): the activation commutes with the shuffle and the shuffle is the conv
         # kernel's own store pattern (the torch copy was 0.8 / 3.3 GB per 2-clip forward)
         hr = self.upsample1[0](hr, act="lrelu", slope=0.1, pixel_shuffle2=True)
         if self.scale == 4:
             hr = self.upsample2[0](hr, act="lrelu", slope=0.1, pixel_shuffle2=True)
         hr = self.conv_hr(hr, act="lrelu", slope=0.1)
-        if lq_tm is None:
-            lq_tm = lqs.transpose(0, 1).reshape(t * n, *lqs.shape[2:])
         # nn.Upsample(scale_factor, 'bilinear', align_corners=False) (:158,359): source coordinate (dst + 0.5) / s - 0.5
         skip = (self.img_upsample(lq_tm) if lq_tm.requires_grad else
                 ops.resize_bilinear(lq_tm, (self.scale * lq_tm.shape[2], self.scale * lq_tm.shape[3])))

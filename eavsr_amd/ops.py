@@ -1496,6 +1496,78 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
     return (out, part) if chan_partial else out
 
 
+_h16_ps_cache = {}
+
+
+def _packed_h16_ps2(weight: Tensor, bias: Optional[Tensor], code: int):
+    """(256, 64, 3, 3) weight of a conv + PixelShuffle(2) stage -> four packed 64 -> 64 matrices (slice k = 2 dy + dx: the output
+    channels 4 c + k as channel c) and the bias in the same order (4 x 64)"""
+    key = (id(weight), weight._version, None if bias is None else (id(bias), bias._version), code)
+    hit = _h16_ps_cache.get(key)
+    if hit is not None and hit[0]() is weight:
+        return hit[1], hit[2]
+    w = _chk(weight.detach(), "weight")
+    if tuple(w.shape) != (256, 64, 3, 3):
+        raise NotImplementedError("the 16-bit pixel-shuffle stage is the 3x3 64 -> 256 convolution")
+    sl = w.view(64, 4, 64, 3, 3).permute(1, 0, 2, 3, 4).contiguous()      # [k][c][ci][3][3]
+    packed = torch.empty(4, 64 * 576, device=w.device, dtype=_H16_TORCH[code])
+    st = _stream(w)
+    with _DeviceOf(w):
+        for k in range(4):
+            N.check(lib().eavsr_pack_conv3x3_c64_h16(_p(sl[k]), _p(packed[k]), code, st), "pack_conv3x3_c64_h16")
+    b4 = None if bias is None else _chk(bias.detach(), "bias").view(64, 4).t().contiguous()
+    for k in [k for k in _h16_ps_cache if k[0] == id(weight)]:
+        _h16_ps_cache.pop(k, None)
+    _h16_ps_cache[key] = (weakref.ref(weight, lambda _r, k=key, c=_h16_ps_cache: c.pop(k, None)), packed, b4)
+    return packed, b4
+
+
+def conv3x3_c64_h16_act(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: Optional[str] = None, slope: float = 0.0,
+                        pixel_shuffle2: bool = False) -> Tensor:
+    """The upsampling tail in the 16-bit modes: x 16-bit NHWC (n,h,w,64); weight (64,64,3,3) -> act(conv + bias), or, with
+    pixel_shuffle2, weight (256,64,3,3) -> act(PixelShuffle(2)(conv + bias)) as (n,2h,2w,64) (eavsrp_model.py:343-357)"""
+    x = _chk_h16(x, "x")
+    n, h, w, c = x.shape
+    if c != 64:
+        raise NotImplementedError("the 16-bit backbone kernel needs 64 channels")
+    code = h16_code(x.dtype)
+    if pixel_shuffle2:
+        wp, b = _packed_h16_ps2(weight, bias, code)
+        out = torch.empty((n, 2 * h, 2 * w, 64), device=x.device, dtype=x.dtype)
+    else:
+        wp = _packed_h16(weight, code)
+        b = None if bias is None else _chk(bias.detach(), "bias")
+        out = torch.empty_like(x)
+    a = ACT[act]
+    st = _stream(x)
+    px = float(n) * h * w
+    co = 256 if pixel_shuffle2 else 64
+    _launch("conv3x3_64to256_h16_ps2" if pixel_shuffle2 else "conv3x3_64to64_h16", 2.0 * 64 * co * 9 * px, px * (128 + 2 * co), x,
+            lambda: lib().eavsr_conv3x3_c64_h16_act(_p(x), _p(wp), _p(b), _p(out), n, h, w, a, float(slope), 1 if pixel_shuffle2 else 0, code, st),
+            "conv3x3_c64_h16_act")
+    return out
+
+
+def conv3x3_c64to3_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], residual: Optional[Tensor] = None) -> Tensor:
+    """conv_last of the tail in the 16-bit modes: x 16-bit NHWC (n,h,w,64), weight (3,64,3,3) fp32 -> fp32 NCHW (n,3,h,w) (+ residual)"""
+    x = _chk_h16(x, "x")
+    n, h, w, c = x.shape
+    wt = _chk(weight.detach(), "weight")
+    if c != 64 or tuple(wt.shape) != (3, 64, 3, 3):
+        raise NotImplementedError("the 16-bit conv_last kernel is the 3x3 64 -> 3 convolution")
+    b = None if bias is None else _chk(bias.detach(), "bias")
+    r = None if residual is None else _chk(residual, "residual")
+    if r is not None and tuple(r.shape) != (n, 3, h, w):
+        raise ValueError("residual must be (n, 3, h, w)")
+    out = torch.empty((n, 3, h, w), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch("conv3x3_64to3_h16", 2.0 * 64 * 3 * 9 * px, px * (128 + 12 + (12 if r is not None else 0)), x,
+            lambda: lib().eavsr_conv3x3_c64to3_h16(_p(x), _p(wt), _p(b), _p(r), _p(out), n, h, w, h16_code(x.dtype), st),
+            "conv3x3_c64to3_h16")
+    return out
+
+
 _h16_pack5_cache = {}
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 24
+#define EAVSR_ABI_VERSION 25
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -449,6 +449,18 @@ int eavsr_pack_conv3x3_c64_h16(const float* weight, void* packed, int32_t dtype,
 int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float* bias, void* out,
                           float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t relu, int32_t dtype,
                           void* stream);
+/* The upsampling tail in the 16-bit modes (models/eavsrp_model.py:343-360; eavsrpx2_model.py likewise).
+ * eavsr_conv3x3_c64_h16_act: out = act(conv3x3(x) + bias), act = EAVSR_ACT_NONE | RELU | LRELU(slope) -- conv_hr (:355-357) with
+ *   pixel_shuffle2 = 0.  pixel_shuffle2 = 1: the 64 -> 256 convolution + nn.PixelShuffle(2) + activation of upsample1 / upsample2
+ *   (:343-352) as four 64 -> 64 slices of the same kernel: weight_packed = FOUR packed matrices, slice k = 2 dy + dx holding the
+ *   reference weight's output channels 4 c + k as its channel c (c = 0..63), bias likewise (4 x 64 floats); out is (n, 2 h, 2 w, 64)
+ *   16-bit NHWC, output pixel (2 y + dy, 2 x + dx) = slice k's pixel (y, x) -- the shuffle is the store pattern.
+ * eavsr_conv3x3_c64to3_h16: conv_last (:359-360): x 16-bit NHWC (n, h, w, 64), weight (3, 64, 3, 3) fp32 (rounded to the 16-bit
+ *   type inside the kernel), fp32 accumulation, out fp32 NCHW (n, 3, h, w) = conv + bias + residual (nullable: the bilinear skip). */
+int eavsr_conv3x3_c64_h16_act(const void* x, const void* weight_packed, const float* bias, void* out, int32_t n, int32_t h,
+                              int32_t w, int32_t act, float slope, int32_t pixel_shuffle2, int32_t dtype, void* stream);
+int eavsr_conv3x3_c64to3_h16(const void* x, const float* weight, const float* bias, const float* residual, float* out,
+                             int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
 /* The predictor's three 5x5 heads (transform_matrix_conv ++ translation_conv ++ mask_conv, models/networks.py:283-285,
  * 298-301) in the 16-bit modes (csrc/conv5_h16.hip): x 16-bit NHWC (n, h, w, 64) -- the front-end feature through
  * eavsr_nchw_f32_to_nhwc_h16 --, weight (cout, 64, 5, 5) fp32 rounded once by the pack call (cout <= 128), fp32 accumulation,

@@ -38,6 +38,45 @@ def test_layout_converters_round_trip(ops, cuda, dt, shape):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape,act", [((1, 8, 32), "lrelu"), ((2, 19, 37), "lrelu"), ((1, 45, 80), None), ((3, 7, 5), "relu")])
+def test_conv3x3_c64_h16_act_and_pixel_shuffle_vs_fp32_on_rounded_inputs(ops, cuda, dt, shape, act):
+    """the upsampling tail in the 16-bit modes (eavsrp_model.py:343-357): conv_hr's LeakyReLU form and the conv 64 -> 256 +
+    PixelShuffle(2) + activation stage as four slices of the backbone kernel, against torch on the same rounded operands"""
+    n, h, w = shape
+    x = cases.randn(11, n, 64, h, w).to(DT[dt])
+    fact = {"lrelu": lambda z: F.leaky_relu(z, 0.1), "relu": F.relu, None: lambda z: z}[act]
+    xh = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    wt = cases.randn(12, 64, 64, 3, 3, scale=1.0 / 24.0)
+    b = cases.randn(13, 64, scale=0.1)
+    ref = fact(F.conv2d(x.float(), wt.to(DT[dt]).float(), b, 1, 1))
+    got = ops.conv3x3_c64_h16_act(xh, wt.to(cuda), b.to(cuda), act=act, slope=0.1).float().permute(0, 3, 1, 2).cpu()
+    assert H.maxabs(got, ref) <= (EPS[dt] * 1.01) * max(1.0, ref.abs().max().item()) + 1e-5
+    w4 = cases.randn(14, 256, 64, 3, 3, scale=1.0 / 24.0)
+    b4 = cases.randn(15, 256, scale=0.1)
+    ref = fact(F.pixel_shuffle(F.conv2d(x.float(), w4.to(DT[dt]).float(), b4, 1, 1), 2))
+    out = ops.conv3x3_c64_h16_act(xh, w4.to(cuda), b4.to(cuda), act=act, slope=0.1, pixel_shuffle2=True)
+    assert out.shape == (n, 2 * h, 2 * w, 64)
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    assert H.maxabs(got, ref) <= (EPS[dt] * 1.01) * max(1.0, ref.abs().max().item()) + 1e-5
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape,res", [((1, 8, 32), True), ((2, 19, 37), False), ((1, 45, 80), True), ((3, 7, 5), True)])
+def test_conv3x3_c64to3_h16_vs_fp64_on_rounded_inputs(ops, cuda, dt, shape, res):
+    """conv_last of the tail (eavsrp_model.py:359-360) in the 16-bit modes: fp32 NCHW out (+ the skip image)"""
+    n, h, w = shape
+    x = cases.randn(21, n, 64, h, w).to(DT[dt])
+    wt = cases.randn(22, 3, 64, 3, 3, scale=1.0 / 24.0)
+    b = cases.randn(23, 3, scale=0.1)
+    r = cases.randn(24, n, 3, h, w) if res else None
+    ref = F.conv2d(x.double(), wt.to(DT[dt]).double(), b.double(), 1, 1) + (r.double() if res else 0.0)
+    got = ops.conv3x3_c64to3_h16(x.permute(0, 2, 3, 1).contiguous().to(cuda), wt.to(cuda), b.to(cuda),
+                                 residual=r.to(cuda) if res else None).cpu()
+    assert got.shape == (n, 3, h, w) and got.dtype == torch.float32
+    assert H.maxabs(got.double(), ref) <= 2e-5 * max(1.0, ref.abs().max().item())      # fp32 accumulation of exact 16-bit products
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape,relu,part", [((1, 8, 32), False, False), ((2, 19, 37), True, True),
                                              ((1, 45, 80), True, False), ((1, 64, 64), False, True),
                                              ((3, 7, 5), True, True)])
