@@ -425,12 +425,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
 // conv_last of the upsampling tail in the 16-bit modes (eavsrp_model.py:359-360): 3x3, 64 -> 3, 16-bit NHWC in, fp32 NCHW out
 // (+ the bilinear skip image).  5,184 FLOP per pixel against 128 bytes read: a streaming kernel.  One thread per output pixel,
 // the 10 x 34-pixel patch of an 8 x 32 tile in LDS (the XOR swizzle of the MFMA kernel's patch: 16 neighbouring pixels of a
-// ds_read_b128 hit 16 different bank quads), the 1,728 weights rounded to 16 bits into LDS by every workgroup (broadcast reads),
-// the contraction by v_dot2c_f32_{bf16,f16} (two channels per instruction, fp32 accumulate).
+// ds_read_b128 hit 16 different bank quads), the 1,728 weights -- wave-uniform -- through SCALAR loads from their 16-bit
+// [tap][8-channel block][co][8] image (as LDS broadcasts they were 3/4 of the kernel's LDS traffic and the kernel was slower
+// than the fp32 one), the contraction by v_dot2c_f32_{bf16,f16} (two channels per instruction, fp32 accumulate).
 // ---------------------------------------------------------------------------------------------
 struct L16Args {
   const void* x;          // (n, h, w, 64) 16-bit
-  const float* weight;    // (3, 64, 3, 3) fp32
+  const void* weight;     // 16-bit [9 taps][8 blocks][3 co][8 channels]: the (3, 64, 3, 3) parameter permuted and rounded
   const float* bias;      // [3] or NULL
   const float* residual;  // (n, 3, h, w) fp32 or NULL
   float* out;             // (n, 3, h, w) fp32
@@ -451,7 +452,6 @@ __device__ __forceinline__ float dot2_h16(unsigned a, unsigned b, float c) {
 template <bool BF16>
 __global__ __launch_bounds__(256) void conv3x3_c64to3_h16_kernel(L16Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char s_patch[HP_BYTES];      // [row][col][8 x 16-byte blocks], blocks swizzled
-  __shared__ __attribute__((aligned(16))) unsigned short s_wt[9 * 8 * 3 * 8];   // [tap][block][co][8 channels]
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x;
   int t = blockIdx.x;
@@ -460,10 +460,6 @@ __global__ __launch_bounds__(256) void conv3x3_c64to3_h16_kernel(L16Args a) {
   const int ty = t % a.tiles_y, bn = t / a.tiles_y;
   const int h = a.h, w = a.w;
   const int y0 = ty * HT_H - 1, x0 = tx * HT_W - 1;
-  for (int e = tid; e < 9 * 8 * 3 * 8; e += 256) {
-    const int j = e & 7, co = (e >> 3) % 3, tb = e / 24, sb = tb & 7, tap = tb >> 3;
-    s_wt[e] = to_h16<BF16>(a.weight[((size_t)co * 64 + sb * 8 + j) * 9 + tap]);
-  }
   const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)bn * h * w * 128;
   for (int e = tid; e < HP_PIX * 8; e += 256) {
     const int pp = e >> 3, sb = e & 7;
@@ -476,21 +472,21 @@ __global__ __launch_bounds__(256) void conv3x3_c64to3_h16_kernel(L16Args a) {
   __syncthreads();
   const int r = tid >> 5, c = tid & 31;
   float acc[3] = {a.bias ? a.bias[0] : 0.f, a.bias ? a.bias[1] : 0.f, a.bias ? a.bias[2] : 0.f};
-#pragma unroll 1      // (fully unrolled the 216 weight reads are hoisted and spill)
+  const unsigned* __restrict__ wq = reinterpret_cast<const unsigned*>(a.weight);      // uniform addresses: scalar loads
+#pragma unroll 1
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll 1
     for (int kx = 0; kx < 3; ++kx) {
       const unsigned char* px = s_patch + ((r + ky) * HP_W + c + kx) * 128;
       const int swz = ((c + kx) >> 1) & 7;
+      const unsigned* wt = wq + (ky * 3 + kx) * (8 * 3 * 4);
 #pragma unroll
       for (int sb = 0; sb < 8; ++sb) {
         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(px + ((sb ^ swz) << 4));
 #pragma unroll
-        for (int co = 0; co < 3; ++co) {
-          const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(s_wt + (((ky * 3 + kx) * 8 + sb) * 3 + co) * 8);
+        for (int co = 0; co < 3; ++co)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[co] = dot2_h16<BF16>(v[q], wv[q], acc[co]);
-        }
+          for (int q = 0; q < 4; ++q) acc[co] = dot2_h16<BF16>(v[q], wt[(sb * 3 + co) * 4 + q], acc[co]);
       }
     }
   const int gy = ty * HT_H + r, gx = tx * HT_W + c;
@@ -666,12 +662,12 @@ static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, cons
                     : launch_conv_h16<false>(a, blocks, ps ? 4 : 1, eavsr::as_stream(stream));
 }
 
-extern "C" int eavsr_conv3x3_c64to3_h16(const void* x, const float* weight, const float* bias, const float* residual, float* out,
+extern "C" int eavsr_conv3x3_c64to3_h16(const void* x, const void* weight, const float* bias, const float* residual, float* out,
                                         int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream) {
   EAVSR_REQUIRE(x && weight && out, -1, "conv3x3_c64to3_h16: NULL pointer");
   EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "conv3x3_c64to3_h16: dtype %d (1 = f16, 2 = bf16)", dtype);
   EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0, -1, "conv3x3_c64to3_h16: bad dims");
-  EAVSR_REQUIRE(((uintptr_t)x & 15) == 0, -1, "conv3x3_c64to3_h16: x must be 16-byte aligned");
+  EAVSR_REQUIRE((((uintptr_t)x | (uintptr_t)weight) & 15) == 0, -1, "conv3x3_c64to3_h16: x and weight must be 16-byte aligned");
   if (n == 0) return 0;
   L16Args a;
   a.x = x; a.weight = weight; a.bias = bias; a.residual = residual; a.out = out;

@@ -384,6 +384,8 @@ HEADS_IN_16BIT = _os.environ.get("EAVSR_HEADS_16BIT", "1") == "1"
 # Optional 16-bit residual backbone: None (exact fp32, the default and the BASELINE headline), "bf16" or "fp16"
 # (set_backbone_dtype / EAVSR_BACKBONE_DTYPE).  Only the RCAGroup internals change precision.
 BACKBONE_DTYPE = _os.environ.get("EAVSR_BACKBONE_DTYPE") or None
+if BACKBONE_DTYPE is not None:
+    ops.set_conv3_h16(BACKBONE_DTYPE)
 
 
 def set_backbone_dtype(dtype):
@@ -392,6 +394,7 @@ def set_backbone_dtype(dtype):
     if dtype is not None:
         ops.h16_code(dtype)
     BACKBONE_DTYPE = dtype
+    ops.set_conv3_h16(dtype)      # ... and the plain 3x3 convolutions outside them (first conv of a backbone, encoder): csrc/conv3_h16.hip
 
 
 import contextlib as _contextlib

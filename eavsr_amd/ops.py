@@ -362,6 +362,66 @@ def _conv_x6(x: Tensor, weights, biases, act, slope, sigmoid_from: int = -1):
     return out
 
 
+# The 16-bit modes' generic 3x3 convolution (csrc/conv3_h16.hip): None = off (fp32 everywhere, the default), "bf16" / "fp16" =
+# every plain 3x3 convolution with >= 32 output channels whose sources have channel counts % 16 == 0 rounds its operands to that
+# type (fp32 NCHW in and out).  Set by networks.set_backbone_dtype (EAVSR_CONV3_16BIT=0 keeps these convolutions fp32: A/B switch).
+CONV3_H16 = None
+CONV3_H16_ENABLED = os.environ.get("EAVSR_CONV3_16BIT", "1") == "1"
+_h16g_pack_cache = {}
+
+
+def set_conv3_h16(dtype) -> None:
+    global CONV3_H16
+    if dtype is not None:
+        h16_code(dtype)
+    CONV3_H16 = dtype if CONV3_H16_ENABLED else None
+
+
+def _packed_h16g(weights: Sequence[Tensor], code: int) -> Tensor:
+    key = tuple((id(w), w._version) for w in weights) + (code,)
+    hit = _h16g_pack_cache.get(key)
+    if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
+        return hit[1]
+    w = _chk(_cat_weights(weights).detach(), "weight")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    packed = torch.empty(int(lib().eavsr_conv3x3_h16g_weight_bytes(cout, cin)), device=w.device, dtype=torch.uint8)
+    with _DeviceOf(w):
+        N.check(lib().eavsr_pack_conv3x3_h16g(_p(w), _p(packed), cout, cin, code, _stream(w)), "pack_conv3x3_h16g")
+    ids = {id(x) for x in weights}
+    for k_ in [k_ for k_ in _h16g_pack_cache if any(isinstance(e, tuple) and e[0] in ids for e in k_)]:
+        _h16g_pack_cache.pop(k_, None)
+    refs = tuple(weakref.ref(x, lambda _r, k_=key, c=_h16g_pack_cache: c.pop(k_, None)) for x in weights)
+    _h16g_pack_cache[key] = (refs, packed)
+    return packed
+
+
+def _conv3x3_h16g(srcs, weights, biases, act, slope, dtype):
+    n, _, h, w = srcs[0].shape
+    cin = sum(int(s_.shape[1]) for s_ in srcs)
+    cout = sum(int(w_.shape[0]) for w_ in weights)
+    code = h16_code(dtype)
+    wp = _packed_h16g(weights, code)
+    b = _bias_of(biases)
+    out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
+    d = N.ConvDesc()
+    for i in range(5):
+        d.src[i] = _p(srcs[i]) if i < len(srcs) else None
+        d.src_c[i] = int(srcs[i].shape[1]) if i < len(srcs) else 0
+    d.n_src = len(srcs)
+    d.ksize = 3
+    d.weight_packed = _p(wp)
+    d.bias = _p(b)
+    d.out = _p(out)
+    d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
+    d.act = ACT[act]
+    d.slope = float(slope)
+    st = _stream(out)
+    px = float(n) * h * w
+    _launch(f"conv3x3_{cin}to{cout}_h16g", 2.0 * cin * cout * 9 * px, 4.0 * px * (cin + cout), out,
+            lambda: lib().eavsr_conv3x3_h16g_f32(C.byref(d), code, st), "conv3x3_h16g")
+    return out
+
+
 def _conv3x3_smallco(x: Tensor, weights, biases, act, slope, residual):
     n, cin, h, w = x.shape
     wt = _cat_weights(weights)
@@ -451,6 +511,10 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     if (((k == 7 and CONV7_MODE == "bf16x6") or (k == 5 and CONV5_MODE == "bf16x6")) and len(srcs) == 1 and cin % 8 == 0
             and residual is None and not chan_partial and ca is None and not pixel_shuffle2):
         return _conv_x6(srcs[0], weights, biases, act, slope, -1 if sigmoid_from is None else int(sigmoid_from))
+    if (CONV3_H16 is not None and k == 3 and sigmoid_from is None and residual is None and not chan_partial and ca is None
+            and not pixel_shuffle2 and w % 4 == 0 and cout >= 32 and not torch.is_grad_enabled()
+            and all(int(s_.shape[1]) % 16 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs)):
+        return _conv3x3_h16g(srcs, weights, biases, act, slope, CONV3_H16)
     if sigmoid_from is not None:
         if residual is not None or chan_partial or ca is not None or pixel_shuffle2:
             raise ValueError("sigmoid_from: plain convolutions only")
@@ -1497,6 +1561,7 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
 
 
 _h16_ps_cache = {}
+_h16_last_cache = {}
 
 
 def _packed_h16_ps2(weight: Tensor, bias: Optional[Tensor], code: int):
@@ -1552,9 +1617,17 @@ def conv3x3_c64to3_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], residu
     """conv_last of the tail in the 16-bit modes: x 16-bit NHWC (n,h,w,64), weight (3,64,3,3) fp32 -> fp32 NCHW (n,3,h,w) (+ residual)"""
     x = _chk_h16(x, "x")
     n, h, w, c = x.shape
-    wt = _chk(weight.detach(), "weight")
-    if c != 64 or tuple(wt.shape) != (3, 64, 3, 3):
+    if c != 64 or tuple(weight.shape) != (3, 64, 3, 3):
         raise NotImplementedError("the 16-bit conv_last kernel is the 3x3 64 -> 3 convolution")
+    key = (id(weight), weight._version, x.dtype)
+    hit = _h16_last_cache.get(key)
+    if hit is not None and hit[0]() is weight:
+        wt = hit[1]
+    else:      # [ky][kx][8-channel block][co][8 channels], rounded to the activation type (scalar loads in the kernel)
+        wt = _chk(weight.detach(), "weight").view(3, 8, 8, 3, 3).permute(3, 4, 1, 0, 2).contiguous().to(x.dtype)
+        for k in [k for k in _h16_last_cache if k[0] == id(weight)]:
+            _h16_last_cache.pop(k, None)
+        _h16_last_cache[key] = (weakref.ref(weight, lambda _r, k=key, c=_h16_last_cache: c.pop(k, None)), wt)
     b = None if bias is None else _chk(bias.detach(), "bias")
     r = None if residual is None else _chk(residual, "residual")
     if r is not None and tuple(r.shape) != (n, 3, h, w):

@@ -455,12 +455,23 @@ int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float*
  *   (:343-352) as four 64 -> 64 slices of the same kernel: weight_packed = FOUR packed matrices, slice k = 2 dy + dx holding the
  *   reference weight's output channels 4 c + k as its channel c (c = 0..63), bias likewise (4 x 64 floats); out is (n, 2 h, 2 w, 64)
  *   16-bit NHWC, output pixel (2 y + dy, 2 x + dx) = slice k's pixel (y, x) -- the shuffle is the store pattern.
- * eavsr_conv3x3_c64to3_h16: conv_last (:359-360): x 16-bit NHWC (n, h, w, 64), weight (3, 64, 3, 3) fp32 (rounded to the 16-bit
- *   type inside the kernel), fp32 accumulation, out fp32 NCHW (n, 3, h, w) = conv + bias + residual (nullable: the bilinear skip). */
+ * eavsr_conv3x3_c64to3_h16: conv_last (:359-360): x 16-bit NHWC (n, h, w, 64); weight: the (3, 64, 3, 3) parameter permuted to
+ *   [ky][kx][8-channel block][co][8 channels] and rounded to the 16-bit type by the caller (1,728 values: w.view(3, 8, 8, 3, 3)
+ *   .permute(3, 4, 1, 0, 2)); fp32 accumulation, out fp32 NCHW (n, 3, h, w) = conv + bias + residual (nullable: the bilinear skip). */
 int eavsr_conv3x3_c64_h16_act(const void* x, const void* weight_packed, const float* bias, void* out, int32_t n, int32_t h,
                               int32_t w, int32_t act, float slope, int32_t pixel_shuffle2, int32_t dtype, void* stream);
-int eavsr_conv3x3_c64to3_h16(const void* x, const float* weight, const float* bias, const float* residual, float* out,
+int eavsr_conv3x3_c64to3_h16(const void* x, const void* weight, const float* bias, const float* residual, float* out,
                              int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
+/* Generic 3x3 convolution of the 16-bit modes (csrc/conv3_h16.hip): same descriptor as eavsr_conv2d_f32 (fp32 NCHW sources as a
+ * virtual concatenation, fp32 NCHW out = act(conv + bias)), the operands rounded once to the 16-bit type, fp32 accumulation.
+ * Takes the 3x3 convolutions that are not the 64 -> 64 NHWC backbone kernel when the caller opted into a 16-bit mode: the first
+ * convolution of each residual backbone (models/eavsrp_model.py:375-381 over the concatenated feature lists) and the encoder's
+ * layers (models/networks.py:522-552).  ksize 3, every source's channel count a multiple of 16, w % 4 == 0, 16-byte aligned
+ * sources; no residual / channel sums / channel-attention prologue / pixel shuffle (-2).  weight_packed: eavsr_pack_conv3x3_h16g
+ * (cout, cin, 3, 3) fp32 -> eavsr_conv3x3_h16g_weight_bytes(cout, cin) bytes, a cache of the library version that made it. */
+int64_t eavsr_conv3x3_h16g_weight_bytes(int32_t cout, int32_t cin);
+int eavsr_pack_conv3x3_h16g(const float* weight, void* packed, int32_t cout, int32_t cin, int32_t dtype, void* stream);
+int eavsr_conv3x3_h16g_f32(const eavsr_conv2d_desc* desc, int32_t dtype, void* stream);
 /* The predictor's three 5x5 heads (transform_matrix_conv ++ translation_conv ++ mask_conv, models/networks.py:283-285,
  * 298-301) in the 16-bit modes (csrc/conv5_h16.hip): x 16-bit NHWC (n, h, w, 64) -- the front-end feature through
  * eavsr_nchw_f32_to_nhwc_h16 --, weight (cout, 64, 5, 5) fp32 rounded once by the pack call (cout <= 128), fp32 accumulation,

@@ -61,6 +61,33 @@ def test_conv3x3_c64_h16_act_and_pixel_shuffle_vs_fp32_on_rounded_inputs(ops, cu
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,h,w,cins,cout,act", [(1, 16, 32, (64,), 64, "relu"), (2, 19, 36, (64, 64), 64, "lrelu"),
+                                                 (1, 45, 80, (64, 64, 64, 64, 64), 64, "lrelu"), (1, 33, 40, (128,), 256, None),
+                                                 (1, 20, 44, (256,), 64, None), (2, 7, 8, (64, 16), 96, "relu"),
+                                                 (1, 16, 32, (32,), 40, "lrelu")])
+def test_conv3x3_h16g_vs_fp64_on_rounded_inputs(ops, cuda, dt, n, h, w, cins, cout, act):
+    """the generic 3x3 convolution of the 16-bit modes (first conv of a backbone over the concatenated feature lists, encoder
+    layers): fp32 NCHW in / out, operands rounded once to the 16-bit type, fp32 accumulation -- against an fp64 convolution
+    of the same rounded operands; and `ops.conv2d` routes to it only while the mode is set"""
+    srcs = [cases.randn(31 + i, n, c, h, w) for i, c in enumerate(cins)]
+    cin = sum(cins)
+    wt = cases.randn(41, cout, cin, 3, 3, scale=1.0 / (3.0 * cin ** 0.5))
+    b = cases.randn(42, cout, scale=0.1)
+    fact = {"lrelu": lambda z: F.leaky_relu(z, 0.1), "relu": F.relu, None: lambda z: z}[act]
+    ref = fact(F.conv2d(torch.cat(srcs, 1).to(DT[dt]).double(), wt.to(DT[dt]).double(), b.double(), 1, 1))
+    assert ops.CONV3_H16 is None
+    ops.set_conv3_h16(dt)
+    try:
+        with torch.no_grad(), ops.profile() as prof:
+            got = ops.conv2d([s_.to(cuda) for s_ in srcs], wt.to(cuda), b.to(cuda), act=act, slope=0.1).cpu()
+    finally:
+        ops.set_conv3_h16(None)
+    assert f"conv3x3_{cin}to{cout}_h16g" in prof.summary()
+    assert got.shape == (n, cout, h, w) and got.dtype == torch.float32
+    assert H.maxabs(got.double(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())      # exact 16-bit products, fp32 accumulation
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape,res", [((1, 8, 32), True), ((2, 19, 37), False), ((1, 45, 80), True), ((3, 7, 5), True)])
 def test_conv3x3_c64to3_h16_vs_fp64_on_rounded_inputs(ops, cuda, dt, shape, res):
     """conv_last of the tail (eavsrp_model.py:359-360) in the 16-bit modes: fp32 NCHW out (+ the skip image)"""
