@@ -655,11 +655,12 @@ def main():
             fp32_dom = entry(dom_name, "mfma")
             dom_name = "conv3x3_64to64_h16"
         dom = entry(dom_name, "mfma")
-        if fp32_dom is not None and dom is not None:
+        if dom_name == "conv3x3_64to64_h16" and dom is not None:
             hb = entry(dom_name, "hbm")
             dom["algorithm"] = "direct sum, 16-bit operands, fp32 accumulation, 16-bit MFMA (csrc/conv_h16.hip)"
             dom["hbm"] = {k: hb[k] for k in ("achieved", "peak", "unit", "frac")}
-            dom["fp32_kernel_of_the_same_shape_outside_the_groups"] = {k: fp32_dom[k] for k in ("kernel", "frac", "avg_ms", "share_of_step")}
+            if fp32_dom is not None:      # (none since the tail and the other 3x3 convolutions run in 16 bits as well)
+                dom["fp32_kernel_of_the_same_shape_outside_the_groups"] = {k: fp32_dom[k] for k in ("kernel", "frac", "avg_ms", "share_of_step")}
         if args.backbone_dtype != "fp32":
             # which kernels of the step ran in 16 bits (the rest is fp32), with their share of the step's kernel time
             names16 = ("conv3x3_64to64_h16", "conv3x3_64to256_h16_ps2", "conv3x3_64to3_h16", "scale_residual_h16", "dcnv2_il16_heads",

@@ -167,6 +167,15 @@ def test_round4_bench_line_names_its_evidence():
     assert syn["sigma_4.0"]["avg_ms"] > syn["sigma_0.5"]["avg_ms"] > 0.0
     assert dcn["on_torch_rand_clips"]["calls"] == dcn["calls"] and dcn["on_torch_rand_clips"]["avg_ms"] > 0.0
     assert line["config"]["dcnv2_schedule"].startswith("eavsr_dcnv2_il2_f32") and "conv3x3_wino4_schedule" in line["config"]
+    # the default run also measures the other BASELINE configurations (child processes): their lines are part of the evidence
+    oc = {e["config"]: e for e in line["other_configs"]}
+    assert set(oc) == {2, 3, 4} and not any("error" in e or "skipped" in e for e in oc.values())
+    assert "configs[2]" in oc[2]["metric"] and "bf16" in oc[2]["dtype"] and oc[2]["psnr_vs_fp32"]["psnr_db"] > 50.0
+    assert "configs[4]" in oc[4]["metric"] and "fp16" in oc[4]["dtype"] and oc[4]["psnr_vs_fp32"]["psnr_db"] > 60.0
+    assert "training" in oc[3]["metric"] and oc[3]["value"] > 0 and "HIP graph" in oc[3]["launch"]
+    for k in (2, 4):
+        assert oc[k]["timed_output_check"]["bit_identical"] and 0.5 < oc[k]["share_of_step_in_16bit"] < 1.0
+        assert "h16" in oc[k]["roofline"]["kernel"] and oc[k]["roofline"]["peak"] == 2500.0 and 0.0 < oc[k]["roofline"]["hbm"]["frac"] < 1.0
     for tag, frames in (("config2_bf16", 7), ("config4_fp16", 15)):
         l2 = json.loads(open(os.path.join(ROOT, "profiles", f"r04_bench_line_{tag}.json")).read().strip().splitlines()[-1])
         c = l2["cpu_baseline"]
