@@ -10,8 +10,8 @@
 //   consecutive input channels of its pixel at one tap = one ds_read_b128 from the NHWC patch (XOR-swizzled 16-byte blocks).
 //   Workgroup = 8 waves, output tile 16 x 32 pixels x 128 channels; wave w owns rows 2w, 2w+1 (A operands shared by both rows):
 //   per tap 4 channel blocks x 4 M-tiles x 2 rows = 32 MFMAs per wave for 16 + 8 ds_read_b128.
-//   The 400 KB of weights do not fit the LDS: one tap (128 co x 64 ci x 2 B = 16 KB) per stage, two stages, LDS-DMA of tap t+1
-//   behind the MFMAs of tap t, one barrier per tap.  The 16-row tile halves the weight re-streaming per pixel (98 MB of
+//   The 400 KB of weights do not fit the LDS: TWO taps (2 x 128 co x 64 ci x 2 B = 32 KB) per stage, two stages, LDS-DMA of the
+//   next pair behind the MFMAs of this one, one barrier per pair of taps (13 per tile).  The 16-row tile halves the weight re-streaming per pixel (98 MB of
 //   L2 -> LDS traffic per launch against 21 us of MFMA per tile).
 //   Output: fp32 NCHW (n, cout, h, w) -- the "heads" operand of eavsr_dcnv2_il16 / eavsr_affine_offsets_f32.
 #include "common.h"
@@ -34,7 +34,8 @@ constexpr int FP_IT = (FP_SEGS + 7) / 8;                        // 12
 constexpr int FCO = 128;                                        // output channels, padded
 constexpr int FW_TAP = FCO * 64 * 2;                            // 16,384 B per tap
 constexpr int FW_SEGS = FW_TAP / 1024;                          // 16 = 2 per wave
-constexpr int F_LDS_BYTES = FP_SEGS * 1024 + 2 * FW_TAP;        // 124,928
+constexpr int FW_PAIR = 2 * FW_TAP;                             // a weight stage holds TWO taps: half as many barriers
+constexpr int F_LDS_BYTES = FP_SEGS * 1024 + 2 * FW_PAIR;       // 157,696
 
 struct F16Args {
   const void* x;      // (n, h, w, 64) 16-bit
@@ -75,12 +76,15 @@ __global__ __launch_bounds__(512, 2) void conv5x5_c64_h16_kernel(F16Args a) {
   const int l31 = lane & 31, half = lane >> 5;
   const int h = a.h, w = a.w;
 
-  auto issue_tap = [&](int tap, int stage) {
-    const char* src = reinterpret_cast<const char*>(a.wp) + (size_t)tap * FW_TAP;
+  // taps 2 pr, 2 pr + 1 (the last pair is the 25th tap alone) into stage `stage`
+  auto issue_pair = [&](int pr, int stage) {
+    const char* src = reinterpret_cast<const char*>(a.wp) + (size_t)pr * FW_PAIR;
+    const int segs = 2 * pr + 1 < FR * FR ? 2 * FW_SEGS : FW_SEGS;
 #pragma unroll
-    for (int i = 0; i < FW_SEGS / 8; ++i) {
+    for (int i = 0; i < 2 * FW_SEGS / 8; ++i) {
       const int seg = i * 8 + wave;
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + seg * 1024 + lane * 16), (lptr_t)(s_w + stage * FW_TAP + seg * 1024), 16, 0, 0);
+      if (seg < segs)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + seg * 1024 + lane * 16), (lptr_t)(s_w + stage * FW_PAIR + seg * 1024), 16, 0, 0);
     }
   };
 
@@ -111,28 +115,37 @@ __global__ __launch_bounds__(512, 2) void conv5x5_c64_h16_kernel(F16Args a) {
         }
       }
     }
-    issue_tap(0, 0);
+    issue_pair(0, 0);
 
+    // the bias is the accumulators' initial value, through LDS (weight stage 1, free until the second pair of taps is requested
+    // behind the first barrier): 128 global loads per lane in the epilogue, one in front of every store, were a third of a tile's time
+    float* s_bias = reinterpret_cast<float*>(s_w + FW_PAIR);
+    if (tid < FCO) s_bias[tid] = (a.bias && tid < a.cout) ? a.bias[tid] : 0.f;
+    __syncthreads();
     f32x16 acc[2][4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[r][m][e] = 0.f;
+      for (int e = 0; e < 16; ++e) {
+        const float bv = s_bias[m * 32 + (e & 3) + 8 * (e >> 2) + 4 * half];
+        acc[0][m][e] = bv;
+        acc[1][m][e] = bv;
+      }
 
 #pragma unroll 1
     for (int tap = 0; tap < FR * FR; ++tap) {
-      const int stage = tap & 1;
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __syncthreads();           // this tap's weights (and the patch) landed; the other weight stage has been read
-      if (tap + 1 < FR * FR) issue_tap(tap + 1, stage ^ 1);
+      const int pr = tap >> 1, stage = pr & 1;
+      if ((tap & 1) == 0) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();           // this pair's weights (and the patch) landed; the other weight stage has been read
+        if (2 * pr + 2 < FR * FR) issue_pair(pr + 1, stage ^ 1);
+      }
       const int ky = tap / FR, kx = tap - FR * ky;
       const int c = l31 + kx;
       const int swz = (c >> 1) & 7;
       const unsigned char* prow0 = s_p + (((2 * wave + ky) * FP_W + c) << 7);
       const unsigned char* prow1 = prow0 + (FP_W << 7);
-      const unsigned char* wst = s_w + stage * FW_TAP;
+      const unsigned char* wst = s_w + stage * FW_PAIR + (tap & 1) * FW_TAP;
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {
         const int boff = ((cb * 2 + half) ^ swz) << 4;
@@ -147,20 +160,25 @@ __global__ __launch_bounds__(512, 2) void conv5x5_c64_h16_kernel(F16Args a) {
       }
     }
 
-    // epilogue: + bias, fp32 NCHW stores (32 consecutive pixels of one channel per half wave)
+    // epilogue: fp32 NCHW stores (32 consecutive pixels of one channel per half wave).  The lane's column goes through an empty
+    // asm so that the address arithmetic stays HERE: hoisted above the tap loop its 128 64-bit results spilled, and every store
+    // sat behind a scratch load (a third of a tile's time).  One base per row, the channel advances by pointer increments.
     const size_t plane = (size_t)h * w;
-    const int gx = tx * FT_W + l31;
+    int gx = tx * FT_W + l31;
+    asm volatile("" : "+v"(gx));
+    const bool full = a.cout == FCO;      // wave-uniform
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int gy = ty * FT_H + 2 * wave + r;
       if (gy < h && gx < w) {
-        float* ob = a.out + (size_t)bn * a.cout * plane + (size_t)gy * w + gx;
+        float* ob = a.out + ((size_t)bn * a.cout + 4 * half) * plane + (size_t)gy * w + gx;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int co = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            if (co < a.cout) ob[(size_t)co * plane] = acc[r][m][e] + (a.bias ? a.bias[co] : 0.f);
+            const int cu = m * 32 + (e & 3) + 8 * (e >> 2);      // channel cu + 4 half
+            if (full || cu + 4 * half < a.cout) *ob = acc[r][m][e];
+            ob += ((e & 3) == 3 ? 5 : 1) * plane;                  // one plane on, five across a group of four
           }
       }
     }
