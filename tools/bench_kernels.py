@@ -50,5 +50,27 @@ if "warp" in which:
         ops.flow_warp(x64, flow)
     for _ in range(reps):
         ops.flow_warp_pair(x64, x64, flow, b_il8=True)
+if "h16" in which:
+    # the 16-bit modes' kernels at configs[2]'s sub-batch shape (4 x 64 x 256 x 256 bf16): backbone conv, generic 3x3 (320 -> 64 over
+    # five sources, 128 -> 256), predictor heads, one conv + PixelShuffle(2) stage, conv_last
+    hn, hh, hw = 4, 256, 256
+    xs = [r(hn, 64, hh, hw) for _ in range(5)]
+    x16 = ops.to_nhwc_h16(xs[0], "bf16")
+    w320, w256 = r(64, 320, 3, 3) * 0.02, r(256, 128, 3, 3) * 0.03
+    x128 = r(hn, 128, hh, hw)
+    wps, bps = r(256, 64, 3, 3) * 0.05, r(256) * 0.1
+    wl, bl = r(3, 64, 3, 3) * 0.05, r(3) * 0.1
+    heads_w = [r(32, 64, 5, 5) * 0.02, r(16, 64, 5, 5) * 0.02, r(72, 64, 5, 5) * 0.02]
+    heads_b = [r(32) * 0.1, r(16) * 0.1, r(72) * 0.1]
+    ops.set_conv3_h16("bf16")
+    with torch.no_grad():
+        for _ in range(reps):
+            ops.conv3x3_c64_h16(x16, w33, b, relu=True)
+            ops.conv2d(xs, w320, b, act="lrelu", slope=0.1)
+            ops.conv2d(x128, w256, None)
+            ops.conv5x5_c64_h16(x16, heads_w, heads_b)
+            y16 = ops.conv3x3_c64_h16_act(x16, wps, bps, act="lrelu", slope=0.1, pixel_shuffle2=True)
+            ops.conv3x3_c64to3_h16(y16, wl, bl)
+    ops.set_conv3_h16(None)
 torch.cuda.synchronize()
 print("done")

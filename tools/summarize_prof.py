@@ -17,6 +17,8 @@ if stats:
         print(f"{float(r['Percentage']):6.2f}%  calls {int(r['Calls']):6d}  avg {float(r['AverageNs'])/1e3:10.1f} us  {r['Name'][:110]}")
 print()
 hot = ("conv_wino6_kernel<3, false", "conv_wino6_kernel<5, false", "conv_x6_kernel<5", "conv_x6_kernel<7", "conv3x3_wino_kernel", "conv2d_mfma_kernel", "dcnv2_grp_kernel", "dcnv2_il_kernel<6, true>", "dcnv2_il_kernel<6, false>", "dcnv2_il2_kernel<6, 1>", "dcnv2_il2_kernel<6, 0>", "dcnv2_il2_kernel<6, 2>", "flow_warp_kernel", "flow_warp_pair_kernel")
+if os.environ.get("HOT"):      # another set of kernels (tools/gpu_profile_h16.sh): substrings of the kernel names, ';'-separated
+    hot = tuple(os.environ["HOT"].split(";"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob(os.path.join(root, "pmc_*", "*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(d)):
@@ -29,7 +31,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_sq", "*", "*kernel_trace.csv")
         for hname in hot:
             if hname in r["Kernel_Name"]:
                 dur[hname].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-print("== PMC (tools/bench_kernels.py: 2 x 64 x 180 x 320 fp32 = one sub-batch of the default bench; one counter group per pass)")
+print(os.environ.get("PMC_TITLE", "== PMC (tools/bench_kernels.py: 2 x 64 x 180 x 320 fp32 = one sub-batch of the default bench; one counter group per pass)"))
 traffic = {}
 for hname in hot:
     c = {k: sum(v) / len(v) for k, v in agg[hname].items()}
