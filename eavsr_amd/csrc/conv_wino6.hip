@@ -415,10 +415,34 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     if (R == 3) {
       // the 6 x 6 patch of tile column l15 starts at column MARG - 1 + 4 l15 = 3 + 4 l15: one b32, one aligned b128, one b32
       const float* pp = smem + ps * IN_PAD + kq * (IH * IW) + (M * tg) * IW + 4 * l15;
+#if !defined(EAVSR_W4_COMPILER_READS)
+      // Grouped schedule: ONE wave per SIMD runs this transform while the others wait at a barrier, so every exposed LDS round
+      // trip is the phase's time.  Left to the compiler the twelve single-dword reads of columns 0 / 5 were sunk behind the first
+      // column passes and each batch waited for with `lgkmcnt(0)` right behind its issue (two exposed round trips).  All eighteen
+      // reads up front as inline assembly, the six quads first: the column passes on them start behind `lgkmcnt(12)` (the counter
+      // is in order) while the twelve dwords land.
+      constexpr bool HAND_READS = GRP;
+#else
+      constexpr bool HAND_READS = false;
+#endif
+      f32x2 e05[6];
       {
         f32x4 q[6];
+        if constexpr (HAND_READS) {
+          const unsigned pp_l = (unsigned)(unsigned long long)(lptr_t)pp;
+#define W4_RDQ(R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q[R]) : "v"(pp_l), "n"(((R) * IW + 4) * 4))
+#define W4_RDE(R)                                                                                              \
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(e05[R].x) : "v"(pp_l), "n"(((R) * IW + 3) * 4));        \
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(e05[R].y) : "v"(pp_l), "n"(((R) * IW + 8) * 4))
+          W4_RDQ(0); W4_RDQ(1); W4_RDQ(2); W4_RDQ(3); W4_RDQ(4); W4_RDQ(5);
+          W4_RDE(0); W4_RDE(1); W4_RDE(2); W4_RDE(3); W4_RDE(4); W4_RDE(5);
+#undef W4_RDQ
+#undef W4_RDE
+          asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]));
+        } else {
 #pragma unroll
-        for (int r = 0; r < 6; ++r) q[r] = *reinterpret_cast<const f32x4*>(pp + r * IW + 4);
+          for (int r = 0; r < 6; ++r) q[r] = *reinterpret_cast<const f32x4*>(pp + r * IW + 4);
+        }
         if (FUSE) {
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
@@ -446,8 +470,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       }
       {
         f32x2 d[6];
+        if constexpr (HAND_READS) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e05[0]), "+v"(e05[1]), "+v"(e05[2]), "+v"(e05[3]), "+v"(e05[4]), "+v"(e05[5]));
 #pragma unroll
-        for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW + 3], pp[r * IW + 8]};
+          for (int r = 0; r < 6; ++r) d[r] = e05[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) d[r] = f32x2{pp[r * IW + 3], pp[r * IW + 8]};
+        }
         if (FUSE) {
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
