@@ -666,7 +666,7 @@ def main():
             names16 = ("conv3x3_64to64_h16", "conv3x3_64to256_h16_ps2", "conv3x3_64to3_h16", "scale_residual_h16", "dcnv2_il16_heads",
                        "dcnv2_il16", "nchw_f32_to_nhwc_h16", "nhwc_h16_to_nchw_f32")
             heads16 = tuple(k for k in summ if (k.startswith("conv5x5_") and k.endswith("_h16"))      # the predictor's 5x5 heads
-                            or k.endswith("_h16g"))                                                  # generic 3x3 (csrc/conv3_h16.hip)
+                            or k.endswith(("_h16g", "_h16x1")))                                      # generic 3x3 (csrc/conv3_h16.hip), SPyNet 7x7 (one plane of conv_x6.hip)
             line["kernels_16bit"] = [e for e in (entry(k, "hbm") for k in names16) if e]
             line["kernels_16bit"] += [e for e in (entry(k, "mfma") for k in heads16) if e]
             names16 = names16 + heads16

@@ -134,6 +134,9 @@ SIGNATURES = {
     "eavsr_conv3x3_h16g_weight_bytes": (C.c_int64, [i32, i32]),
     "eavsr_pack_conv3x3_h16g": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "eavsr_conv3x3_h16g_f32": (C.c_int, [vp, i32, vp]),
+    "eavsr_conv_weight_h16x1_bytes": (C.c_size_t, [i32, i32, i32]),
+    "eavsr_pack_conv_weight_h16x1": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_conv_h16x1": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "eavsr_nchw_f32_to_nhwc_h16": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_nhwc_h16_to_nchw_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_scale_residual_h16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),

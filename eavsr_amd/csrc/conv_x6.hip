@@ -39,7 +39,9 @@ constexpr int S_NW = 8, S_TW = 32;
 // KS: kernel size (7, 5); MT: 32-channel output tiles per workgroup; NT: image rows per wave (tile = 8 NT rows x 32 pixels).
 // NT = 1 and MT = 1 exist for the coarse pyramid levels, where a launch is a handful of workgroups and its time is ONE
 // workgroup's chain of k-steps.
-template <int KS, int MT, int NT> struct C7 {
+// NP: operand planes -- 3 = the exact fp32 split (six partial products), 1 = the 16-bit modes' form (operands rounded ONCE to
+// bf16 / fp16, one product; eavsr_conv_h16x1: SPyNet's 7x7 layers under BASELINE configs[2] / [4]).
+template <int KS, int MT, int NT, int NP = 3> struct C7 {
   static constexpr int PAD = KS / 2, KK = KS * KS;
   static constexpr int KSTEPS = (KK + 1) / 2;                  // tap pairs per chunk: 25 (49 taps + a zero tap), 13 (25 + one)
   static constexpr int SLAB = KS == 7 ? 5 : 7;                 // k-steps per weight slab (the last slab of a 5x5 chunk has 6)
@@ -49,8 +51,8 @@ template <int KS, int MT, int NT> struct C7 {
   static constexpr int IW = S_TW + KS;                         // columns x0-PAD .. x0+32+PAD-1, and one that stays zero (the zero tap)
   static constexpr int NPIX = IH * IW;
   static constexpr int PLANE_B = NPIX * 16;                    // bytes of one bf16 plane of the patch (8 channels per pixel)
-  static constexpr int PATCH_B = 3 * PLANE_B;                  // 7x7: 41,184 (NT = 2); 5x5: 35,520
-  static constexpr int KS_U4 = 3 * MT * 64;                    // 16-byte elements of one k-step's A operands
+  static constexpr int PATCH_B = NP * PLANE_B;                 // 7x7: 41,184 (NT = 2); 5x5: 35,520 (three planes)
+  static constexpr int KS_U4 = NP * MT * 64;                   // 16-byte elements of one k-step's A operands
   static constexpr int SLAB_U4 = SLAB * KS_U4;                 // of a (full) weight slab
   static constexpr size_t LDS_BYTES = 2 * (size_t)PATCH_B + 2 * (size_t)SLAB_U4 * 16 + 64 * 4;   // 7x7: 144,064, 5x5: 157,312 at MT = NT = 2
   static_assert(NPIX <= 1024, "two patch pixels per thread");
@@ -82,6 +84,17 @@ __device__ __forceinline__ void s_split2(float a, float b, unsigned& hi, unsigne
 __device__ __forceinline__ f32x16 s_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+typedef _Float16 s_h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 s_mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(s_h16x8, a), __builtin_bit_cast(s_h16x8, b), c, 0, 0, 0);
+}
+// two fp32 values rounded (nearest even) to one packed 16-bit pair: DT 1 = fp16, 2 = bf16
+template <int DT> __device__ __forceinline__ unsigned s_round2(float a, float b) {
+  if (DT == 1) return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)b) << 16);
+  typedef float f2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f2_{a, b}, b2_));
+}
 
 #ifdef EAVSR_C7_STAMPS
 // diagnostic build only (tools/build_c7_diag.sh): shader cycles per phase, summed over wave 0 of every workgroup
@@ -96,9 +109,10 @@ __device__ unsigned long long g_c7_stamps[8];
 #define C7_STAMP(i) do { } while (0)
 #endif
 
-template <int KS, int MT, int NT, int WMT>
+template <int KS, int MT, int NT, int WMT, int NP = 3, int DT = 0>
 __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
-  using K = C7<KS, MT, NT>;
+  static_assert((NP == 3 && DT == 0) || (NP == 1 && (DT == 1 || DT == 2)), "three exact bf16 planes, or one rounded fp16 / bf16 plane");
+  using K = C7<KS, MT, NT, NP>;
   constexpr int S_NT = NT, S_TH = K::TH, S_NPIX = K::NPIX, S_PLANE_B = K::PLANE_B, S_PATCH_B = K::PATCH_B;
   constexpr int S_PAD = K::PAD, S_IW = K::IW, S_KSTEPS = K::KSTEPS, S_SLAB = K::SLAB, S_NSLAB = K::NSLAB;
 #ifdef EAVSR_C7_STAMPS
@@ -157,15 +171,19 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (i == 0 ? tid >= S_NPIX : !second) break;          // (5x5 on 8-row tiles: 444 patch pixels)
-      u32x4 pl[3];
+      u32x4 pl[NP];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        unsigned h2, m2, l2;
-        s_split2(pv[i][2 * c], pv[i][2 * c + 1], h2, m2, l2);
-        pl[0][c] = h2; pl[1][c] = m2; pl[2][c] = l2;
+        if constexpr (NP == 3) {
+          unsigned h2, m2, l2;
+          s_split2(pv[i][2 * c], pv[i][2 * c + 1], h2, m2, l2);
+          pl[0][c] = h2; pl[1][c] = m2; pl[2][c] = l2;
+        } else {
+          pl[0][c] = s_round2<DT>(pv[i][2 * c], pv[i][2 * c + 1]);
+        }
       }
 #pragma unroll
-      for (int p3 = 0; p3 < 3; ++p3)
+      for (int p3 = 0; p3 < NP; ++p3)
         *reinterpret_cast<u32x4*>(s_patch + stage * S_PATCH_B + p3 * S_PLANE_B + plo[i]) = pl[p3];
     }
   };
@@ -177,11 +195,11 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
   const int wcot = cot / wsplit_n, wsub = (cot - wcot * wsplit_n) * MT;
   auto issue_slab = [&](int gs, int ch, int si) __attribute__((always_inline)) {      // si (slab of its chunk) is a constant at every call
     const int nks = (si + 1) * S_SLAB <= S_KSTEPS ? S_SLAB : S_KSTEPS - si * S_SLAB;   // k-steps of this slab
-    const int segs = nks * 3 * MT;
+    const int segs = nks * NP * MT;
     const char* wsrc = reinterpret_cast<const char*>(a.wsplit + (((size_t)wcot * nch + ch) * S_KSTEPS + si * S_SLAB) * (K::KS_U4 * wsplit_n));
     u32x4* dst = s_w + (gs & 1) * K::SLAB_U4;
 #pragma unroll
-    for (int i = 0; i < (S_SLAB * 3 * MT + S_NW - 1) / S_NW; ++i) {
+    for (int i = 0; i < (S_SLAB * NP * MT + S_NW - 1) / S_NW; ++i) {
       const int seg = i * S_NW + wave;                      // piece (k-step, plane, tile m) = seg / MT, seg % MT of this workgroup
       if (seg < segs) {  // wave-uniform
         const int sp = MT == 1 ? seg * WMT + wsub : (seg >> 1) * WMT + wsub + (seg & 1);
@@ -200,18 +218,18 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
   const int b_same = bbase + (kg ? 16 : 0);
   const int b_wrap = bbase + (kg ? (S_IW - (KS - 1)) * 16 : 0);
   const int b_last = kg ? (S_IW - 1) * 16 - ((KS - 1) * S_IW + KS - 1) * 16 : bbase;
-  auto read_b = [&](int stage, int s, u32x4 (&b)[S_NT][3]) __attribute__((always_inline)) {
+  auto read_b = [&](int stage, int s, u32x4 (&b)[S_NT][NP]) __attribute__((always_inline)) {
     const int tap0 = 2 * s, ky = tap0 / KS, kx = tap0 - KS * ky;
     const unsigned char* base = s_patch + stage * S_PATCH_B + ((s == S_KSTEPS - 1 ? b_last : kx == KS - 1 ? b_wrap : b_same) + (ky * S_IW + kx) * 16);
 #pragma unroll
     for (int t = 0; t < S_NT; ++t)
 #pragma unroll
-      for (int p3 = 0; p3 < 3; ++p3) b[t][p3] = *reinterpret_cast<const u32x4*>(base + t * S_IW * 16 + p3 * S_PLANE_B);
+      for (int p3 = 0; p3 < NP; ++p3) b[t][p3] = *reinterpret_cast<const u32x4*>(base + t * S_IW * 16 + p3 * S_PLANE_B);
   };
-  auto read_a = [&](int gs, int sl, u32x4 (&av)[3][MT]) __attribute__((always_inline)) {
+  auto read_a = [&](int gs, int sl, u32x4 (&av)[NP][MT]) __attribute__((always_inline)) {
     const u32x4* ws = s_w + (gs & 1) * K::SLAB_U4 + sl * K::KS_U4 + lane;
 #pragma unroll
-    for (int p3 = 0; p3 < 3; ++p3)
+    for (int p3 = 0; p3 < NP; ++p3)
 #pragma unroll
       for (int m = 0; m < MT; ++m) av[p3][m] = ws[(p3 * MT + m) * 64];
   };
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
       for (int t = 0; t < S_NT; ++t) acc[m][t][r] = bv;
     }
   if (nslabs > 1) issue_slab(1, S_NSLAB > 1 ? 0 : 1, S_NSLAB > 1 ? 1 : 0);
-  u32x4 acur[3][MT], bcur[S_NT][3];
+  u32x4 acur[NP][MT], bcur[S_NT][NP];
   read_a(0, 0, acur);
   read_b(0, 0, bcur);
   C7_STAMP(0);      // prologue
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
       }
       if (ks == STORE_KS && more) store_patch(pst ^ 1);     // published by the slab barriers behind it
       // operands of the next k-step
-      u32x4 anext[3][MT], bnext[S_NT][3];
+      u32x4 anext[NP][MT], bnext[S_NT][NP];
       const bool last = ks == S_KSTEPS - 1;
       if (!last) {
         read_a(slab_end ? gs + 1 : gs, slab_end ? 0 : sl + 1, anext);
@@ -279,30 +297,38 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           f32x16 c_ = acc[m][t];
-          c_ = s_mfma(acur[2][m], bcur[t][0], c_);
-          c_ = s_mfma(acur[0][m], bcur[t][2], c_);
-          c_ = s_mfma(acur[1][m], bcur[t][1], c_);
-          c_ = s_mfma(acur[1][m], bcur[t][0], c_);
-          c_ = s_mfma(acur[0][m], bcur[t][1], c_);
-          c_ = s_mfma(acur[0][m], bcur[t][0], c_);
+          if constexpr (NP == 3) {
+            c_ = s_mfma(acur[2][m], bcur[t][0], c_);
+            c_ = s_mfma(acur[0][m], bcur[t][2], c_);
+            c_ = s_mfma(acur[1][m], bcur[t][1], c_);
+            c_ = s_mfma(acur[1][m], bcur[t][0], c_);
+            c_ = s_mfma(acur[0][m], bcur[t][1], c_);
+            c_ = s_mfma(acur[0][m], bcur[t][0], c_);
+          } else if constexpr (DT == 1) {
+            c_ = s_mfma_f16(acur[0][m], bcur[t][0], c_);
+          } else {
+            c_ = s_mfma(acur[0][m], bcur[t][0], c_);
+          }
           acc[m][t] = c_;
         }
       // issue order: the next k-step's reads go out between the first MFMAs of this one (one MFMA, one read, ..), the rest of
       // the MFMAs cover their latency; nothing crosses the end of the k-step (the scheduler otherwise sinks every read to just
       // in front of its first use, behind an s_waitcnt lgkmcnt(0))
       {
-        constexpr int NRD = 3 * MT + 3 * S_NT, NMF = 6 * MT * S_NT;
+        constexpr int NRD = NP * MT + NP * S_NT, NMF = (NP == 3 ? 6 : 1) * MT * S_NT;
+        constexpr int NIL = NRD < NMF ? NRD : NMF;      // (one product per operand pair: fewer MFMAs than reads on the small tiles)
 #pragma unroll
-        for (int i = 0; i < NRD; ++i) {
+        for (int i = 0; i < NIL; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // (the MFMA first: its wait for the operands read during the
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      //  previous k-step then does not cover a read issued just now)
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+        if constexpr (NMF > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+        if constexpr (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (!last || more) {
 #pragma unroll
-        for (int p3 = 0; p3 < 3; ++p3) {
+        for (int p3 = 0; p3 < NP; ++p3) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) acur[p3][m] = anext[p3][m];
 #pragma unroll
@@ -349,14 +375,15 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
 
 // (cout, cin, KS, KS) fp32 -> [cot][chunk][k-step][plane][mt][lane] 16-byte elements: lane (r = lane & 31, g = lane >> 5) holds
 // A[row r][k = 8 g + j] = W[cot * 32 MT + mt * 32 + r][chunk * 8 + j][tap 2 s + g], j = 0..7, plane 0 / 1 / 2 = hi / mid / lo
-__global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p, int cout, int cin, int kk, int mt_n, long total) {
+__global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p, int cout, int cin, int kk, int mt_n, long total,
+                             int np = 3, int dt = 0) {
   const int ksteps = (kk + 1) / 2;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   long q = e;
   const int lane = (int)(q % 64); q /= 64;
   const int mt = (int)(q % mt_n); q /= mt_n;
-  const int pl = (int)(q % 3); q /= 3;
+  const int pl = (int)(q % np); q /= np;
   const int s = (int)(q % ksteps); q /= ksteps;
   const int nch = cin / 8;
   const int ch = (int)(q % nch);
@@ -372,24 +399,28 @@ __global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p
       const int ci = ch * 8 + 2 * c + u;
       v[u] = (co < cout && tap < kk) ? wt[((size_t)co * cin + ci) * kk + tap] : 0.f;
     }
-    unsigned h2, m2, l2;
-    s_split2(v[0], v[1], h2, m2, l2);
-    o[c] = pl == 0 ? h2 : pl == 1 ? m2 : l2;
+    if (np == 3) {
+      unsigned h2, m2, l2;
+      s_split2(v[0], v[1], h2, m2, l2);
+      o[c] = pl == 0 ? h2 : pl == 1 ? m2 : l2;
+    } else {
+      o[c] = dt == 1 ? s_round2<1>(v[0], v[1]) : s_round2<2>(v[0], v[1]);
+    }
   }
   p[e] = o;
 }
 
 int mt_of(int cout) { return cout > 32 ? 2 : 1; }
 
-template <int KS, int MT, int NT, int WMT>
+template <int KS, int MT, int NT, int WMT, int NP = 3, int DT = 0>
 int launch7(const C7Args& a, void* stream) {
-  using K = C7<KS, MT, NT>;
+  using K = C7<KS, MT, NT, NP>;
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
   static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
   hipError_t& attr_err = attr_err_pd[dev_];
   std::call_once(once_pd.flag[dev_], [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<KS, MT, NT, WMT>),
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<KS, MT, NT, WMT, NP, DT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
@@ -401,25 +432,25 @@ int launch7(const C7Args& a, void* stream) {
   const long blocks = (long)b.tiles_x * b.tiles_y * b.n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv_f32x6: too many tiles");
   dim3 grid((unsigned)blocks, eavsr::cdiv(a.cout, 32 * MT));
-  hipLaunchKernelGGL((conv_x6_kernel<KS, MT, NT, WMT>), grid, dim3(64 * S_NW), K::LDS_BYTES, eavsr::as_stream(stream), b);
+  hipLaunchKernelGGL((conv_x6_kernel<KS, MT, NT, WMT, NP, DT>), grid, dim3(64 * S_NW), K::LDS_BYTES, eavsr::as_stream(stream), b);
   return eavsr::launch_status("conv_f32x6");
 }
 
 // Tile height and channel tiles per workgroup: the full 16-row, all-channel workgroup where that gives the GPU enough of them;
 // otherwise 8-row tiles, then one 32-channel tile per workgroup -- a coarse pyramid level is a few dozen workgroups and takes as
 // long as ONE of them.  Every output is the same sum in the same order whichever shape computes it.
-template <int KS>
+template <int KS, int NP = 3, int DT = 0>
 int dispatch7(const C7Args& a, void* stream) {
   const long wg2 = (long)a.tiles_x * eavsr::cdiv(a.h, 16) * a.n;
   const long wg1 = (long)a.tiles_x * eavsr::cdiv(a.h, 8) * a.n;
   EAVSR_REQUIRE(wg1 * 2 < (1L << 31), -1, "conv_f32x6: too many tiles");
   if (mt_of(a.cout) == 2) {     // (the packed weight has two 32-channel tiles per `cot`)
-    if (wg2 >= 128) return launch7<KS, 2, 2, 2>(a, stream);
-    if (wg1 >= 128) return launch7<KS, 2, 1, 2>(a, stream);
-    return launch7<KS, 1, 1, 2>(a, stream);
+    if (wg2 >= 128) return launch7<KS, 2, 2, 2, NP, DT>(a, stream);
+    if (wg1 >= 128) return launch7<KS, 2, 1, 2, NP, DT>(a, stream);
+    return launch7<KS, 1, 1, 2, NP, DT>(a, stream);
   }
-  if (wg2 >= 128) return launch7<KS, 1, 2, 1>(a, stream);
-  return launch7<KS, 1, 1, 1>(a, stream);
+  if (wg2 >= 128) return launch7<KS, 1, 2, 1, NP, DT>(a, stream);
+  return launch7<KS, 1, 1, 1, NP, DT>(a, stream);
 }
 
 }  // namespace
@@ -473,4 +504,41 @@ extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const flo
   a.tiles_y = 0;   // per tile height, in launch7
   a.act = act; a.slope = slope; a.sig_from = sigmoid_from < 0 ? -1 : sigmoid_from;
   return ksize == 7 ? dispatch7<7>(a, stream) : dispatch7<5>(a, stream);
+}
+
+// ---- the 16-bit modes' form of the same kernel (NP = 1): operands rounded once to fp16 (dtype 1) / bf16 (dtype 2), one product ----
+extern "C" size_t eavsr_conv_weight_h16x1_bytes(int32_t ksize, int32_t cout, int32_t cin) {
+  return eavsr_conv_weight_x6_bytes(ksize, cout, cin) / 3;
+}
+
+extern "C" int eavsr_pack_conv_weight_h16x1(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, int32_t dtype,
+                                            void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight_h16x1: NULL pointer");
+  EAVSR_REQUIRE(ksize == 7, -2, "pack_conv_weight_h16x1: kernel size %d (7 only)", ksize);
+  EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "pack_conv_weight_h16x1: dtype %d (1 = f16, 2 = bf16)", dtype);
+  EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % 8 == 0, -1, "pack_conv_weight_h16x1: cin %d must be a multiple of 8", cin);
+  const long total = (long)(eavsr_conv_weight_h16x1_bytes(ksize, cout, cin) / 16);
+  hipLaunchKernelGGL(pack7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
+                     reinterpret_cast<u32x4*>(packed), cout, cin, ksize * ksize, mt_of(cout), total, 1, dtype);
+  return eavsr::launch_status("pack_conv_weight_h16x1");
+}
+
+extern "C" int eavsr_conv_h16x1(const float* x, const void* weight_h16x1, const float* bias, float* out, int32_t n, int32_t cin,
+                                int32_t cout, int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t dtype, void* stream) {
+  EAVSR_REQUIRE(ksize == 7, -2, "conv_h16x1: kernel size %d (7 only)", ksize);
+  EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "conv_h16x1: dtype %d (1 = f16, 2 = bf16)", dtype);
+  EAVSR_REQUIRE(n >= 0 && cin > 0 && cout > 0 && h > 0 && w > 0, -1, "conv_h16x1: bad dims");
+  if (n == 0) return 0;
+  EAVSR_REQUIRE(x && weight_h16x1 && out, -1, "conv_h16x1: NULL pointer");
+  EAVSR_REQUIRE(cin % 8 == 0, -2, "conv_h16x1: cin %d must be a multiple of 8", cin);
+  EAVSR_REQUIRE(act >= 0 && act <= 2, -1, "conv_h16x1: act %d", act);
+  EAVSR_REQUIRE(act != EAVSR_ACT_LRELU || (slope >= 0.f && slope <= 1.f), -2, "conv_h16x1: leaky-ReLU slope %g outside [0, 1]", (double)slope);
+  EAVSR_REQUIRE((long)h * w < (1L << 31), -1, "conv_h16x1: image plane too large for 32-bit pixel offsets");
+  C7Args a;
+  a.x = x; a.wsplit = reinterpret_cast<const u32x4*>(weight_h16x1); a.bias = bias; a.out = out;
+  a.n = n; a.cin = cin; a.cout = cout; a.h = h; a.w = w;
+  a.tiles_x = eavsr::cdiv(w, S_TW);
+  a.tiles_y = 0;
+  a.act = act; a.slope = slope; a.sig_from = -1;
+  return dtype == 1 ? dispatch7<7, 1, 1>(a, stream) : dispatch7<7, 1, 2>(a, stream);
 }

@@ -49,7 +49,7 @@ class GraphedForward:
         # per-parameter caches: hold them, so that clearing or refreshing a cache cannot free memory the graph still uses
         from . import ops
         self._weights_alive = [dict(ops.pack_cache._d)] + [dict(getattr(ops, n)) for n in (
-            "_bias_cache", "_wcat_cache", "_x9_pack_cache", "_wino_pack_cache", "_h16_pack_cache", "_h16_ps_cache", "_h16_last_cache", "_h16g_pack_cache", "_h16_pack5_cache", "_il16_pack_cache", "_smallco_pack_cache", "_conv7_pack_cache", "_il2_pack_cache") if hasattr(ops, n)]
+            "_bias_cache", "_wcat_cache", "_x9_pack_cache", "_wino_pack_cache", "_h16_pack_cache", "_h16_ps_cache", "_h16_last_cache", "_h16g_pack_cache", "_h16x1_pack_cache", "_h16_pack5_cache", "_il16_pack_cache", "_smallco_pack_cache", "_conv7_pack_cache", "_il2_pack_cache") if hasattr(ops, n)]
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype or x.device != self.static_in.device:
@@ -107,7 +107,7 @@ def clear_weight_caches():
     entry built outside it, or the replays would keep reading that stale copy."""
     from . import autograd, ops
     ops.pack_cache.clear()
-    for name in ("_bias_cache", "_wcat_cache", "_x9_pack_cache", "_wino_pack_cache", "_h16_pack_cache", "_h16_ps_cache", "_h16_last_cache", "_h16g_pack_cache",
+    for name in ("_bias_cache", "_wcat_cache", "_x9_pack_cache", "_wino_pack_cache", "_h16_pack_cache", "_h16_ps_cache", "_h16_last_cache", "_h16g_pack_cache", "_h16x1_pack_cache",
                  "_h16_pack5_cache", "_il16_pack_cache", "_smallco_pack_cache", "_conv7_pack_cache", "_il2_pack_cache"):
         d = getattr(ops, name, None)
         if d is not None:

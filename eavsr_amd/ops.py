@@ -395,6 +395,41 @@ def _packed_h16g(weights: Sequence[Tensor], code: int) -> Tensor:
     return packed
 
 
+# SPyNet's 7x7 layers with >= 16 output channels in the 16-bit modes (one operand plane of csrc/conv_x6.hip); EAVSR_CONV7_16BIT=0
+# keeps them on the exact bf16x6 form (A/B switch)
+CONV7_H16_ENABLED = os.environ.get("EAVSR_CONV7_16BIT", "1") == "1"
+_h16x1_pack_cache = {}
+
+
+def _conv_h16x1(x: Tensor, weights, biases, act, slope, dtype):
+    n, cin, h, w = x.shape
+    cout = sum(int(w_.shape[0]) for w_ in weights)
+    k = int(weights[0].shape[-1])
+    code = h16_code(dtype)
+    key = tuple((id(w_), w_._version) for w_ in weights) + (code,)
+    hit = _h16x1_pack_cache.get(key)
+    if hit is not None and all(r() is w_ for r, w_ in zip(hit[0], weights)):
+        wp = hit[1]
+    else:
+        wc = _chk(_cat_weights(weights).detach(), "weight")
+        wp = torch.empty(lib().eavsr_conv_weight_h16x1_bytes(k, cout, cin), device=wc.device, dtype=torch.uint8)
+        with _DeviceOf(wc):
+            N.check(lib().eavsr_pack_conv_weight_h16x1(_p(wc), _p(wp), k, cout, cin, code, _stream(wc)), "pack_conv_weight_h16x1")
+        ids = {id(x_) for x_ in weights}
+        for k_ in [k_ for k_ in _h16x1_pack_cache if any(isinstance(e, tuple) and e[0] in ids for e in k_)]:
+            _h16x1_pack_cache.pop(k_, None)
+        refs = tuple(weakref.ref(x_, lambda _r, k_=key, c=_h16x1_pack_cache: c.pop(k_, None)) for x_ in weights)
+        _h16x1_pack_cache[key] = (refs, wp)
+    b = _bias_of(biases)
+    out = torch.empty((n, cout, h, w), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    px = float(n * h * w)
+    _launch(f"conv{k}x{k}_{cin}to{cout}_h16x1", 2.0 * cin * cout * k * k * px, 4.0 * px * (cin + cout), x,
+            lambda: lib().eavsr_conv_h16x1(_p(x), _p(wp), _p(b), _p(out), n, cin, cout, h, w, k, ACT[act], float(slope), code, st),
+            "conv_h16x1")
+    return out
+
+
 def _conv3x3_h16g(srcs, weights, biases, act, slope, dtype):
     n, _, h, w = srcs[0].shape
     cin = sum(int(s_.shape[1]) for s_ in srcs)
@@ -508,6 +543,9 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None:
         y = _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
         return torch.nn.functional.pixel_shuffle(y, 2) if pixel_shuffle2 else y
+    if (CONV3_H16 is not None and k == 7 and CONV7_H16_ENABLED and sigmoid_from is None and len(srcs) == 1 and cin % 8 == 0 and cout >= 16
+            and residual is None and not chan_partial and ca is None and not pixel_shuffle2 and not torch.is_grad_enabled()):
+        return _conv_h16x1(srcs[0], weights, biases, act, slope, CONV3_H16)      # SPyNet's feature layers (its 16 -> 2 flow head stays exact)
     if (((k == 7 and CONV7_MODE == "bf16x6") or (k == 5 and CONV5_MODE == "bf16x6")) and len(srcs) == 1 and cin % 8 == 0
             and residual is None and not chan_partial and ca is None and not pixel_shuffle2):
         return _conv_x6(srcs[0], weights, biases, act, slope, -1 if sigmoid_from is None else int(sigmoid_from))

@@ -472,6 +472,14 @@ int eavsr_conv3x3_c64to3_h16(const void* x, const void* weight, const float* bia
 int64_t eavsr_conv3x3_h16g_weight_bytes(int32_t cout, int32_t cin);
 int eavsr_pack_conv3x3_h16g(const float* weight, void* packed, int32_t cout, int32_t cin, int32_t dtype, void* stream);
 int eavsr_conv3x3_h16g_f32(const eavsr_conv2d_desc* desc, int32_t dtype, void* stream);
+/* SPyNet's 7x7 layers (models/eavsrp_model.py:398-431) in the 16-bit modes: the kernel of eavsr_conv_f32x6 (csrc/conv_x6.hip) with ONE
+ * operand plane -- fp32 NCHW in and out, operands rounded once (nearest even) to dtype 1 = fp16 / 2 = bf16, one product per operand
+ * pair instead of six, fp32 accumulation.  ksize 7, cin % 8 == 0; the packed weight (eavsr_pack_conv_weight_h16x1,
+ * eavsr_conv_weight_h16x1_bytes) is a cache of the library version that made it. */
+size_t eavsr_conv_weight_h16x1_bytes(int32_t ksize, int32_t cout, int32_t cin);
+int eavsr_pack_conv_weight_h16x1(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, int32_t dtype, void* stream);
+int eavsr_conv_h16x1(const float* x, const void* weight_h16x1, const float* bias, float* out, int32_t n, int32_t cin, int32_t cout,
+                     int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t dtype, void* stream);
 /* The predictor's three 5x5 heads (transform_matrix_conv ++ translation_conv ++ mask_conv, models/networks.py:283-285,
  * 298-301) in the 16-bit modes (csrc/conv5_h16.hip): x 16-bit NHWC (n, h, w, 64) -- the front-end feature through
  * eavsr_nchw_f32_to_nhwc_h16 --, weight (cout, 64, 5, 5) fp32 rounded once by the pack call (cout <= 128), fp32 accumulation,

@@ -88,6 +88,30 @@ def test_conv3x3_h16g_vs_fp64_on_rounded_inputs(ops, cuda, dt, n, h, w, cins, co
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("n,cin,cout,h,w,act", [(2, 8, 32, 24, 40, "relu"), (1, 32, 64, 45, 80, "relu"), (1, 64, 32, 17, 33, "relu"),
+                                               (3, 32, 16, 9, 12, None), (12, 32, 64, 48, 80, "relu")])
+def test_conv7x7_h16x1_vs_fp64_on_rounded_inputs(ops, cuda, dt, n, cin, cout, h, w, act):
+    """SPyNet's 7x7 layers in the 16-bit modes (one operand plane of the bf16x6 kernel): against an fp64 convolution of the
+    operands rounded to the 16-bit type; the 16 -> 2 flow head is not routed (it stays exact)"""
+    x = cases.randn(51, n, cin, h, w)
+    wt = cases.randn(52, cout, cin, 7, 7, scale=1.0 / (7.0 * cin ** 0.5))
+    b = cases.randn(53, cout, scale=0.1)
+    ref = F.conv2d(x.to(DT[dt]).double(), wt.to(DT[dt]).double(), b.double(), 1, 3)
+    ref = F.relu(ref) if act == "relu" else ref
+    ops.set_conv3_h16(dt)
+    try:
+        with torch.no_grad(), ops.profile() as prof:
+            got = ops.conv2d(x.to(cuda), wt.to(cuda), b.to(cuda), act=act).cpu()
+            w2 = cases.randn(54, 2, 16, 7, 7, scale=0.05)
+            ops.conv2d(cases.randn(55, 1, 16, h, w).to(cuda), w2.to(cuda), None)
+    finally:
+        ops.set_conv3_h16(None)
+    names = prof.summary()
+    assert f"conv7x7_{cin}to{cout}_h16x1" in names and "conv7x7_16to2_x6" in names
+    assert H.maxabs(got.double(), ref) <= 3e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape,res", [((1, 8, 32), True), ((2, 19, 37), False), ((1, 45, 80), True), ((3, 7, 5), True)])
 def test_conv3x3_c64to3_h16_vs_fp64_on_rounded_inputs(ops, cuda, dt, shape, res):
     """conv_last of the tail (eavsrp_model.py:359-360) in the 16-bit modes: fp32 NCHW out (+ the skip image)"""
