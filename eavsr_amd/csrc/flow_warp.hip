@@ -146,14 +146,22 @@ __global__ __launch_bounds__(256) void flow_warp_pair_kernel(
   if (second && b_il8) {
     // c % 8 == 0 (checked on the host): this thread owns whole octets; 32 contiguous bytes per (pixel, octet)
     for (int o = 0; o < cend / 8; ++o) {
-      float v[8];
+      // all 32 corner loads of the octet first, THEN the blends (a scheduling fence between them): in the 16-bit forms the
+      // compiler otherwise reuses one temporary and waits for every load before issuing the next (2x the kernel's time)
+      float l[8][4];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float* p = xp + (size_t)(o * 8 + e) * plane;
-        float t = p[i_nw] * w_nw;
-        t += p[i_ne] * w_ne;
-        t += p[i_sw] * w_sw;
-        t += p[i_se] * w_se;
+        l[e][0] = p[i_nw]; l[e][1] = p[i_ne]; l[e][2] = p[i_sw]; l[e][3] = p[i_se];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = l[e][0] * w_nw;
+        t += l[e][1] * w_ne;
+        t += l[e][2] * w_sw;
+        t += l[e][3] * w_se;
         v[e] = t;
       }
       const size_t unit = (((size_t)bn * (c / 8) + (c0 / 8 + o)) * h + py) * w + px;
