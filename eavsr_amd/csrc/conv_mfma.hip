@@ -285,13 +285,29 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
   const int gx = x0 + l31;
   const bool xok = gx < w;
   float csum[MT][16];
+  // the lane's 16 MT bias values in one batch (a uniform branch on the nullable pointer): loaded where they are used, each sat
+  // behind its own branch and a vmcnt(0) -- 32 dependent round trips in the epilogue of a workgroup
+  float bvs[MT][16];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bvs[m][r] = 0.f;
+  if (a.bias) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        bvs[m][r] = a.bias[min(co, a.cout - 1)];      // (clamped: rows >= cout are never stored)
+      }
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cot * CO + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const bool cok = co < a.cout;
-      const float b = (cok && a.bias) ? a.bias[co] : 0.f;
+      const float b = bvs[m][r];
       float sum = 0.f;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {

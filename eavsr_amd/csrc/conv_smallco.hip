@@ -300,17 +300,36 @@ __global__ __launch_bounds__((TH / PXR) * TW) void conv3x3_smallco_lite_kernel(S
   const int gx = x0 + lx;
   if (gx < w) {
     const float act_s = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope;
+    // every bias and every residual value FIRST, in one batch (uniform branches on the two nullable pointers): loaded where
+    // they are used each sat behind its own branch and a vmcnt(0) -- up to 12 dependent round trips at the end of a workgroup
+    float bv[COUT], rv[PXR][COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) bv[co] = 0.f;
+    if (a.bias) {
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) bv[co] = a.bias[co];
+    }
+#pragma unroll
+    for (int p = 0; p < PXR; ++p)
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) rv[p][co] = 0.f;
+    if (a.residual) {
+#pragma unroll
+      for (int p = 0; p < PXR; ++p) {
+        const int gy = min(y0 + PXR * ly + p, h - 1);      // (clamped: the value of a row below the image is not used)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) rv[p][co] = a.residual[((size_t)bn * COUT + co) * (plane4 / 4) + (size_t)gy * w + gx];
+      }
+    }
 #pragma unroll
     for (int p = 0; p < PXR; ++p) {
       const int gy = y0 + PXR * ly + p;
       if (gy < h) {
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
-          float v = acc[co][p] + (a.bias ? a.bias[co] : 0.f);
+          float v = acc[co][p] + bv[co];
           v = fmaxf(v, eavsr_mul_legacy(v, act_s));
-          const size_t o = ((size_t)bn * COUT + co) * (plane4 / 4) + (size_t)gy * w + gx;
-          if (a.residual) v += a.residual[o];
-          a.out[o] = v;
+          a.out[((size_t)bn * COUT + co) * (plane4 / 4) + (size_t)gy * w + gx] = v + rv[p][co];
         }
       }
     }
