@@ -114,13 +114,19 @@ __global__ __launch_bounds__(256) void gconv3x3_fwd_kernel(const float* __restri
   for (int j = 0; j < cpg; ++j) {
     const float* q = x + ((size_t)bn * co * cpg + (size_t)o * cpg + j) * h * w;
     const float* wk = wt + ((size_t)o * cpg + j) * 9;
+    float qv[9];      // clamped addresses, all nine loads first (see gconv3x3_dgrad_kernel)
+    bool ok[9];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int yy = py + ky - 1, xx = px + kx - 1;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) v += wk[ky * 3 + kx] * q[(size_t)yy * w + xx];
+        ok[ky * 3 + kx] = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        qv[ky * 3 + kx] = q[(size_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
       }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if (ok[k]) v += wk[k] * qv[k];
   }
   if (act == EAVSR_ACT_LRELU) v = v > 0.f ? v : v * slope;
   out[((size_t)bn * co + o) * h * w + (size_t)py * w + px] = v;
@@ -135,14 +141,21 @@ __global__ __launch_bounds__(256) void gconv3x3_dgrad_kernel(const float* __rest
   const int o = ci / cpg, j = ci - o * cpg;
   const float* q = g + ((size_t)bn * co + o) * h * w;
   const float* wk = wt + ((size_t)o * cpg + j) * 9;
-  float v = 0.f;
+  // the nine taps with clamped addresses, all loads first (as nine conditional loads each sat behind its own branch and wait)
+  float qv[9];
+  bool ok[9];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int yy = py - ky + 1, xx = px - kx + 1;
-      if (yy >= 0 && yy < h && xx >= 0 && xx < w) v += wk[ky * 3 + kx] * q[(size_t)yy * w + xx];
+      ok[ky * 3 + kx] = yy >= 0 && yy < h && xx >= 0 && xx < w;
+      qv[ky * 3 + kx] = q[(size_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
     }
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+    if (ok[k]) v += wk[k] * qv[k];      // (a select: the same sum in the same order as before)
   dx[((size_t)bn * co * cpg + ci) * h * w + (size_t)py * w + px] = v;
 }
 
@@ -162,14 +175,20 @@ __global__ __launch_bounds__(1024) void gconv3x3_wgrad_kernel(const float* __res
     for (int p = threadIdx.x; p < hw; p += 1024) {
       const int py = p / w, px = p - py * w;
       const float gv = gq[p];
-      acc[9] += gv;
+      float xv[9];
+      bool ok[9];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        for (int kx = 0; kx < 3; ++kx) {      // clamped addresses, all loads first (nine conditional loads were nine round trips)
           const int yy = py + ky - 1, xx = px + kx - 1;
-          if (yy >= 0 && yy < h && xx >= 0 && xx < w) acc[ky * 3 + kx] += gv * xq[(size_t)yy * w + xx];
+          ok[ky * 3 + kx] = yy >= 0 && yy < h && xx >= 0 && xx < w;
+          xv[ky * 3 + kx] = xq[(size_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
         }
+      acc[9] += gv;
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (ok[k]) acc[k] += gv * xv[k];
     }
   }
 #pragma unroll
