@@ -24,8 +24,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float ld_b16(const float* base, unsigned byte_off) {
+// parameter load as (wave-uniform base in a scalar register pair) + (32-bit lane offset): `global_load_dword v, v_off, s[base]` -- left
+// alone the compiler forms a 64-bit vector address per load with a quarter-rate v_mad_u64_u32 (20 per (tile, group) step); the base
+// goes through an empty asm as an integer (csrc/dcnv2_il2.hip's ld_b)
+typedef const __attribute__((address_space(1))) char* h_gcp;
+__device__ __forceinline__ float ld_b16v(const float* base, unsigned byte_off) {      // per-lane base (the rare fix-up path)
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float ld_b16(const float* base, unsigned byte_off) {
+  unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  asm volatile("" : "+s"(b));
+  return *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<h_gcp>(b) + byte_off);
 }
 
 constexpr int HT_ROWS = 8, HT_W = 32;
@@ -313,18 +322,18 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il16_kernel(IL16Args a) {
             const char* hb = reinterpret_cast<const char*>(a.offset) + (size_t)bn * 15 * a.dg * pl4;
             float tt[6];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tt[j] = ld_b16(reinterpret_cast<const float*>(hb + (size_t)(dgi * 4 + j) * pl4), pix * 4u);
+            for (int j = 0; j < 4; ++j) tt[j] = ld_b16v(reinterpret_cast<const float*>(hb + (size_t)(dgi * 4 + j) * pl4), pix * 4u);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) tt[4 + j] = ld_b16(reinterpret_cast<const float*>(hb + (size_t)(4 * a.dg + dgi * 2 + j) * pl4), pix * 4u);
+            for (int j = 0; j < 2; ++j) tt[4 + j] = ld_b16v(reinterpret_cast<const float*>(hb + (size_t)(4 * a.dg + dgi * 2 + j) * pl4), pix * 4u);
             dy = (tt[0] * ryt + tt[1] * rxt) - ryt + tt[4];
             dx = (tt[2] * ryt + tt[3] * rxt) - rxt + tt[5];
-            m = eavsr_sigmoid_fast(ld_b16(reinterpret_cast<const float*>(hb + (size_t)(6 * a.dg + dgi * 9 + tap) * pl4), pix * 4u));
+            m = eavsr_sigmoid_fast(ld_b16v(reinterpret_cast<const float*>(hb + (size_t)(6 * a.dg + dgi * 9 + tap) * pl4), pix * 4u));
           } else {
             const char* ob = reinterpret_cast<const char*>(a.offset) + ((size_t)bn * a.dg + dgi) * 18 * pl4;
             const char* mb = reinterpret_cast<const char*>(a.mask) + ((size_t)bn * a.dg + dgi) * 9 * pl4;
-            dy = ld_b16(reinterpret_cast<const float*>(ob + (size_t)(2 * tap) * pl4), pix * 4u);
-            dx = ld_b16(reinterpret_cast<const float*>(ob + (size_t)(2 * tap + 1) * pl4), pix * 4u);
-            m = ld_b16(reinterpret_cast<const float*>(mb + (size_t)tap * pl4), pix * 4u);
+            dy = ld_b16v(reinterpret_cast<const float*>(ob + (size_t)(2 * tap) * pl4), pix * 4u);
+            dx = ld_b16v(reinterpret_cast<const float*>(ob + (size_t)(2 * tap + 1) * pl4), pix * 4u);
+            m = ld_b16v(reinterpret_cast<const float*>(mb + (size_t)tap * pl4), pix * 4u);
           }
           const float py = (fgy + ryt) + dy, px = (fgx + rxt) + dx;
           if (!(py > -1.f && px > -1.f && py < (float)h && px < (float)w)) m = 0.f;
