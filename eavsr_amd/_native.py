@@ -128,6 +128,7 @@ SIGNATURES = {
     "eavsr_conv5x5_c64_h16_weight_bytes": (C.c_int64, []),
     "eavsr_pack_conv5x5_c64_h16": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_conv5x5_c64_h16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "eavsr_conv_h16_partial_rows": (i32, [i32, i32, i32]),
     "eavsr_conv3x3_c64_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_c64_h16_act": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "eavsr_conv3x3_c64to3_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

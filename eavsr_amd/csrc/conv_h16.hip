@@ -64,6 +64,9 @@ struct H16Args {
   int n, h, w, tiles_x, tiles_y, num_tiles;
   int act;            // 0 none, 1 ReLU, 2 LeakyReLU(slope)
   float slope;
+  int sum_rows;       // 0: chan_partial holds one row per tile; > 0: one row per (workgroup, wave group) and sample (2 x gridDim.x rows per
+                      // sample), the sums of that group's tiles of the sample added up in the kernel -- large images, where the ONE
+                      // workgroup of ca_scale would otherwise read thousands of per-tile rows
   int ps;             // 1: conv 64 -> 256 + PixelShuffle(2) as four 64 -> 64 slices (blockIdx.y = 2 dy + dx): slice k holds the output
                       // channels 4 c + k of the reference weight as its channel c, and its pixel (y, x) is output pixel (2 y + dy, 2 x + dx)
 };
@@ -165,6 +168,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
   const bool tail_lane = ((10 * 4 + w4) * 64 + lane) >> 3 < HP_PIX;   // the last piece is partial
 
   f32x16 acc[2][2];   // [row][m]
+  float run = 0.f;     // sum_rows mode, wave 0 of a group: this group's channel sums of sample run_bn so far (lane = channel)
+  int run_bn = -1;
+  auto flush_rows = [&](int upto_bn) __attribute__((always_inline)) {      // rows of samples run_bn (the sums) .. upto_bn - 1 (zeros)
+    const size_t row0 = (size_t)blockIdx.x * 2 + grp;
+    if (run_bn >= 0) a.chan_partial[((size_t)run_bn * a.sum_rows + row0) * 64 + lane] = run;
+    for (int sb = run_bn + 1; sb < upto_bn; ++sb) a.chan_partial[((size_t)sb * a.sum_rows + row0) * 64 + lane] = 0.f;
+  };
   for (int p = 0; p <= p_end; ++p) {
     const int q = p - grp;
     const int j = q >> 1;
@@ -328,7 +338,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         float v = s_red[(grp * 4) * 64 + lane];
 #pragma unroll
         for (int k = 1; k < 4; ++k) v += s_red[(grp * 4 + k) * 64 + lane];
-        a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx) * 64 + lane] = v;
+        if (a.sum_rows == 0) {
+          a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx) * 64 + lane] = v;
+        } else {      // (a group's tiles come in increasing order: the sample index never decreases)
+          if (bn != run_bn) {
+            flush_rows(bn);
+            run = 0.f;
+            run_bn = bn;
+          }
+          run += v;
+        }
       }
       if (j < cnt_g) {
 #pragma unroll
@@ -414,6 +433,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
     asm volatile("" ::: "memory");
     H16_STAMP(0);         // waiting for the DMA and the barrier
   }
+  if (a.chan_partial && a.sum_rows > 0 && w4 == 0) flush_rows(a.n);      // the last sample's sums; zero rows for the samples this group never saw
 #ifdef EAVSR_H16_STAMPS
   if (tid == 0 || tid == 256)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_h16_stamps[i], st_acc[i]);
@@ -611,6 +631,14 @@ extern "C" int eavsr_debug_h16_stamps(unsigned long long* host_out, int reset) {
 
 extern "C" int32_t eavsr_conv_h16_tiles(int32_t h, int32_t w) { return eavsr::cdiv(h, HT_H) * eavsr::cdiv(w, HT_W); }
 
+// rows per sample of eavsr_conv3x3_c64_h16's chan_partial: one per tile, or -- where a sample has more tiles than twice the
+// persistent workgroups -- one per (workgroup, wave group): the kernel adds up each group's tiles of a sample itself
+extern "C" int32_t eavsr_conv_h16_partial_rows(int32_t n, int32_t h, int32_t w) {
+  const long per = (long)eavsr_conv_h16_tiles(h, w), total = per * (n > 0 ? n : 1);
+  const long blocks = total < 256 ? total : 256;
+  return (int32_t)(per > 2 * blocks ? 2 * blocks : per);
+}
+
 extern "C" int eavsr_pack_conv3x3_c64_h16(const float* weight, void* packed, int32_t dtype, void* stream) {
   EAVSR_REQUIRE(weight && packed, -1, "pack_conv3x3_c64_h16: NULL pointer");
   EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "pack_conv3x3_c64_h16: dtype %d (1 = f16, 2 = bf16)", dtype);
@@ -656,6 +684,10 @@ static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, cons
   EAVSR_REQUIRE(tiles < (1L << 31), -1, "conv3x3_c64_h16: too many tiles");
   a.num_tiles = (int)tiles;
   a.act = act; a.slope = slope; a.ps = ps;
+  {
+    const int rows = eavsr_conv_h16_partial_rows(n, h, w);
+    a.sum_rows = (chan_partial && !ps && rows != a.tiles_x * a.tiles_y) ? rows : 0;
+  }
   const int per = ps ? 64 : 256;                      // persistent: one workgroup per CU (four slices: 64 each)
   const int blocks = tiles < per ? (int)tiles : per;
   return dtype == 2 ? launch_conv_h16<true>(a, blocks, ps ? 4 : 1, eavsr::as_stream(stream))

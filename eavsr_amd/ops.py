@@ -1589,7 +1589,7 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
     out = torch.empty_like(x)
     part = None
     if chan_partial:
-        part = torch.empty((n, lib().eavsr_conv_h16_tiles(h, w), 64), device=x.device, dtype=torch.float32)
+        part = torch.empty((n, lib().eavsr_conv_h16_partial_rows(n, h, w), 64), device=x.device, dtype=torch.float32)
     st = _stream(x)
     px = float(n) * h * w
     _launch("conv3x3_64to64_h16", 2.0 * 64 * 64 * 9 * px, 2.0 * px * 128, x,

@@ -444,8 +444,11 @@ int eavsr_gconv3x3_bwd_f32(const float* g, const float* x, const float* weight, 
 int32_t eavsr_conv_h16_tiles(int32_t h, int32_t w);
 /* weight (64,64,3,3) fp32 -> 64*576 16-bit values in MFMA fragment order */
 int eavsr_pack_conv3x3_c64_h16(const float* weight, void* packed, int32_t dtype, void* stream);
-/* out = [relu](conv3x3(x) + bias); chan_partial (nullable): fp32 (n, eavsr_conv_h16_tiles(h,w), 64) per-tile
- * channel sums of the output as stored (after the rounding to 16 bits: what the next layer reads) */
+/* out = [relu](conv3x3(x) + bias); chan_partial (nullable): fp32 (n, eavsr_conv_h16_partial_rows(n,h,w), 64) partial channel
+ * sums of the output as stored (after the rounding to 16 bits: what the next layer reads) -- one row per tile, or, where a sample
+ * has more tiles than twice the persistent workgroups (large images), one row per (workgroup, wave group) with that group's tiles
+ * of the sample already added up; either way the rows of a sample sum to its channel sums, in a fixed order */
+int32_t eavsr_conv_h16_partial_rows(int32_t n, int32_t h, int32_t w);
 int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float* bias, void* out,
                           float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t relu, int32_t dtype,
                           void* stream);

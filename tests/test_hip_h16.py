@@ -130,7 +130,7 @@ def test_conv3x3_c64to3_h16_vs_fp64_on_rounded_inputs(ops, cuda, dt, shape, res)
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape,relu,part", [((1, 8, 32), False, False), ((2, 19, 37), True, True),
                                              ((1, 45, 80), True, False), ((1, 64, 64), False, True),
-                                             ((3, 7, 5), True, True)])
+                                             ((3, 7, 5), True, True), ((1, 264, 512), True, True), ((2, 272, 512), False, True)])
 def test_conv3x3_c64_h16_vs_fp32_on_rounded_inputs(ops, cuda, dt, shape, relu, part):
     n, h, w = shape
     x = cases.randn(1, n, 64, h, w).to(DT[dt])
