@@ -286,7 +286,7 @@ def other_configs(which, budget_s):
     return out
 
 
-def train_bench(args, rank, world, device):
+def train_bench(args, rank, world, device, ranks_seen=1):
     """BASELINE.json configs[3]: eavsrp x4 training step, 2 clips/GPU x 7 x 3 x 96 x 96, data parallel."""
     from argparse import Namespace
     from eavsr_amd import shard
@@ -332,7 +332,7 @@ def train_bench(args, rank, world, device):
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
     if rank == 0:
         print(json.dumps({
-            "per_rank_ms": per_rank_ms, "per_rank_device": per_rank_device,
+            "per_rank_ms": per_rank_ms, "per_rank_device": per_rank_device, "rccl_ranks_seen": ranks_seen,
             "metric": "training LR frames/sec, eavsrp x4 step (forward + backward + grad all-reduce + Adam)",
             "value": world * n * t * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -415,9 +415,10 @@ def dry_bench(args):
     per_rank = shard.all_ranks(1e3 * own / max(args.steps, 1))
     per_dev = shard.all_ranks_str(f"cpu:{rank}")
     thread_cap = shard.cap_host_threads(world)
+    seen = shard.ranks_seen()              # the same call the GPU path makes on its device (there: over RCCL)
     if rank == 0:
         print(json.dumps({
-            "per_rank_ms": per_rank, "per_rank_device": per_dev, "host_threads_per_rank": thread_cap,
+            "per_rank_ms": per_rank, "per_rank_device": per_dev, "host_threads_per_rank": thread_cap, "rccl_ranks_seen": seen,
             "metric": "DRY RUN -- no kernels, no GPU: launch / barrier / max-over-ranks plumbing only (not a measurement)",
             "value": world * n * t * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -453,9 +454,15 @@ def main():
         # the N ranks the line reports are N live RCCL ranks, one per GPU (or EAVSR_DIST_BACKEND=gloo in shared-GPU tests)
         assert torch.distributed.get_world_size() == args.gpus, (torch.distributed.get_world_size(), args.gpus)
 
+    # what the DATA-PATH backend itself sees: one 4-byte device all-reduce over RCCL before anything is timed (the control plane
+    # is gloo and cannot vouch for RCCL).  Inference has no other device collective; training all-reduces its gradients there.
+    ranks_seen = shard.ranks_seen(device) if world > 1 else 1
+    if world > 1:
+        assert ranks_seen == args.gpus, (ranks_seen, args.gpus)
+
     from eavsr_amd.utils.synthetic import synthetic_clip
     if args.mode == "train":
-        return train_bench(args, rank, world, device)
+        return train_bench(args, rank, world, device, ranks_seen)
     net, sd = build_model(device, args.preset, args.scale)
     if args.backbone_dtype != "fp32":
         from eavsr_amd import networks as _nw
@@ -556,6 +563,7 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         # every rank's own time per step (the job is quoted on their MAX) and the device each one ran on
         "per_rank_ms": per_rank_ms, "per_rank_device": per_rank_device, "host_threads_per_rank": thread_cap,
+        "rccl_ranks_seen": ranks_seen,      # ranks counted by a device all-reduce on the data-path backend itself (1 on one process)
         # median over the timed steps (device-side step boundaries; max over ranks of the per-rank medians)
         "ms_per_step_median": med_ms,
         "value_median": world * n * t / (med_ms * 1e-3),
@@ -588,7 +596,7 @@ def main():
                                       " | 5x5 heads: " + {"bf16x6": "the same kernel"}.get(ops.CONV5_MODE, "Winograd F(2x2,5x5), fp32 MFMA"),
                    "conv3x3_wino4_schedule": ("grouped (transform phases of two chunks, pure GEMM iterations)"
                                               if ops.lib().eavsr_wino4_schedule() else "duty pair (EAVSR_W4_GRP=0)"),
-                   "dcnv2_schedule": {"il2": "eavsr_dcnv2_il2_f32 (round 4: taps of two groups paired, one pipeline across groups / tiles)",
+                   "dcnv2_schedule": {"il2": "eavsr_dcnv2_il2_f32 (round 4: taps of two groups paired, one pipeline across groups / tiles; round 5: buffer-addressed)",
                                       "il": "eavsr_dcnv2_il_f32 (round 2)", "ws": "eavsr_dcnv2_ws_f32 (wave-specialised)"}[ops.DCN_IL_IMPL],
                    "launch": (f"{args.streams} HIP graphs on {args.streams} streams per step" if args.streams > 1 else
                               "one HIP graph per step" if args.graph else "eager (one launch per kernel)")},
@@ -737,7 +745,7 @@ def main():
                 rn = lambda *sh: torch.randn(*sh, device=device, generator=g4)
                 ident = torch.tensor([1.0, 0, 0, 1.0], device=device).repeat(8).view(1, 32, 1, 1)
                 res4 = {}
-                for sg in (0.5, 4.0):
+                for sg in (0.5, 2.0, 4.0):
                     act_m = ops.heads_mask_activated(64)      # as the fused alignment calls it: masks activated by the heads' epilogue
                     mk = rn(sub_n, 72, h, w)
                     hd = torch.cat([rn(sub_n, 32, h, w) * 0.25 + ident, rn(sub_n, 16, h, w) * sg, torch.sigmoid(mk) if act_m else mk], 1)
@@ -780,6 +788,22 @@ def main():
                                                   "near-identity transforms; 20 back-to-back launches per figure"}
             except Exception as ex:      # measurement garnish must not void the line
                 dcn_entry["offset_stats_error"] = repr(ex)
+        if dcn_entry is not None and "roofline" in line:
+            # BASELINE.json's north-star figure inside `roofline` itself (the driver's record keeps `roofline`
+            # and drops `kernels`): DCNv2 on SURVEY 8d's algorithmic bytes against the 8 TB/s HBM peak, measured in THIS run by
+            # the same HIP-event brackets as every other kernel figure of the line
+            ns = {k: dcn_entry[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "calls", "share_of_step")}
+            ns["target_frac"] = 0.30
+            ns["launch_shape"] = f"{n // args.streams} x 64 x {h} x {w}, 8 deformable groups, 3x3"
+            if "bytes_per_px" in dcn_entry:
+                ns["bytes_per_px"] = dcn_entry["bytes_per_px"]["algorithmic"]
+                ns["frac_on_moved_bytes"] = dcn_entry["moved"]["frac"]
+            if "synthetic_offsets" in dcn_entry:
+                ns["frac_at_sigma_px"] = {k.replace("sigma_", ""): round(v["frac"], 4) for k, v in dcn_entry["synthetic_offsets"].items()
+                                          if isinstance(v, dict)}
+            if "offset_stats" in dcn_entry:
+                ns["workload_offsets_px"] = {k: dcn_entry["offset_stats"].get(k) for k in ("mean_norm", "max_abs", "frac_outside_lds_window")}
+            line["roofline"]["north_star"] = ns
         line["kernels"] = [e for e in (dcn_entry, entry("flow_warp_pair", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),

@@ -69,21 +69,38 @@ struct IL2Args {
   int n, cin, h, w, cout, dg, opg_shift, tiles_x, tiles_y, ntiles;
 };
 
-// One dword at (wave-uniform base) + (per-lane 32-bit byte offset): global_load / global_store v_off, s[base].  The base
-// goes through an empty asm as an integer so that it IS a scalar register pair at the access: left alone, the compiler
-// re-associates such addresses into (common base + lane offset) + uniform strides, i.e. one 64-bit VECTOR addition per
-// access and a vector register pair per address.
-typedef const __attribute__((address_space(1))) char* j_gcp;
-typedef __attribute__((address_space(1))) char* j_gp;
-__device__ __forceinline__ float ld_b(const char* base, unsigned byte_off) {
-  unsigned long long b = reinterpret_cast<unsigned long long>(base);
-  asm volatile("" : "+s"(b));
-  return *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<j_gcp>(b) + byte_off);
+// Every global access of the pipeline is a BUFFER instruction (round 5): a 128-bit resource (base + extent, four scalar
+// registers, rebuilt once per tile) + one per-lane 32-bit offset register that lives as long as the tile + one scalar offset
+// computed where it is used (one s_mul_i32 / s_add_i32).  The round-4 form (global_load / global_store / global_load_lds
+// with 64-bit addresses) cost 4 scalar + 1-2 vector instructions per access for address arithmetic, a branch + two
+// compares + two selects per window request of a border tile (zero padding) and an exec-mask region per store; here the
+// hardware's range check does both jobs: a lane whose offset register holds J_OOB reads zeros (also into LDS) and its
+// store is dropped.  The loop is bound by instruction ISSUE (one instruction per ~4 cycles and SIMD over both resident
+// waves, scalar and branch instructions included: DESIGN.md 4b-r5), so every instruction removed is time.
+typedef __amdgpu_buffer_rsrc_t j_rsrc;
+constexpr unsigned J_OOB = 0x80000000u;      // beyond every extent the launcher accepts (< 2^31 bytes)
+__device__ __forceinline__ j_rsrc j_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ void st_b(char* base, unsigned byte_off, float v) {
-  unsigned long long b = reinterpret_cast<unsigned long long>(base);
-  asm volatile("" : "+s"(b));
-  *reinterpret_cast<__attribute__((address_space(1))) float*>(reinterpret_cast<j_gp>(b) + byte_off) = v;
+// scalar offset = c * s where c is a compile-time constant: computed AT the use by one s_mul_i32 the optimizer cannot hoist
+// (hoisted, the ~60 distinct products of a pair step become long-lived scalar registers, spill, and a spilled scalar costs
+// VECTOR instructions: v_readlane / v_writelane)
+__device__ __forceinline__ unsigned j_smul(unsigned s, int c) {      // c: a constant once the caller is inlined / unrolled
+  unsigned r;
+  asm volatile("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(s), "i"(c));
+  return r;
+}
+__device__ __forceinline__ float j_ld(j_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 j_ld4(j_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void j_st(j_rsrc r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void j_dma16(j_rsrc r, unsigned voff, unsigned soff, char* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)lds_dst, 16, voff, soff, 0, 0);
 }
 
 // exact three-way split of two fp32 values into packed bf16 pairs (low half = first value)
@@ -145,7 +162,6 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   const int h = a.h, w = a.w;
   const size_t plane = (size_t)h * w;
   const unsigned uplane = (unsigned)plane;
-  const size_t pl4 = plane * 4;
   const unsigned upl4 = uplane * 4u;
   const int ngroups = a.cin / JG;
   const int npairs = ngroups >> 1;
@@ -177,12 +193,13 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   };
 
   // ---- window DMA: piece p = i * 8 + wave (p < 30) is 64 sixteen-byte units e = p * 64 + lane of [half][row][col] -------
+  // Per lane and piece: (row, column) inside the window and the unit's byte offset from the window origin; per TILE (below)
+  // the unit's byte offset inside a group's IL8 image, or J_OOB where the unit lies outside the image: the buffer range check
+  // then writes zeros into LDS, which IS the sampler's corner-wise zero padding and its validity gate.
   constexpr int WIN_IT = (JWIN_SEGS + 7) / 8;   // 4
   int prc[WIN_IT];
   unsigned poff[WIN_IT];
-#ifdef EAVSR_IL2_EXP_CONTIG
-  unsigned poffc[WIN_IT];
-#endif
+  unsigned winvo[WIN_IT];
 #pragma unroll
   for (int i = 0; i < WIN_IT; ++i) {
     const int e = (i * 8 + wave) * 64 + lane;
@@ -192,89 +209,93 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     const int cc = rem - rr * JPW;
     prc[i] = (rr << 8) | cc;
     poff[i] = (unsigned)((rr * w + cc) * 32 + hh * 16);
-#ifdef EAVSR_IL2_EXP_CONTIG      // timing only (results wrong), interior tiles only (so that every address stays inside the image):
-    poffc[i] = (unsigned)(rr * w * 32 + hh * 768 + cc * 16);      // the same bytes of the window row as two contiguous 768-byte runs
-#endif
   }
-  // the address of the zero unit once, kept in scalar registers: rematerialised at its uses it is a scalar load (and an
-  // `lgkmcnt(0)` that also drains the LDS reads in flight) at every window request of a border tile
-  const char* zero_src = reinterpret_cast<const char*>(g_il2_zero);
-  asm volatile("" : "+s"(zero_src));
-  auto issue_win = [&](int i, const char* xorg, int y0, int x0, bool interior, int wslot) __attribute__((always_inline)) {
-    const int p = i * 8 + wave;  // wave-uniform
-    if (p < JWIN_SEGS) {
-      char* dst = smem + JL_WIN + wslot * JWIN_B + p * 1024;
-#ifdef EAVSR_IL2_EXP_CONTIG
-      const char* src = xorg + (interior ? poffc[i] : poff[i]);
-#else
-      const char* src = xorg + poff[i];
-#endif
-      if (!interior) {
-        const int ylo = y0 - JPY0, xlo = x0 - JPX0;
-        const bool ok = (unsigned)(ylo + (prc[i] >> 8)) < (unsigned)h && (unsigned)(xlo + (prc[i] & 255)) < (unsigned)w;
-        src = ok ? src : zero_src;     // that IS the sampler's zero padding
-      }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-    }
-  };
-  // weights of pair slab `ws`: set "Ib" = k-steps 0,1,2,3 (24 pieces, i = 0..2) and k-step 8 (6 pieces, i = 3, waves 0..5)
-  // -> regions A, U3[q], U8[q];  set "Ia" = k-steps 4..7 (24 pieces, i = 0..2) -> region B2
-  auto issue_wgt_ib = [&](int i, const char* ws, int q) __attribute__((always_inline)) {
-    if (i < 3) {
-      const int wp = i * 8 + wave;
-      const int dsto = JL_A + wp * 1024 + (wp >= 18 ? q * JKS_B : 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(ws + (unsigned)(wp * 1024 + lane * 16)), (lptr_t)(smem + dsto), 16, 0, 0);
-    } else if (wave < 6) {
-      const int dsto = JL_U8 + q * JKS_B + wave * 1024;
-      __builtin_amdgcn_global_load_lds((gptr_t)(ws + (unsigned)(8 * JKS_B + wave * 1024 + lane * 16)), (lptr_t)(smem + dsto), 16, 0,
-                                       0);
-    }
-  };
-  auto issue_wgt_ia = [&](int i, const char* ws) __attribute__((always_inline)) {
-    const int wp = i * 8 + wave;
-    __builtin_amdgcn_global_load_lds((gptr_t)(ws + (unsigned)(4 * JKS_B + wp * 1024 + lane * 16)),
-                                     (lptr_t)(smem + JL_B2 + wp * 1024), 16, 0, 0);
-  };
+  const unsigned grp_b = uplane * (unsigned)(JG * 4);      // bytes of one group's IL8 image
+  const unsigned wA = (unsigned)lane * 16u;
+  const unsigned wv1k = (unsigned)wave * 1024u;
+  const int jks_w2 = wave >= 2 ? JKS_B : 0;
+
+  // buffer resources: the weight slab of this output-channel tile (fixed); of the NEXT pair step's image: its IL8 groups, its
+  // heads (or offset) planes, its mask planes (explicit mode)
+  const j_rsrc r_w = j_make_rsrc(a.wpair + (size_t)cot * npairs * JPAIR_U4, (unsigned)npairs * (unsigned)(JPAIR_U4 * 16));
+  j_rsrc r_x, r_h, r_m;
+  j_rsrc r_xc;      // the IL8 groups of the CURRENT pair step's image (the rare path of the gather reads it)
 
   // ---- contexts: the pair step being contracted ("cc") and the one after it ("nn": set up, gathered, loaded ahead) -------
   struct Ctx {
     int bn, y0, x0, P;       // image, tile origin, pair index inside the tile (groups 2P, 2P+1)
+    int wy0, wx0;            // origin of the LDS window in the image: y0 - 6, x0 - 8
     bool ok;                 // this lane's pixel exists
-    bool inter;              // the whole LDS window lies inside the image (wave-uniform)
+    unsigned long long okm;  // ... as a lane mask
     float fgy, fgx;          // its row (wave-uniform) and column as floats
     unsigned po;             // its byte offset inside a plane (0 when the pixel does not exist)
-    const char* xw;          // window origin of group 0 in the IL8 image (may point before the image)
-    const char* ws;          // this pair's weight slab
-    const char* hb;          // heads mode: the image's head planes;  explicit mode: its offset planes
-    const char* mb;          // explicit mode: its mask planes
+  };
+  Ctx cc, nn;
+  unsigned n_wso = 0;        // byte offset of nn's pair slab inside r_w
+  unsigned n_xso = 0;        // byte offset of nn's even group inside r_x
+  // scalar byte offsets (inside r_h / r_m) of the parameter planes of nn's even / odd group
+  unsigned n_sm[2] = {0, 0}, n_st[2] = {0, 0}, n_sr[2] = {0, 0};
+  auto pair_ctx = [&]() __attribute__((always_inline)) {      // after nn.P changed
+    n_wso = (unsigned)nn.P * (unsigned)(JPAIR_U4 * 16);
+    n_xso = (unsigned)(2 * nn.P) * grp_b;
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const unsigned dgi = (unsigned)((2 * nn.P + par) >> a.opg_shift);
+      if (HEADS) {
+        n_sm[par] = (6u * D + dgi * 9u) * upl4;      // mask logits / masks
+        n_st[par] = (dgi * 4u) * upl4;               // 2x2 transform
+        n_sr[par] = (4u * D + dgi * 2u) * upl4;      // translation
+      } else {
+        n_sm[par] = (dgi * 9u) * upl4;               // masks (r_m)
+        n_st[par] = (dgi * 18u) * upl4;              // offsets (r_h)
+      }
+    }
   };
   auto tile_ctx = [&](Ctx& c) __attribute__((always_inline)) {      // after bn / y0 / x0 changed; P = 0
     const int gy = c.y0 + wave, gx = c.x0 + l31;
     c.ok = gy < h && gx < w;
+    c.okm = __builtin_amdgcn_ballot_w64(c.ok);
+    c.wy0 = c.y0 - JPY0;
+    c.wx0 = c.x0 - JPX0;
     c.po = c.ok ? (unsigned)(gy * w + gx) * 4u : 0u;
     c.fgy = (float)gy;
     c.fgx = (float)gx;
-    c.inter = c.y0 - JPY0 >= 0 && c.y0 - JPY0 + JPH <= h && c.x0 - JPX0 >= 0 && c.x0 - JPX0 + JPW <= w;
-    c.xw = reinterpret_cast<const char*>(a.xil + (size_t)c.bn * ngroups * plane * JG) + ((long)(c.y0 - JPY0) * w + (c.x0 - JPX0)) * 32;
-    c.ws = reinterpret_cast<const char*>(a.wpair + (size_t)cot * npairs * JPAIR_U4);
-    c.hb = reinterpret_cast<const char*>(a.offset) + (size_t)c.bn * (HEADS ? 15 : 18) * D * pl4;
-    c.mb = HEADS ? nullptr : reinterpret_cast<const char*>(a.mask) + (size_t)c.bn * 9 * D * pl4;
     c.P = 0;
+    r_x = j_make_rsrc(a.xil + (size_t)c.bn * ngroups * plane * JG, (unsigned)ngroups * grp_b);
+    r_h = j_make_rsrc(a.offset + (size_t)c.bn * (HEADS ? 15 : 18) * D * plane, (unsigned)((HEADS ? 15 : 18) * D) * upl4);
+    if (!HEADS) r_m = j_make_rsrc(a.mask + (size_t)c.bn * 9 * D * plane, (unsigned)(9 * D) * upl4);
+    const int ylo = c.wy0, xlo = c.wx0;
+    const unsigned torg = (unsigned)((ylo * w + xlo) * 32);      // wraps for windows that begin before the image: so does the sum
+#pragma unroll
+    for (int i = 0; i < WIN_IT; ++i) {
+      const bool ok = (unsigned)(ylo + (prc[i] >> 8)) < (unsigned)h && (unsigned)(xlo + (prc[i] & 255)) < (unsigned)w;
+      winvo[i] = ok ? poff[i] + torg : J_OOB;
+    }
   };
-  // the plane stride as a value the optimizer cannot see through: every parameter address below is then computed where it is
-  // used (a few scalar instructions) instead of being hoisted out of the loop as one more long-lived scalar register pair --
-  // the kernel has ~100 of those and every spilled one costs VECTOR instructions (v_readlane / v_writelane)
-  auto pl_ = [&]() __attribute__((always_inline)) {
-    unsigned v = upl4;
-    asm volatile("" : "+s"(v));
-    return v;
+  auto issue_win = [&](int i, unsigned xso, int wslot) __attribute__((always_inline)) {
+    if (i < 3 || wave < JWIN_SEGS - 24)      // piece i * 8 + wave < 30 (wave-uniform)
+      j_dma16(r_x, winvo[i], xso, smem + JL_WIN + wslot * JWIN_B + i * 8192 + wv1k);
   };
-  Ctx cc, nn;
+  // weights of the pair slab at `wso`: set "Ib" = k-steps 0,1,2,3 (24 pieces, i = 0..2) and k-step 8 (6 pieces, i = 3, waves
+  // 0..5) -> regions A, U3[q], U8[q];  set "Ia" = k-steps 4..7 (24 pieces, i = 0..2) -> region B2
+  auto issue_wgt_ib = [&](int i, unsigned wso, int q) __attribute__((always_inline)) {
+    if (i < 3) {
+      // pieces 18.. (i = 2, waves 2..7) are k-step 3: parity slot q
+      const int dsto = JL_A + i * 8192 + (i == 2 ? q * jks_w2 : 0);
+      j_dma16(r_w, wA, wso + (unsigned)(i * 8192) + wv1k, smem + dsto + wv1k);
+    } else if (wave < 6) {
+      j_dma16(r_w, wA, wso + (unsigned)(8 * JKS_B) + wv1k, smem + JL_U8 + q * JKS_B + wv1k);
+    }
+  };
+  auto issue_wgt_ia = [&](int i, unsigned wso) __attribute__((always_inline)) {
+    j_dma16(r_w, wA, wso + (unsigned)(4 * JKS_B + i * 8192) + wv1k, smem + JL_B2 + i * 8192 + wv1k);
+  };
+
   int ti_ = 0;
   tile_of(0, nn.bn, nn.y0, nn.x0);
   tile_ctx(nn);
+  pair_ctx();
   const int total = my_tiles * npairs;
-  const size_t grp_b = plane * (JG * 4);      // bytes of one group's IL8 image
 
   // sampling parameters, reloaded in place for the next pair step right after their last use
   float pa[JU], pb[JU], pm[JU];   // explicit: dy, dx, mask of the lane's tap of k-step u;  heads: pm = mask logit
@@ -282,35 +303,42 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   // per-lane byte offsets of the parameter loads of the NEXT pair step: own tap (kg = 1: one tap further) ...
   unsigned n_pm, n_po2, n_pmX, n_poX;
   auto lane_voffs = [&]() __attribute__((always_inline)) {
-    n_pm = nn.po + (kg ? upl4 : 0u);
+    // a lane without a pixel must contribute nothing: its MASK offsets hold J_OOB, the range check makes the value zero
+    // (HEADS == 1 takes logits: there the set-up gates the activated value instead)
+    const unsigned pom = (HEADS == 1 || nn.ok) ? nn.po : J_OOB;
+    n_pm = pom + (kg ? upl4 : 0u);
     n_po2 = nn.po + (kg ? 2u * upl4 : 0u);
     // ... and of k-step 4 (kg = 0: tap 8 of the even group; kg = 1: tap 0 of the odd group): in one deformable group the
     // base is tap 0 and the kg = 0 lanes go 8 taps up, in two consecutive ones the base is tap 8 and kg = 1 goes one up
-    n_pmX = same_dg ? nn.po + (kg ? 0u : 8u * upl4) : n_pm;
+    n_pmX = same_dg ? pom + (kg ? 0u : 8u * upl4) : n_pm;
     n_poX = same_dg ? nn.po + (kg ? 0u : 16u * upl4) : n_po2;
   };
   lane_voffs();
-  // wave-uniform bases of the next pair step's parameter planes (recomputed per use from few values: scalar work is cheap,
-  // long-lived scalar registers are not)
   auto load_m = [&](int u) __attribute__((always_inline)) {
     const int seq0 = 2 * u, par0 = seq0 / 9, tap0 = seq0 % 9;         // the kg = 0 lanes' (group parity, tap)
-    const int dgi = (2 * nn.P + par0) >> a.opg_shift;
-    const int tapb = (u == 4 && same_dg) ? 0 : tap0;                    // see lane_voffs
+    // u == 4: in one deformable group the base is tap 0 (see lane_voffs), else tap 8: a run-time choice of two scalars.
+    // (Every operand below is read BY VALUE first: a ternary of two captured variables is a select of two addresses, which
+    // keeps both in scratch memory.)
+    const unsigned vm = u == 4 ? 0u + n_pmX : 0u + n_pm, vo = u == 4 ? 0u + n_poX : 0u + n_po2;
+    const unsigned sm0 = n_sm[0], sm1 = n_sm[1], so0 = n_st[0], so1 = n_st[1];
+    const unsigned x8 = u == 4 ? (same_dg ? 0u : j_smul(upl4, 8)) : 0u;
     if (HEADS) {
-      pm[u] = ld_b(nn.hb + (unsigned)(6 * D + dgi * 9 + tapb) * pl_(), u == 4 ? n_pmX : n_pm);
+      const unsigned so = u == 4 ? sm0 + x8 : (par0 ? sm1 : sm0) + (tap0 ? j_smul(upl4, tap0) : 0u);
+      pm[u] = j_ld(r_h, vm, so);
     } else {
-      pa[u] = ld_b(nn.hb + (unsigned)(dgi * 18 + 2 * tapb) * pl_(), u == 4 ? n_poX : n_po2);
-      pb[u] = ld_b(nn.hb + (unsigned)(dgi * 18 + 2 * tapb + 1) * pl_(), u == 4 ? n_poX : n_po2);
-      pm[u] = ld_b(nn.mb + (unsigned)(dgi * 9 + tapb) * pl_(), u == 4 ? n_pmX : n_pm);
+      const unsigned so2 = u == 4 ? so0 + 2u * x8 : (par0 ? so1 : so0) + (tap0 ? j_smul(upl4, 2 * tap0) : 0u);
+      const unsigned sm = u == 4 ? sm0 + x8 : (par0 ? sm1 : sm0) + (tap0 ? j_smul(upl4, tap0) : 0u);
+      pa[u] = j_ld(r_h, vo, so2);
+      pb[u] = j_ld(r_h, vo, so2 + upl4);
+      pm[u] = j_ld(r_m, vm, sm);
     }
   };
   auto load_tf = [&](float (&tf)[6], int par) __attribute__((always_inline)) {
     if (HEADS) {
-      const int dgi = (2 * nn.P + par) >> a.opg_shift;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tf[j] = ld_b(nn.hb + (unsigned)(dgi * 4 + j) * pl_(), nn.po);
+      for (int j = 0; j < 4; ++j) tf[j] = j_ld(r_h, nn.po, n_st[par] + (j ? j_smul(upl4, j) : 0u));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) tf[4 + j] = ld_b(nn.hb + (unsigned)(4 * D + dgi * 2 + j) * pl_(), nn.po);
+      for (int j = 0; j < 2; ++j) tf[4 + j] = j_ld(r_h, nn.po, n_sr[par] + (j ? j_smul(upl4, j) : 0u));
     }
   };
   constexpr int M_LOADS = HEADS ? 1 : 3;      // vector-memory instructions of one load_m
@@ -342,15 +370,18 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   u32x4 bop[3][3];
   f32x16 acc[2];
 
-  const unsigned wA = (unsigned)lane * 16u;
   unsigned wpar = wA;                 // + (pair-step parity) * JKS_B
+  unsigned dummy_ad = (unsigned)JL_WIN;     // where lanes outside the window read (any valid address)
+  asm volatile("" : "+v"(dummy_ad));
   int sE = 0, sO = 1, sEn = 0;        // window slots: even / odd group of the current pair step, even group of the next
 
+  // LDS by absolute byte address: this kernel has no static LDS, its dynamic allocation begins at 0 (through `smem + x` the
+  // address of a gather costs one more vector instruction, an addition of the zero base the optimizer no longer folds)
   auto lds_f4 = [&](unsigned byte_addr) __attribute__((always_inline)) {
-    return *reinterpret_cast<const f32x4*>(smem + byte_addr);
+    return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(byte_addr);
   };
   auto lds_u4 = [&](unsigned byte_addr) __attribute__((always_inline)) {
-    return *reinterpret_cast<const u32x4*>(smem + byte_addr);
+    return *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(byte_addr);
   };
 
   // Set-up of the lane's (pixel, tap) of k-step u (0..8) of context c (window slots wslE / wslO).  The window is zero outside
@@ -372,9 +403,12 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     const float lh = py - fy0, lw = px - fx0;
     const float hh = 1.f - lh, hw = 1.f - lw;
     // v_cvt_i32_f32 saturates (and maps NaN to 0): wild offsets stay defined and simply fail the window test
-    const int ry = (int)fy0 - (c.y0 - JPY0), rx = (int)fx0 - (c.x0 - JPX0);
-    const bool in_win = (unsigned)ry <= (unsigned)(JPH - 2) && (unsigned)rx <= (unsigned)(JPW - 2);
-    const float mf = c.ok ? m : 0.f;
+    const int ry = (int)fy0 - c.wy0, rx = (int)fx0 - c.wx0;
+    // lanes whose corners leave the window, as a lane mask straight from the two compares (a ballot of the bool costs two more
+    // vector instructions)
+    const unsigned long long outm = __builtin_amdgcn_uicmp((unsigned)ry, (unsigned)(JPH - 2), 34 /* ugt */) |
+                                    __builtin_amdgcn_uicmp((unsigned)rx, (unsigned)(JPW - 2), 34);
+    const float mf = HEADS == 1 ? (c.ok ? m : 0.f) : m;      // HEADS != 1: zero already (lane_voffs)
     const float hm = hh * mf, lm = lh * mf;
     Pos& ps = pos[u % 3];
     ps.w1 = hm * hw; ps.w2 = hm * lw; ps.w3 = lm * hw; ps.w4 = lm * lw;
@@ -382,12 +416,12 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     const int wsl = u < 4 ? wslE : (u > 4 ? wslO : (kg ? wslO : wslE));
     const unsigned base = (unsigned)(JL_WIN + wsl * JWIN_B);
     const unsigned ad = __umul24((unsigned)ry, (unsigned)JROW_B) + (((unsigned)rx << 4) + base);
-    ps.ad = in_win ? ad : (unsigned)JL_WIN;
-    slowm[u % 3] = __builtin_amdgcn_ballot_w64(c.ok && !in_win);
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(ps.ad) : "v"(ad), "v"(dummy_ad), "s"(outm));
+    slowm[u % 3] = outm & c.okm;
   };
   // the four corners (channel half `half`) of k-step u's sample: from the LDS window; lanes outside it read the image itself
   // with corner-wise zero padding (their corner weights are gated once, with the low half)
-  auto gather = [&](int u, int half, const Ctx& c) __attribute__((always_inline)) {
+  auto gather = [&](int u, int half, const Ctx& c, j_rsrc rxc) __attribute__((always_inline)) {
 #ifdef EAVSR_IL2_EXP_NO_GATHER
 #pragma unroll
     for (int j = 0; j < 4; ++j) gat[j] = f32x4{pos[u % 3].w1, pos[u % 3].w2, (float)(pos[u % 3].ad + half), pos[u % 3].w4};
@@ -406,7 +440,10 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
       gat[3] = lds_f4(ps.ad + JPLANE_B + JROW_B + 16);
     }
 #ifndef EAVSR_IL2_EXP_NO_FIXUP
-    const unsigned long long sm = slowm[u % 3];
+    unsigned long long sm = slowm[u % 3];
+    // (tested afresh for either half: a boolean carried from the first test to the second costs three more scalar
+    // instructions per k-step than a second s_cmp_lg_u64)
+    asm volatile("" : "+s"(sm));
     if (__builtin_expect(sm != 0, 0)) {      // wave-uniform, rare: the block is laid out away from the pipeline
       const bool mine = (sm >> lane) & 1ull;
       f32x4 tq[4];
@@ -427,12 +464,13 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
         }
         const int cy0 = min(max(hl, 0), h - 1), cy1 = min(max(hh_i, 0), h - 1);
         const int cx0 = min(max(wl, 0), w - 1), cx1 = min(max(wh_i, 0), w - 1);
-        const int par = u < 4 ? 0 : (u > 4 ? 1 : kg);       // the lane's group of the pair
-        const char* xg = reinterpret_cast<const char*>(a.xil + ((size_t)c.bn * ngroups + 2 * c.P + par) * plane * JG) + half * 16;
-        tq[0] = *reinterpret_cast<const f32x4*>(xg + (unsigned)(cy0 * w + cx0) * 32u);
-        tq[1] = *reinterpret_cast<const f32x4*>(xg + (unsigned)(cy0 * w + cx1) * 32u);
-        tq[2] = *reinterpret_cast<const f32x4*>(xg + (unsigned)(cy1 * w + cx0) * 32u);
-        tq[3] = *reinterpret_cast<const f32x4*>(xg + (unsigned)(cy1 * w + cx1) * 32u);
+        // the lane's group of the pair: 2 P (+ 1 for the odd group: the kg = 1 lanes of k-step 4, every lane past it)
+        const unsigned so = (unsigned)(2 * c.P + (u > 4 ? 1 : 0)) * grp_b;
+        const unsigned vb = (u == 4 && kg ? grp_b : 0u) + (unsigned)(half * 16);
+        tq[0] = j_ld4(rxc, vb + (unsigned)(cy0 * w + cx0) * 32u, so);
+        tq[1] = j_ld4(rxc, vb + (unsigned)(cy0 * w + cx1) * 32u, so);
+        tq[2] = j_ld4(rxc, vb + (unsigned)(cy1 * w + cx0) * 32u, so);
+        tq[3] = j_ld4(rxc, vb + (unsigned)(cy1 * w + cx1) * 32u, so);
       }
       // the loads complete HERE, inside the rare branch: past the join nothing waits on vector memory (window DMA, tile
       // stores and parameter loads stay in flight on the common path)
@@ -496,31 +534,28 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
         for (int e = 0; e < 4; ++e) acc[m][e4 * 4 + e] = b4[e];
       }
   };
-  // finished tile: lane (n, kg) holds channels m * 32 + (e & 3) + 8 (e >> 2) + 4 kg of its pixel; the channel stride walks on
-  // the scalar side (one wave-uniform base per store), the lane part of the address is one register
+  // finished tile: lane (n, kg) holds channels m * 32 + (e & 3) + 8 (e >> 2) + 4 kg of its pixel.  One buffer store per
+  // value: the resource covers this tile's (up to) 64 output planes, the channel is a scalar offset (one s_mul_i32), the lane
+  // part one register for the whole tile; a lane without a pixel holds J_OOB there and its stores are dropped by the range
+  // check (no exec-mask region per store)
   bool st_pending = false;
   int st_bn = 0;
-  unsigned st_po = 0;
-  bool st_ok = false;
+  unsigned st_vo = J_OOB;
   auto store_tile = [&]() __attribute__((always_inline)) {
+    const int nco = min(64, a.cout - cot * 64);
+    const j_rsrc r_o = j_make_rsrc(a.out + ((size_t)st_bn * a.cout + (size_t)cot * 64) * plane, (unsigned)nco * upl4);
 #ifdef EAVSR_IL2_EXP_NO_STORE
-    if (st_ok && never) {
+    if (never) {
 #else
-    if (st_ok) {
+    {
 #endif
-      char* ob = reinterpret_cast<char*>(a.out + ((size_t)st_bn * a.cout + (size_t)cot * 64) * plane);
-      const unsigned voff = st_po + (kg ? 4u * upl4 : 0u);
-      if (__builtin_expect(cot * 64 + 64 <= a.cout, 1)) {      // wave-uniform
+      if (__builtin_expect(nco == 64, 1)) {      // wave-uniform
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-#ifdef EAVSR_IL2_NT_STORE
-            __builtin_nontemporal_store(acc[m][e], reinterpret_cast<float*>(ob + voff));
-#else
-            *reinterpret_cast<float*>(ob + voff) = acc[m][e];
-#endif
-            ob += ((e & 3) == 3 ? 5u : 1u) * upl4;      // channel cu + 4 kg: 1 plane on, 5 planes across a group of four
+            const int cu = m * 32 + (e & 3) + 8 * (e >> 2);
+            j_st(r_o, st_vo, cu ? j_smul(upl4, cu) : 0u, acc[m][e]);
           }
       } else {
 #pragma unroll
@@ -528,8 +563,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int cu = m * 32 + (e & 3) + 8 * (e >> 2);
-            if (cot * 64 + cu + 4 * kg < a.cout) *reinterpret_cast<float*>(ob + voff) = acc[m][e];
-            ob += ((e & 3) == 3 ? 5u : 1u) * upl4;
+            j_st(r_o, cu + 4 * kg < nco ? st_vo : J_OOB, cu ? j_smul(upl4, cu) : 0u, acc[m][e]);
           }
       }
     }
@@ -538,24 +572,23 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   constexpr int ST_STORES = 32;
 
 #define J_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // all DMA of the "Ia" set of context c: odd group's window (slot wsl) + k-steps 4..7 of its weights
-  auto issue_ia = [&](const Ctx& c, int wsl, int part) __attribute__((always_inline)) {
-    const char* xo = c.xw + grp_b * (size_t)(2 * c.P + 1);
-    if (part == 0) { issue_win(0, xo, c.y0, c.x0, c.inter, wsl); issue_win(1, xo, c.y0, c.x0, c.inter, wsl); issue_wgt_ia(0, c.ws); }
-    if (part == 1) { issue_win(2, xo, c.y0, c.x0, c.inter, wsl); issue_win(3, xo, c.y0, c.x0, c.inter, wsl); issue_wgt_ia(1, c.ws); }
-    if (part == 2) { issue_wgt_ia(2, c.ws); }
+  // all DMA of the "Ia" set of the next pair step: odd group's window (slot wsl) + k-steps 4..7 of its weights
+  auto issue_ia = [&](int wsl, int part) __attribute__((always_inline)) {
+    const unsigned g = n_xso + grp_b;
+    if (part == 0) { issue_win(0, g, wsl); issue_win(1, g, wsl); issue_wgt_ia(0, n_wso); }
+    if (part == 1) { issue_win(2, g, wsl); issue_win(3, g, wsl); issue_wgt_ia(1, n_wso); }
+    if (part == 2) { issue_wgt_ia(2, n_wso); }
   };
 
   // ---- run prologue: everything a previous pair step would have requested for the first one ------------------------------
   {
-    const char* xe = nn.xw;
 #pragma unroll
-    for (int i = 0; i < WIN_IT; ++i) issue_win(i, xe, nn.y0, nn.x0, nn.inter, 0);
+    for (int i = 0; i < WIN_IT; ++i) issue_win(i, n_xso, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_wgt_ib(i, nn.ws, 0);
-    issue_ia(nn, 1, 0);
-    issue_ia(nn, 1, 1);
-    issue_ia(nn, 1, 2);
+    for (int i = 0; i < 4; ++i) issue_wgt_ib(i, n_wso, 0);
+    issue_ia(1, 0);
+    issue_ia(1, 1);
+    issue_ia(1, 2);
     load_tf(tfA, 0);
     load_tf(tfB, 1);
 #pragma unroll
@@ -570,21 +603,24 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     __syncthreads();
     init_acc();
     setup(0, nn, 0, 1);
-    gather(0, 0, nn);
+    gather(0, 0, nn, r_x);
     load_a(0, 0);
     setup(1, nn, 0, 1);
     blend_pair(0, 0);
     blend_pair(0, 1);
     J_FENCE();
-    gather(0, 1, nn);
+    gather(0, 1, nn, r_x);
     J_FENCE();
     blend_pair(0, 2);
     blend_pair(0, 3);
     J_FENCE();
   }
-  // advance: the next pair step becomes current; the one after it is next (pointers move by increments)
+  // advance: the next pair step becomes current; the one after it is next.  Past the end of the run `nn` stays where it is:
+  // the last pair step then requests (and never reads) its own operands once more into the slots that are free by rotation --
+  // the requests of a pair step are unconditional (no branch per request), and the run ends with a vmcnt(0).
   auto advance = [&](int it_next) __attribute__((always_inline)) {
     cc = nn;
+    r_xc = r_x;
     if (it_next + 1 < total) {
       if (nn.P + 1 == npairs) {
         ++ti_;
@@ -593,8 +629,8 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
         lane_voffs();
       } else {
         ++nn.P;
-        nn.ws += (size_t)JPAIR_U4 * 16;
       }
+      pair_ctx();
     }
   };
   advance(0);
@@ -606,7 +642,6 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   bool stored_now = false;      // this pair step began with a tile store: its stores are still in flight at the first barrier
   for (int it = 0; it < total; ++it) {
     J_STAMP(0);      // loop bookkeeping (advance, slot rotation)
-    const int more_n = total - 1 - it;      // > 0: there is a next pair step (an integer: a bool carried across the body is copied through vector registers)
     const int q = it & 1;
     wpar = wA + (unsigned)(q * JKS_B);
     // window slots rotate by two per pair step: even group of the next pair step = slot after this pair's odd group
@@ -645,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
       }
       const int u1 = (u + 1) % JU, u2 = (u + 2) % JU;          // k-steps being blended / set up under this one's MFMAs
       const bool nx1 = u + 1 >= JU, nx2 = u + 2 >= JU;         // ... they belong to the next pair step
-      if (nx1) gather(u1, 0, nn); else gather(u1, 0, cc);
+      if (nx1) gather(u1, 0, nn, r_x); else gather(u1, 0, cc, r_xc);
       load_a(u, 1);
       J_FENCE();
       constexpr int NM = 2 * NPROD, CH = NM / 6;      // MFMAs per k-step; per chunk (2 for x6, 3 for x9)
@@ -687,25 +722,25 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
           }
           // DMA: the next pair step's odd-group window + weights 4..7 all in k-step 8 (right behind the barrier that retired
           // their slots: 4 k-steps to land), its even-group window + weights 0..3, 8 over k-steps 3..6
-          if (u == 8 && more_n > 0 && dma_on) issue_ia(nn, sOn, 0);
-          if (u >= 3 && u <= 6 && more_n > 0 && dma_on) issue_win(u - 3, nn.xw + grp_b * (size_t)(2 * nn.P), nn.y0, nn.x0, nn.inter, sEn);
+          if (u == 8 && dma_on) issue_ia(sOn, 0);
+          if (u >= 3 && u <= 6 && dma_on) issue_win(u - 3, n_xso, sEn);
         }
         if (k == 2 && blend_on) blend_pair(u1, 0);
         if (k == 3) {
           if (blend_on) blend_pair(u1, 1);
-          if (nx1) gather(u1, 1, nn); else gather(u1, 1, cc);
+          if (nx1) gather(u1, 1, nn, r_x); else gather(u1, 1, cc, r_xc);
           load_a(u1, 0);
         }
         if (k == 4) {
-          if (u == 8 && more_n > 0 && dma_on) issue_ia(nn, sOn, 1);
-          if (u >= 3 && u <= 6 && more_n > 0 && dma_on) issue_wgt_ib(u - 3, nn.ws, q ^ 1);
+          if (u == 8 && dma_on) issue_ia(sOn, 1);
+          if (u >= 3 && u <= 6 && dma_on) issue_wgt_ib(u - 3, n_wso, q ^ 1);
         }
         if (k == 5) {
           if (blend_on) {
             blend_pair(u1, 2);
             blend_pair(u1, 3);
           }
-          if (u == 8 && more_n > 0 && dma_on) issue_ia(nn, sOn, 2);
+          if (u == 8 && dma_on) issue_ia(sOn, 2);
         }
         (void)nx1;
         J_FENCE();
@@ -716,13 +751,16 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     // ---- end of a pair step -----------------------------------------------------------------------------------------------
     if (cc.P + 1 == npairs) {      // the tile is complete: its accumulators leave at the top of the next k-step 0
       st_pending = true;
-      st_bn = cc.bn; st_po = cc.po; st_ok = cc.ok;
+      st_bn = cc.bn;
+      st_vo = cc.ok ? cc.po + (kg ? 4u * upl4 : 0u) : J_OOB;
     }
     sE = sEn;
     sO = sOn;
     advance(it + 1);
   }
   if (st_pending) store_tile();
+  // the last pair step's requests (see advance) must have landed before this workgroup's LDS is handed to another one
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 #undef J_FENCE
 #ifdef EAVSR_IL2_STAMPS
   J_STAMP(10);
@@ -816,9 +854,10 @@ extern "C" int eavsr_dcnv2_il2_f32(const float* x_il8, const float* offset_or_he
   EAVSR_REQUIRE(cpg % 8 == 0, -2, "dcnv2_il2: %d channels per deformable group unsupported (must be a multiple of 8)", cpg);
   EAVSR_REQUIRE(cin % 16 == 0, -2, "dcnv2_il2: cin %d must be a multiple of 16 (groups are contracted in pairs)", cin);
   EAVSR_REQUIRE(nprod == 6 || nprod == 9, -2, "dcnv2_il2: nprod %d (6 or 9)", nprod);
-  EAVSR_REQUIRE((long)h * w * 64 < (1L << 32), -1, "dcnv2_il2: plane too large for 32-bit byte offsets");
-  EAVSR_REQUIRE((long)h * w * 15 * deform_groups * 4 < (1L << 32) || !heads, -1, "dcnv2_il2: heads tensor too large");
-  EAVSR_REQUIRE((long)h * w * 18 * 4 < (1L << 32), -1, "dcnv2_il2: offset planes too large");
+  // every per-image extent is a buffer resource addressed with 32-bit offsets, and J_OOB (2^31) must lie beyond each of them
+  EAVSR_REQUIRE((long)h * w * 4 * cin < (1L << 31), -1, "dcnv2_il2: one image of x exceeds 2 GiB");
+  EAVSR_REQUIRE((long)h * w * 4 * (heads ? 15 : 18) * deform_groups < (1L << 31), -1, "dcnv2_il2: one image of the heads / offsets exceeds 2 GiB");
+  EAVSR_REQUIRE((long)h * w * 4 * 64 < (1L << 31), -1, "dcnv2_il2: 64 output planes exceed 2 GiB");
   EAVSR_REQUIRE((((uintptr_t)x_il8) & 15) == 0, -2, "dcnv2_il2: x must be 16-byte aligned");
   if (n == 0) return 0;
   IL2Args a;

@@ -412,6 +412,15 @@ class EAVSRPModel:
             from .shard import GradientAllReducer
             self.grad_sync = GradientAllReducer(trainable)
             self.netEAVSRP.train()
+        self.sync_parameters()
+
+    def sync_parameters(self, src: int = 0) -> int:
+        """Several processes (one per GPU): every rank takes rank `src`'s parameters and buffers, once -- at construction and
+        after `load_networks` -- so that data-parallel replicas start identical whatever each rank seeded or loaded.  The
+        reference gets this from nn.DataParallel's per-forward replication (models/networks.py:67-74); here it is one start-up
+        broadcast and nothing per step (eavsr_amd.shard.broadcast_module).  No-op on one process."""
+        from .shard import broadcast_module
+        return broadcast_module(self.netEAVSRP, src)
 
     def setup(self, opt=None):
         """base_model.py:56-70, what train_basic.py:42 / test_basic.py call after construction: learning-rate schedulers
@@ -553,6 +562,7 @@ class EAVSRPModel:
                 raise RuntimeError("While copying the parameter named [%s], whose dimensions in the model are %s and "
                                    "whose dimensions in the checkpoint are %s." % (k, list(own[k].shape), list(v.shape)))
         self.netEAVSRP.load_state_dict(sd, strict=True)
+        self.sync_parameters()
         if isinstance(epoch_or_path, int):
             self.start_epoch = epoch_or_path
         return path

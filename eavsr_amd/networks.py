@@ -292,7 +292,7 @@ class MultiAdSTN(ModulatedDeformConv2d):
                 heads = self.adastn.heads(nbr, ref_feat_l[0])
                 return ops.dcnv2_il16(feat_il, heads, None, self.weight, self.bias, self.deform_groups, heads=True)
             nbr, feat_il = ops.flow_warp_pair(nbr_feat_l[0], feat_prop, offset, b_il8=True)          # :621, :623
-            act = ops.heads_mask_activated(int(self.weight.shape[1]))      # the mask sigmoid in the heads' epilogue (:313-314)
+            act = ops.heads_mask_activated(int(self.weight.shape[1]), self.deform_groups)      # the mask sigmoid in the heads' epilogue (:313-314)
             heads = self.adastn.heads(nbr, ref_feat_l[0], mask_activated=act)                        # :625
             return ops.dcnv2_il(feat_il, heads, None, self.weight, self.bias, self.deform_groups,
                                 nprod=int(ops.DCN_MODE[2]), heads=True, mask_activated=act)          # :627-630

@@ -540,6 +540,18 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError("pixel_shuffle2: cout % 4 == 0, no residual / channel sums / channel-attention prologue")
     if ca_out and ca is None:      # before any early return (the bf16x6 route used to skip this check)
         raise ValueError("ca_out needs ca")
+    if sigmoid_from is not None:   # validated once, for every route (routes used to differ)
+        sigmoid_from = int(sigmoid_from)
+        if not 0 <= sigmoid_from < cout:
+            raise ValueError(f"sigmoid_from {sigmoid_from}: 0 <= value < cout = {cout}")
+        if residual is not None or chan_partial or ca is not None or pixel_shuffle2:
+            raise ValueError("sigmoid_from: plain convolutions only")
+        fused = (((k == 7 and CONV7_MODE == "bf16x6") or (k == 5 and CONV5_MODE == "bf16x6")) and len(srcs) == 1
+                 and cin % 8 == 0 and sigmoid_from % 8 == 0)
+        if not fused:              # every other kernel: the activation is one more pass over those channels
+            y = conv2d(srcs, weights, biases, act, slope)
+            y[:, sigmoid_from:] = torch.sigmoid(y[:, sigmoid_from:])
+            return y
     if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None:
         y = _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
         return torch.nn.functional.pixel_shuffle(y, 2) if pixel_shuffle2 else y
@@ -553,12 +565,6 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
             and not pixel_shuffle2 and w % 4 == 0 and cout >= 32 and not torch.is_grad_enabled()
             and all(int(s_.shape[1]) % 16 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs)):
         return _conv3x3_h16g(srcs, weights, biases, act, slope, CONV3_H16)
-    if sigmoid_from is not None:
-        if residual is not None or chan_partial or ca is not None or pixel_shuffle2:
-            raise ValueError("sigmoid_from: plain convolutions only")
-        y = conv2d(srcs, weights, biases, act, slope)
-        y[:, sigmoid_from:] = torch.sigmoid(y[:, sigmoid_from:])
-        return y
     ck = lib().eavsr_conv2d_ck(k)
     if any(int(s.shape[1]) % ck for s in srcs[:-1]):
         srcs = [torch.cat(srcs, 1)]  # ragged middle source: materialise (tiny SPyNet inputs only)
@@ -789,11 +795,13 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
     return out
 
 
-def heads_mask_activated(cin: int) -> bool:
+def heads_mask_activated(cin: int, deform_groups: int = 8) -> bool:
     """True when the fused alignment should ask the predictor's heads convolution for MASKS (sigmoid in its epilogue,
     networks.py:313-314) rather than mask logits: the round-4 DCNv2 schedule takes them as they are (heads = 2), which moves four
-    vector instructions per sample out of the kernel whose bound is vector issue."""
-    return DCN_IL_IMPL == "il2" and cin % 16 == 0 and CONV5_MODE == "bf16x6" and HEADS_MASK_ACTIVATED
+    vector instructions per sample out of the kernel whose bound is vector issue.  The epilogue activates whole octets of output
+    channels, so the first mask channel 6 D must be a multiple of 8 (D = 4, 8, ..; ADVICE r4: D = 1 / 2 used to raise)."""
+    return (DCN_IL_IMPL == "il2" and cin % 16 == 0 and CONV5_MODE == "bf16x6" and HEADS_MASK_ACTIVATED
+            and (6 * int(deform_groups)) % 8 == 0)
 
 
 _dcn_probe = None      # bench.py: a list that collects offset statistics of every heads-mode DCNv2 call inside `dcn_probe()`

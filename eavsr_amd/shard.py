@@ -19,7 +19,8 @@ What overlaps in practice: the training step accumulates the convolution weight 
 nearly every bucket holds a convolution parameter -- so almost all of the 49 MB is reduced in `finish()`,
 AFTER backward, not under it.  That is a deliberate trade: the sink removes ~12,000 launches per step,
 while the whole all-reduce is ~0.6 ms at the per-link xGMI bound against a 0.4 s step.  No parameter
-broadcast per step (the reference's nn.DataParallel re-broadcasts all 54.9 MB every forward).
+broadcast per step (the reference's nn.DataParallel re-broadcasts all 54.9 MB every forward): `broadcast_module` runs ONCE, when
+the model is constructed and after a checkpoint is loaded, so that ranks agree whatever each of them seeded or loaded.
 """
 from __future__ import annotations
 
@@ -162,6 +163,54 @@ def gather_outputs(local: torch.Tensor, n_clips: int, rank: int, world: int) -> 
         idx = clip_indices(n_clips, r, world)
         out[idx] = bufs[r][:len(idx)]
     return out
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 64 << 20) -> int:
+    """Every parameter and buffer of `module` takes rank `src`'s value: ONE start-up collective per ~64 MB bucket (the model is
+    54.9 MB: one or two broadcasts), never per step -- the reference's nn.DataParallel re-broadcasts the replica every forward
+    (models/networks.py:67-74).  Ranks agree afterwards even when only rank `src` loaded a checkpoint or when the ranks were
+    seeded differently (until round 5 they agreed only because every rank seeded identically).
+    Tensors travel in `state_dict()` order, grouped by dtype, packed flat on the tensors' own device (RCCL for device tensors,
+    gloo for host tensors).  Returns the number of bytes broadcast; a no-op (0) on one process."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    tensors = [t for t in module.state_dict(keep_vars=True).values() if isinstance(t, torch.Tensor) and t.numel() > 0]
+    total = 0
+    by_type = {}
+    for t in tensors:
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    with torch.no_grad():
+        for (dtype, device), group in by_type.items():
+            cur, size = [], 0
+            buckets = []
+            for t in group:
+                cur.append(t)
+                size += t.numel() * t.element_size()
+                if size >= bucket_bytes:
+                    buckets.append(cur)
+                    cur, size = [], 0
+            if cur:
+                buckets.append(cur)
+            for bucket in buckets:
+                flat = torch.cat([t.detach().reshape(-1) for t in bucket])
+                dist.broadcast(flat, src=src)
+                o = 0
+                for t in bucket:
+                    n = t.numel()
+                    t.detach().copy_(flat[o:o + n].view_as(t))
+                    o += n
+                total += flat.numel() * flat.element_size()
+    return total
+
+
+def ranks_seen(device=None) -> int:
+    """How many ranks the DATA-PATH backend itself sees: one 4-byte all-reduce of ones on `device` (RCCL when it is a GPU; the
+    control plane's gloo group cannot answer for it).  bench.py prints it as `rccl_ranks_seen` before the timed region."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
 
 
 class GradientAllReducer:

@@ -2,7 +2,8 @@
 
 configs[1]  eavsrp x4, 7 x 3 x 180 x 320 fp32          -- one full-size clip against the CPU oracle (<= 1e-3 max abs, the
             north star's bound), in the DEFAULT kernel mode, asserting that the kernels the bench times really ran.
-configs[2]  eavsrpx2, 8 clips x 7 x 3 x 256 x 256 bf16 -- full size: 16-bit backbone against the fp32 HIP forward by PSNR.
+configs[2]  eavsrpx2, 8 clips x 7 x 3 x 256 x 256 bf16 -- full size: one clip against the CPU oracle (fp32 <= 1e-3; bf16 by PSNR
+            against the oracle), the batch 16-bit vs fp32 by PSNR.
 configs[3]  eavsrp x4 training step, 2 x 7 x 3 x 96 x 96 -- full size: the loss is finite and decreases.
 configs[4]  eavsrp x4, 15 x 3 x 540 x 960 fp16          -- the 15-frame recurrence and the x4 + fp16 backbone against the
             oracle at a size the CPU affords (1 x 15 x 3 x 64 x 96), and the full-size clip as a property test.
@@ -205,27 +206,45 @@ def test_config4_full_size_long_sequence_fp16(cuda):
 
 # ---------------------------------------------------------------------------------------------------------- configs[2]
 def test_config2_x2_model_full_size_bf16(cuda):
-    """BASELINE.json configs[2]: eavsrpx2, 8 clips x 7 x 3 x 256 x 256, bf16 backbone, against the exact fp32 forward of
-    the same model by PSNR (the x2 model's arithmetic is pinned to the reference by golden G8 x2 at 64 x 64)."""
-    from eavsr_amd import networks as Nw
-    net, _ = _net(cuda, "x2")
-    clip = _clip(8, 7, 256, 256, seed=2).to(cuda)
+    """BASELINE.json configs[2]: eavsrpx2, 8 clips x 7 x 3 x 256 x 256.  Pinned to the reference at FULL resolution (VERDICT r4
+    item 4): clip 5 of the batch through the CPU oracle's `eavsrp_forward(sd, clip, 2)` (models/eavsrpx2_model.py:124-365, ~20 s of
+    host time) -- the HIP fp32 forward in the default kernel mode within 1e-3 max abs of it (with the kernels the bench times
+    asserted), and the bf16-backbone output quoted by PSNR against that ORACLE output, not against our own fp32 forward."""
+    from eavsr_amd import networks as Nw, ops
+    assert ops.CONV_MODE == "winograd4" and ops.DCN_MODE == "il6" and ops.CONV5_MODE == "bf16x6" and ops.CONV7_MODE == "bf16x6"
+    net, sd = _net(cuda, "x2")
+    clip_cpu = _clip(8, 7, 256, 256, seed=2)
+    clip = clip_cpu.to(cuda)
     with torch.no_grad():
-        y32 = net(clip)
+        with ops.profile() as prof:
+            y32 = net(clip)
+        names32 = set(prof.summary())
         try:
             Nw.set_backbone_dtype("bf16")
-            y16 = net(clip)
+            with ops.profile() as prof16:
+                y16 = net(clip)
+            names16 = set(prof16.summary())
         finally:
             Nw.set_backbone_dtype(None)
-    assert tuple(y16.shape) == (8, 7, 3, 512, 512)
+        ref5 = O.eavsrp_forward(sd, clip_cpu[5:6], 2)
+    assert tuple(y16.shape) == (8, 7, 3, 512, 512) and tuple(ref5.shape) == (1, 7, 3, 512, 512)
     assert torch.isfinite(y32).all() and torch.isfinite(y16).all()
-    psnr = O.psnr_255(y16.cpu(), y32.cpu())
+    assert {"conv3x3_64to64_wino4", "conv5x5_64to120_x6", "dcnv2_il_heads", "flow_warp_pair"} <= names32, names32
+    assert {"conv3x3_64to64_h16", "dcnv2_il16_heads"} <= names16, names16
+    err = H.maxabs(y32[5:6].cpu(), ref5)
+    assert err <= 1e-3, err                       # the north star's fp32 bound, at the size and in the mode the bench runs
+    psnr32 = O.psnr_255(y32[5:6].cpu(), ref5)
+    psnr16 = O.psnr_255(y16[5:6].cpu(), ref5)     # bf16 backbone against the REFERENCE arithmetic
+    assert psnr32 >= 80.0, psnr32
+    assert psnr16 >= 50.0, psnr16
+    psnr = O.psnr_255(y16.cpu(), y32.cpu())       # the whole batch, 16-bit against fp32 (what bench.py's psnr_vs_fp32 reports)
     assert psnr >= 50.0, psnr
     # clips are independent: clip 5 of the batch equals clip 5 on its own (fp32)
     with torch.no_grad():
         one = net(clip[5:6])
     assert H.maxabs(one.cpu(), y32[5:6].cpu()) <= 1e-5
-    print(f"configs[2] x2 8x7x3x256x256: bf16-backbone PSNR vs fp32 {psnr:.1f} dB")
+    print(f"configs[2] x2 8x7x3x256x256: clip 5 fp32 max|hip - oracle| = {err:.3e} (PSNR {psnr32:.1f} dB); bf16 backbone vs the oracle "
+          f"{psnr16:.1f} dB, vs our fp32 forward over the batch {psnr:.1f} dB")
 
 
 # ---------------------------------------------------------------------------------------------------------- configs[3]

@@ -102,6 +102,23 @@ def test_multiadstn_golden_in_every_dcn_mode(nets, cuda, preset, mode, fuse_leve
     assert H.maxabs(out.cpu(), gold["out"]) <= 1e-4
 
 
+@pytest.mark.parametrize("D", [1, 2, 4])
+def test_multiadstn_other_deformable_group_counts_vs_oracle(nets, cuda, D):
+    """deformable_groups != 8 through the fused alignment (D = 1 / 2 asked the heads convolution for an activation
+    boundary at channel 6 D that is not a whole octet and raised): D = 1, 2 take mask logits into the sampler, D = 4 activated
+    masks; all three against the CPU oracle (networks.py:597-631 with the reference's constructor argument)."""
+    from eavsr_amd import ops
+    Nw, _ = nets
+    sd = H.filled(H.multiadstn_shapes("g5.align.", D), "trained_like")
+    m = load(Nw.MultiAdSTN(OPT, 64, 64, deformable_groups=D), sd, "g5.align.", cuda)
+    nbr, ref, fp, flow = cases.g5_inputs()
+    want = O.multi_adstn(sd, "g5.align.", nbr, ref, fp, flow, D)
+    with torch.no_grad(), ops.profile() as prof:
+        out = m(dev(nbr, cuda), dev(ref, cuda), fp.to(cuda), flow.to(cuda))
+    assert "dcnv2_il_heads" in set(prof.summary())
+    assert H.maxabs(out.cpu(), want) <= 1e-4
+
+
 @pytest.mark.parametrize("preset", ["default", "trained_like"])
 def test_backbone_blocks_golden(nets, cuda, preset):
     Nw, Mw = nets

@@ -211,6 +211,9 @@ def test_heads_mask_activation_is_chosen_only_where_the_kernel_takes_it():
         ops.set_dcn_il_impl("il2")
         assert ops.heads_mask_activated(64) == (ops.CONV5_MODE == "bf16x6")
         assert ops.heads_mask_activated(24) is False              # cin % 16 != 0: the round-2 kernel runs, which wants logits
+        assert ops.heads_mask_activated(64, 4) == ops.heads_mask_activated(64, 8)
+        assert ops.heads_mask_activated(64, 2) is False           # 6 D = 12 is not a whole octet of heads channels
+        assert ops.heads_mask_activated(64, 1) is False
         ops.set_dcn_il_impl("il")
         assert ops.heads_mask_activated(64) is False
         ops.set_dcn_il_impl("il2")

@@ -225,7 +225,138 @@ def test_bench_dry_line_carries_per_rank_fields():
     line = lines[0]
     assert len(line["per_rank_ms"]) == 2 and line["per_rank_ms"][1] > line["per_rank_ms"][0] >= 9.0      # rank r sleeps 10 (1 + r) ms
     assert line["per_rank_device"] == ["cpu:0", "cpu:1"] and line["host_threads_per_rank"] >= 1
+    assert line["rccl_ranks_seen"] == 2      # counted by an all-reduce on the collective backend itself (gloo here, RCCL on GPUs)
     assert abs(max(line["per_rank_ms"]) - line["ms_per_step"]) < 5.0
+
+
+def _bcast_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from eavsr_amd import shard
+    shard.init_process_group("gloo")
+    torch.manual_seed(1000 + rank)             # DIFFERENT replicas on purpose (a checkpoint loaded on rank 0 only looks like this)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Linear(8, 4))
+    net[1].running_mean.fill_(float(rank))     # buffers travel too, also the integer one (num_batches_tracked)
+    net[1].num_batches_tracked.fill_(7 + rank)
+    before = [v.clone() for v in net.state_dict().values()]
+    nbytes = shard.broadcast_module(net, src=0, bucket_bytes=256)      # several buckets
+    after = list(net.state_dict().values())
+    unchanged = all(torch.equal(a, b) for a, b in zip(before, after))
+    seen = shard.ranks_seen()
+    q.put((rank, [v.tolist() for v in after], nbytes, unchanged, seen))
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_parameters_are_broadcast_from_rank_0_once():
+    """ranks agreed only because every rank seeded identically.  Two ranks with different seeds end with rank
+    0's parameters AND buffers after `broadcast_module` (the call `EAVSRPModel` makes at construction and after
+    `load_networks`); rank 0 itself is unchanged; `ranks_seen` counts the ranks over the collective backend itself."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, sd0, nb0, same0, seen0), (_, sd1, nb1, same1, seen1) = res
+    assert sd0 == sd1                              # identical replicas afterwards
+    assert same0 and not same1                     # ... and they are rank 0's
+    assert nb0 == nb1 > 0 and seen0 == seen1 == 2
+    torch.manual_seed(1000)
+    want = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Linear(8, 4))
+    assert sd0[0] == want[0].weight.tolist()
+    assert sd1[-2] == want[2].weight.tolist() and sd1[4] == [0.0] * 8 and sd1[6] == 7      # running_mean / num_batches_tracked of rank 0
+
+
+class _StubGraph:
+    """what a replay of the captured forward + backward leaves behind: gradients in the bound `.grad` tensors"""
+
+    def __init__(self, fn):
+        self.fn, self.replays = fn, 0
+
+    def replay(self):
+        self.replays += 1
+        self.fn()
+
+
+def _graph_step_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from argparse import Namespace
+    from eavsr_amd import shard
+    from eavsr_amd.graph import GraphedTrainStep
+    shard.init_process_group("gloo")
+    torch.manual_seed(50 + rank)               # different replicas; the broadcast below makes them one
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    shard.broadcast_module(net)
+    opt = torch.optim.Adam([{"params": net[0].parameters(), "lr": 1e-2}, {"params": net[2].parameters(), "lr": 1e-3}])
+    model = Namespace(netEAVSRP=net, optimizer_EAVSRP=opt, grad_sync=shard.GradientAllReducer(net.parameters(), bucket_bytes=64),
+                      data_lr_seq=None, data_hr_seq=None)
+    g = torch.Generator().manual_seed(900 + rank)      # every rank its own data
+    st = object.__new__(GraphedTrainStep)              # the capture needs a GPU; the control flow around a replay does not
+    st.model, st.world = model, world
+    st.static_lr, st.static_hr = torch.zeros(4, 6), torch.zeros(4, 2)
+    grads = [(p, torch.zeros_like(p)) for p in net.parameters()]
+    st._grads = grads
+
+    def replayed():      # forward + backward of the "captured" step, writing into the captured gradient tensors
+        out = net(st.static_lr)
+        gs = torch.autograd.grad((out - st.static_hr).abs().mean(), list(net.parameters()))
+        for (_, buf), gi in zip(grads, gs):
+            buf.copy_(gi)
+    st.graph = _StubGraph(replayed)
+    for _ in range(3):
+        # an eager step in between rebinds .grad (zero_grad(set_to_none=True)): step() must bind the captured tensors back
+        for p in net.parameters():
+            p.grad = None
+        st.step({"lr_seq": torch.randn(4, 6, generator=g), "hr_seq": torch.randn(4, 2, generator=g)})
+    q.put((rank, [p.detach().tolist() for p in net.parameters()], st.graph.replays,
+           all(p.grad is buf for p, buf in grads)))
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_graphed_train_step_world_2_keeps_the_replicas_identical():
+    """`GraphedTrainStep.step()` with world size 2 (eavsr_amd/graph.py): the graph ends after backward, the bucketed all-reduce
+    and Adam run eagerly behind each replay.  The capture itself needs a GPU, so the graph is a stub that does what a replay
+    does (gradients written into the captured `.grad` tensors); everything around it is the product's code.  After 3 steps on
+    DIFFERENT data both ranks hold the same parameters, equal to a single-process run on the averaged gradients."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graph_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, n0, bound0), (_, p1, n1, bound1) = res
+    assert n0 == n1 == 3 and bound0 and bound1
+    assert p0 == p1                                   # bit-identical replicas after three data-parallel steps
+    # single-process restatement: mean of the two ranks' gradients, same Adam
+    torch.manual_seed(50)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    opt = torch.optim.Adam([{"params": net[0].parameters(), "lr": 1e-2}, {"params": net[2].parameters(), "lr": 1e-3}])
+    gens = [torch.Generator().manual_seed(900 + r) for r in range(world)]
+    for _ in range(3):
+        acc = [torch.zeros_like(p) for p in net.parameters()]
+        for g in gens:
+            x, y = torch.randn(4, 6, generator=g), torch.randn(4, 2, generator=g)
+            gs = torch.autograd.grad((net(x) - y).abs().mean(), list(net.parameters()))
+            for a, gi in zip(acc, gs):
+                a.add_(gi)
+        for p, a in zip(net.parameters(), acc):
+            p.grad = a / world
+        opt.step()
+    for got, want in zip(p0, net.parameters()):
+        assert torch.allclose(torch.tensor(got), want.detach(), rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.gpu
