@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   };
   auto issue_win = [&](int i, unsigned xso, int wslot) __attribute__((always_inline)) {
     if (i < 3 || wave < JWIN_SEGS - 24)      // piece i * 8 + wave < 30 (wave-uniform)
-      j_dma16(r_x, winvo[i], xso, smem + JL_WIN + wslot * JWIN_B + i * 8192 + wv1k);
+      j_dma16(r_x, winvo[i], xso, smem + wslot + i * 8192 + wv1k);      // wslot: the slot's byte address in LDS
   };
   // weights of the pair slab at `wso`: set "Ib" = k-steps 0,1,2,3 (24 pieces, i = 0..2) and k-step 8 (6 pieces, i = 3, waves
   // 0..5) -> regions A, U3[q], U8[q];  set "Ia" = k-steps 4..7 (24 pieces, i = 0..2) -> region B2
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   float tfA[6], tfB[6];           // heads: 2x2 transform + translation of the even / odd group
   // per-lane byte offsets of the parameter loads of the NEXT pair step: own tap (kg = 1: one tap further) ...
   unsigned n_pm, n_po2, n_pmX, n_poX;
+  unsigned n_poj[4];      // heads: the pixel's offset in plane j of a group's transform / translation block (no scalar arithmetic per load)
   auto lane_voffs = [&]() __attribute__((always_inline)) {
     // a lane without a pixel must contribute nothing: its MASK offsets hold J_OOB, the range check makes the value zero
     // (HEADS == 1 takes logits: there the set-up gates the activated value instead)
@@ -311,6 +312,10 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     // ... and of k-step 4 (kg = 0: tap 8 of the even group; kg = 1: tap 0 of the odd group): in one deformable group the
     // base is tap 0 and the kg = 0 lanes go 8 taps up, in two consecutive ones the base is tap 8 and kg = 1 goes one up
     n_pmX = same_dg ? pom + (kg ? 0u : 8u * upl4) : n_pm;
+    if (HEADS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) n_poj[j] = nn.po + (unsigned)j * upl4;
+    }
     n_poX = same_dg ? nn.po + (kg ? 0u : 16u * upl4) : n_po2;
   };
   lane_voffs();
@@ -336,9 +341,9 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   auto load_tf = [&](float (&tf)[6], int par) __attribute__((always_inline)) {
     if (HEADS) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tf[j] = j_ld(r_h, nn.po, n_st[par] + (j ? j_smul(upl4, j) : 0u));
+      for (int j = 0; j < 4; ++j) tf[j] = j_ld(r_h, n_poj[j], par ? 0u + n_st[1] : 0u + n_st[0]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) tf[4 + j] = j_ld(r_h, nn.po, n_sr[par] + (j ? j_smul(upl4, j) : 0u));
+      for (int j = 0; j < 2; ++j) tf[4 + j] = j_ld(r_h, n_poj[j], par ? 0u + n_sr[1] : 0u + n_sr[0]);
     }
   };
   constexpr int M_LOADS = HEADS ? 1 : 3;      // vector-memory instructions of one load_m
@@ -373,7 +378,10 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   unsigned wpar = wA;                 // + (pair-step parity) * JKS_B
   unsigned dummy_ad = (unsigned)JL_WIN;     // where lanes outside the window read (any valid address)
   asm volatile("" : "+v"(dummy_ad));
-  int sE = 0, sO = 1, sEn = 0;        // window slots: even / odd group of the current pair step, even group of the next
+  // window slots (as LDS byte addresses: no multiplication where they are used): even / odd group of the current pair step,
+  // even group of the next
+  constexpr int S0 = JL_WIN, S1 = JL_WIN + JWIN_B, S2 = JL_WIN + 2 * JWIN_B;
+  int sE = S0, sO = S1, sEn = S0;
 
   // LDS by absolute byte address: this kernel has no static LDS, its dynamic allocation begins at 0 (through `smem + x` the
   // address of a gather costs one more vector instruction, an addition of the zero base the optimizer no longer folds)
@@ -414,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     ps.w1 = hm * hw; ps.w2 = hm * lw; ps.w3 = lm * hw; ps.w4 = lm * lw;
     ps.py = py; ps.px = px;
     const int wsl = u < 4 ? wslE : (u > 4 ? wslO : (kg ? wslO : wslE));
-    const unsigned base = (unsigned)(JL_WIN + wsl * JWIN_B);
+    const unsigned base = (unsigned)wsl;
     const unsigned ad = __umul24((unsigned)ry, (unsigned)JROW_B) + (((unsigned)rx << 4) + base);
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(ps.ad) : "v"(ad), "v"(dummy_ad), "s"(outm));
     slowm[u % 3] = outm & c.okm;
@@ -428,17 +436,14 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     return;
 #endif
     Pos& ps = pos[u % 3];
-    if (half == 0) {
-      gat[0] = lds_f4(ps.ad);
-      gat[1] = lds_f4(ps.ad + 16);
-      gat[2] = lds_f4(ps.ad + JROW_B);
-      gat[3] = lds_f4(ps.ad + JROW_B + 16);
-    } else {
-      gat[0] = lds_f4(ps.ad + JPLANE_B);
-      gat[1] = lds_f4(ps.ad + JPLANE_B + 16);
-      gat[2] = lds_f4(ps.ad + JPLANE_B + JROW_B);
-      gat[3] = lds_f4(ps.ad + JPLANE_B + JROW_B + 16);
-    }
+    // requested LAST corner first: the blend's first instruction needs the first corner, which is then the youngest read, and
+    // the one wait in front of it covers all four (requested in blend order, each corner's first use gets a wait of its own:
+    // six more s_waitcnt per k-step in a loop whose bound is instruction issue)
+    const unsigned hb_ = half ? (unsigned)JPLANE_B : 0u;
+    gat[3] = lds_f4(ps.ad + hb_ + JROW_B + 16);
+    gat[2] = lds_f4(ps.ad + hb_ + JROW_B);
+    gat[1] = lds_f4(ps.ad + hb_ + 16);
+    gat[0] = lds_f4(ps.ad + hb_);
 #ifndef EAVSR_IL2_EXP_NO_FIXUP
     unsigned long long sm = slowm[u % 3];
     // (tested afresh for either half: a boolean carried from the first test to the second costs three more scalar
@@ -583,12 +588,12 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
   // ---- run prologue: everything a previous pair step would have requested for the first one ------------------------------
   {
 #pragma unroll
-    for (int i = 0; i < WIN_IT; ++i) issue_win(i, n_xso, 0);
+    for (int i = 0; i < WIN_IT; ++i) issue_win(i, n_xso, S0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) issue_wgt_ib(i, n_wso, 0);
-    issue_ia(1, 0);
-    issue_ia(1, 1);
-    issue_ia(1, 2);
+    issue_ia(S1, 0);
+    issue_ia(S1, 1);
+    issue_ia(S1, 2);
     load_tf(tfA, 0);
     load_tf(tfB, 1);
 #pragma unroll
@@ -602,10 +607,10 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
     __syncthreads();
     init_acc();
-    setup(0, nn, 0, 1);
+    setup(0, nn, S0, S1);
     gather(0, 0, nn, r_x);
     load_a(0, 0);
-    setup(1, nn, 0, 1);
+    setup(1, nn, S0, S1);
     blend_pair(0, 0);
     blend_pair(0, 1);
     J_FENCE();
@@ -645,8 +650,8 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     const int q = it & 1;
     wpar = wA + (unsigned)(q * JKS_B);
     // window slots rotate by two per pair step: even group of the next pair step = slot after this pair's odd group
-    sEn = sO == 2 ? 0 : sO + 1;
-    const int sOn = sEn == 2 ? 0 : sEn + 1;
+    sEn = sO == S2 ? S0 : sO + JWIN_B;
+    const int sOn = sEn == S2 ? S0 : sEn + JWIN_B;
     J_FENCE();
 
 #pragma unroll

@@ -44,6 +44,10 @@ if "dcn" in which:
                     ops.dcnv2_il(xil, off, mask, w33, b, 8, nprod=nprod)
                 for _ in range(reps):
                     ops.dcnv2_il(xil, heads, None, w33, b, 8, nprod=nprod, heads=True)
+                if impl == "il2" and nprod == 6:      # what the bench step launches: masks activated by the heads' epilogue (heads = 2)
+                    heads_act = torch.cat([heads[:, :48], torch.sigmoid(heads[:, 48:])], 1)
+                    for _ in range(reps):
+                        ops.dcnv2_il(xil, heads_act, None, w33, b, 8, nprod=nprod, heads=True, mask_activated=True)
 if "warp" in which:
     flow = r(n, 2, h, w) * 2
     for _ in range(reps):
