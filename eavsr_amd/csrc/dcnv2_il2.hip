@@ -440,15 +440,24 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     // the one wait in front of it covers all four (requested in blend order, each corner's first use gets a wait of its own:
     // six more s_waitcnt per k-step in a loop whose bound is instruction issue)
     const unsigned hb_ = half ? (unsigned)JPLANE_B : 0u;
+#ifdef EAVSR_IL2_GATHER_FWD
+    gat[0] = lds_f4(ps.ad + hb_);
+    gat[1] = lds_f4(ps.ad + hb_ + 16);
+    gat[2] = lds_f4(ps.ad + hb_ + JROW_B);
+    gat[3] = lds_f4(ps.ad + hb_ + JROW_B + 16);
+#else
     gat[3] = lds_f4(ps.ad + hb_ + JROW_B + 16);
     gat[2] = lds_f4(ps.ad + hb_ + JROW_B);
     gat[1] = lds_f4(ps.ad + hb_ + 16);
     gat[0] = lds_f4(ps.ad + hb_);
+#endif
 #ifndef EAVSR_IL2_EXP_NO_FIXUP
     unsigned long long sm = slowm[u % 3];
     // (tested afresh for either half: a boolean carried from the first test to the second costs three more scalar
     // instructions per k-step than a second s_cmp_lg_u64)
+#ifndef EAVSR_IL2_SLOW_BOOL
     asm volatile("" : "+s"(sm));
+#endif
     if (__builtin_expect(sm != 0, 0)) {      // wave-uniform, rare: the block is laid out away from the pipeline
       const bool mine = (sm >> lane) & 1ull;
       f32x4 tq[4];
@@ -591,20 +600,27 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     for (int i = 0; i < WIN_IT; ++i) issue_win(i, n_xso, S0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) issue_wgt_ib(i, n_wso, 0);
-    issue_ia(S1, 0);
-    issue_ia(S1, 1);
-    issue_ia(S1, 2);
     load_tf(tfA, 0);
     load_tf(tfB, 1);
 #pragma unroll
     for (int u = 0; u < JU; ++u) load_m(u);
+    float bias_v = 0.f;
     if (tid < 64) {
       // [kg][m * 16 + e] = bias of channel m * 32 + (e & 3) + 8 (e >> 2) + 4 kg
       const int kk = tid >> 5, idx = tid & 31, m = idx >> 4, e = idx & 15;
       const int co = cot * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-      reinterpret_cast<float*>(smem + JL_BIAS)[tid] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+      bias_v = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    // the "Ia" set (odd group's window, weights of k-steps 4..7) LAST: k-steps 0..2 do not read it, so it stays in flight across
+    // the first barrier (6 or 7 requests per wave: vmcnt(6) covers both) and is waited for at k-step 3 like in every other pair
+    // step -- the run starts ~1/3 of a prologue's DMA earlier
+    J_FENCE();
+    issue_ia(S1, 0);
+    issue_ia(S1, 1);
+    issue_ia(S1, 2);
+    J_FENCE();
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 6);      // vmcnt(6)
+    if (tid < 64) reinterpret_cast<float*>(smem + JL_BIAS)[tid] = bias_v;
     __syncthreads();
     init_acc();
     setup(0, nn, S0, S1);
