@@ -255,7 +255,7 @@ def other_configs(which, budget_s):
     bench.  A child that fails or runs out of the time budget is reported as such; nothing here touches the headline figures."""
     import subprocess
     keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "psnr_vs_fp32", "share_of_step_in_16bit",
-            "timed_output_check", "degraded", "loss")
+            "timed_output_check", "degraded", "loss", "step_breakdown_ms", "launches_per_step", "step_kernel_ms_library")
     out, t_end = [], time.perf_counter() + budget_s
     for k in which:
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--also", ""]
@@ -276,7 +276,8 @@ def other_configs(which, budget_s):
             e = {"config": k, **{f: ln[f] for f in keep if f in ln}, "workload": ln["config"]["workload"], "launch": ln["config"].get("launch"),
                  "child_wall_s": round(time.perf_counter() - t0, 1)}
             if "roofline" in ln:
-                e["roofline"] = {f: ln["roofline"][f] for f in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "share_of_step", "hbm")
+                e["roofline"] = {f: ln["roofline"][f] for f in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_ms", "share_of_step", "hbm",
+                                                                   "share_of_library_kernel_time", "conv_wgrad")
                                  if f in ln["roofline"]}
             out.append(e)
         except subprocess.TimeoutExpired:
@@ -289,7 +290,7 @@ def other_configs(which, budget_s):
 def train_bench(args, rank, world, device, ranks_seen=1):
     """BASELINE.json configs[3]: eavsrp x4 training step, 2 clips/GPU x 7 x 3 x 96 x 96, data parallel."""
     from argparse import Namespace
-    from eavsr_amd import shard
+    from eavsr_amd import ops, shard
     from eavsr_amd.eavsrp_model import EAVSRPModel
     from eavsr_amd.utils.synthetic import fill_state_dict, shapes_of, synthetic_clip
     n, t = 2, 7
@@ -330,8 +331,46 @@ def train_bench(args, rank, world, device, ranks_seen=1):
     per_rank_ms = shard.all_ranks(1e3 * own_elapsed / args.steps, device=device if on_dev else None)
     per_rank_device = shard.all_ranks_str(f"cuda:{device.index} {torch.cuda.get_device_name(device)}")
     elapsed = shard.max_over_ranks(elapsed, device=device if on_dev else None)
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_kernel_profile:      # (one process only: an extra step on one rank would wait for the others' all-reduce)
+        # one more EAGER step (same work as the timed ones) with HIP events around every launch of the library, enqueued behind a
+        # device-side delay so that the kernels run back to back: where a training step's time goes.  ATen
+        # kernels (autograd's gradient sums, Adam) carry no events: profiles/*train* has the rocprofv3 census of every kernel.
+        try:
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(0.6 * 2.0e9))
+            with ops.profile() as prof:
+                model.optimize_parameters()
+            summ = prof.summary()
+            lib_ms = sum(v["ms"] for v in summ.values())
+            extra["step_breakdown_ms"] = {k: round(v["ms"], 3) for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+            extra["launches_per_step"] = {"library_kernels": sum(v["calls"] for v in summ.values()),
+                                          "by_kernel": {k: v["calls"] for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["calls"])[:12]},
+                                          "note": "C-ABI launches of one eager step (each = one or two kernels); ATen kernels of autograd / Adam "
+                                                  "not counted: profiles/*train* has the rocprofv3 census of all of them"}
+            extra["step_kernel_ms_library"] = lib_ms
+
+            def roof(name, what):
+                v = summ.get(name)
+                if not v or v["ms"] <= 0:
+                    return None
+                ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
+                return {"kernel": what, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / PEAK_MFMA_F32_TFLOPS, "avg_ms": v["ms"] / v["calls"], "calls": v["calls"],
+                        "share_of_library_kernel_time": v["ms"] / lib_ms, "traffic": None,
+                        "note": "algorithmic FLOP (2 cin cout k k per output pixel) / HIP-event time of the launches of one eager step"}
+            convs = sorted(((k, v) for k, v in summ.items() if k.startswith("conv3x3_64to64")), key=lambda kv: -kv[1]["ms"])
+            if convs:
+                extra["roofline"] = roof(convs[0][0], f"{convs[0][0]} (forward and input-gradient 3x3 64->64 convolutions at 2 x 64 x 96 x 96)")
+            rw = roof("conv_wgrad3x3", "conv_wgrad3_kernel (weight gradient 3x3, K = pixels x frames: the uses of a weight across the "
+                                       "recurrence are segments of one launch)")
+            if rw is not None:
+                extra.setdefault("roofline", {})["conv_wgrad"] = rw
+        except Exception as ex:      # measurement garnish must not void the line
+            extra["step_breakdown_error"] = repr(ex)
     if rank == 0:
         print(json.dumps({
+            **extra,
             "per_rank_ms": per_rank_ms, "per_rank_device": per_rank_device, "rccl_ranks_seen": ranks_seen,
             "metric": "training LR frames/sec, eavsrp x4 step (forward + backward + grad all-reduce + Adam)",
             "value": world * n * t * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

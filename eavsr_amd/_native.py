@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -110,6 +110,7 @@ SIGNATURES = {
     "eavsr_act_bwd_f32": (C.c_int, [vp, vp, vp, i64, i32, f32, vp]),
     "eavsr_plane_sum_f32": (C.c_int, [vp, vp, vp, i32, i32, f32, vp]),
     "eavsr_channel_sum_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_channel_sum_multi_f32": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "eavsr_scale_residual_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_ca_mlp_bwd_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, vp]),
     "eavsr_flow_warp_bwd_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, vp]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "eavsr_affine_offsets_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_conv_wgrad_blocks": (i32, [i32, i32, i32, i32]),
     "eavsr_conv_wgrad_f32": (C.c_int, [vp, vp, vp, vp] + [i32] * 11 + [vp]),
+    "eavsr_conv_wgrad_multi_f32": (C.c_int, [vp, vp, i32, vp, vp] + [i32] * 11 + [vp]),
     "eavsr_dcnv2_im2col_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_col2im_f32": (C.c_int, [vp] * 7 + [i32, i32, i32, i32, i32, vp]),
     "eavsr_gconv3x3_fwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),

@@ -68,20 +68,45 @@ class grad_sink:
         return grad_sink._active is not None and all(
             isinstance(p, torch.Tensor) and p.is_leaf and p.requires_grad and p.is_cuda for p in params)
 
-    def buffers(self, ws, bs, k):
-        """(dW buffer over the concatenated output channels, db buffer or None, first use?)"""
+    # uses of one weight that wait for their (batched) weight-gradient launch: at most this many per launch
+    BATCH = ops.WGRAD_MAX_SEGMENTS
+
+    def add_use(self, ws, bs, k, g, srcs):
+        """One use of the weights `ws` (+ biases `bs`): dY = g over the sources `srcs`.  The gradient launch is DEFERRED: uses of
+        the same call site and shapes wait until BATCH of them are there (or backward ends) and go through
+        ops.conv_wgrad_multi / channel_sum_multi as segments of ONE launch -- a weight of the recurrent path is used once per
+        frame, and a 2 x 96 x 96 crop fills 72 tiles into 256 CUs per use.  Same sums, K extended over the uses; fixed order."""
         key = tuple(id(w) for w in ws)
         e = self.entries.get(key)
-        if e is not None:
-            return e[2], e[3], False
-        cout = sum(int(w.shape[0]) for w in ws)
-        dW = torch.empty((cout, int(ws[0].shape[1]), k, k), device=ws[0].device, dtype=torch.float32)
-        db = torch.empty((cout,), device=ws[0].device, dtype=torch.float32) if bs is not None else None
-        self.entries[key] = (list(ws), None if bs is None else list(bs), dW, db)
-        return dW, db, True
+        if e is None:
+            cout = sum(int(w.shape[0]) for w in ws)
+            dW = torch.empty((cout, int(ws[0].shape[1]), k, k), device=ws[0].device, dtype=torch.float32)
+            db = torch.empty((cout,), device=ws[0].device, dtype=torch.float32) if bs is not None else None
+            e = {"ws": list(ws), "bs": None if bs is None else list(bs), "dW": dW, "db": db, "k": k, "written": False, "pending": []}
+            self.entries[key] = e
+        if e["pending"] and (tuple(e["pending"][0][0].shape) != tuple(g.shape)
+                             or [tuple(s_.shape) for s_ in e["pending"][0][1]] != [tuple(s_.shape) for s_ in srcs]):
+            self._launch(e)       # another shape at the same call site: what waits goes first
+        e["pending"].append((g, list(srcs)))
+        if len(e["pending"]) >= self.BATCH:
+            self._launch(e)
+
+    @staticmethod
+    def _launch(e):
+        pend = e["pending"]
+        if not pend:
+            return
+        acc = e["written"]
+        ops.conv_wgrad_multi([g for g, _ in pend], [ss for _, ss in pend], e["k"], out=e["dW"], accumulate=acc)
+        if e["db"] is not None:
+            ops.channel_sum_multi([g for g, _ in pend], out=e["db"], accumulate=acc)
+        e["written"] = True
+        e["pending"] = []
 
     def flush(self):
-        for ws, bs, dW, db in self.entries.values():
+        for e in self.entries.values():
+            self._launch(e)
+            ws, bs, dW, db = e["ws"], e["bs"], e["dW"], e["db"]
             c0 = 0
             for i, w_ in enumerate(ws):
                 c = int(w_.shape[0])
@@ -149,10 +174,7 @@ class _ConvFn(Function):
         dws: List[Optional[Tensor]] = [None] * n_w
         pw, pb = ctx.params
         if all(need_w) and (not has_bias or all(need[n_w:2 * n_w])) and grad_sink.eligible(pw + (pb or [])):
-            dW, db, first = grad_sink._active.buffers(pw, pb, k)
-            ops.conv_wgrad(g, srcs, k, out=dW, accumulate=not first)
-            if has_bias:
-                ops.channel_sum(g, out=db, accumulate=not first)
+            grad_sink._active.add_use(pw, pb if has_bias else None, k, g, srcs)      # launched in batches of uses (grad_sink)
             need_w = [False] * n_w
             has_bias_grad = False
         else:

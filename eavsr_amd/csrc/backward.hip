@@ -55,26 +55,36 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2] + red[3]) * scale;
 }
 
-// per-channel reduction over batch and plane (bias gradients): out[c] = sum_n sum_hw a[n,c,hw].  One workgroup of
-// 1024 threads per channel, fixed summation order.
-__global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restrict__ a, float* __restrict__ out, int n,
-                                                           int c, int hw, int accumulate) {
+// per-channel reduction over batch and plane (bias gradients): out[c] = sum_seg sum_n sum_hw a_seg[n,c,hw].  One workgroup of
+// 1024 threads per channel, fixed summation order.  Up to CS_MAX_SEG tensors of one shape per launch (the uses of one bias
+// across the frames of the recurrence: see conv_wgrad.hip), their pointers by value in the kernel arguments.
+constexpr int CS_MAX_SEG = 8;
+struct ChanSumArgs {
+  const float* av[CS_MAX_SEG];
+  float* out;
+  int nseg, n, c, hw, accumulate;
+};
+__global__ __launch_bounds__(1024) void channel_sum_kernel(ChanSumArgs g) {
   __shared__ float red[16];
   const int ch = blockIdx.x;
+  const int n = g.n, c = g.c, hw = g.hw;
   float s0 = 0.f, s1 = 0.f;
-  for (int b = 0; b < n; ++b) {
-    const float* p = a + ((size_t)b * c + ch) * hw;
-    if ((hw & 3) == 0) {
-      const float4* p4 = reinterpret_cast<const float4*>(p);
-      const int q = hw >> 2;
-      for (int i = threadIdx.x; i < q; i += 2048) {
-        const int j = i + 1024;
-        const float4 x0 = p4[i], x1 = j < q ? p4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s0 += (x0.x + x0.y) + (x0.z + x0.w);
-        s1 += (x1.x + x1.y) + (x1.z + x1.w);
+  for (int sg = 0; sg < g.nseg; ++sg) {
+    const float* a = g.av[sg];
+    for (int b = 0; b < n; ++b) {
+      const float* p = a + ((size_t)b * c + ch) * hw;
+      if ((hw & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        const int q = hw >> 2;
+        for (int i = threadIdx.x; i < q; i += 2048) {
+          const int j = i + 1024;
+          const float4 x0 = p4[i], x1 = j < q ? p4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+          s0 += (x0.x + x0.y) + (x0.z + x0.w);
+          s1 += (x1.x + x1.y) + (x1.z + x1.w);
+        }
+      } else {
+        for (int i = threadIdx.x; i < hw; i += 1024) s0 += p[i];
       }
-    } else {
-      for (int i = threadIdx.x; i < hw; i += 1024) s0 += p[i];
     }
   }
   float s = s0 + s1;
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(1024) void channel_sum_kernel(const float* __restri
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += red[k];
-    out[ch] = accumulate ? out[ch] + t : t;
+    g.out[ch] = g.accumulate ? g.out[ch] + t : t;
   }
 }
 
@@ -328,14 +338,27 @@ extern "C" int eavsr_plane_sum_f32(const float* a, const float* b, float* out, i
   return eavsr::launch_status("plane_sum");
 }
 
+extern "C" int eavsr_channel_sum_multi_f32(const void* const* a_list, int32_t nseg, float* out, int32_t n, int32_t c, int32_t hw,
+                                           int32_t accumulate, void* stream) {
+  EAVSR_REQUIRE(a_list && out, -1, "channel_sum: NULL pointer");
+  EAVSR_REQUIRE(nseg >= 1 && nseg <= CS_MAX_SEG, -1, "channel_sum: %d segments (1..%d)", nseg, CS_MAX_SEG);
+  EAVSR_REQUIRE(n >= 0 && c >= 0 && hw > 0, -1, "channel_sum: bad dims");
+  if (c == 0) return 0;
+  ChanSumArgs g;
+  for (int s = 0; s < CS_MAX_SEG; ++s) {
+    g.av[s] = reinterpret_cast<const float*>(a_list[s < nseg ? s : 0]);
+    EAVSR_REQUIRE(g.av[s], -1, "channel_sum: NULL segment pointer");
+  }
+  g.out = out; g.nseg = nseg; g.n = n; g.c = c; g.hw = hw; g.accumulate = accumulate;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(1024), 0, eavsr::as_stream(stream), g);
+  return eavsr::launch_status("channel_sum");
+}
+
 extern "C" int eavsr_channel_sum_f32(const float* a, float* out, int32_t n, int32_t c, int32_t hw, int32_t accumulate,
                                      void* stream) {
   EAVSR_REQUIRE(a && out, -1, "channel_sum: NULL pointer");
-  EAVSR_REQUIRE(n >= 0 && c >= 0 && hw > 0, -1, "channel_sum: bad dims");
-  if (c == 0) return 0;
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(c), dim3(1024), 0, eavsr::as_stream(stream), a, out, n, c, hw,
-                     accumulate);
-  return eavsr::launch_status("channel_sum");
+  const void* al[1] = {a};
+  return eavsr_channel_sum_multi_f32(al, 1, out, n, c, hw, accumulate, stream);
 }
 
 extern "C" int eavsr_scale_residual_bwd_f32(const float* d, const float* scale, const float* dmean, float* dr,

@@ -17,11 +17,17 @@
 
 namespace {
 
+constexpr int WG_MAX_SEG = 8;
 struct WgradArgs {
-  const float* dy;   // (n, cout_total, h, w), this launch uses channels co0 .. co0+63
-  const float* x;    // (n, cin_src, h, w),   this launch uses channels ci0 .. ci0+63
+  // Up to WG_MAX_SEG SEGMENTS per launch (round 5): segment s is one (dY, X) pair of the same shapes -- one use of the weight.  A
+  // weight of the recurrent path is used once per frame (7 uses per branch); its per-use gradients used to be 7 launches that
+  // each fill 72 tiles of a 2 x 96 x 96 crop into 256 CUs and accumulate into dW one after the other.  As segments of ONE launch
+  // the K dimension is pixels x frames: 504 tiles, one slab reduction instead of seven.  The pointers travel by value in the
+  // kernel arguments (no table in device memory: the launch is captured in a HIP graph with them).
+  const float* dyv[WG_MAX_SEG];   // (n, cout_total, h, w) each, this launch uses channels co0 .. co0+63
+  const float* xv[WG_MAX_SEG];    // (n, cin_src, h, w) each,   this launch uses channels ci0 .. ci0+63
   float* ws;         // [blocks][64][64][KK]
-  int n, h, w, cout_total, co0, co_valid, cin_src, ci0, ci_valid, tiles_x, tiles_y, num_tiles;
+  int n, h, w, cout_total, co0, co_valid, cin_src, ci0, ci_valid, tiles_x, tiles_y, num_tiles;   // n: images per segment
 };
 
 template <int KS>
@@ -85,8 +91,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
       // training-crop sizes).  Loads go through a wave-uniform base + 32-bit byte offset.
       constexpr int A_N = 64 * PX, B_N = 64 * IH * IW;
       constexpr int BATCH = 16;
-      const char* dyb = reinterpret_cast<const char*>(a.dy + ((size_t)bn * a.cout_total + a.co0) * plane);
-      const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin_src + a.ci0) * plane);
+      const int seg = bn / a.n, bl = bn - seg * a.n;      // wave-uniform
+      const char* dyb = reinterpret_cast<const char*>(a.dyv[seg] + ((size_t)bl * a.cout_total + a.co0) * plane);
+      const char* xb = reinterpret_cast<const char*>(a.xv[seg] + ((size_t)bl * a.cin_src + a.ci0) * plane);
       __syncthreads();  // previous tile's MFMAs are done with the LDS tiles
       // dY tile: 64 channels x PX pixels (zero beyond the image / beyond co_valid)
 #pragma unroll 1
@@ -213,8 +220,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3_kernel(WgradArgs a) {
     const int bn = t / a.tiles_y;
     const int y0 = ty * Cfg::TH, x0 = tx * TW;
     constexpr int A_N = 32 * PX, B_N = 32 * IH * IW;
-    const char* dyb = reinterpret_cast<const char*>(a.dy + ((size_t)bn * a.cout_total + a.co0 + 32 * mt) * plane);
-    const char* xb = reinterpret_cast<const char*>(a.x + ((size_t)bn * a.cin_src + a.ci0 + 32 * ct) * plane);
+    const int seg = bn / a.n, bl = bn - seg * a.n;      // wave-uniform
+    const char* dyb = reinterpret_cast<const char*>(a.dyv[seg] + ((size_t)bl * a.cout_total + a.co0 + 32 * mt) * plane);
+    const char* xb = reinterpret_cast<const char*>(a.xv[seg] + ((size_t)bl * a.cin_src + a.ci0 + 32 * ct) * plane);
     __syncthreads();  // the previous tile's MFMAs are done with the LDS tiles
     {
       // one batch of loads for dY and two for the X patch, every load of a batch in flight before its first LDS
@@ -372,17 +380,23 @@ extern "C" int32_t eavsr_conv_wgrad_blocks(int32_t n, int32_t h, int32_t w, int3
   return (int32_t)(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
 }
 
-extern "C" int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float* workspace,
-                                    int32_t n, int32_t h, int32_t w, int32_t cout_total, int32_t co0,
-                                    int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,
-                                    int32_t accumulate, void* stream) {
-  EAVSR_REQUIRE(dy && x && dweight && workspace, -1, "conv_wgrad: NULL pointer");
+extern "C" int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void* const* x_list, int32_t nseg, float* dweight,
+                                          float* workspace, int32_t n, int32_t h, int32_t w, int32_t cout_total, int32_t co0,
+                                          int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,
+                                          int32_t accumulate, void* stream) {
+  EAVSR_REQUIRE(dy_list && x_list && dweight && workspace, -1, "conv_wgrad: NULL pointer");
+  EAVSR_REQUIRE(nseg >= 1 && nseg <= WG_MAX_SEG, -1, "conv_wgrad: %d segments (1..%d)", nseg, WG_MAX_SEG);
   EAVSR_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, -2, "conv_wgrad: kernel size %d unsupported (1, 3, 5)", ksize);
   EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && cout_total > 0 && cin_src > 0 && cin_total > 0, -1, "conv_wgrad: bad dims");
   EAVSR_REQUIRE(co0 >= 0 && co0 < cout_total && ci0 >= 0 && ci0 < cin_src && ci_dst0 >= 0 && ci_dst0 < cin_total, -1,
                 "conv_wgrad: channel offsets out of range");
   WgradArgs a;
-  a.dy = dy; a.x = x; a.ws = workspace;
+  for (int s = 0; s < WG_MAX_SEG; ++s) {
+    a.dyv[s] = reinterpret_cast<const float*>(dy_list[s < nseg ? s : 0]);
+    a.xv[s] = reinterpret_cast<const float*>(x_list[s < nseg ? s : 0]);
+    EAVSR_REQUIRE(a.dyv[s] && a.xv[s], -1, "conv_wgrad: NULL segment pointer");
+  }
+  a.ws = workspace;
   a.n = n; a.h = h; a.w = w;
   a.cout_total = cout_total; a.co0 = co0; a.co_valid = cout_total - co0 < 64 ? cout_total - co0 : 64;
   a.cin_src = cin_src; a.ci0 = ci0; a.ci_valid = cin_src - ci0 < 64 ? cin_src - ci0 : 64;
@@ -390,8 +404,9 @@ extern "C" int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dwei
   const int th = ksize <= 3 ? 8 : 4;
   a.tiles_x = eavsr::cdiv(w, 32);
   a.tiles_y = eavsr::cdiv(h, th);
-  a.num_tiles = a.tiles_x * a.tiles_y * n;
-  const int blocks = eavsr_conv_wgrad_blocks(n, h, w, ksize);
+  EAVSR_REQUIRE((long)a.tiles_x * a.tiles_y * n * nseg < (1L << 31), -1, "conv_wgrad: too many tiles");
+  a.num_tiles = a.tiles_x * a.tiles_y * n * nseg;
+  const int blocks = eavsr_conv_wgrad_blocks(n * nseg, h, w, ksize);
   hipStream_t st = eavsr::as_stream(stream);
   int rc;
   switch (ksize) {
@@ -404,4 +419,15 @@ extern "C" int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dwei
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64 * kk), dim3(256), 0, st, workspace, dweight,
                      n == 0 ? 0 : blocks, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate);
   return eavsr::launch_status("conv_wgrad_reduce");
+}
+
+extern "C" int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float* workspace,
+                                    int32_t n, int32_t h, int32_t w, int32_t cout_total, int32_t co0,
+                                    int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,
+                                    int32_t accumulate, void* stream) {
+  EAVSR_REQUIRE(dy && x, -1, "conv_wgrad: NULL pointer");
+  const void* dl[1] = {dy};
+  const void* xl[1] = {x};
+  return eavsr_conv_wgrad_multi_f32(dl, xl, 1, dweight, workspace, n, h, w, cout_total, co0, cin_src, ci0, cin_total, ci_dst0, ksize,
+                                    accumulate, stream);
 }

@@ -1463,6 +1463,77 @@ def conv_wgrad(dy: Tensor, srcs: Sequence[Tensor], ksize: int, out: Optional[Ten
     return dw
 
 
+WGRAD_MAX_SEGMENTS = 8      # csrc/conv_wgrad.hip: WG_MAX_SEG (pointers by value in the kernel arguments)
+
+
+def _ptr_array(tensors):
+    import ctypes as _C
+    return (_C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def conv_wgrad_multi(dys: Sequence[Tensor], srcs_list: Sequence[Sequence[Tensor]], ksize: int, out: Tensor,
+                     accumulate: bool = False) -> Tensor:
+    """`conv_wgrad` over several USES of one weight in one launch per (source, 64-channel block): dys[s] / srcs_list[s] are
+    the (dY, sources) pairs of use s, all of the same shapes (the frames of the recurrence: eavsrp_model.py:271-324).  The K
+    dimension of the weight-gradient GEMM becomes pixels x uses -- a 2 x 96 x 96 training crop has 72 tiles per use for 256
+    CUs -- and the per-use accumulation into `out` becomes one slab reduction.  At most WGRAD_MAX_SEGMENTS uses per call."""
+    nseg = len(dys)
+    if not 1 <= nseg <= WGRAD_MAX_SEGMENTS or len(srcs_list) != nseg:
+        raise ValueError(f"conv_wgrad_multi: 1..{WGRAD_MAX_SEGMENTS} segments")
+    dys = [_chk(d, "dy") for d in dys]
+    srcs_list = [[_chk(s_, "src") for s_ in ss] for ss in srcs_list]
+    n, cout, h, w = dys[0].shape
+    shapes = [tuple(s_.shape) for s_ in srcs_list[0]]
+    for d, ss in zip(dys, srcs_list):
+        if tuple(d.shape) != (n, cout, h, w) or [tuple(s_.shape) for s_ in ss] != shapes:
+            raise ValueError("conv_wgrad_multi: every segment must have the shapes of the first")
+    cin = sum(sh[1] for sh in shapes)
+    dw = out
+    if (tuple(dw.shape) != (cout, cin, ksize, ksize) or not dw.is_contiguous() or dw.dtype != torch.float32
+            or dw.device != dys[0].device):
+        raise ValueError("conv_wgrad_multi: out must be a contiguous fp32 (cout, cin, k, k) tensor on dy's device")
+    acc = int(accumulate)
+    blocks = lib().eavsr_conv_wgrad_blocks(n * nseg, h, w, ksize)
+    if blocks <= 0:
+        raise NotImplementedError(f"conv_wgrad: kernel size {ksize}")
+    ws = torch.empty(blocks * 64 * 64 * ksize * ksize, device=dw.device, dtype=torch.float32)
+    st = _stream(dw)
+    dyl = _ptr_array(dys)
+    base = 0
+    for si, sh in enumerate(shapes):
+        cs = int(sh[1])
+        xl = _ptr_array([ss[si] for ss in srcs_list])
+        for ci0 in range(0, cs, 64):
+            for co0 in range(0, cout, 64):
+                _launch(f"conv_wgrad{ksize}x{ksize}", 2.0 * min(64, cout - co0) * min(64, cs - ci0) * ksize * ksize * n * nseg * h * w,
+                        4.0 * n * nseg * h * w * 128, dw,
+                        lambda xl=xl, cs=cs, ci0=ci0, co0=co0, base=base: lib().eavsr_conv_wgrad_multi_f32(
+                            dyl, xl, nseg, _p(dw), _p(ws), n, h, w, cout, co0, cs, ci0, cin, base + ci0, ksize, acc, st),
+                        "conv_wgrad")
+        base += cs
+    return dw
+
+
+def channel_sum_multi(tensors: Sequence[Tensor], out: Tensor, accumulate: bool = False) -> Tensor:
+    """`channel_sum` over several tensors of one shape in one launch (the bias gradient of conv_wgrad_multi's segments)"""
+    nseg = len(tensors)
+    if not 1 <= nseg <= WGRAD_MAX_SEGMENTS:
+        raise ValueError(f"channel_sum_multi: 1..{WGRAD_MAX_SEGMENTS} segments")
+    tensors = [_chk(t, "a") for t in tensors]
+    n, c, h, w = tensors[0].shape
+    if any(tuple(t.shape) != (n, c, h, w) for t in tensors):
+        raise ValueError("channel_sum_multi: every segment must have the shape of the first")
+    if tuple(out.shape) != (c,) or not out.is_contiguous() or out.dtype != torch.float32 or out.device != tensors[0].device:
+        raise ValueError("channel_sum: out must be a contiguous fp32 (c,) tensor on the input's device")
+    if n == 0 or c == 0:
+        return out if accumulate else out.zero_()
+    st = _stream(out)
+    al = _ptr_array(tensors)
+    _launch("channel_sum", float(tensors[0].numel() * nseg), 4.0 * tensors[0].numel() * nseg, out,
+            lambda: lib().eavsr_channel_sum_multi_f32(al, nseg, _p(out), n, c, h * w, int(accumulate), st), "channel_sum")
+    return out
+
+
 def dcnv2_im2col(x: Tensor, offset: Tensor, mask: Tensor, dg: int) -> Tensor:
     x, offset, mask = _chk(x, "x"), _chk(offset, "offset"), _chk(mask, "mask")
     n, c, h, w = x.shape

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 25
+#define EAVSR_ABI_VERSION 26
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -384,6 +384,10 @@ int eavsr_plane_sum_f32(const float* a, const float* b, float* out, int32_t nc, 
  * (a parameter used once per frame sums its per-use gradients in place) */
 int eavsr_channel_sum_f32(const float* a, float* out, int32_t n, int32_t c, int32_t hw, int32_t accumulate,
                           void* stream);
+/* ... over up to 8 tensors of one shape in one launch (ABI 26; a_list: HOST array of nseg device pointers): the bias gradient of
+ * the segments of eavsr_conv_wgrad_multi_f32 */
+int eavsr_channel_sum_multi_f32(const void* const* a_list, int32_t nseg, float* out, int32_t n, int32_t c, int32_t hw,
+                                int32_t accumulate, void* stream);
 /* backward of out = r * scale[n,c] + x w.r.t. r:  dr = d * scale[n,c] + dmean[n,c] (dmean nullable) */
 int eavsr_scale_residual_bwd_f32(const float* d, const float* scale, const float* dmean, float* dr,
                                  int32_t n, int32_t c, int32_t hw, void* stream);
@@ -416,6 +420,15 @@ int32_t eavsr_conv_wgrad_blocks(int32_t n, int32_t h, int32_t w, int32_t ksize);
 int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float* workspace, int32_t n, int32_t h,
                          int32_t w, int32_t cout_total, int32_t co0, int32_t cin_src, int32_t ci0,
                          int32_t cin_total, int32_t ci_dst0, int32_t ksize, int32_t accumulate, void* stream);
+/* The same over up to 8 SEGMENTS in one launch (ABI 26): dy_list[s] / x_list[s] are HOST arrays of device pointers to nseg (dY, X)
+ * pairs of identical shapes -- the uses of one weight across the frames of the recurrence (models/eavsrp_model.py:271-324: the
+ * same backbone / alignment weights at every time step), whose gradients autograd would compute and sum one use at a time
+ * (loss.backward(), models/eavsrp_model.py:109-113).  n is the batch of ONE segment; workspace:
+ * eavsr_conv_wgrad_blocks(n * nseg, h, w, ksize) * 64*64*ksize*ksize floats.  The pointers are read on the host at the call. */
+int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void* const* x_list, int32_t nseg, float* dweight,
+                               float* workspace, int32_t n, int32_t h, int32_t w, int32_t cout_total, int32_t co0,
+                               int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,
+                               int32_t accumulate, void* stream);
 
 /* DCNv2 backward samplers (the two GEMMs run on eavsr_conv_wgrad_f32 / eavsr_conv2d_f32 with k = 1):
  * columns (n, c*9, h, w) = im2col(x, offset, mask);  from dcolumns: dx (pre-zeroed, atomics; NULL = skip),

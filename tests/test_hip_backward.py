@@ -469,6 +469,44 @@ def test_channel_and_plane_sums(cuda, n, c, h, w):
             assert H.maxabs(got.double(), want) <= 1e-4
 
 
+@pytest.mark.parametrize("k,nseg,shape", [(3, 7, (2, 64, 96, 96)), (3, 3, (1, 64, 19, 37)), (1, 8, (2, 64, 24, 40)), (5, 2, (1, 64, 16, 32))])
+def test_conv_wgrad_over_several_uses_in_one_launch(cuda, k, nseg, shape):
+    """eavsr_conv_wgrad_multi_f32 / eavsr_channel_sum_multi_f32 (ABI 26): the uses of one weight across the frames of the
+    recurrence as segments of ONE launch, against the sum of the per-use gradients in float64 (torch CPU) and against the
+    per-use launches accumulated one after the other; two sources (a virtual concatenation), `accumulate` on top."""
+    from eavsr_amd import ops
+    n, c, h, w = shape
+    cout = 64 if k != 5 else 120
+    dys = [cases.randn(300 + i, n, cout, h, w) for i in range(nseg)]
+    xa = [cases.randn(400 + i, n, c, h, w) for i in range(nseg)]
+    xb = [cases.randn(500 + i, n, 24, h, w) for i in range(nseg)]
+    want = torch.zeros(cout, c + 24, k, k, dtype=torch.float64)
+    for d, a, b in zip(dys, xa, xb):
+        want += torch.nn.grad.conv2d_weight(torch.cat([a, b], 1).double(), (cout, c + 24, k, k), d.double(), padding=k // 2)
+    want_b = sum(d.double().sum(dim=(0, 2, 3)) for d in dys)
+    gd, ga, gb = [d.to(cuda) for d in dys], [a.to(cuda) for a in xa], [b.to(cuda) for b in xb]
+    out = torch.empty(cout, c + 24, k, k, device=cuda)
+    ops.conv_wgrad_multi(gd, [[a, b] for a, b in zip(ga, gb)], k, out=out)
+    one = torch.empty_like(out)
+    for i in range(nseg):
+        ops.conv_wgrad(gd[i], [ga[i], gb[i]], k, out=one, accumulate=i > 0)
+    scale = max(1.0, want.abs().max().item())
+    assert H.maxabs(out.cpu().double(), want) <= 2e-5 * scale
+    assert H.maxabs(out.cpu(), one.cpu()) <= 2e-5 * scale
+    ops.conv_wgrad_multi(gd[:1], [[ga[0], gb[0]]], k, out=out, accumulate=True)       # (+)= one more use
+    want1 = want + torch.nn.grad.conv2d_weight(torch.cat([xa[0], xb[0]], 1).double(), (cout, c + 24, k, k), dys[0].double(), padding=k // 2)
+    assert H.maxabs(out.cpu().double(), want1) <= 2e-5 * scale
+    db = torch.empty(cout, device=cuda)
+    ops.channel_sum_multi(gd, out=db)
+    assert H.maxabs(db.cpu().double(), want_b) <= 1e-5 * max(1.0, want_b.abs().max().item()) + 1e-4
+    ops.channel_sum_multi(gd[:2], out=db, accumulate=True)
+    assert H.maxabs(db.cpu().double(), want_b + dys[0].double().sum(dim=(0, 2, 3)) + dys[1].double().sum(dim=(0, 2, 3))) <= 1e-3
+    with pytest.raises(ValueError):
+        ops.conv_wgrad_multi([gd[0]] * 9, [[ga[0], gb[0]]] * 9, k, out=out)      # > 8 segments
+    with pytest.raises(ValueError):
+        ops.conv_wgrad_multi(gd[:2], [[ga[0], gb[0]], [ga[1][:, :32], gb[1]]], k, out=out)          # shapes differ
+
+
 def test_grad_sink_matches_autograd_accumulation(AG, cuda):
     """In-place accumulation of the per-use parameter gradients (autograd.grad_sink, what optimize_parameters runs)
     against autograd's own sum of the same per-use gradients, for every trainable parameter."""
