@@ -112,6 +112,7 @@ SIGNATURES = {
     "eavsr_channel_sum_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_channel_sum_multi_f32": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "eavsr_scale_residual_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "eavsr_rcab_tail_bwd_f32": (C.c_int, [vp] * 13 + [i32] * 5 + [vp]),
     "eavsr_ca_mlp_bwd_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, vp]),
     "eavsr_flow_warp_bwd_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, vp]),
     "eavsr_resize_bilinear_ac_bwd_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),

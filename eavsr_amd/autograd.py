@@ -103,8 +103,24 @@ class grad_sink:
         e["written"] = True
         e["pending"] = []
 
+    def raw(self, params):
+        """Buffers of the parameters' shapes that a backward kernel writes (first use) or adds to (later uses) itself:
+        (buffers, accumulate?).  For gradients that are not a convolution's (the channel-attention MLP of the RCAB tail)."""
+        key = ("raw",) + tuple(id(p) for p in params)
+        e = self.entries.get(key)
+        if e is None:
+            e = {"raw": [torch.empty_like(p) for p in params], "params": list(params), "written": False}
+            self.entries[key] = e
+        acc = e["written"]
+        e["written"] = True
+        return e["raw"], acc
+
     def flush(self):
         for e in self.entries.values():
+            if "raw" in e:
+                for p, g in zip(e["params"], e["raw"]):
+                    p.grad = g if p.grad is None else p.grad + g
+                continue
             self._launch(e)
             ws, bs, dW, db = e["ws"], e["bs"], e["dW"], e["db"]
             c0 = 0
@@ -401,6 +417,7 @@ class _RcabTailFn(Function):
         mean = ops.plane_sum(r, None, 1.0 / (h * w))
         scale = ops.ca_scale(mean.view(n, 1, c), 1, w1, b1, w2, b2)
         ctx.save_for_backward(r, mean, scale, w1, b1, w2, b2)
+        ctx.params = [w1, b1, w2, b2]      # the caller's tensor objects (grad_sink keys on them)
         return ops.scale_residual(r, scale, x)
 
     @staticmethod
@@ -408,6 +425,14 @@ class _RcabTailFn(Function):
         r, mean, scale, w1, b1, w2, b2 = ctx.saved_tensors
         d = d.contiguous()
         n, c, h, w = r.shape
+        if ops.rcab_tail_bwd_supported(c, int(w1.shape[0])):
+            # plane sums + ONE launch; inside grad_sink the four parameter gradients are added in place by that launch
+            if all(ctx.needs_input_grad[2:]) and grad_sink.eligible(ctx.params):
+                bufs, acc = grad_sink._active.raw(ctx.params)
+                dr = ops.rcab_tail_bwd(d, r, mean, scale, w1, b1, w2, b2, grads=tuple(bufs), accumulate=acc)[0]
+                return dr, d, None, None, None, None
+            dr, dw1, db1, dw2, db2 = ops.rcab_tail_bwd(d, r, mean, scale, w1, b1, w2, b2)
+            return dr, d, dw1, db1, dw2, db2
         dscale = ops.plane_sum(d, r)
         dmean, dw1, db1, dw2, db2 = ops.ca_mlp_bwd(mean, w1, b1, w2, b2, dscale)
         dr = ops.scale_residual_bwd(d, scale, dmean * (1.0 / (h * w)))

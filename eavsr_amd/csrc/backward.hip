@@ -191,6 +191,124 @@ __global__ __launch_bounds__(256) void ca_mlp_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// The whole backward of the RCAB tail out = r * s + x, s = sigmoid(W2 relu(W1 mean_hw(r) + b1) + b2) (networks.py:444-447,
+// 463-464) behind the plane sums ds[n,c] = sum_hw d r, as ONE launch (round 5): it used to be ca_mlp_bwd (one workgroup, 17-23 us
+// of dependent global round trips) -> an ATen multiplication by 1 / hw -> scale_residual_bwd, plus four ATen additions that
+// summed the MLP's parameter gradients over the uses of a block -- ~56 us per block, 845 blocks per training step of
+// configs[3].  Here every streaming workgroup (one per (n, c) plane) recomputes the 64 -> CR -> 64 MLP of its sample in wave 0
+// (lane = channel; the CR hidden sums by wave reductions) and applies dr = d * s[n,c] + dmean[n,c] / hw to its plane; ONE
+// extra workgroup evaluates the parameter gradients over all samples in a fixed order and writes or ADDS them to the caller's
+// buffers (autograd.grad_sink: no per-use tensors, no ATen sums).  c = 64, cr <= 8 (the path's CALayer: 64 / 16 = 4).
+// ---------------------------------------------------------------------------------------------
+struct RcabBwdArgs {
+  const float* d;        // (n, 64, hw) gradient of the block's output
+  const float* scale;    // (n, 64) the forward's s
+  const float* mean;     // (n, 64) the forward's mean_hw(r)
+  const float* w1;       // (cr, 64)
+  const float* b1;       // (cr)
+  const float* w2;       // (64, cr)
+  const float* b2;       // (64)
+  const float* ds;       // (n, 64) sum_hw d * r
+  float* dr;             // (n, 64, hw)
+  float* dw1; float* db1; float* dw2; float* db2;
+  int n, cr, hw, accumulate;
+  float inv_hw;
+};
+
+__device__ __forceinline__ float rb_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+template <int CR>
+__global__ __launch_bounds__(256) void rcab_tail_bwd_kernel(RcabBwdArgs a) {
+  constexpr int C = 64;
+  __shared__ float sh[2 + 4 * C];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nplanes = a.n * C;
+  if ((int)blockIdx.x < nplanes) {
+    const int b = blockIdx.x / C, ch = blockIdx.x - b * C;
+    if (tid < 64) {      // wave 0: the MLP of sample b, lane = channel
+      const float m = a.mean[(size_t)b * C + lane], dsv = a.ds[(size_t)b * C + lane];
+      float hid[CR], z2 = a.b2[lane];
+#pragma unroll
+      for (int j = 0; j < CR; ++j) {
+        hid[j] = fmaxf(rb_wave_sum(a.w1[j * C + lane] * m) + a.b1[j], 0.f);
+        z2 += a.w2[lane * CR + j] * hid[j];
+      }
+      const float sg = 1.f / (1.f + expf(-z2));
+      const float dz2 = dsv * sg * (1.f - sg);
+      float dm = 0.f;
+#pragma unroll
+      for (int j = 0; j < CR; ++j) {
+        const float dz1 = hid[j] > 0.f ? rb_wave_sum(a.w2[lane * CR + j] * dz2) : 0.f;
+        dm += a.w1[j * C + lane] * dz1;
+      }
+      if (lane == ch) {
+        sh[0] = a.scale[(size_t)b * C + ch];
+        sh[1] = dm * a.inv_hw;
+      }
+    }
+    __syncthreads();
+    const float sc = sh[0], add = sh[1];
+    const size_t base = (size_t)blockIdx.x * a.hw;
+    if ((a.hw & 3) == 0) {
+      const float4* d4 = reinterpret_cast<const float4*>(a.d + base);
+      float4* o4 = reinterpret_cast<float4*>(a.dr + base);
+      for (int i = tid; i < (a.hw >> 2); i += 256) {
+        const float4 v = d4[i];
+        o4[i] = make_float4(v.x * sc + add, v.y * sc + add, v.z * sc + add, v.w * sc + add);
+      }
+    } else {
+      for (int i = tid; i < a.hw; i += 256) a.dr[base + i] = a.d[base + i] * sc + add;
+    }
+    return;
+  }
+  // ---- the parameter gradients: one workgroup, samples in order (deterministic) -----------------------------------------
+  float* m = sh + 2;      // [C]
+  float* hidv = m + C;    // [CR] (C reserved)
+  float* dz2 = hidv + C;  // [C]
+  float* dz1 = dz2 + C;   // [CR]
+  for (int b = 0; b < a.n; ++b) {
+    const bool first = b == 0 && !a.accumulate;
+    if (tid < C) m[tid] = a.mean[(size_t)b * C + tid];
+    __syncthreads();
+    if (tid < 64) {
+      float z2 = a.b2[lane];
+#pragma unroll
+      for (int j = 0; j < CR; ++j) {
+        const float hj = fmaxf(rb_wave_sum(a.w1[j * C + lane] * m[lane]) + a.b1[j], 0.f);
+        if (lane == 0) hidv[j] = hj;
+        z2 += a.w2[lane * CR + j] * hj;
+      }
+      const float sg = 1.f / (1.f + expf(-z2));
+      const float g2 = a.ds[(size_t)b * C + lane] * sg * (1.f - sg);
+      dz2[lane] = g2;
+#pragma unroll
+      for (int j = 0; j < CR; ++j) {
+        const float t = rb_wave_sum(a.w2[lane * CR + j] * g2);
+        if (lane == 0) dz1[j] = t;
+      }
+    }
+    __syncthreads();
+    if (tid < CR) dz1[tid] = hidv[tid] > 0.f ? dz1[tid] : 0.f;
+    __syncthreads();
+    for (int i = tid; i < C * CR; i += 256) {
+      const int ci = i / CR, j = i - ci * CR;   // dw2[ci][j]
+      const float g2 = dz2[ci] * hidv[j];
+      a.dw2[i] = first ? g2 : a.dw2[i] + g2;
+      const int j1 = i / C, k = i - j1 * C;      // dw1[j1][k]
+      const float g1 = dz1[j1] * m[k];
+      a.dw1[i] = first ? g1 : a.dw1[i] + g1;
+    }
+    if (tid < C) a.db2[tid] = first ? dz2[tid] : a.db2[tid] + dz2[tid];
+    if (tid < CR) a.db1[tid] = first ? dz1[tid] : a.db1[tid] + dz1[tid];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // flow_warp backward (zeros padding; the border mode only occurs inside the frozen SPyNet).
 // One thread per pixel, all channels: dx gets 4 atomic adds per channel, dflow is summed in registers.
 // d(sample position)/d(flow) = 1 (the reference's normalise / un-normalise pair cancels).
@@ -382,6 +500,30 @@ extern "C" int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const fl
                      (size_t)(2 * c + 2 * cr + (staged ? 2 * c * cr : 0)) * sizeof(float), eavsr::as_stream(stream), mean,
                      w1, b1, w2, b2, dscale, dmean, dw1, db1, dw2, db2, n, c, cr, staged);
   return eavsr::launch_status("ca_mlp_bwd");
+}
+
+extern "C" int eavsr_rcab_tail_bwd_f32(const float* d, const float* scale, const float* mean, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, const float* dscale, float* dr, float* dw1, float* db1,
+                                       float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, int32_t hw, int32_t accumulate,
+                                       void* stream) {
+  EAVSR_REQUIRE(d && scale && mean && w1 && b1 && w2 && b2 && dscale && dr && dw1 && db1 && dw2 && db2, -1, "rcab_tail_bwd: NULL pointer");
+  EAVSR_REQUIRE(c == 64 && (cr == 4 || cr == 8 || cr == 2 || cr == 1), -2,
+                "rcab_tail_bwd: %d channels / %d hidden units unsupported (64 channels, 1 / 2 / 4 / 8 hidden units)", c, cr);
+  EAVSR_REQUIRE(n >= 1 && hw > 0 && (long)n * c < 65535, -1, "rcab_tail_bwd: bad dims");
+  EAVSR_REQUIRE((((uintptr_t)d | (uintptr_t)dr) & 15) == 0 || (hw & 3), -2, "rcab_tail_bwd: d / dr must be 16-byte aligned");
+  RcabBwdArgs a;
+  a.d = d; a.scale = scale; a.mean = mean; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.ds = dscale; a.dr = dr;
+  a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2;
+  a.n = n; a.cr = cr; a.hw = hw; a.accumulate = accumulate; a.inv_hw = 1.0f / (float)hw;
+  hipStream_t st = eavsr::as_stream(stream);
+  const dim3 grid(n * c + 1), block(256);
+  switch (cr) {
+    case 1: hipLaunchKernelGGL(rcab_tail_bwd_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(rcab_tail_bwd_kernel<2>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(rcab_tail_bwd_kernel<4>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(rcab_tail_bwd_kernel<8>, grid, block, 0, st, a); break;
+  }
+  return eavsr::launch_status("rcab_tail_bwd");
 }
 
 extern "C" int eavsr_flow_warp_bwd_f32(const float* x, const float* flow, const float* flow2, const float* dout,

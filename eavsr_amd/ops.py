@@ -1375,6 +1375,36 @@ def ca_mlp_bwd(mean: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, dsc
     return dmean, dw1, db1, dw2, db2
 
 
+def rcab_tail_bwd_supported(c: int, cr: int) -> bool:
+    return c == 64 and cr in (1, 2, 4, 8)
+
+
+def rcab_tail_bwd(d: Tensor, r: Tensor, mean: Tensor, scale: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor,
+                  grads=None, accumulate: bool = False):
+    """Backward of out = r * sigmoid(W2 relu(W1 mean_hw(r) + b1) + b2) + x w.r.t. r and the four MLP parameters: the plane
+    sums sum_hw d r, then ONE launch (eavsr_rcab_tail_bwd_f32) for the MLP's backward, the broadcast of the mean's gradient and
+    dr = d * scale + dmean / hw.  `grads` = (dw1, db1, dw2, db2) buffers to write or, with `accumulate`, to add to; fresh ones
+    when None.  Returns (dr, dw1, db1, dw2, db2)."""
+    d, r, mean, scale = _chk(d, "d"), _chk(r, "r"), _chk(mean, "mean"), _chk(scale, "scale")
+    w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
+    n, c, h, w = d.shape
+    cr = int(w1.shape[0])
+    if not rcab_tail_bwd_supported(c, cr):
+        raise NotImplementedError(f"rcab_tail_bwd: {c} channels / {cr} hidden units")
+    dscale = plane_sum(d, r)
+    if grads is None:
+        grads = (torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2))
+        accumulate = False
+    dw1, db1, dw2, db2 = grads
+    dr = torch.empty_like(d)
+    st = _stream(d)
+    _launch("rcab_tail_bwd", 2.0 * d.numel(), 8.0 * d.numel(), d,
+            lambda: lib().eavsr_rcab_tail_bwd_f32(_p(d), _p(scale), _p(mean), _p(w1), _p(b1), _p(w2), _p(b2), _p(dscale), _p(dr),
+                                                  _p(dw1), _p(db1), _p(dw2), _p(db2), n, c, cr, h * w, int(accumulate), st),
+            "rcab_tail_bwd")
+    return dr, dw1, db1, dw2, db2
+
+
 def flow_warp_bwd(x: Tensor, flow: Tensor, flow2: Optional[Tensor], dout: Tensor, need_dx: bool, need_dflow: bool):
     x, flow, dout = _chk(x, "x"), _chk(flow, "flow"), _chk(dout, "dout")
     n, c, h, w = x.shape

@@ -396,6 +396,15 @@ int eavsr_scale_residual_bwd_f32(const float* d, const float* scale, const float
 int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
                          const float* dscale, float* dmean, float* dw1, float* db1, float* dw2, float* db2,
                          int32_t n, int32_t c, int32_t cr, void* stream);
+/* The whole backward of the RCAB tail out = r * s + x, s = sigmoid(W2 relu(W1 mean_hw(r) + b1) + b2) (networks.py:444-447,463-464)
+ * behind the plane sums dscale[n,c] = sum_hw d r (eavsr_plane_sum_f32), as one launch (ABI 26): dr = d * scale[n,c] +
+ * dmean[n,c] / hw with dmean from the MLP's backward, and the four parameter gradients summed over n in a fixed order, written
+ * (accumulate = 0) or ADDED (accumulate != 0) to dw1 (cr, 64), db1 (cr), dw2 (64, cr), db2 (64).  c = 64, cr in {1, 2, 4, 8};
+ * other shapes: eavsr_ca_mlp_bwd_f32 + eavsr_scale_residual_bwd_f32. */
+int eavsr_rcab_tail_bwd_f32(const float* d, const float* scale, const float* mean, const float* w1, const float* b1,
+                            const float* w2, const float* b2, const float* dscale, float* dr, float* dw1, float* db1,
+                            float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, int32_t hw, int32_t accumulate,
+                            void* stream);
 /* backward of eavsr_flow_warp_f32 (zeros padding, NCHW flow): dx (pre-zeroed, accumulated with float
  * atomics; NULL = skip) and dflow (n,2,h,w; NULL = skip).  flow2 as in the forward. */
 int eavsr_flow_warp_bwd_f32(const float* x, const float* flow, const float* flow2, const float* dout,

@@ -184,10 +184,14 @@ def test_resampling_backward(AG, cuda):
     check(got, ref, 1e-6, ["x"])
 
 
-def test_rcab_tail_backward(AG, cuda):
+@pytest.mark.parametrize("hw", [(10, 14), (9, 7), (96, 96)])
+def test_rcab_tail_backward(AG, cuda, hw):
+    """the RCAB tail's backward (plane sums + eavsr_rcab_tail_bwd_f32: MLP backward, mean broadcast and dr in one launch) against
+    CPU autograd of the oracle's CALayer; float4 and ragged planes; then two uses inside grad_sink (the launch ADDS the
+    parameter gradients of the second use in place) against the sum of two autograd runs"""
     sd = H.filled(H.rcab_shapes("b."), "trained_like")
     keys = ["b.ca.conv_du.0.weight", "b.ca.conv_du.0.bias", "b.ca.conv_du.2.weight", "b.ca.conv_du.2.bias"]
-    r, x, G = cases.randn(1, 2, 64, 10, 14), cases.randn(2, 2, 64, 10, 14), cases.randn(3, 2, 64, 10, 14)
+    r, x, G = cases.randn(1, 2, 64, *hw), cases.randn(2, 2, 64, *hw), cases.randn(3, 2, 64, *hw)
     cp = {k: leaf(sd[k]) for k in keys}
     cr, cx = leaf(r), leaf(x)
     ref = grads(O.ca_layer({**sd, **cp}, "b.ca.", cr) + cx, G, [cr, cx] + [cp[k] for k in keys])
@@ -195,6 +199,18 @@ def test_rcab_tail_backward(AG, cuda):
     gr, gx = leaf(r, cuda), leaf(x, cuda)
     got = grads(AG.rcab_tail(gr, gx, *[gp[k] for k in keys]), G.to(cuda), [gr, gx] + [gp[k] for k in keys])
     check(got, ref, 2e-5, ["r", "x"] + keys)
+    # two uses of the same parameters under grad_sink: out = tail(tail(r, x), x)
+    cp2 = {k: leaf(sd[k]) for k in keys}
+    cr2, cx2 = leaf(r), leaf(x)
+    y1 = O.ca_layer({**sd, **cp2}, "b.ca.", cr2) + cx2
+    ref2 = grads(O.ca_layer({**sd, **cp2}, "b.ca.", y1) + cx2, G, [cr2, cx2] + [cp2[k] for k in keys])
+    gp2 = {k: torch.nn.Parameter(sd[k].to(cuda)) for k in keys}
+    gr2, gx2 = leaf(r, cuda), leaf(x, cuda)
+    with AG.grad_sink():
+        y = AG.rcab_tail(AG.rcab_tail(gr2, gx2, *[gp2[k] for k in keys]), gx2, *[gp2[k] for k in keys])
+        (y * G.to(cuda)).sum().backward()
+    got2 = [gr2.grad, gx2.grad] + [gp2[k].grad for k in keys]
+    check(got2, ref2, 5e-5, ["r", "x"] + keys)
 
 
 def _grads_of_module(mod, sd, prefix, loss_fn):
