@@ -682,7 +682,7 @@ def main():
                 ach = alg / red
                 # `achieved` / `frac`: FLOP the matrix pipe actually performs per second against its fp32 peak (<= 1 by
                 # construction); the algorithmic-equivalent rate (SURVEY 8d's 2*cin*cout*k*k per pixel) is its own key
-                peak = PEAK_MFMA_16BIT_TFLOPS if name.endswith(("_h16", "_x6")) else PEAK_MFMA_F32_TFLOPS
+                peak = PEAK_MFMA_16BIT_TFLOPS if (name.endswith("_x6") or "_h16" in name) else PEAK_MFMA_F32_TFLOPS      # (_h16, _h16g, _h16x1, _h16_ps2)
                 return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "traffic": None, "avg_ms": avg_ms, "calls": v["calls"],
                         "share_of_step": v["ms"] / total_ms, "algorithm": how,
