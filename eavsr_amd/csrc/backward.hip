@@ -313,16 +313,22 @@ __global__ __launch_bounds__(256) void rcab_tail_bwd_kernel(RcabBwdArgs a) {
 // One thread per pixel, all channels: dx gets 4 atomic adds per channel, dflow is summed in registers.
 // d(sample position)/d(flow) = 1 (the reference's normalise / un-normalise pair cancels).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
-                                                            const float* __restrict__ flow2,
-                                                            const float* __restrict__ dout, float* __restrict__ dx,
-                                                            float* __restrict__ dflow, int c, int h, int w) {
+// Round 5: one workgroup = 64 pixels of a row x FWB_SL channel slices (threadIdx.y); a thread walks c / FWB_SL channels, so a
+// pixel's 4 c atomics are in flight from FWB_SL waves instead of queued behind one another in one thread (81 -> see DESIGN.md 6),
+// and the slices' d(flow) partial sums meet in LDS (fixed order).
+constexpr int FWB_SL = 8;
+__global__ __launch_bounds__(64 * FWB_SL) void flow_warp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                                    const float* __restrict__ flow2,
+                                                                    const float* __restrict__ dout, float* __restrict__ dx,
+                                                                    float* __restrict__ dflow, int c, int h, int w) {
+  __shared__ float s_g[2][FWB_SL][64];
   const int px = blockIdx.x * 64 + threadIdx.x;
-  const int py = blockIdx.y * 4 + threadIdx.y;
+  const int py = blockIdx.y;
+  const int sl = threadIdx.y;
   const int bn = blockIdx.z;
-  if (px >= w || py >= h) return;
+  const bool live = px < w;
   const size_t plane = (size_t)h * w;
-  const size_t fo = (size_t)bn * 2 * plane + (size_t)py * w + px;
+  const size_t fo = (size_t)bn * 2 * plane + (size_t)py * w + min(px, w - 1);
   float fx = flow[fo], fy = flow[fo + plane];
   if (flow2) { fx += flow2[fo]; fy += flow2[fo + plane]; }
   const float gx = (float)px + fx, gy = (float)py + fy;
@@ -337,19 +343,22 @@ __global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float* __restr
   const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = (fx0 + 1.0f) - ix, wy0 = (fy0 + 1.0f) - iy;
   const bool vx0 = (x0 >= 0) & (x0 < w), vx1 = (x1 >= 0) & (x1 < w);
   const bool vy0 = (y0 >= 0) & (y0 < h), vy1 = (y1 >= 0) & (y1 < h);
-  const bool v_nw = vx0 & vy0, v_ne = vx1 & vy0, v_sw = vx0 & vy1, v_se = vx1 & vy1;
+  const bool v_nw = vx0 & vy0 & live, v_ne = vx1 & vy0 & live, v_sw = vx0 & vy1 & live, v_se = vx1 & vy1 & live;
   const int cx0 = min(max(x0, 0), w - 1), cx1 = min(max(x1, 0), w - 1);
   const int cy0 = min(max(y0, 0), h - 1), cy1 = min(max(y1, 0), h - 1);
   const int i_nw = cy0 * w + cx0, i_ne = cy0 * w + cx1, i_sw = cy1 * w + cx0, i_se = cy1 * w + cx1;
+  const float w_nw = wx0 * wy0, w_ne = wx1 * wy0, w_sw = wx0 * wy1, w_se = wx1 * wy1;
   float gix = 0.f, giy = 0.f;
-  for (int cc = 0; cc < c; ++cc) {
+  const int cper = (c + FWB_SL - 1) / FWB_SL;
+  const int c_lo = sl * cper, c_hi = min(c, c_lo + cper);
+  for (int cc = c_lo; cc < c_hi; ++cc) {
     const size_t cb = ((size_t)bn * c + cc) * plane;
-    const float g = dout[cb + (size_t)py * w + px];
+    const float g = live ? dout[cb + (size_t)py * w + px] : 0.f;
     if (dx != nullptr) {
-      if (v_nw) atomicAdd(dx + cb + i_nw, g * wx0 * wy0);
-      if (v_ne) atomicAdd(dx + cb + i_ne, g * wx1 * wy0);
-      if (v_sw) atomicAdd(dx + cb + i_sw, g * wx0 * wy1);
-      if (v_se) atomicAdd(dx + cb + i_se, g * wx1 * wy1);
+      if (v_nw) atomicAdd(dx + cb + i_nw, g * w_nw);
+      if (v_ne) atomicAdd(dx + cb + i_ne, g * w_ne);
+      if (v_sw) atomicAdd(dx + cb + i_sw, g * w_sw);
+      if (v_se) atomicAdd(dx + cb + i_se, g * w_se);
     }
     if (dflow != nullptr) {
       const float a = v_nw ? x[cb + i_nw] : 0.f, b = v_ne ? x[cb + i_ne] : 0.f;
@@ -358,9 +367,16 @@ __global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float* __restr
       giy += g * ((cv - a) * wx0 + (d - b) * wx1);
     }
   }
-  if (dflow != nullptr) {
-    dflow[fo] = gix;
-    dflow[fo + plane] = giy;
+  if (dflow != nullptr) {      // (uniform over the workgroup)
+    s_g[0][sl][threadIdx.x] = gix;
+    s_g[1][sl][threadIdx.x] = giy;
+    __syncthreads();
+    if (sl < 2 && live) {
+      float v = s_g[sl][0][threadIdx.x];
+#pragma unroll
+      for (int k = 1; k < FWB_SL; ++k) v += s_g[sl][k][threadIdx.x];
+      dflow[fo + (sl ? plane : 0)] = v;
+    }
   }
 }
 
@@ -532,7 +548,8 @@ extern "C" int eavsr_flow_warp_bwd_f32(const float* x, const float* flow, const 
   EAVSR_REQUIRE(x && flow && dout, -1, "flow_warp_bwd: NULL pointer");
   EAVSR_REQUIRE(n >= 0 && c >= 0 && h > 0 && w > 0 && n <= 65535, -1, "flow_warp_bwd: bad dims");
   if (n == 0 || c == 0) return 0;
-  dim3 grid(eavsr::cdiv(w, 64), eavsr::cdiv(h, 4), n), block(64, 4, 1);
+  EAVSR_REQUIRE(h <= 65535, -1, "flow_warp_bwd: image too tall for the launch grid");
+  dim3 grid(eavsr::cdiv(w, 64), h, n), block(64, FWB_SL, 1);
   hipLaunchKernelGGL(flow_warp_bwd_kernel, grid, block, 0, eavsr::as_stream(stream), x, flow, flow2, dout, dx, dflow, c,
                      h, w);
   return eavsr::launch_status("flow_warp_bwd");
