@@ -134,6 +134,8 @@ SIGNATURES = {
     "eavsr_conv_h16_partial_rows": (i32, [i32, i32, i32]),
     "eavsr_conv3x3_c64_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_c64_h16_act": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
+    "eavsr_rcab_convs_h16": (C.c_int, [vp] * 7 + [i32] * 4 + [vp]),
+    "eavsr_rcab_h16_partial_rows": (i32, [i32, i32, i32]),
     "eavsr_conv3x3_c64to3_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_h16g_weight_bytes": (C.c_int64, [i32, i32]),
     "eavsr_pack_conv3x3_h16g": (C.c_int, [vp, vp, i32, i32, i32, vp]),

@@ -384,6 +384,16 @@ HEADS_IN_16BIT = _os.environ.get("EAVSR_HEADS_16BIT", "1") == "1"
 # Optional 16-bit residual backbone: None (exact fp32, the default and the BASELINE headline), "bf16" or "fp16"
 # (set_backbone_dtype / EAVSR_BACKBONE_DTYPE).  Only the RCAGroup internals change precision.
 BACKBONE_DTYPE = _os.environ.get("EAVSR_BACKBONE_DTYPE") or None
+# conv -> ReLU -> conv of an RCAB as ONE launch in the 16-bit modes (eavsr_rcab_convs_h16, csrc/rcab_h16.hip: streamed weights, the
+# intermediate in LDS; r bit-identical to the two launches).  OPT-IN (EAVSR_RCAB_H16_FUSED=1): back to back it is 49.7 us against
+# 52.3 for the two launches at 4 x 64 x 256 x 256 (25.3 against 31.0 at 2 x 180 x 320, 94.1 against 81.7 at 1 x 540 x 960), but
+# configs[2]'s two-stream step is 197.3 ms with it against 195.3 without (DESIGN.md 3.6 has the per-phase stamps).
+RCAB_H16_FUSED = _os.environ.get("EAVSR_RCAB_H16_FUSED", "0") == "1"
+
+
+def set_rcab_h16_fused(on: bool) -> None:
+    global RCAB_H16_FUSED
+    RCAB_H16_FUSED = bool(on)
 if BACKBONE_DTYPE is not None:
     ops.set_conv3_h16(BACKBONE_DTYPE)
 
@@ -432,8 +442,11 @@ class RCAGroup(nn.Module):
         xs = ops.to_nhwc_h16(x, dtype)
         for blk in blocks:
             c1, c2 = blk.res[0], blk.res[2]
-            t = ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True)
-            r, partial = ops.conv3x3_c64_h16(t, c2.weight, c2.bias, chan_partial=True)
+            if RCAB_H16_FUSED and ops.rcab_convs_h16_preferred(xs):      # conv -> ReLU -> conv as ONE launch (csrc/rcab_h16.hip)
+                r, partial = ops.rcab_convs_h16(xs, c1.weight, c1.bias, c2.weight, c2.bias, chan_partial=True)
+            else:
+                t = ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True)
+                r, partial = ops.conv3x3_c64_h16(t, c2.weight, c2.bias, chan_partial=True)
             xs = ops.scale_residual_h16(r, blk.ca.scale_from_partial(partial, hw), xs)
         y = ops.conv3x3_c64_h16(xs, last.weight, last.bias)
         return ops.from_nhwc_h16(y, residual=x)

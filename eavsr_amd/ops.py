@@ -1707,6 +1707,43 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
     return (out, part) if chan_partial else out
 
 
+# The one-launch RCAB convolutions stream their weights per tile (11.5 us per tile whatever the launch); the resident-weights
+# kernel amortises its weight load and prologue over a workgroup's tiles (7.1 us per tile and convolution at 4 tiles per
+# workgroup, 5 us at 8).  Measured (tools/gpu_rcab_h16_time.py): 4 x 256 x 256 (4 tiles per workgroup) 49.7 us against 52.3 for the two
+# launches, 2 x 180 x 320 (1.8) 25.3 against 31.0, 1 x 540 x 960 (8) 94.1 against 81.7 -- so the fused form is the default up to
+# RCAB_FUSED_MAX_TILES tiles per launch (EAVSR_RCAB_FUSED_MAX_TILES overrides).
+RCAB_FUSED_MAX_TILES = int(os.environ.get("EAVSR_RCAB_FUSED_MAX_TILES", "1536"))
+
+
+def rcab_convs_h16_preferred(x: Tensor) -> bool:
+    n, h, w, _ = x.shape
+    return n * ((h + 7) // 8) * ((w + 31) // 32) <= RCAB_FUSED_MAX_TILES
+
+
+def rcab_convs_h16(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], chan_partial: bool = True):
+    """r = conv3x3(ReLU(conv3x3(x))) of one RCAB (networks.py:461-462) as ONE launch on 16-bit NHWC tensors
+    (csrc/rcab_h16.hip: streamed weights, the intermediate lives in LDS); with `chan_partial` also the channel sums of r for the
+    channel attention, in the row layout of conv3x3_c64_h16."""
+    x = _chk_h16(x, "x")
+    n, h, w, c = x.shape
+    if c != 64:
+        raise NotImplementedError("the 16-bit backbone kernel needs 64 channels")
+    code = h16_code(x.dtype)
+    wp1, wp2 = _packed_h16(w1, code), _packed_h16(w2, code)
+    bb1 = None if b1 is None else _chk(b1.detach(), "bias")
+    bb2 = None if b2 is None else _chk(b2.detach(), "bias")
+    out = torch.empty_like(x)
+    part = None
+    if chan_partial:
+        part = torch.empty((n, lib().eavsr_rcab_h16_partial_rows(n, h, w), 64), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch("rcab_convs_h16", 2.0 * 2.0 * 64 * 64 * 9 * px, 2.0 * px * 128, x,
+            lambda: lib().eavsr_rcab_convs_h16(_p(x), _p(wp1), _p(bb1), _p(wp2), _p(bb2), _p(out), _p(part), n, h, w, code, st),
+            "rcab_convs_h16")
+    return (out, part) if chan_partial else out
+
+
 _h16_ps_cache = {}
 _h16_last_cache = {}
 

@@ -485,6 +485,15 @@ int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float*
  *   .permute(3, 4, 1, 0, 2)); fp32 accumulation, out fp32 NCHW (n, 3, h, w) = conv + bias + residual (nullable: the bilinear skip). */
 int eavsr_conv3x3_c64_h16_act(const void* x, const void* weight_packed, const float* bias, void* out, int32_t n, int32_t h,
                               int32_t w, int32_t act, float slope, int32_t pixel_shuffle2, int32_t dtype, void* stream);
+/* conv3x3 -> ReLU -> conv3x3 of one RCAB (RCABlock.forward, models/networks.py:461-462, mode 'CRC') as ONE launch in the 16-bit
+ * modes (ABI 26): r = conv2(ReLU(conv1(x) + bias1)) + bias2 on 16-bit NHWC tensors, both weights in the packed form of
+ * eavsr_pack_conv3x3_c64_h16, the intermediate rounded to 16 bits in LDS (never in HBM) and zero outside the image (the second
+ * convolution's own padding).  r is bit-identical to two eavsr_conv3x3_c64_h16 launches.  chan_partial (nullable): (n,
+ * eavsr_rcab_h16_partial_rows(n, h, w), 64) fp32, one row per workgroup of the launch and sample (zeros where a workgroup has no
+ * tile of the sample); the rows of a sample add up to the channel sums of r over its pixels. */
+int32_t eavsr_rcab_h16_partial_rows(int32_t n, int32_t h, int32_t w);
+int eavsr_rcab_convs_h16(const void* x, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2,
+                         void* out, float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
 int eavsr_conv3x3_c64to3_h16(const void* x, const void* weight, const float* bias, const float* residual, float* out,
                              int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
 /* Generic 3x3 convolution of the 16-bit modes (csrc/conv3_h16.hip): same descriptor as eavsr_conv2d_f32 (fp32 NCHW sources as a

@@ -203,6 +203,19 @@ def test_rcagroup_16bit_backbone_vs_fp32_oracle(ops, cuda, dt):
         Nw.set_backbone_dtype(None)
     rel = H.maxabs(out, ref) / ref.abs().max().item()
     assert rel <= (4e-2 if dt == "bf16" else 6e-3), rel
+    # the same group with each RCAB's two convolutions as ONE launch (csrc/rcab_h16.hip, opt-in): same r, channel sums by another
+    # summation tree -- the group output may differ by a 16-bit rounding flip here and there, never by more
+    try:
+        Nw.set_backbone_dtype(dt)
+        Nw.set_rcab_h16_fused(True)
+        with torch.no_grad(), ops.profile() as prof:
+            out1 = grp(x.to(cuda)).cpu()
+        assert "rcab_convs_h16" in set(prof.summary())
+    finally:
+        Nw.set_rcab_h16_fused(False)
+        Nw.set_backbone_dtype(None)
+    assert H.maxabs(out1, out) <= 4 * EPS[dt] * ref.abs().max().item()
+    assert H.maxabs(out1, ref) / ref.abs().max().item() <= (4e-2 if dt == "bf16" else 6e-3)
     with torch.no_grad():
         exact = grp(x.to(cuda)).cpu()          # back to the exact fp32 path
     assert H.maxabs(exact, ref) <= 2e-5 * max(1.0, ref.abs().max().item())
@@ -316,3 +329,36 @@ def test_multiadstn_16bit_alignment_vs_reference_golden(ops, cuda, dt):
     assert "conv5x5_64to120_h16" in names and "conv5x5_64to120_wino" not in names, names     # the heads ran in 16 bits too
     rel = H.maxabs(out, gold["out"]) / gold["out"].abs().max().item()
     assert rel <= (2e-2 if dt == "bf16" else 3e-3), rel
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(1, 8, 32), (2, 19, 37), (1, 45, 80), (3, 7, 5), (1, 64, 96), (2, 256, 256)])
+def test_rcab_convs_in_one_launch_equal_the_two_launches(ops, cuda, dt, shape):
+    """eavsr_rcab_convs_h16 (csrc/rcab_h16.hip): conv3x3 -> ReLU -> conv3x3 of RCABlock.forward (networks.py:461-462) as ONE
+    launch -- streamed weights, the intermediate rounded to 16 bits in LDS and zero outside the image.  r must equal the two
+    eavsr_conv3x3_c64_h16 launches BIT FOR BIT (same operands, same k-step order), on single tiles, ragged edges (the intermediate's
+    zero padding), several samples and a multi-tile-per-workgroup launch; the channel sums (another summation tree) to rounding;
+    and against torch on the same rounded operands."""
+    n, h, w = shape
+    x = cases.randn(31, n, 64, h, w).to(DT[dt])
+    xh = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    w1, w2 = cases.randn(32, 64, 64, 3, 3, scale=1.0 / 24.0), cases.randn(33, 64, 64, 3, 3, scale=1.0 / 24.0)
+    b1, b2 = cases.randn(34, 64, scale=0.1), cases.randn(35, 64, scale=0.1)
+    gw1, gw2, gb1, gb2 = w1.to(cuda), w2.to(cuda), b1.to(cuda), b2.to(cuda)
+    t = ops.conv3x3_c64_h16(xh, gw1, gb1, relu=True)
+    r_two, part_two = ops.conv3x3_c64_h16(t, gw2, gb2, chan_partial=True)
+    r_one, part_one = ops.rcab_convs_h16(xh, gw1, gb1, gw2, gb2, chan_partial=True)
+    assert r_one.shape == r_two.shape and r_one.dtype == r_two.dtype
+    assert torch.equal(r_one, r_two), H.maxabs(r_one.float().cpu(), r_two.float().cpu())
+    s_one, s_two = part_one.sum(1).cpu(), part_two.sum(1).cpu()
+    want = r_two.float().sum(dim=(1, 2)).cpu()
+    scale = max(1.0, want.abs().max().item())
+    assert H.maxabs(s_one, want) <= 2e-5 * scale * (h * w) ** 0.5 and H.maxabs(s_one, s_two) <= 2e-5 * scale * (h * w) ** 0.5
+    r_nop = ops.rcab_convs_h16(xh, gw1, None, gw2, None, chan_partial=False)      # no biases, no sums
+    t0 = ops.conv3x3_c64_h16(xh, gw1, None, relu=True)
+    assert torch.equal(r_nop, ops.conv3x3_c64_h16(t0, gw2, None))
+    if h * w <= 64 * 96:
+        tt = F.relu(F.conv2d(x.float(), w1.to(DT[dt]).float(), b1, 1, 1)).to(DT[dt]).float()
+        ref = F.conv2d(tt, w2.to(DT[dt]).float(), b2, 1, 1)
+        got = r_one.float().permute(0, 3, 1, 2).cpu()
+        assert H.maxabs(got, ref) <= (EPS[dt] * 1.5) * max(1.0, ref.abs().max().item()) + 1e-4
