@@ -622,6 +622,9 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
     __builtin_amdgcn_s_waitcnt(0x0F70 | 6);      // vmcnt(6)
     if (tid < 64) reinterpret_cast<float*>(smem + JL_BIAS)[tid] = bias_v;
     __syncthreads();
+#ifdef EAVSR_IL2_STAGGER
+    if (wave >= 4) __builtin_amdgcn_s_sleep(EAVSR_IL2_STAGGER);
+#endif
     init_acc();
     setup(0, nn, S0, S1);
     gather(0, 0, nn, r_x);
@@ -688,6 +691,11 @@ __global__ __launch_bounds__(512, 2) void dcnv2_il2_kernel(IL2Args a) {
         }
         J_STAMP(u == 3 ? 3 : 6);                 // wait for the own DMA share
         __builtin_amdgcn_s_barrier();
+#ifdef EAVSR_IL2_STAGGER
+        // A/B: the two waves of a SIMD (w, w + 4) leave every meeting EAVSR_IL2_STAGGER x 64 cycles apart, so that one's MFMA
+        // chunks fall beside the other's vector chunks instead of on top of them (MI355X_MICROARCH.md, two waves per SIMD, item 9)
+        if (wave >= 4) __builtin_amdgcn_s_sleep(EAVSR_IL2_STAGGER);
+#endif
         J_STAMP(u == 3 ? 4 : 7);                 // wait for the other waves
 #endif
       }

@@ -76,5 +76,17 @@ if "h16" in which:
             y16 = ops.conv3x3_c64_h16_act(x16, wps, bps, act="lrelu", slope=0.1, pixel_shuffle2=True)
             ops.conv3x3_c64to3_h16(y16, wl, bl)
     ops.set_conv3_h16(None)
+if "h16b" in which:
+    # ONE launch shape per kernel name (the h16 set averages the backbone launch with the four-slice pixel-shuffle
+    # launch): the 16-bit backbone convolution at configs[2]'s sub-batch shape, and the one-launch RCAB convolutions (csrc/rcab_h16.hip)
+    hn, hh, hw = 4, 256, 256
+    x16 = ops.to_nhwc_h16(r(hn, 64, hh, hw), "bf16")
+    w33b = r(64, 64, 3, 3) * 0.05
+    with torch.no_grad():
+        for _ in range(reps):
+            t16 = ops.conv3x3_c64_h16(x16, w33, b, relu=True)
+            ops.conv3x3_c64_h16(t16, w33b, b, chan_partial=True)
+        for _ in range(reps):
+            ops.rcab_convs_h16(x16, w33, b, w33b, b, chan_partial=True)
 torch.cuda.synchronize()
 print("done")
