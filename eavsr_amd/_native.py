@@ -94,6 +94,7 @@ SIGNATURES = {
     "eavsr_pack_conv_weight_x6": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "eavsr_conv_f32x6": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "eavsr_ca_scale_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "eavsr_ca_scale_mean_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_scale_residual_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_ca_tail_f32": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_adapt_frontend_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -112,7 +113,7 @@ SIGNATURES = {
     "eavsr_channel_sum_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_channel_sum_multi_f32": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "eavsr_scale_residual_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
-    "eavsr_rcab_tail_bwd_f32": (C.c_int, [vp] * 13 + [i32] * 5 + [vp]),
+    "eavsr_rcab_tail_bwd_f32": (C.c_int, [vp] * 13 + [i32] * 6 + [vp]),
     "eavsr_ca_mlp_bwd_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, vp]),
     "eavsr_flow_warp_bwd_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, vp]),
     "eavsr_resize_bilinear_ac_bwd_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),

@@ -443,6 +443,66 @@ def rcab_tail(r, x, w1, b1, w2, b2):
     return _RcabTailFn.apply(r, x, w1, b1, w2, b2)
 
 
+# ------------------------------------------------------------------------------------------ whole RCAB
+class _RcabFn(Function):
+    """out = x + r * sigmoid(W_b relu(W_a mean_hw(r) + b_a) + b_b),  r = conv3x3(relu(conv3x3(x)))   (RCABlock.forward,
+    networks.py:461-464, mode 'CRC') as ONE autograd node for the training step (round 5): the forward takes the channel
+    sums from the second convolution's epilogue (no plane-sum launch), the backward hands the residual path's gradient to the
+    last input-gradient convolution as its `residual` (no ATen addition by autograd), and the weight / bias gradients of both
+    convolutions and the four channel-attention parameters go through grad_sink when it is active."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, wa, ba, wb, bb):
+        n, c, h, w = x.shape
+        t = ops.conv2d([x], [w1], [b1], act="relu")
+        r, partial = ops.conv2d([t], [w2], [b2], chan_partial=True)
+        scale, mean = ops.ca_scale(partial, h * w, wa, ba, wb, bb, with_mean=True)
+        ctx.save_for_backward(x, t, r, mean, scale, w1, w2, wa, ba, wb, bb)
+        ctx.params = ([w1], [b1], [w2], [b2], [wa, ba, wb, bb])      # the caller's tensor objects (grad_sink keys on them)
+        return ops.scale_residual(r, scale, x)
+
+    @staticmethod
+    def backward(ctx, d):
+        x, t, r, mean, scale, w1, w2, wa, ba, wb, bb = ctx.saved_tensors
+        pw1, pb1, pw2, pb2, pca = ctx.params
+        d = d.contiguous()
+        sink = grad_sink._active if grad_sink.eligible(pw1 + pb1 + pw2 + pb2 + pca) else None
+        # tail: plane sums of d * r, then one launch (MLP backward, mean broadcast, dr; the mean came out of the forward's ca_scale)
+        if sink is not None:
+            bufs, acc = sink.raw(pca)
+            dr = ops.rcab_tail_bwd(d, r, mean, scale, wa, ba, wb, bb, grads=tuple(bufs), accumulate=acc)[0]
+            dca = (None, None, None, None)
+        else:
+            dr, *dca = ops.rcab_tail_bwd(d, r, mean, scale, wa, ba, wb, bb)
+        # second convolution
+        if sink is not None:
+            sink.add_use(pw2, pb2, 3, dr, [t])
+            dW2 = db2 = None
+        else:
+            dW2, db2 = ops.conv_wgrad(dr, [t], 3), ops.channel_sum(dr)
+        dt = ops.conv2d(dr, _dgrad_weight([w2], 0, 64), None)
+        g1 = ops.act_bwd(dt, t, "relu", 0.0)
+        # first convolution; the residual path's gradient d rides in its input-gradient convolution
+        if sink is not None:
+            sink.add_use(pw1, pb1, 3, g1, [x])
+            dW1 = db1 = None
+        else:
+            dW1, db1 = ops.conv_wgrad(g1, [x], 3), ops.channel_sum(g1)
+        dx = ops.conv2d(g1, _dgrad_weight([w1], 0, 64), None, residual=d)
+        return (dx, dW1, db1, dW2, db2) + tuple(dca)
+
+
+def rcab_supported(x, params) -> bool:
+    """the one-node RCAB: 64 channels, every parameter and the input trainable (anything else: the per-op nodes)"""
+    return (x.dim() == 4 and int(x.shape[1]) == 64 and x.requires_grad and all(p is not None and p.requires_grad for p in params)
+            and tuple(params[0].shape) == (64, 64, 3, 3) and tuple(params[2].shape) == (64, 64, 3, 3)
+            and ops.rcab_tail_bwd_supported(64, int(params[4].shape[0])))
+
+
+def rcab(x, w1, b1, w2, b2, wa, ba, wb, bb):
+    return _RcabFn.apply(x, w1, b1, w2, b2, wa, ba, wb, bb)
+
+
 # the remaining ops have no trainable use on the path: forwarded as is
 selftest_mfma = ops.selftest_mfma
 ca_scale = ops.ca_scale

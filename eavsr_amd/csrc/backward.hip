@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256) void ca_mlp_bwd_kernel(const float* __restrict
 struct RcabBwdArgs {
   const float* d;        // (n, 64, hw) gradient of the block's output
   const float* scale;    // (n, 64) the forward's s
-  const float* mean;     // (n, 64) the forward's mean_hw(r)
+  const float* mean;     // rows == 0: (n, 64) the forward's mean_hw(r);  rows > 0: (n, rows, 64) partial channel SUMS of r (the conv
+                         // epilogue's per-tile sums), added up here and scaled by 1 / hw
+  int rows;
   const float* w1;       // (cr, 64)
   const float* b1;       // (cr)
   const float* w2;       // (64, cr)
@@ -214,6 +216,20 @@ struct RcabBwdArgs {
   int n, cr, hw, accumulate;
   float inv_hw;
 };
+
+// mean of channel `lane` of sample b (wave-wide: lane = channel)
+__device__ __forceinline__ float rb_mean(const RcabBwdArgs& a, int b, int lane) {
+  if (a.rows == 0) return a.mean[(size_t)b * 64 + lane];
+  const float* p = a.mean + (size_t)b * a.rows * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  int t = 0;
+  for (; t + 1 < a.rows; t += 2) {
+    s0 += p[(size_t)t * 64];
+    s1 += p[(size_t)(t + 1) * 64];
+  }
+  if (t < a.rows) s0 += p[(size_t)t * 64];
+  return (s0 + s1) * a.inv_hw;
+}
 
 __device__ __forceinline__ float rb_wave_sum(float v) {
 #pragma unroll
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(256) void rcab_tail_bwd_kernel(RcabBwdArgs a) {
   if ((int)blockIdx.x < nplanes) {
     const int b = blockIdx.x / C, ch = blockIdx.x - b * C;
     if (tid < 64) {      // wave 0: the MLP of sample b, lane = channel
-      const float m = a.mean[(size_t)b * C + lane], dsv = a.ds[(size_t)b * C + lane];
+      const float m = rb_mean(a, b, lane), dsv = a.ds[(size_t)b * C + lane];
       float hid[CR], z2 = a.b2[lane];
 #pragma unroll
       for (int j = 0; j < CR; ++j) {
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256) void rcab_tail_bwd_kernel(RcabBwdArgs a) {
   float* dz1 = dz2 + C;   // [CR]
   for (int b = 0; b < a.n; ++b) {
     const bool first = b == 0 && !a.accumulate;
-    if (tid < C) m[tid] = a.mean[(size_t)b * C + tid];
+    if (tid < C) m[tid] = rb_mean(a, b, tid);
     __syncthreads();
     if (tid < 64) {
       float z2 = a.b2[lane];
@@ -520,17 +536,17 @@ extern "C" int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const fl
 
 extern "C" int eavsr_rcab_tail_bwd_f32(const float* d, const float* scale, const float* mean, const float* w1, const float* b1,
                                        const float* w2, const float* b2, const float* dscale, float* dr, float* dw1, float* db1,
-                                       float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, int32_t hw, int32_t accumulate,
-                                       void* stream) {
+                                       float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, int32_t hw, int32_t mean_rows,
+                                       int32_t accumulate, void* stream) {
   EAVSR_REQUIRE(d && scale && mean && w1 && b1 && w2 && b2 && dscale && dr && dw1 && db1 && dw2 && db2, -1, "rcab_tail_bwd: NULL pointer");
   EAVSR_REQUIRE(c == 64 && (cr == 4 || cr == 8 || cr == 2 || cr == 1), -2,
                 "rcab_tail_bwd: %d channels / %d hidden units unsupported (64 channels, 1 / 2 / 4 / 8 hidden units)", c, cr);
-  EAVSR_REQUIRE(n >= 1 && hw > 0 && (long)n * c < 65535, -1, "rcab_tail_bwd: bad dims");
+  EAVSR_REQUIRE(n >= 1 && hw > 0 && (long)n * c < 65535 && mean_rows >= 0, -1, "rcab_tail_bwd: bad dims");
   EAVSR_REQUIRE((((uintptr_t)d | (uintptr_t)dr) & 15) == 0 || (hw & 3), -2, "rcab_tail_bwd: d / dr must be 16-byte aligned");
   RcabBwdArgs a;
   a.d = d; a.scale = scale; a.mean = mean; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.ds = dscale; a.dr = dr;
   a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2;
-  a.n = n; a.cr = cr; a.hw = hw; a.accumulate = accumulate; a.inv_hw = 1.0f / (float)hw;
+  a.n = n; a.cr = cr; a.hw = hw; a.accumulate = accumulate; a.inv_hw = 1.0f / (float)hw; a.rows = mean_rows;
   hipStream_t st = eavsr::as_stream(stream);
   const dim3 grid(n * c + 1), block(256);
   switch (cr) {

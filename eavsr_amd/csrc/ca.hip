@@ -17,7 +17,7 @@ constexpr int CA_THREADS = 1024;
 __global__ __launch_bounds__(CA_THREADS) void ca_scale_kernel(const float* __restrict__ partial, int tiles, float inv_hw,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       float* __restrict__ scale, int c, int cr) {
+                                                       float* __restrict__ scale, float* __restrict__ mean_out, int c, int cr) {
   extern __shared__ float sm[];  // part[Q*c] then mean[c] then hidden[cr]
   const int Q = CA_THREADS / c;
   float* part = sm;
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(CA_THREADS) void ca_scale_kernel(const float* __res
     float s = 0.f;
     for (int k = 0; k < Q; ++k) s += part[k * c + tid];
     mean[tid] = s * inv_hw;
+    if (mean_out) mean_out[(size_t)bn * c + tid] = s * inv_hw;      // the training step's backward wants it (no second reduction)
   }
   __syncthreads();
   if (tid < cr) {
@@ -171,17 +172,23 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int eavsr_ca_scale_f32(const float* chan_partial, int32_t tiles, int32_t hw, const float* w1,
-                                  const float* b1, const float* w2, const float* b2, float* scale, int32_t n,
-                                  int32_t c, int32_t cr, void* stream) {
+extern "C" int eavsr_ca_scale_mean_f32(const float* chan_partial, int32_t tiles, int32_t hw, const float* w1,
+                                       const float* b1, const float* w2, const float* b2, float* scale, float* mean_out,
+                                       int32_t n, int32_t c, int32_t cr, void* stream) {
   EAVSR_REQUIRE(chan_partial && w1 && b1 && w2 && b2 && scale, -1, "ca_scale: NULL pointer");
   EAVSR_REQUIRE(n >= 0 && c > 0 && cr > 0 && tiles > 0 && hw > 0, -1, "ca_scale: bad dims");
   EAVSR_REQUIRE(c <= 256 && cr <= 256, -2, "ca_scale: c=%d / cr=%d unsupported (<= 256)", c, cr);
   if (n == 0) return 0;
   const int Q = CA_THREADS / c;
   hipLaunchKernelGGL(ca_scale_kernel, dim3(n), dim3(CA_THREADS), (size_t)(Q * c + c + cr) * sizeof(float), eavsr::as_stream(stream),
-                     chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, scale, c, cr);
+                     chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, scale, mean_out, c, cr);
   return eavsr::launch_status("ca_scale");
+}
+
+extern "C" int eavsr_ca_scale_f32(const float* chan_partial, int32_t tiles, int32_t hw, const float* w1,
+                                  const float* b1, const float* w2, const float* b2, float* scale, int32_t n,
+                                  int32_t c, int32_t cr, void* stream) {
+  return eavsr_ca_scale_mean_f32(chan_partial, tiles, hw, w1, b1, w2, b2, scale, nullptr, n, c, cr, stream);
 }
 
 extern "C" int eavsr_scale_residual_f32(const float* r, const float* scale, const float* x, float* out, int32_t n,

@@ -341,7 +341,14 @@ class RCABlock(nn.Module):
     def forward(self, x):
         a, b = self.ca.conv_du[0], self.ca.conv_du[2]
         if AG.needs_grad(x, list(self.parameters())):
-            # training: un-fused mean / MLP / scale so that every piece has its backward kernel
+            # training: the whole block as one autograd node where it applies (autograd.rcab), else per-op nodes: un-fused mean /
+            # MLP / scale so that every piece has its backward kernel
+            if (RCAB_ONE_NODE and len(self.res) == 3 and isinstance(self.res[1], _Act) and self.res[1].kind == "relu"
+                    and torch.is_grad_enabled()):
+                c1, c2 = self.res[0], self.res[2]
+                ps = [c1.weight, c1.bias, c2.weight, c2.bias, a.weight, a.bias, b.weight, b.bias]
+                if AG.rcab_supported(x, ps):
+                    return AG.rcab(x, *ps)
             r = _run_fused(self.res, x)
             return AG.rcab_tail(r, x, a.weight, a.bias, b.weight, b.bias)
         r, partial = _run_fused(self.res, x, chan_partial=True)     # conv-ReLU-conv, + channel sums
@@ -363,6 +370,8 @@ import os as _os
 # scale_residual waves fit per SIMD beside a convolution but one 32-register wave of the fused kernel, each holding its slot through a
 # latency-bound MLP prologue, while ca_scale's two workgroups leave the GPU to the other stream.
 FUSE_CA_TAIL = _os.environ.get("EAVSR_FUSE_CA_TAIL", "0") == "1"
+# training: one autograd node per RCAB (autograd._RcabFn); EAVSR_RCAB_ONE_NODE=0: the per-op nodes of rounds 1-4
+RCAB_ONE_NODE = _os.environ.get("EAVSR_RCAB_ONE_NODE", "1") != "0"
 FUSE_CA_INTO_CONV = _os.environ.get("EAVSR_FUSE_CA", "0") == "1"
 # One kernel per pyramid level of the residual-flow refinement (eavsr_flow_level_f32: front end + 64 -> 6 heads + affine +
 # 18 -> 2 conv, only the two inputs and the 2-channel flow touch HBM) instead of four launches.  Correct (goldens G2 / G5,

@@ -1258,18 +1258,19 @@ def concat3(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------
 # channel attention
 # ------------------------------------------------------------------------------------------
-def ca_scale(partial: Tensor, hw: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
-    """partial (n, tiles, c) channel sums -> sigmoid(W2 relu(W1 mean + b1) + b2), shape (n, c)"""
+def ca_scale(partial: Tensor, hw: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, with_mean: bool = False):
+    """partial (n, tiles, c) channel sums -> sigmoid(W2 relu(W1 mean + b1) + b2), shape (n, c); with_mean: also the means (n, c)"""
     partial = _chk(partial, "partial")
     n, tiles, c = partial.shape
     cr = int(w1.shape[0])
     scale = torch.empty((n, c), device=partial.device, dtype=torch.float32)
+    mean = torch.empty((n, c), device=partial.device, dtype=torch.float32) if with_mean else None
     w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
     st = _stream(partial)
     _launch("ca_scale", 0.0, 4.0 * partial.numel(), partial,
-            lambda: lib().eavsr_ca_scale_f32(_p(partial), tiles, hw, _p(w1), _p(b1), _p(w2), _p(b2), _p(scale), n, c,
-                                             cr, st), "ca_scale")
-    return scale
+            lambda: lib().eavsr_ca_scale_mean_f32(_p(partial), tiles, hw, _p(w1), _p(b1), _p(w2), _p(b2), _p(scale), _p(mean), n, c,
+                                                  cr, st), "ca_scale")
+    return (scale, mean) if with_mean else scale
 
 
 def ca_tail(r: Tensor, partial: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, x: Tensor) -> Tensor:
@@ -1391,6 +1392,15 @@ def rcab_tail_bwd(d: Tensor, r: Tensor, mean: Tensor, scale: Tensor, w1: Tensor,
     cr = int(w1.shape[0])
     if not rcab_tail_bwd_supported(c, cr):
         raise NotImplementedError(f"rcab_tail_bwd: {c} channels / {cr} hidden units")
+    # `mean` (n, c), or the conv epilogue's partial channel sums (n, rows, c) that the kernel adds up itself
+    if mean.dim() == 3:
+        if tuple(mean.shape[::2]) != (n, c):
+            raise ValueError("rcab_tail_bwd: partial sums must be (n, rows, c)")
+        mean_rows = int(mean.shape[1])
+    elif tuple(mean.shape) == (n, c):
+        mean_rows = 0
+    else:
+        raise ValueError("rcab_tail_bwd: mean must be (n, c) or (n, rows, c)")
     dscale = plane_sum(d, r)
     if grads is None:
         grads = (torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2))
@@ -1400,7 +1410,7 @@ def rcab_tail_bwd(d: Tensor, r: Tensor, mean: Tensor, scale: Tensor, w1: Tensor,
     st = _stream(d)
     _launch("rcab_tail_bwd", 2.0 * d.numel(), 8.0 * d.numel(), d,
             lambda: lib().eavsr_rcab_tail_bwd_f32(_p(d), _p(scale), _p(mean), _p(w1), _p(b1), _p(w2), _p(b2), _p(dscale), _p(dr),
-                                                  _p(dw1), _p(db1), _p(dw2), _p(db2), n, c, cr, h * w, int(accumulate), st),
+                                                  _p(dw1), _p(db1), _p(dw2), _p(db2), n, c, cr, h * w, mean_rows, int(accumulate), st),
             "rcab_tail_bwd")
     return dr, dw1, db1, dw2, db2
 

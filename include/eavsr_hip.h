@@ -311,6 +311,11 @@ int eavsr_wino4_schedule(void);
 int eavsr_ca_scale_f32(const float* chan_partial, int32_t tiles, int32_t hw,
                        const float* w1, const float* b1, const float* w2, const float* b2,
                        float* scale, int32_t n, int32_t c, int32_t cr, void* stream);
+/* the same with the sample means (n, c) written to mean_out (nullable; ABI 26): the training step's backward of the RCAB tail
+ * (eavsr_rcab_tail_bwd_f32) takes them */
+int eavsr_ca_scale_mean_f32(const float* chan_partial, int32_t tiles, int32_t hw, const float* w1, const float* b1,
+                            const float* w2, const float* b2, float* scale, float* mean_out, int32_t n, int32_t c, int32_t cr,
+                            void* stream);
 /* RCABlock tail (networks.py:447,464): out = r * scale[n,c] + x */
 int eavsr_scale_residual_f32(const float* r, const float* scale, const float* x, float* out,
                              int32_t n, int32_t c, int32_t hw, void* stream);
@@ -400,11 +405,12 @@ int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const float* b1, co
  * behind the plane sums dscale[n,c] = sum_hw d r (eavsr_plane_sum_f32), as one launch (ABI 26): dr = d * scale[n,c] +
  * dmean[n,c] / hw with dmean from the MLP's backward, and the four parameter gradients summed over n in a fixed order, written
  * (accumulate = 0) or ADDED (accumulate != 0) to dw1 (cr, 64), db1 (cr), dw2 (64, cr), db2 (64).  c = 64, cr in {1, 2, 4, 8};
- * other shapes: eavsr_ca_mlp_bwd_f32 + eavsr_scale_residual_bwd_f32. */
+ * other shapes: eavsr_ca_mlp_bwd_f32 + eavsr_scale_residual_bwd_f32.  mean_rows = 0: `mean` is (n, 64); mean_rows > 0: `mean` is the
+ * convolution epilogue's (n, mean_rows, 64) partial channel SUMS of r, added up and divided by hw here. */
 int eavsr_rcab_tail_bwd_f32(const float* d, const float* scale, const float* mean, const float* w1, const float* b1,
                             const float* w2, const float* b2, const float* dscale, float* dr, float* dw1, float* db1,
-                            float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, int32_t hw, int32_t accumulate,
-                            void* stream);
+                            float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, int32_t hw, int32_t mean_rows,
+                            int32_t accumulate, void* stream);
 /* backward of eavsr_flow_warp_f32 (zeros padding, NCHW flow): dx (pre-zeroed, accumulated with float
  * atomics; NULL = skip) and dflow (n,2,h,w; NULL = skip).  flow2 as in the forward. */
 int eavsr_flow_warp_bwd_f32(const float* x, const float* flow, const float* flow2, const float* dout,
