@@ -480,8 +480,8 @@ class _RcabFn(Function):
             dW2 = db2 = None
         else:
             dW2, db2 = ops.conv_wgrad(dr, [t], 3), ops.channel_sum(dr)
-        dt = ops.conv2d(dr, _dgrad_weight([w2], 0, 64), None)
-        g1 = ops.act_bwd(dt, t, "relu", 0.0)
+        # the ReLU's backward mask (t > 0) leaves in the epilogue of conv-2's input-gradient convolution
+        g1 = ops.conv2d(dr, _dgrad_weight([w2], 0, 64), None, act="relu_mask", residual=t)
         # first convolution; the residual path's gradient d rides in its input-gradient convolution
         if sink is not None:
             sink.add_use(pw1, pb1, 3, g1, [x])

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
       for (int t = 0; t < NT; ++t) {
         const int gy = y0 + wave * NT + t;
         float v = acc[m][t][r] + b;
-        v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope));   // branch-free: max(v, v s), 0 <= s <= 1
+        v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_RELU ? 0.f : a.act == EAVSR_ACT_LRELU ? a.slope : 1.f));   // branch-free: max(v, v s), 0 <= s <= 1
 #ifdef EAVSR_CONV_EXP_NOSTORE   // timing ablation only (tools/gpu_conv_ablate.py)
         if (cok && xok && gy < h && v == 12345.678f) {
 #else
@@ -321,7 +321,8 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
 #endif
           const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
           sum += v;
-          if (a.residual) v += a.residual[o];
+          if (a.act == EAVSR_ACT_RELU_MASK) v = a.residual[o] > 0.f ? v : 0.f;      // ReLU's backward mask (the forward output)
+          else if (a.residual) v += a.residual[o];
           a.out[o] = v;
         }
       }
@@ -532,12 +533,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_small_kernel(ConvArgs a) {
       const int co = co_base + col;
       const bool cok = co < a.cout;
       float v = acc[m][r] + bb[m][r];
-      v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope));   // branch-free: max(v, v s), 0 <= s <= 1
+      v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_RELU ? 0.f : a.act == EAVSR_ACT_LRELU ? a.slope : 1.f));   // branch-free: max(v, v s), 0 <= s <= 1
       float sum = 0.f;
       if (cok && pok) {
         const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
         sum = v;
-        a.out[o] = v + rr[m][r];
+        // EAVSR_ACT_RELU_MASK: `residual` is the forward output of a ReLU whose backward mask this input-gradient convolution applies
+        a.out[o] = a.act == EAVSR_ACT_RELU_MASK ? (rr[m][r] > 0.f ? v : 0.f) : v + rr[m][r];
       }
       if (a.chan_partial) {
         sum += __shfl_xor(sum, 16);
@@ -689,7 +691,9 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
   EAVSR_REQUIRE(d->weight_packed && d->out, -1, "conv2d: NULL weight/out");
   EAVSR_REQUIRE(d->out_shuffle == 0, -2, "conv2d: the pixel-shuffle epilogue exists in eavsr_conv3x3_wino4_f32 only");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv2d: bad dims");
-  EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv2d: act %d", d->act);
+  EAVSR_REQUIRE(d->act >= 0 && d->act <= EAVSR_ACT_RELU_MASK, -1, "conv2d: act %d", d->act);
+  EAVSR_REQUIRE(d->act != EAVSR_ACT_RELU_MASK || (d->residual != nullptr && d->chan_partial == nullptr && d->ca_scale == nullptr), -1,
+                "conv2d: EAVSR_ACT_RELU_MASK takes the mask source in `residual` (no channel sums, no fused prologue)");
   EAVSR_REQUIRE(d->act != EAVSR_ACT_LRELU || (d->slope >= 0.f && d->slope <= 1.f), -2,
                 "conv2d: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)d->slope);
   const int ck = chunk_of(d->ksize);

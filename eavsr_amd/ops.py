@@ -19,7 +19,7 @@ from . import _native as N
 
 Tensor = torch.Tensor
 
-ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2}
+ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "relu_mask": 3}      # relu_mask: conv2d(residual = the ReLU's forward output), direct kernels only
 
 
 def _chk(t: Tensor, name: str) -> Tensor:
@@ -538,6 +538,9 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError(f"weight expects {[int(x.shape[1]) for x in weights]} input channels, sources give {cin}")
     if pixel_shuffle2 and (cout % 4 or residual is not None or chan_partial or ca is not None):
         raise ValueError("pixel_shuffle2: cout % 4 == 0, no residual / channel sums / channel-attention prologue")
+    masked = act == "relu_mask"    # out = residual > 0 ? conv : 0 (a ReLU's backward inside the input-gradient convolution): direct kernels only
+    if masked and (residual is None or chan_partial or ca is not None or pixel_shuffle2 or sigmoid_from is not None):
+        raise ValueError("act='relu_mask': residual = the ReLU's forward output; no channel sums / prologue / shuffle / sigmoid")
     if ca_out and ca is None:      # before any early return (the bf16x6 route used to skip this check)
         raise ValueError("ca_out needs ca")
     if sigmoid_from is not None:   # validated once, for every route (routes used to differ)
@@ -552,7 +555,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
             y = conv2d(srcs, weights, biases, act, slope)
             y[:, sigmoid_from:] = torch.sigmoid(y[:, sigmoid_from:])
             return y
-    if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None:
+    if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None and not masked:
         y = _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
         return torch.nn.functional.pixel_shuffle(y, 2) if pixel_shuffle2 else y
     if (CONV3_H16 is not None and k == 7 and CONV7_H16_ENABLED and sigmoid_from is None and len(srcs) == 1 and cin % 8 == 0 and cout >= 16
@@ -572,8 +575,8 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     b = _bias_of(biases)
     out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
     base_ok = (k == 3 and w % 4 == 0 and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs))
-    x9_ok = base_ok and ca is None
-    use_wino = (CONV_MODE in ("winograd", "winograd4") and base_ok
+    x9_ok = base_ok and ca is None and not masked
+    use_wino = (CONV_MODE in ("winograd", "winograd4") and base_ok and not masked
                 and n * lib().eavsr_conv3x3_wino_tiles(h, w) >= WINO_MIN_TILES
                 and (ca is None or (len(srcs) == 1 and cin <= 256 and ca[1].data_ptr() % 16 == 0)))
     # F(4x4, 3x3): same 512-pixel-per-workgroup granularity (8 x 64), no fused channel-attention prologue
@@ -583,7 +586,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     if pixel_shuffle2 and not (use_wino4 and FUSE_PIXEL_SHUFFLE):      # every other kernel: plain output, shuffled by torch
         return torch.nn.functional.pixel_shuffle(conv2d(srcs, weights, biases, act=act, slope=slope), 2)
     # 5x5 (the predictor's offset / mask heads) by F(2x2, 5x5): the same 6 x 6 tile pipeline, 4 x 32-pixel tiles
-    use_wino5 = (CONV_MODE == "winograd4" and k == 5 and ca is None and w % 4 == 0 and out.data_ptr() % 8 == 0
+    use_wino5 = (CONV_MODE == "winograd4" and k == 5 and ca is None and not masked and w % 4 == 0 and out.data_ptr() % 8 == 0
                  and all(int(s_.shape[1]) % 4 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs)
                  and (residual is None or residual.data_ptr() % 8 == 0)
                  and n * lib().eavsr_conv5x5_wino_tiles(h, w) * ((cout + 63) // 64) >= 2 * WINO_MIN_TILES)

@@ -32,6 +32,10 @@ extern "C" {
 #define EAVSR_ACT_NONE 0
 #define EAVSR_ACT_RELU 1
 #define EAVSR_ACT_LRELU 2 /* negative slope in desc.slope */
+/* eavsr_conv2d_f32 only (ABI 26): out = desc.residual > 0 ? conv + bias : 0 -- the backward mask of a ReLU whose forward output is
+ * given in `residual` (which is NOT added), fused into the input-gradient convolution that produces the masked gradient
+ * (RCABlock's conv -> ReLU -> conv, models/networks.py:461-462, in loss.backward()) */
+#define EAVSR_ACT_RELU_MASK 3
 
 /* padding modes of eavsr_flow_warp_f32 (torch grid_sample padding_mode) */
 #define EAVSR_PAD_ZEROS 0

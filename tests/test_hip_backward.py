@@ -485,6 +485,27 @@ def test_channel_and_plane_sums(cuda, n, c, h, w):
             assert H.maxabs(got.double(), want) <= 1e-4
 
 
+@pytest.mark.parametrize("n,h,w", [(4, 64, 64), (2, 19, 37), (1, 180, 320)])
+def test_conv2d_relu_mask_epilogue_equals_conv_then_act_bwd(cuda, n, h, w):
+    """act="relu_mask" (EAVSR_ACT_RELU_MASK): the ReLU's backward mask inside the input-gradient convolution of RCABlock's
+    second conv (networks.py:461-462) -- bit-identical to the convolution followed by act_bwd, on both direct kernels"""
+    from eavsr_amd import ops
+    g = cases.randn(70, n, 64, h, w).to(cuda)
+    t = torch.relu(cases.randn(71, n, 64, h, w)).to(cuda)       # a ReLU's forward output: exact zeros where it clipped
+    wt = cases.randn(72, 64, 64, 3, 3, scale=1.0 / 24).to(cuda)
+    b = cases.randn(73, 64, scale=0.1).to(cuda)
+    for bias in (None, b):
+        with ops.modes(conv="direct"):       # the masked epilogue exists on the direct kernels: compare like with like
+            want = ops.act_bwd(ops.conv2d(g, wt, bias), t, "relu", 0.0)
+        got = ops.conv2d(g, wt, bias, act="relu_mask", residual=t)
+        assert torch.equal(got, want)
+        assert (got[t == 0] == 0).all()
+    with pytest.raises(ValueError):
+        ops.conv2d(g, wt, None, act="relu_mask")
+    with pytest.raises(ValueError):
+        ops.conv2d(g, wt, None, act="relu_mask", residual=t, chan_partial=True)
+
+
 @pytest.mark.parametrize("k,nseg,shape", [(3, 7, (2, 64, 96, 96)), (3, 3, (1, 64, 19, 37)), (1, 8, (2, 64, 24, 40)), (5, 2, (1, 64, 16, 32))])
 def test_conv_wgrad_over_several_uses_in_one_launch(cuda, k, nseg, shape):
     """eavsr_conv_wgrad_multi_f32 / eavsr_channel_sum_multi_f32 (ABI 26): the uses of one weight across the frames of the
