@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -78,6 +78,8 @@ SIGNATURES = {
     "eavsr_pack_conv_weight_wino4": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_conv3x3_wino4_tiles": (i32, [i32, i32]),
     "eavsr_conv3x3_wino4_f32": (C.c_int, [vp, vp, vp]),
+    "eavsr_conv3x3_x6s_tiles": (i32, [i32, i32]),
+    "eavsr_conv3x3_f32x6s": (C.c_int, [vp, vp, vp]),
     "eavsr_pack_conv_weight_wino5x5": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_conv5x5_wino_tiles": (i32, [i32, i32]),
     "eavsr_conv5x5_wino_f32": (C.c_int, [vp, vp, vp]),

@@ -468,14 +468,14 @@ extern "C" int eavsr_debug_c7_stamps(unsigned long long* host_out, int reset) {
 #endif
 
 extern "C" size_t eavsr_conv_weight_x6_bytes(int32_t ksize, int32_t cout, int32_t cin) {
-  if ((ksize != 5 && ksize != 7) || cout <= 0 || cin <= 0 || cin % 8) return 0;
+  if ((ksize != 3 && ksize != 5 && ksize != 7) || cout <= 0 || cin <= 0 || cin % 8) return 0;
   const int mt = mt_of(cout);
   return (size_t)eavsr::cdiv(cout, 32 * mt) * (cin / 8) * ((ksize * ksize + 1) / 2) * 3 * mt * 64 * 16;
 }
 
 extern "C" int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, void* stream) {
   EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight_x6: NULL pointer");
-  EAVSR_REQUIRE(ksize == 5 || ksize == 7, -2, "pack_conv_weight_x6: kernel size %d (5 and 7 only)", ksize);
+  EAVSR_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, -2, "pack_conv_weight_x6: kernel size %d (3, 5 and 7 only)", ksize);
   EAVSR_REQUIRE(cout > 0 && cin > 0 && cin % 8 == 0, -1, "pack_conv_weight_x6: cin %d must be a multiple of 8", cin);
   const long total = (long)(eavsr_conv_weight_x6_bytes(ksize, cout, cin) / 16);
   hipLaunchKernelGGL(pack7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
@@ -486,7 +486,7 @@ extern "C" int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int3
 extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,
                                 int32_t cout, int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t sigmoid_from,
                                 void* stream) {
-  EAVSR_REQUIRE(ksize == 5 || ksize == 7, -2, "conv_f32x6: kernel size %d (5 and 7 only; 3x3 is eavsr_conv2d_f32 / eavsr_conv3x3_wino4_f32)", ksize);
+  EAVSR_REQUIRE(ksize == 5 || ksize == 7, -2, "conv_f32x6: kernel size %d (5 and 7 only; 3x3 is eavsr_conv2d_f32 / eavsr_conv3x3_wino4_f32 / eavsr_conv3x3_f32x6s)", ksize);
   EAVSR_REQUIRE(n >= 0 && cin > 0 && cout > 0 && h > 0 && w > 0, -1, "conv_f32x6: bad dims");
   if (n == 0) return 0;      // (an empty batch has no buffers)
   EAVSR_REQUIRE(x && weight_x6 && out, -1, "conv_f32x6: NULL pointer");

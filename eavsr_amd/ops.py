@@ -571,7 +571,6 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     ck = lib().eavsr_conv2d_ck(k)
     if any(int(s.shape[1]) % ck for s in srcs[:-1]):
         srcs = [torch.cat(srcs, 1)]  # ragged middle source: materialise (tiny SPyNet inputs only)
-    wp = pack_cache.get(weights)
     b = _bias_of(biases)
     out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
     base_ok = (k == 3 and w % 4 == 0 and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs))
@@ -590,9 +589,15 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
                  and all(int(s_.shape[1]) % 4 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs)
                  and (residual is None or residual.data_ptr() % 8 == 0)
                  and n * lib().eavsr_conv5x5_wino_tiles(h, w) * ((cout + 63) // 64) >= 2 * WINO_MIN_TILES)
+    # small launches of the 64-channel 3x3 convolution (a training crop, a pyramid level): exact bf16x6 instead of the fp32 MFMA
+    # (the explicit modes "direct" / "bf16x9" keep their own kernels: they are the A/B references)
+    use_x6s = (CONV3_SMALL == "x6s" and CONV_MODE in ("winograd", "winograd4") and k == 3 and len(srcs) == 1 and cin == 64
+               and ca is None and not pixel_shuffle2 and not use_wino
+               and n * lib().eavsr_conv3x3_x6s_tiles(h, w) <= X6S_MAX_TILES)
+    wp = None if use_x6s else pack_cache.get(weights)      # (the x6s kernel has its own packed form)
     part = None
     if chan_partial:
-        tiles = (lib().eavsr_conv5x5_wino_tiles(h, w) if use_wino5 else lib().eavsr_conv3x3_wino4_tiles(h, w) if use_wino4 else lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino
+        tiles = (lib().eavsr_conv3x3_x6s_tiles(h, w) if use_x6s else lib().eavsr_conv5x5_wino_tiles(h, w) if use_wino5 else lib().eavsr_conv3x3_wino4_tiles(h, w) if use_wino4 else lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino
                  else lib().eavsr_conv2d_tiles(n, h, w, k))
         part = torch.empty((n, tiles, cout), device=out.device, dtype=torch.float32)
     if residual is not None:
@@ -605,7 +610,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         d.src_c[i] = int(srcs[i].shape[1]) if i < len(srcs) else 0
     d.n_src = len(srcs)
     d.ksize = k
-    d.weight_packed = _p(wp)
+    d.weight_packed = _p(wp) if wp is not None else None
     d.bias = _p(b)
     d.residual = _p(residual)
     d.out = _p(out)
@@ -632,6 +637,12 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError("ca_out needs ca")
     st = _stream(out)
     px = float(n) * h * w
+    if use_x6s:
+        wq = _packed_conv_x6(weights)
+        _launch(f"conv3x3_{cin}to{cout}_x6s", 2.0 * cin * cout * 9 * px,
+                4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
+                lambda: lib().eavsr_conv3x3_f32x6s(C.byref(d), _p(wq), st), "conv3x3_f32x6s")
+        return out if not chan_partial else (out, part)
     if use_wino5:
         wu = _packed_wino(weights, kind="f5")
         _launch(f"conv5x5_{cin}to{cout}_wino", 2.0 * cin * cout * 25 * px,
@@ -1032,6 +1043,10 @@ def _norm_conv_mode(mode: str) -> str:
 
 
 CONV_MODE = _norm_conv_mode(os.environ.get("EAVSR_CONV_MODE", "winograd4"))
+# 3x3 64 -> cout launches of at most X6S_MAX_TILES 8 x 32-pixel tiles (where the fp32-MFMA small kernel's time is one workgroup's
+# chain of matrix instructions): "x6s" = csrc/conv3_x6s.hip (exact bf16x6), "direct" = the fp32 MFMA kernels (A/B switch)
+CONV3_SMALL = os.environ.get("EAVSR_CONV3_SMALL", "x6s")
+X6S_MAX_TILES = int(os.environ.get("EAVSR_X6S_MAX_TILES", "256"))
 WINO_MIN_TILES = int(os.environ.get("EAVSR_WINO_MIN_TILES", "192"))   # 8 x 32-px tiles per launch below which the direct kernel runs
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 26
+#define EAVSR_ABI_VERSION 27
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -300,6 +300,14 @@ size_t eavsr_conv_weight_x6_bytes(int32_t ksize, int32_t cout, int32_t cin);
 int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, void* stream);
 int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin, int32_t cout,
                      int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t sigmoid_from, void* stream);
+/* The 3x3 form for SMALL launches (ABI 27): 64 input channels, one source, the same exact bf16x6 arithmetic; the descriptor's bias,
+ * activation (incl. EAVSR_ACT_RELU_MASK), residual and per-tile channel sums (eavsr_conv3x3_x6s_tiles(h, w) rows per sample, 8 x 32
+ * pixel tiles) -- no channel-attention prologue, no pixel-shuffle store (-2: call eavsr_conv2d_f32).  RCABlock's convolutions
+ * (models/networks.py:456-464) and their input-gradient convolutions at a training crop (2 x 64 x 96 x 96 per launch,
+ * eavsrp_model.py:109-119), where a launch is fewer workgroups than the GPU has CUs and its time is one workgroup's chain of
+ * matrix instructions: six bf16 products take 0.375 x the fp32 MFMA's cycles.  weight_x6 = eavsr_pack_conv_weight_x6(ksize 3). */
+int32_t eavsr_conv3x3_x6s_tiles(int32_t h, int32_t w);
+int eavsr_conv3x3_f32x6s(const eavsr_conv2d_desc* desc, const void* weight_x6, void* stream);
 /* sigmoid_from: -1, or a multiple of 8: output channels >= sigmoid_from leave through the sigmoid instead of `act` -- the mask
  * head of AdaptBlockOffset (mask = torch.sigmoid(mask_conv(..)), models/networks.py:313-314) when the three heads run as one
  * convolution; eavsr_dcnv2_il2_f32 (heads = 2) then takes the masks as they are. */

@@ -495,11 +495,16 @@ def test_conv2d_relu_mask_epilogue_equals_conv_then_act_bwd(cuda, n, h, w):
     wt = cases.randn(72, 64, 64, 3, 3, scale=1.0 / 24).to(cuda)
     b = cases.randn(73, 64, scale=0.1).to(cuda)
     for bias in (None, b):
-        with ops.modes(conv="direct"):       # the masked epilogue exists on the direct kernels: compare like with like
+        with ops.modes(conv="direct"):       # the fp32-MFMA direct kernels: the same sum with and without the mask, bit for bit
             want = ops.act_bwd(ops.conv2d(g, wt, bias), t, "relu", 0.0)
-        got = ops.conv2d(g, wt, bias, act="relu_mask", residual=t)
+            got = ops.conv2d(g, wt, bias, act="relu_mask", residual=t)
         assert torch.equal(got, want)
         assert (got[t == 0] == 0).all()
+        with ops.profile() as prof:          # the default mode: the small-launch bf16x6 kernel has the same epilogue
+            got6 = ops.conv2d(g, wt, bias, act="relu_mask", residual=t)
+        assert list(prof.summary()) == ["conv3x3_64to64_x6s"]
+        assert (got6[t == 0] == 0).all()
+        assert H.maxabs(got6.cpu(), want.cpu()) <= 2e-5 * max(1.0, want.abs().max().item())
     with pytest.raises(ValueError):
         ops.conv2d(g, wt, None, act="relu_mask")
     with pytest.raises(ValueError):

@@ -242,6 +242,56 @@ def test_conv5x5_bf16x6_matches_fp64_and_winograd(ops, cuda, case):
     assert e6 <= 3e-6 and e6 <= 2.0 * ew + 2e-7, (e6, ew)
 
 
+@pytest.mark.parametrize("case", [(64, 2, 96, 96, "relu", None), (64, 2, 96, 96, None, "sums"), (64, 2, 96, 96, None, "residual"),
+                                  (64, 2, 96, 96, "relu_mask", None), (64, 1, 45, 80, "lrelu", "residual"), (40, 3, 19, 37, "relu", "sums"),
+                                  (32, 1, 8, 32, None, None), (70, 1, 1, 1, None, "residual"), (64, 2, 3, 2, "relu", "sums"),
+                                  (64, 1, 23, 200, "relu_mask", None), (6, 1, 30, 50, None, None), (64, 0, 9, 9, None, None)])
+def test_conv3x3_small_launches_bf16x6_matches_fp64_and_the_fp32_kernel(ops, cuda, case):
+    """round 5: eavsr_conv3x3_f32x6s -- RCABlock's convolutions and their input-gradient convolutions (networks.py:456-464) at a
+    training crop and below: every epilogue of the descriptor (bias, ReLU / LReLU, residual, EAVSR_ACT_RELU_MASK, per-tile channel
+    sums), tiles cut by the image, couts that are not multiples of 32, a single pixel, an empty batch -- against an fp64 evaluation
+    (as accurate as the fp32-MFMA kernel, whose error is measured beside it)."""
+    cout, n, h, w, act, extra = case
+    x = cases.randn(90, n, 64, h, w)
+    wt = cases.randn(91, cout, 64, 3, 3, scale=1.0 / 24)
+    b = cases.randn(92, cout, scale=0.1)
+    r = torch.relu(cases.randn(93, n, cout, h, w)) if (extra == "residual" or act == "relu_mask") else None
+    ref64 = F.conv2d(x.double(), wt.double(), b.double(), 1, 1)
+    ref64 = F.relu(ref64) if act == "relu" else F.leaky_relu(ref64, 0.1) if act == "lrelu" else ref64
+    sums64 = ref64.sum((2, 3))
+    if act == "relu_mask":
+        ref64 = torch.where(r > 0, ref64, torch.zeros_like(ref64))
+    elif r is not None:
+        ref64 = ref64 + r.double()
+    outs, sums = {}, {}
+    was = ops.CONV3_SMALL
+    try:
+        for mode in ("x6s", "direct") if n else ("x6s",):
+            ops.CONV3_SMALL = mode
+            with ops.profile() as prof:
+                y = ops.conv2d(g(x, cuda), g(wt, cuda), g(b, cuda), act=act, slope=0.1, residual=None if r is None else g(r, cuda),
+                               chan_partial=extra == "sums")
+            if extra == "sums":
+                y, part = y
+                sums[mode] = part.sum(1).cpu()
+            outs[mode] = y.cpu()
+            if n and cout not in (6,):
+                assert (list(prof.summary()) == [f"conv3x3_64to{cout}_x6s"]) == (mode == "x6s"), list(prof.summary())
+    finally:
+        ops.CONV3_SMALL = was
+    assert outs["x6s"].shape == ref64.shape
+    if n == 0:
+        return
+    scale = max(1.0, ref64.abs().max().item())
+    e6 = (outs["x6s"].double() - ref64).abs().max().item() / scale
+    e32 = (outs["direct"].double() - ref64).abs().max().item() / scale
+    assert e6 <= 3e-6 and e6 <= 2.0 * e32 + 2e-7, (e6, e32)
+    if extra == "sums":
+        assert (sums["x6s"].double() - sums64).abs().max().item() <= 2e-5 * max(1.0, sums64.abs().max().item())
+    if act == "relu_mask":
+        assert (outs["x6s"][r == 0] == 0).all()
+
+
 @pytest.mark.parametrize("k", [5, 7])
 @pytest.mark.parametrize("shape", [(8, 1, 1, 1, 1), (8, 33, 2, 3, 2), (16, 64, 1, 5, 200), (8, 5, 3, 2, 37), (40, 3, 0, 9, 9)])
 def test_conv_bf16x6_degenerate_shapes(ops, cuda, k, shape):
@@ -549,6 +599,15 @@ def test_conv3x3_winograd_small_problems_run_the_direct_kernel(conv_wino, cuda):
     x, wt = cases.randn(1, 1, 64, 20, 32), cases.randn(2, 64, 64, 3, 3, scale=0.05)
     with conv_wino.profile() as prof:
         out = conv_wino.conv2d(g(x, cuda), g(wt, cuda), None)
+    assert list(prof.summary()) == ["conv3x3_64to64_x6s"]      # (round 5: the small-launch kernel, exact bf16x6)
+    assert H.maxabs(out.cpu(), F.conv2d(x, wt, None, 1, 1)) <= 2e-5
+    was = conv_wino.CONV3_SMALL
+    try:
+        conv_wino.CONV3_SMALL = "direct"
+        with conv_wino.profile() as prof:
+            out = conv_wino.conv2d(g(x, cuda), g(wt, cuda), None)
+    finally:
+        conv_wino.CONV3_SMALL = was
     assert list(prof.summary()) == ["conv3x3_64to64"]
     assert H.maxabs(out.cpu(), F.conv2d(x, wt, None, 1, 1)) <= 2e-5
 
@@ -749,7 +808,7 @@ def test_conv3x3_winograd4_error_against_fp64_and_fallbacks(ops, cuda):
         with ops.profile() as prof:
             xs, wsm = cases.randn(3, 1, 64, 20, 32), cases.randn(4, 64, 64, 3, 3, scale=0.05)
             small = ops.conv2d(g(xs, cuda), g(wsm, cuda), None)
-        assert list(prof.summary()) == ["conv3x3_64to64"]
+        assert list(prof.summary()) == ["conv3x3_64to64_x6s"]
         assert H.maxabs(small.cpu(), F.conv2d(xs, wsm, None, 1, 1)) <= 2e-5
         r, xx, sc = cases.randn(5, n, 64, h, w), cases.randn(6, n, 64, h, w), cases.rand(7, n, 64)
         with ops.profile() as prof:
