@@ -87,7 +87,26 @@ __device__ unsigned long long g_q_stamps[8];
 #define Q_STAMP(i) do { } while (0)
 #endif
 
-template <int NCH>
+// eight channels of four consecutive pixels (one float4 per channel) -> the four pixels' 16-byte units of the three planes
+__device__ __forceinline__ void q_store_quad(const f32x4 (&q)[8], unsigned char* dst) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u32x4 pl[3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned h2, m2, l2;
+      q_split2(q[2 * c][i], q[2 * c + 1][i], h2, m2, l2);
+      pl[0][c] = h2; pl[1][c] = m2; pl[2][c] = l2;
+    }
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3) *reinterpret_cast<u32x4*>(dst + i * 16 + p3 * Q_PLANE_B) = pl[p3];
+  }
+}
+
+// VEC: w % 4 == 0 and 16-byte aligned x / out / residual -- the patch is requested as float4 row segments (a wave's load
+// instruction costs the texture path 16 cycles whatever its width: 64 dword requests per thread were 6 K cycles of a 32 K-cycle
+// workgroup) and the output tile leaves through an LDS transpose as float4 row segments (16 dword stores per lane: 5.8 K cycles).
+template <int NCH, bool VEC>
 __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
   using K = QCfg<NCH>;
 #ifdef EAVSR_X6S_STAMPS
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
     }
   };
 
-  // ---- patch producer: thread t < 340 owns patch pixel t, all 64 channels ---------------------------------------
+  // ---- patch producer, !VEC: thread t < 340 owns patch pixel t, all 64 channels; chunk c + 1 is split under chunk c's MFMAs -----
   const int pr = tid / Q_IW, pc = tid - pr * Q_IW;
   const int pgy = y0 - 1 + pr, pgx = x0 - 1 + pc;
   const bool pok = tid < Q_NPIX && pgy >= 0 && pgy < h && pgx >= 0 && pgx < w;
@@ -174,19 +193,67 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
   // ---- prologue --------------------------------------------------------------------------------------------------
   issue_slab(0);
   if (NCH > 1) issue_slab(1);
-  {
+  if constexpr (VEC) {
+    // work items: (chunk, patch row, quad of interior columns 1 + 4 q .. 4 + 4 q) = 80 NCH quad items of 8 channels x float4, and
+    // (chunk, patch row, left / right halo column) = 20 NCH halo items of 8 dwords.  Thread t takes quad item t; threads 0..127
+    // quad item 512 + t (NCH = 8: 640 items); threads 128..128 + 20 NCH - 1 a halo item.  Everything is split and stored here.
+    static_assert(80 * NCH <= 512 + 128 && 128 + 20 * NCH <= 512, "item assignment");
+    auto quad_item = [&](int q, f32x4 (&v)[8], int& lds) __attribute__((always_inline)) {
+      const int ch = q / 80, rem = q - ch * 80, row = rem >> 3, quad = rem & 7;
+      const int gy = y0 - 1 + row, gx = x0 + 4 * quad;
+      const bool ok = q < 80 * NCH && gy >= 0 && gy < h && gx < w;      // (w % 4 == 0: gx + 3 < w as well)
+      const float* sp = a.x + ((size_t)bn * (NCH * 8) + ch * 8) * plane + (ok ? (size_t)gy * w + gx : 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ok ? *reinterpret_cast<const f32x4*>(sp + (size_t)j * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
+      lds = ch * Q_CHUNK_B + (row * Q_IW + 1 + 4 * quad) * 16;
+    };
+    f32x4 qa[8], qb[8];
+    float hv[8];
+    int lds_a, lds_b = 0, lds_h = 0;
+    quad_item(tid, qa, lds_a);
+    const bool has_b = 512 + tid < 80 * NCH;                              // (wave-uniform: waves 0, 1)
+    const bool has_h = tid >= 128 && tid < 128 + 20 * NCH;
+    if (has_b) quad_item(512 + tid, qb, lds_b);
+    if (has_h) {
+      const int e = tid - 128, ch = e / 20, rem = e - ch * 20, row = rem >> 1, col = (rem & 1) * (Q_IW - 1);
+      const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+      const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
+      const float* sp = a.x + ((size_t)bn * (NCH * 8) + ch * 8) * plane + (ok ? (size_t)gy * w + gx : 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[j] = ok ? sp[(size_t)j * plane] : 0.f;
+      lds_h = ch * Q_CHUNK_B + (row * Q_IW + col) * 16;
+    }
+    if (tid < 32) {
+      const int co = cot * 32 + tid;
+      s_bias[tid] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+    }
+    Q_STAMP(0);      // requests issued
+    if (tid < 80 * NCH) q_store_quad(qa, s_patch + lds_a);
+    if (has_b) q_store_quad(qb, s_patch + lds_b);
+    if (has_h) {
+      u32x4 pl[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unsigned h2, m2, l2;
+        q_split2(hv[2 * c], hv[2 * c + 1], h2, m2, l2);
+        pl[0][c] = h2; pl[1][c] = m2; pl[2][c] = l2;
+      }
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) *reinterpret_cast<u32x4*>(s_patch + lds_h + p3 * Q_PLANE_B) = pl[p3];
+    }
+  } else {
     const float* sp = a.x + (size_t)bn * (NCH * 8) * plane + (pok ? (size_t)pgy * w + pgx : 0);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
       for (int j = 0; j < 8; ++j) pv[ch][j] = pok ? sp[(size_t)(ch * 8 + j) * plane] : 0.f;
+    if (tid < 32) {
+      const int co = cot * 32 + tid;
+      s_bias[tid] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
+    }
+    Q_STAMP(0);      // requests issued
+    store_patch(0);
   }
-  if (tid < 32) {
-    const int co = cot * 32 + tid;
-    s_bias[tid] = (a.bias && co < a.cout) ? a.bias[co] : 0.f;
-  }
-  Q_STAMP(0);      // requests issued
-  store_patch(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   Q_STAMP(1);      // loads landed, chunk 0 split
   __syncthreads();
@@ -212,7 +279,8 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
         __syncthreads();
         if (ch + 2 < NCH) issue_slab(ch + 2);
       }
-      if (ks == 1 && more) store_patch(ch + 1);
+      if constexpr (!VEC)
+        if (ks == 1 && more) store_patch(ch + 1);
       u32x4 anext[3], bnext[3];
       if (!last) {
         read_a(ch, ks + 1, anext);
@@ -253,6 +321,70 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
   const bool pxok = gx < w && gy < h;
   const float act_s = a.act == EAVSR_ACT_RELU ? 0.f : a.act == EAVSR_ACT_LRELU ? a.slope : 1.f;
   const int co0 = cot * 32 + 4 * kg;
+  if constexpr (VEC) {
+    // activation and channel sums in the accumulator layout; then the tile is transposed through LDS (the patch region: eight
+    // private 32-channel x 36-float tiles once every wave has read its last operands) so that residual loads and output stores
+    // are float4 row segments: 4 + 4 instructions per lane instead of 16 + 16
+    float vv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cu = (r & 3) + 8 * (r >> 2);
+      float v = acc[r];
+      v = fmaxf(v, eavsr_mul_legacy(v, act_s));      // branch-free: max(v, v s), 0 <= s <= 1
+      vv[r] = v;
+      if (a.chan_partial) {
+        float sum = (pxok && co0 + cu < a.cout) ? v : 0.f;
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 8);
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 1);
+        if (l31 == 0) s_red[wave * 32 + cu + 4 * kg] = sum;
+      }
+    }
+    const int q4 = lane & 7, rsub = lane >> 3;
+    const int gx4 = x0 + 4 * q4;
+    const bool pok4 = gx4 < w && gy < h;               // (w % 4 == 0: gx4 + 3 < w as well)
+    f32x4 rr4[4];
+    size_t o4[4];
+    bool ok4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co = cot * 32 + i * 8 + rsub;
+      ok4[i] = pok4 && co < a.cout;
+      o4[i] = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx4;
+      rr4[i] = (a.residual && ok4[i]) ? *reinterpret_cast<const f32x4*>(a.residual + o4[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (a.chan_partial && tid < 32) {
+      const int co = cot * 32 + tid;
+      if (co < a.cout) {
+        float v = s_red[tid];
+#pragma unroll
+        for (int k = 1; k < Q_NW; ++k) v += s_red[k * 32 + tid];
+        a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx) * a.cout + co] = v;
+      }
+    }
+    float* tile = reinterpret_cast<float*>(s_patch) + wave * (32 * 36);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * kg) * 36 + l31] = vv[r];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + (i * 8 + rsub) * 36 + 4 * q4);
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = a.act == EAVSR_ACT_RELU_MASK ? (rr4[i][c] > 0.f ? v[c] : 0.f) : v[c] + rr4[i][c];
+      if (ok4[i]) *reinterpret_cast<f32x4*>(a.out + o4[i]) = o;
+    }
+#ifdef EAVSR_X6S_STAMPS
+    Q_STAMP(4);      // epilogue issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Q_STAMP(5);      // stores acknowledged
+    if (tid == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(&g_q_stamps[i], st_acc[i]);
+#endif
+    return;
+  }
   const size_t obase = ((size_t)bn * a.cout + co0) * plane + (size_t)gy * w + gx;
   float rr[16];
 #pragma unroll
@@ -301,7 +433,7 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
   }
 }
 
-template <int NCH>
+template <int NCH, bool VEC>
 int launch_q(const QArgs& a, void* stream) {
   using K = QCfg<NCH>;
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
@@ -309,7 +441,7 @@ int launch_q(const QArgs& a, void* stream) {
   static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
   hipError_t& attr_err = attr_err_pd[dev_];
   std::call_once(once_pd.flag[dev_], [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x6s_kernel<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_x6s_kernel<NCH, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)K::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
@@ -319,7 +451,7 @@ int launch_q(const QArgs& a, void* stream) {
   const long blocks = (long)a.tiles_x * a.tiles_y * a.n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv3x3_f32x6s: too many tiles");
   dim3 grid((unsigned)blocks, eavsr::cdiv(a.cout, 32));
-  hipLaunchKernelGGL((conv3x3_x6s_kernel<NCH>), grid, dim3(64 * Q_NW), K::LDS_BYTES, eavsr::as_stream(stream), a);
+  hipLaunchKernelGGL((conv3x3_x6s_kernel<NCH, VEC>), grid, dim3(64 * Q_NW), K::LDS_BYTES, eavsr::as_stream(stream), a);
   return eavsr::launch_status("conv3x3_f32x6s");
 }
 
@@ -364,5 +496,10 @@ extern "C" int eavsr_conv3x3_f32x6s(const eavsr_conv2d_desc* d, const void* weig
   a.tiles_x = eavsr::cdiv(d->w, Q_TW); a.tiles_y = eavsr::cdiv(d->h, Q_TH);
   a.wmt = d->cout > 32 ? 2 : 1;
   a.act = d->act; a.slope = d->slope;
-  return launch_q<8>(a, stream);
+  const bool vec = d->w % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.out) |
+                                       reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0;
+#ifdef EAVSR_X6S_NO_VEC
+  return launch_q<8, false>(a, stream);
+#endif
+  return vec ? launch_q<8, true>(a, stream) : launch_q<8, false>(a, stream);
 }

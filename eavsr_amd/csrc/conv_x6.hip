@@ -44,7 +44,7 @@ constexpr int S_NW = 8, S_TW = 32;
 template <int KS, int MT, int NT, int NP = 3> struct C7 {
   static constexpr int PAD = KS / 2, KK = KS * KS;
   static constexpr int KSTEPS = (KK + 1) / 2;                  // tap pairs per chunk: 25 (49 taps + a zero tap), 13 (25 + one)
-  static constexpr int SLAB = KS == 7 ? 5 : 7;                 // k-steps per weight slab (the last slab of a 5x5 chunk has 6)
+  static constexpr int SLAB = KS == 5 ? 7 : 5;                 // k-steps per weight slab (the last slab of a 5x5 chunk has 6; 3x3: the chunk)
   static constexpr int NSLAB = (KSTEPS + SLAB - 1) / SLAB;     // 5, 2
   static constexpr int TH = S_NW * NT;
   static constexpr int IH = TH + KS - 1;                       // patch rows y0-PAD .. y0+TH+PAD-1
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
     if (more) load_patch(ch + 1);
 #pragma unroll
     for (int ks = 0; ks < S_KSTEPS; ++ks) {
-      constexpr int STORE_KS = KS == 7 ? 11 : 7;            // (behind a slab barrier: the chunk's loads have landed by its vmcnt(0))
+      constexpr int STORE_KS = KS == 7 ? 11 : KS == 5 ? 7 : 3;   // (7x7, 5x5: behind a slab barrier, the chunk's loads have landed by its vmcnt(0))
       const int si = ks / S_SLAB, sl = ks % S_SLAB;
       const int gs = ch * S_NSLAB + si;
       const bool slab_end = sl == S_SLAB - 1 || ks == S_KSTEPS - 1;
@@ -486,7 +486,11 @@ extern "C" int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int3
 extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,
                                 int32_t cout, int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t sigmoid_from,
                                 void* stream) {
+  // (KS = 3 instantiates and is correct, but at the bench's launch shape it takes 51 us against the fp32 Winograd kernel's 41:
+  //  tools/gpu_conv3_x6_time.py, round 5; small 3x3 launches have their own kernel, conv3_x6s.hip)
+#ifndef EAVSR_X6_KS3
   EAVSR_REQUIRE(ksize == 5 || ksize == 7, -2, "conv_f32x6: kernel size %d (5 and 7 only; 3x3 is eavsr_conv2d_f32 / eavsr_conv3x3_wino4_f32 / eavsr_conv3x3_f32x6s)", ksize);
+#endif
   EAVSR_REQUIRE(n >= 0 && cin > 0 && cout > 0 && h > 0 && w > 0, -1, "conv_f32x6: bad dims");
   if (n == 0) return 0;      // (an empty batch has no buffers)
   EAVSR_REQUIRE(x && weight_x6 && out, -1, "conv_f32x6: NULL pointer");
@@ -503,6 +507,9 @@ extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const flo
   a.tiles_x = eavsr::cdiv(w, S_TW);
   a.tiles_y = 0;   // per tile height, in launch7
   a.act = act; a.slope = slope; a.sig_from = sigmoid_from < 0 ? -1 : sigmoid_from;
+#ifdef EAVSR_X6_KS3      // A/B build only (tools/gpu_conv3_x6_time.py)
+  if (ksize == 3) return dispatch7<3>(a, stream);
+#endif
   return ksize == 7 ? dispatch7<7>(a, stream) : dispatch7<5>(a, stream);
 }
 
