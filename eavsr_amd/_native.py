@@ -78,6 +78,7 @@ SIGNATURES = {
     "eavsr_pack_conv_weight_wino4": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_conv3x3_wino4_tiles": (i32, [i32, i32]),
     "eavsr_conv3x3_wino4_f32": (C.c_int, [vp, vp, vp]),
+    "eavsr_wgrad3_mode": (C.c_int, []),
     "eavsr_conv3x3_x6s_tiles": (i32, [i32, i32]),
     "eavsr_conv3x3_f32x6s": (C.c_int, [vp, vp, vp]),
     "eavsr_pack_conv_weight_wino5x5": (C.c_int, [vp, vp, i32, i32, vp]),

@@ -14,6 +14,8 @@
 #include "common.h"
 
 #include <mutex>
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -306,6 +308,275 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad3_kernel(WgradArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 on the bf16 matrix pipe (round 5): both operands split exactly into three bf16 terms on their way into LDS, six partial
+// products per 16 pixels of K (v_mfma_f32_32x32x16_bf16: 0.375 x the fp32 MFMA's cycles for the same sum; no operand rounded,
+// the dropped products are below 2^-24 of the result -- as conv_x6.hip / dcnv2_il2.hip).  Weight gradients of RCABlock's
+// convolutions (models/networks.py:456-464) at a training crop: 352 launches of 7 segments x 2 x 96 x 96 per step, 54 ms of the
+// 241 ms step on the fp32 kernel above (0.37 of the fp32 MFMA peak, staging and multiplying in turns).
+//
+// One workgroup = FOUR waves on one (co half, ci half) quadrant and a 4 x 32-pixel tile; wave r takes pixel row r (two k-steps of
+// 16 pixels), all nine taps: 144 accumulator registers.  73,728 bytes of LDS, so that TWO workgroups share a CU and one stages
+// while the other multiplies; a workgroup's own next tile is requested (float4 row segments, 42 registers) before it multiplies the
+// current one.
+// LDS, per plane (hi / mid / lo):  dY [32 co][4 rows][32 px] bf16, 272 bytes per channel (16 B of padding: the 16 lanes of a
+// ds_read_b128 group hit 16 different bank quads);  X [32 ci][6 rows][40 el] bf16, patch column c (gx = x0 - 1 + c) stored at
+// element c + 1, 496 bytes per channel.  K runs over pixels, so a lane's B operand is EIGHT CONSECUTIVE PIXELS of one input
+// channel shifted by the tap: elements c0 + kx + 1 .. c0 + kx + 8 of a row, c0 = 16 s + 8 g.  One aligned ds_read_b128 at c0 plus
+// a ds_read_b64 behind it give dwords D0..D5; kx = 1 is D1..D4 as they are, kx = 0 / 2 are funnel shifts by 16 bits
+// (v_alignbyte_b32), five per row and plane for both.
+struct Wx6Cfg {
+  static constexpr int TH = 4, TW = 32, IH = TH + 2;
+  static constexpr int A_PITCH = TH * 64 + 16, A_PLANE = 32 * A_PITCH;          // 272, 8,704
+  static constexpr int B_ROW = 80, B_PITCH = IH * B_ROW + 16, B_PLANE = 32 * B_PITCH;   // 496, 15,872
+  static constexpr size_t LDS_BYTES = 3 * (size_t)A_PLANE + 3 * (size_t)B_PLANE;        // 73,728
+};
+
+typedef unsigned wx_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wx_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wx_bf16x8 __attribute__((ext_vector_type(8)));
+
+// exact three-way split of two fp32 values into packed bf16 pairs (low half = first value)
+__device__ __forceinline__ void wx_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);
+  const unsigned uma = __float_as_uint(ra), umb = __float_as_uint(rb);
+  const float la = ra - __uint_as_float(uma & 0xFFFF0000u), lb = rb - __uint_as_float(umb & 0xFFFF0000u);
+  hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+  mid = __builtin_amdgcn_perm(umb, uma, 0x07060302u);
+  lo = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+}
+
+typedef __amdgpu_buffer_rsrc_t wx_rsrc;
+constexpr unsigned WX_OOB = 0x80000000u;      // beyond every extent the launcher accepts (< 2^31 bytes per 32-channel image block)
+__device__ __forceinline__ wx_rsrc wx_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ unsigned wx_smul(unsigned s_, int c) {      // c: a constant once the caller is unrolled
+  unsigned r;
+  asm volatile("s_mul_i32 %0, %1, %2" : "=s"(r) : "s"(s_), "i"(c));
+  return r;
+}
+__device__ __forceinline__ float wx_ld(wx_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 wx_ld4(wx_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ f32x16 wx_mfma(const wx_u32x4& a, const wx_u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wx_bf16x8, a), __builtin_bit_cast(wx_bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3_x6_kernel(WgradArgs a) {
+  using Cfg = Wx6Cfg;
+  constexpr int KK = 9, TH = Cfg::TH, TW = Cfg::TW, IH = Cfg::IH;
+  constexpr int A_PITCH = Cfg::A_PITCH, A_PLANE = Cfg::A_PLANE, B_ROW = Cfg::B_ROW, B_PITCH = Cfg::B_PITCH, B_PLANE = Cfg::B_PLANE;
+  static_assert(4 * 1024 * 4 <= Cfg::LDS_BYTES, "the cross-wave sum reuses the operand tiles");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* sA = reinterpret_cast<unsigned char*>(smem);
+  unsigned char* sB = sA + 3 * A_PLANE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int mt = blockIdx.y & 1, ct = blockIdx.y >> 1;
+  const int co_valid = min(a.co_valid - 32 * mt, 32), ci_valid = min(a.ci_valid - 32 * ct, 32);
+  if (co_valid <= 0 || ci_valid <= 0) return;   // the reduction never reads this quadrant
+  const int h = a.h, w = a.w;
+  const size_t plane = (size_t)h * w;
+
+  f32x16 acc[KK];
+#pragma unroll
+  for (int t = 0; t < KK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging items of a tile: thread t = (channel t >> 3 of the quadrant, quad q = t & 7 of four pixels) takes that channel's quad
+  // of every row -- 4 rows of dY, 6 rows of the X patch interior (patch columns 1..32) -- and, for (t & 7) < 6, the two halo
+  // pixels (patch columns 0 and 33) of patch row t & 7: 12 requests per thread and tile.  All of them are buffer loads: one
+  // per-thread offset for the life of the kernel, the tile's row as the scalar offset, channels beyond the valid ones beyond
+  // the resource (the range check returns zeros); rows outside the image are wave-uniform (no request), columns per thread.
+  const unsigned upl4 = (unsigned)plane * 4u, uw4 = (unsigned)w * 4u;
+  const int chn = tid >> 3, q8 = tid & 7;
+  const unsigned vo_q = (unsigned)chn * upl4 + (unsigned)q8 * 16u;
+  const unsigned vo_c = (unsigned)chn * upl4;                                  // halo: + its row, per tile
+  unsigned char* lds_a = sA + chn * A_PITCH + q8 * 8;
+  unsigned char* lds_b = sB + chn * B_PITCH + 4 + q8 * 8;                       // elements 2 + 4 q .. 5 + 4 q of patch row 0
+  unsigned char* lds_h = sB + chn * B_PITCH + q8 * B_ROW;                       // element 0 of patch row q8
+  f32x4 va[4], vb[6];
+  float vh[2];
+  auto request = [&](int tile) __attribute__((always_inline)) {
+    int t = tile;
+    const int tx = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty = t % a.tiles_y;
+    const int bn = t / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int seg = bn / a.n, bl = bn - seg * a.n;      // wave-uniform
+    const wx_rsrc r_dy = wx_make_rsrc(a.dyv[seg] + ((size_t)bl * a.cout_total + a.co0 + 32 * mt) * plane, (unsigned)co_valid * upl4);
+    const wx_rsrc r_x = wx_make_rsrc(a.xv[seg] + ((size_t)bl * a.cin_src + a.ci0 + 32 * ct) * plane, (unsigned)ci_valid * upl4);
+    const unsigned vq = x0 + 4 * q8 < w ? vo_q : WX_OOB;      // (w % 4 == 0: the whole quad is inside or outside)
+    const unsigned so0 = (unsigned)(y0 * w + x0) * 4u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      va[i] = y0 + i < h ? wx_ld4(r_dy, vq, so0 + wx_smul(uw4, i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int gy = y0 - 1 + i;
+      vb[i] = (gy >= 0 && gy < h) ? wx_ld4(r_x, vq, so0 + wx_smul(uw4, i) - uw4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // (the scalar offset is not range-checked and must not go negative: the halo's row lives in the per-thread offset)
+    const int hy = y0 - 1 + q8;
+    const unsigned vh_ = (q8 < 6 && hy >= 0 && hy < h) ? vo_c + (unsigned)hy * uw4 : WX_OOB;
+    vh[0] = x0 > 0 ? wx_ld(r_x, vh_, (unsigned)x0 * 4u - 4u) : 0.f;
+    vh[1] = x0 + TW < w ? wx_ld(r_x, vh_, (unsigned)x0 * 4u + TW * 4u) : 0.f;
+  };
+  auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      wx_split2(va[i][0], va[i][1], h0, m0, l0);
+      wx_split2(va[i][2], va[i][3], h1, m1, l1);
+      unsigned char* d = lds_a + i * 64;
+      *reinterpret_cast<wx_u32x2*>(d) = wx_u32x2{h0, h1};
+      *reinterpret_cast<wx_u32x2*>(d + A_PLANE) = wx_u32x2{m0, m1};
+      *reinterpret_cast<wx_u32x2*>(d + 2 * A_PLANE) = wx_u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      wx_split2(vb[i][0], vb[i][1], h0, m0, l0);
+      wx_split2(vb[i][2], vb[i][3], h1, m1, l1);
+      unsigned* d = reinterpret_cast<unsigned*>(lds_b + i * B_ROW);
+      d[0] = h0; d[1] = h1;
+      d[B_PLANE / 4] = m0; d[B_PLANE / 4 + 1] = m1;
+      d[2 * (B_PLANE / 4)] = l0; d[2 * (B_PLANE / 4) + 1] = l1;
+    }
+    if (q8 < 6) {
+      unsigned h0, m0, l0;
+      wx_split2(vh[0], vh[1], h0, m0, l0);      // low halves: patch column 0 (element 1), high halves: column 33 (element 34)
+      unsigned short* d = reinterpret_cast<unsigned short*>(lds_h);
+      d[1] = (unsigned short)h0; d[34] = (unsigned short)(h0 >> 16);
+      d[B_PLANE / 2 + 1] = (unsigned short)m0; d[B_PLANE / 2 + 34] = (unsigned short)(m0 >> 16);
+      d[2 * (B_PLANE / 2) + 1] = (unsigned short)l0; d[2 * (B_PLANE / 2) + 34] = (unsigned short)(l0 >> 16);
+    }
+  };
+
+#ifdef EAVSR_WX6_PREFETCH      // A/B: a workgroup's own next tile in flight under its MFMAs (42 more registers)
+  int tile = blockIdx.x;
+  if (tile < a.num_tiles) request(tile);
+  for (; tile < a.num_tiles; tile += gridDim.x) {
+    __syncthreads();  // the previous tile's MFMAs are done with the LDS tiles
+    stage();
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.num_tiles) request(tile + gridDim.x);
+#else
+  for (int tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
+#ifdef EAVSR_WX6_EXP_NO_LOADS       // ablation: one request per workgroup
+    if (tile == (int)blockIdx.x)
+#endif
+    request(tile);      // (the other workgroup of the CU multiplies meanwhile)
+    __syncthreads();    // the previous tile's MFMAs are done with the LDS tiles
+#ifdef EAVSR_WX6_EXP_NO_STAGE       // ablation: one split + store per workgroup
+    if (tile == (int)blockIdx.x)
+#endif
+    stage();
+    __syncthreads();
+#endif
+    // K loop of this wave: pixel row `wave`, two k-steps of 16 pixels x three filter rows = six groups of 18 MFMAs; the raw
+    // operand dwords of group g + 1 are read before the MFMAs of group g, nothing else crosses a group boundary (left alone the
+    // scheduler hoists every read of the tile to the top and spills the accumulators)
+    const unsigned char* ap = sA + l31 * A_PITCH + wave * 64 + kg * 16;
+    const unsigned char* bp = sB + l31 * B_PITCH + wave * B_ROW + kg * 16;
+    wx_u32x4 av[3], d03[3], n03[3];
+    wx_u32x2 d45[3], n45[3];
+    auto read_raw = [&](int g, wx_u32x4 (&r03)[3], wx_u32x2 (&r45)[3]) __attribute__((always_inline)) {
+      const int s_ = g / 3, ky = g - 3 * s_;
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) {
+        r03[p3] = *reinterpret_cast<const wx_u32x4*>(bp + p3 * B_PLANE + ky * B_ROW + s_ * 32);
+        r45[p3] = *reinterpret_cast<const wx_u32x2*>(bp + p3 * B_PLANE + ky * B_ROW + s_ * 32 + 16);
+      }
+    };
+#ifndef EAVSR_WX6_NO_READAHEAD
+    read_raw(0, d03, d45);
+#endif
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const int s_ = g / 3, ky = g - 3 * s_;
+      if (ky == 0) {
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) av[p3] = *reinterpret_cast<const wx_u32x4*>(ap + p3 * A_PLANE + s_ * 32);
+      }
+#ifdef EAVSR_WX6_NO_READAHEAD      // A/B (with EAVSR_WX6_PREFETCH: 18 registers less)
+      read_raw(g, d03, d45);
+#else
+      if (g + 1 < 6) read_raw(g + 1, n03, n45);
+#endif
+      wx_u32x4 b0[3], b1[3], b2[3];
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) {
+        const unsigned s10 = __builtin_amdgcn_alignbyte(d03[p3][1], d03[p3][0], 2), s21 = __builtin_amdgcn_alignbyte(d03[p3][2], d03[p3][1], 2);
+        const unsigned s32 = __builtin_amdgcn_alignbyte(d03[p3][3], d03[p3][2], 2), s43 = __builtin_amdgcn_alignbyte(d45[p3][0], d03[p3][3], 2);
+        const unsigned s54 = __builtin_amdgcn_alignbyte(d45[p3][1], d45[p3][0], 2);
+        b0[p3] = wx_u32x4{s10, s21, s32, s43};                                  // elements c0 + 1 .. c0 + 8: tap kx = 0
+        b1[p3] = wx_u32x4{d03[p3][1], d03[p3][2], d03[p3][3], d45[p3][0]};      // c0 + 2 .. c0 + 9:  kx = 1
+        b2[p3] = wx_u32x4{s21, s32, s43, s54};                                  // c0 + 3 .. c0 + 10: kx = 2
+      }
+      // the six partial products, smallest first: (A plane, B plane) = (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
+#define WX_TAP(T, B)                             \
+      acc[T] = wx_mfma(av[2], B[0], acc[T]);     \
+      acc[T] = wx_mfma(av[0], B[2], acc[T]);     \
+      acc[T] = wx_mfma(av[1], B[1], acc[T]);     \
+      acc[T] = wx_mfma(av[1], B[0], acc[T]);     \
+      acc[T] = wx_mfma(av[0], B[1], acc[T]);     \
+      acc[T] = wx_mfma(av[0], B[0], acc[T]);
+#ifdef EAVSR_WX6_EXP_NO_MFMA      // ablation (tools/gpu_wgrad_diag.py): operands read and shifted, not multiplied
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) asm volatile("" ::"v"(b0[p3]), "v"(b1[p3]), "v"(b2[p3]), "v"(av[p3]));
+#else
+      WX_TAP(ky * 3 + 0, b0)
+      WX_TAP(ky * 3 + 1, b1)
+      WX_TAP(ky * 3 + 2, b2)
+#endif
+#undef WX_TAP
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef EAVSR_WX6_NO_READAHEAD
+      if (g + 1 < 6) {
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) {
+          d03[p3] = n03[p3];
+          d45[p3] = n45[p3];
+        }
+      }
+#endif
+    }
+  }
+
+  // partial slab of this workgroup, ws[blk][co][ci][tap]: sum of the four waves, wave 0 first
+#pragma unroll
+  for (int tap = 0; tap < KK; ++tap) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) smem[wave * 1024 + r * 64 + lane] = acc[tap][r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + j * 256;
+      float v = smem[e];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) v += smem[k * 1024 + e];
+      const int r = e >> 6, ln = e & 63;
+      const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+      const int ci = ct * 32 + (ln & 31);
+      a.ws[(((size_t)blockIdx.x * 64 + co) * 64 + ci) * KK + tap] = v;
+    }
+  }
+}
+
 // dW[co0+co][ci_dst0+ci][tap] (+)= sum_blk ws[blk][co][ci][tap].  64 outputs per workgroup; the four waves take every
 // fourth slab (four independent load streams per output instead of one serial chain) and are added in wave order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
@@ -372,7 +643,33 @@ int launch_wgrad3(const WgradArgs& a, int blocks, hipStream_t st) {
   return eavsr::launch_status("conv_wgrad");
 }
 
+int launch_wgrad3_x6(const WgradArgs& a, int blocks, hipStream_t st) {
+  static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
+  const int dev_ = eavsr::current_device();
+  std::once_flag& once = once_pd.flag[dev_];
+  static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
+  hipError_t& attr_err = attr_err_pd[dev_];
+  std::call_once(once, [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_x6_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Wx6Cfg::LDS_BYTES);
+  });
+  if (attr_err != hipSuccess) {
+    eavsr::set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
+    return (int)attr_err;
+  }
+  hipLaunchKernelGGL(conv_wgrad3_x6_kernel, dim3(blocks, 4), dim3(256), Wx6Cfg::LDS_BYTES, st, a);
+  return eavsr::launch_status("conv_wgrad");
+}
+
+// EAVSR_WGRAD3=fp32 keeps the 3x3 weight gradient on the fp32 MFMA kernel (A/B switch; chosen once per process)
+bool wgrad3_x6_enabled() {
+  static const bool on = [] { const char* e = getenv("EAVSR_WGRAD3"); return e == nullptr || strcmp(e, "fp32") != 0; }();
+  return on;
+}
+
 }  // namespace
+
+extern "C" int eavsr_wgrad3_mode(void) { return wgrad3_x6_enabled() ? 1 : 0; }
 
 extern "C" int32_t eavsr_conv_wgrad_blocks(int32_t n, int32_t h, int32_t w, int32_t ksize) {
   const int th = ksize <= 3 ? 8 : 4;
@@ -408,16 +705,30 @@ extern "C" int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void
   a.num_tiles = a.tiles_x * a.tiles_y * n * nseg;
   const int blocks = eavsr_conv_wgrad_blocks(n * nseg, h, w, ksize);
   hipStream_t st = eavsr::as_stream(stream);
-  int rc;
-  switch (ksize) {
-    case 1: rc = launch_wgrad<1>(a, blocks, st); break;
-    case 3: rc = launch_wgrad3(a, blocks, st); break;
-    default: rc = launch_wgrad<5>(a, blocks, st); break;
+  int rc, slabs = blocks;
+  // the bf16x6 kernel: float4 row segments, i.e. w % 4 == 0 and 16-byte aligned tensors (anything else: the fp32 kernel)
+  bool x6 = ksize == 3 && n > 0 && w % 4 == 0 && (long)h * w * 128 < (1L << 31) && wgrad3_x6_enabled();
+  for (int s = 0; x6 && s < nseg; ++s)
+    x6 = ((reinterpret_cast<uintptr_t>(a.dyv[s]) | reinterpret_cast<uintptr_t>(a.xv[s])) & 15) == 0;
+  if (x6) {
+    WgradArgs b = a;
+    b.tiles_y = eavsr::cdiv(h, Wx6Cfg::TH);
+    EAVSR_REQUIRE((long)b.tiles_x * b.tiles_y * n * nseg < (1L << 31), -1, "conv_wgrad: too many tiles");
+    b.num_tiles = b.tiles_x * b.tiles_y * n * nseg;
+    slabs = b.num_tiles < 128 ? b.num_tiles : 128;      // two 4-wave workgroups per CU; never more slabs than `blocks`
+    if (slabs > blocks) slabs = blocks;
+    rc = launch_wgrad3_x6(b, slabs, st);
+  } else {
+    switch (ksize) {
+      case 1: rc = launch_wgrad<1>(a, blocks, st); break;
+      case 3: rc = launch_wgrad3(a, blocks, st); break;
+      default: rc = launch_wgrad<5>(a, blocks, st); break;
+    }
   }
   if (rc) return rc;
   const int kk = ksize * ksize;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64 * kk), dim3(256), 0, st, workspace, dweight,
-                     n == 0 ? 0 : blocks, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate);
+                     n == 0 ? 0 : slabs, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate);
   return eavsr::launch_status("conv_wgrad_reduce");
 }
 

@@ -452,6 +452,10 @@ int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float*
  * same backbone / alignment weights at every time step), whose gradients autograd would compute and sum one use at a time
  * (loss.backward(), models/eavsrp_model.py:109-113).  n is the batch of ONE segment; workspace:
  * eavsr_conv_wgrad_blocks(n * nseg, h, w, ksize) * 64*64*ksize*ksize floats.  The pointers are read on the host at the call. */
+/* ksize 3 with w % 4 == 0 and 16-byte aligned tensors runs on the bf16 matrix pipe with both operands split exactly into three
+ * bf16 terms (ABI 27; six partial products, fp32 accumulation: no operand rounded); eavsr_wgrad3_mode() = 1.  EAVSR_WGRAD3=fp32 in
+ * the environment keeps the fp32-MFMA kernel (0; chosen once per process, reported so that measurements state which ran). */
+int eavsr_wgrad3_mode(void);
 int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void* const* x_list, int32_t nseg, float* dweight,
                                float* workspace, int32_t n, int32_t h, int32_t w, int32_t cout_total, int32_t co0,
                                int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,

@@ -511,11 +511,14 @@ def test_conv2d_relu_mask_epilogue_equals_conv_then_act_bwd(cuda, n, h, w):
         ops.conv2d(g, wt, None, act="relu_mask", residual=t, chan_partial=True)
 
 
-@pytest.mark.parametrize("k,nseg,shape", [(3, 7, (2, 64, 96, 96)), (3, 3, (1, 64, 19, 37)), (1, 8, (2, 64, 24, 40)), (5, 2, (1, 64, 16, 32))])
+@pytest.mark.parametrize("k,nseg,shape", [(3, 7, (2, 64, 96, 96)), (3, 3, (1, 64, 19, 37)), (1, 8, (2, 64, 24, 40)), (5, 2, (1, 64, 16, 32)),
+                                          (3, 2, (1, 64, 18, 40)), (3, 2, (3, 40, 7, 4)), (3, 8, (1, 8, 45, 80))])
 def test_conv_wgrad_over_several_uses_in_one_launch(cuda, k, nseg, shape):
     """eavsr_conv_wgrad_multi_f32 / eavsr_channel_sum_multi_f32 (ABI 26): the uses of one weight across the frames of the
     recurrence as segments of ONE launch, against the sum of the per-use gradients in float64 (torch CPU) and against the
-    per-use launches accumulated one after the other; two sources (a virtual concatenation), `accumulate` on top."""
+    per-use launches accumulated one after the other; two sources (a virtual concatenation), `accumulate` on top.
+    3x3 with w % 4 == 0 runs the bf16x6 kernel (ABI 27: 4 x 32-pixel tiles cut by the image in both directions, fewer than 32
+    valid input channels in a quadrant), 19 x 37 the fp32-MFMA kernel."""
     from eavsr_amd import ops
     n, c, h, w = shape
     cout = 64 if k != 5 else 120
@@ -546,7 +549,7 @@ def test_conv_wgrad_over_several_uses_in_one_launch(cuda, k, nseg, shape):
     with pytest.raises(ValueError):
         ops.conv_wgrad_multi([gd[0]] * 9, [[ga[0], gb[0]]] * 9, k, out=out)      # > 8 segments
     with pytest.raises(ValueError):
-        ops.conv_wgrad_multi(gd[:2], [[ga[0], gb[0]], [ga[1][:, :32], gb[1]]], k, out=out)          # shapes differ
+        ops.conv_wgrad_multi(gd[:2], [[ga[0], gb[0]], [ga[1][:, :c // 2], gb[1]]], k, out=out)      # shapes differ
 
 
 def test_grad_sink_matches_autograd_accumulation(AG, cuda):
