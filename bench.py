@@ -350,20 +350,29 @@ def train_bench(args, rank, world, device, ranks_seen=1):
                                                   "not counted: profiles/*train* has the rocprofv3 census of all of them"}
             extra["step_kernel_ms_library"] = lib_ms
 
-            def roof(name, what):
+            def roof(name, what, x6):
+                """x6: the kernel runs on the bf16 matrix pipe with both fp32 operands split exactly into three bf16 terms -- six
+                partial products per multiplication: `achieved` counts the FLOP the pipe PERFORMS (6 x algorithmic) against the
+                dense bf16 peak (<= 1 by construction); the algorithmic rate has its own key"""
                 v = summ.get(name)
                 if not v or v["ms"] <= 0:
                     return None
-                ach = v["flops"] / (v["ms"] * 1e-3) / 1e12
-                return {"kernel": what, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_MFMA_F32_TFLOPS, "avg_ms": v["ms"] / v["calls"], "calls": v["calls"],
+                alg = v["flops"] / (v["ms"] * 1e-3) / 1e12
+                ach, peak = (6.0 * alg, PEAK_MFMA_16BIT_TFLOPS) if x6 else (alg, PEAK_MFMA_F32_TFLOPS)
+                return {"kernel": what, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                        "frac": ach / peak, "avg_ms": v["ms"] / v["calls"], "calls": v["calls"],
                         "share_of_library_kernel_time": v["ms"] / lib_ms, "traffic": None,
-                        "note": "algorithmic FLOP (2 cin cout k k per output pixel) / HIP-event time of the launches of one eager step"}
+                        "algorithmic_equivalent": {"achieved": alg, "unit": "TFLOP/s", "x_fp32_mfma_peak": alg / PEAK_MFMA_F32_TFLOPS},
+                        "note": ("algorithmic FLOP (2 cin cout k k per output pixel) / HIP-event time of the launches of one eager step"
+                                 + ("; exact bf16x6: six bf16 partial products per fp32 multiplication, priced on the bf16 MFMA peak" if x6 else ""))}
             convs = sorted(((k, v) for k, v in summ.items() if k.startswith("conv3x3_64to64")), key=lambda kv: -kv[1]["ms"])
             if convs:
-                extra["roofline"] = roof(convs[0][0], f"{convs[0][0]} (forward and input-gradient 3x3 64->64 convolutions at 2 x 64 x 96 x 96)")
-            rw = roof("conv_wgrad3x3", "conv_wgrad3_kernel (weight gradient 3x3, K = pixels x frames: the uses of a weight across the "
-                                       "recurrence are segments of one launch)")
+                extra["roofline"] = roof(convs[0][0], f"{convs[0][0]} (forward and input-gradient 3x3 64->64 convolutions at 2 x 64 x 96 x 96)",
+                                         convs[0][0].endswith(("_x6s", "_x6")))
+            wg_x6 = bool(ops.lib().eavsr_wgrad3_mode()) and w % 4 == 0
+            rw = roof("conv_wgrad3x3", ("conv_wgrad3_x6_kernel" if wg_x6 else "conv_wgrad3_kernel") +
+                      " (weight gradient 3x3, K = pixels x frames: the uses of a weight across the recurrence are segments of one launch; "
+                      "the time includes the slab-reduction kernel behind it)", wg_x6)
             if rw is not None:
                 extra.setdefault("roofline", {})["conv_wgrad"] = rw
         except Exception as ex:      # measurement garnish must not void the line

@@ -557,50 +557,66 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_x6_kernel(WgradArgs a) {
   }
 
   // partial slab of this workgroup, ws[blk][co][ci][tap]: sum of the four waves, wave 0 first
+#ifdef EAVSR_WX6_EXP_NO_EPI      // ablation: no cross-wave sum, no slab
 #pragma unroll
-  for (int tap = 0; tap < KK; ++tap) {
+  for (int tap = 0; tap < KK; ++tap) asm volatile("" ::"v"(acc[tap]));
+  return;
+#endif
+  // Three taps per round (48 KB of LDS, two barriers); the slab is TAP-MAJOR, ws[blk][tap][co][ci], so that a half-wave stores
+  // 32 consecutive input channels (the [co][ci][tap] form of the fp32 kernels is a 36-byte stride per lane: nine partial passes
+  // over every line; 10 us of a 27 us one-segment launch together with nine rounds of barriers).
+  static_assert(3 * 4 * 1024 * 4 <= Cfg::LDS_BYTES, "three taps of four waves");
+#pragma unroll
+  for (int t3 = 0; t3 < KK; t3 += 3) {
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) smem[wave * 1024 + r * 64 + lane] = acc[tap][r];
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) smem[(u * 4 + wave) * 1024 + r * 64 + lane] = acc[t3 + u][r];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = tid + j * 256;
-      float v = smem[e];
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
-      for (int k = 1; k < 4; ++k) v += smem[k * 1024 + e];
-      const int r = e >> 6, ln = e & 63;
-      const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-      const int ci = ct * 32 + (ln & 31);
-      a.ws[(((size_t)blockIdx.x * 64 + co) * 64 + ci) * KK + tap] = v;
-    }
+      for (int j = 0; j < 4; ++j) {
+        const int e = tid + j * 256;
+        float v = smem[u * 4096 + e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) v += smem[u * 4096 + k * 1024 + e];
+        const int r = e >> 6, ln = e & 63;
+        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int ci = ct * 32 + (ln & 31);
+        a.ws[(((size_t)blockIdx.x * KK + t3 + u) * 64 + co) * 64 + ci] = v;
+      }
   }
 }
 
-// dW[co0+co][ci_dst0+ci][tap] (+)= sum_blk ws[blk][co][ci][tap].  64 outputs per workgroup; the four waves take every
-// fourth slab (four independent load streams per output instead of one serial chain) and are added in wave order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+// dW[co0+co][ci_dst0+ci][tap] (+)= sum_blk ws[blk][..].  64 outputs per workgroup; the eight waves take every eighth slab, four
+// loads in flight each (a launch of 128-256 slabs is one or two latency round trips per wave instead of sixteen), and are added
+// in wave order: deterministic.  tap_major: the slab is [tap][co][ci] (the bf16x6 3x3 kernel), otherwise [co][ci][tap].
+__global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int blocks, int kk, int co0, int co_valid, int ci_dst0,
-                                                           int ci_valid, int cin_total, int accumulate) {
-  __shared__ float part[4][64];
+                                                           int ci_valid, int cin_total, int accumulate, int tap_major) {
+  __shared__ float part[8][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const int total = 64 * 64 * kk;   // a multiple of 64
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int b = wv;
-  for (; b + 4 < blocks; b += 8) {
-    s0 += ws[(size_t)b * total + i];
-    s1 += ws[(size_t)(b + 4) * total + i];
+  for (; b + 24 < blocks; b += 32) {
+    const float v0 = ws[(size_t)b * total + i], v1 = ws[(size_t)(b + 8) * total + i];
+    const float v2 = ws[(size_t)(b + 16) * total + i], v3 = ws[(size_t)(b + 24) * total + i];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
   }
-  if (b < blocks) s0 += ws[(size_t)b * total + i];
-  part[wv][lane] = s0 + s1;
+  for (; b < blocks; b += 8) s0 += ws[(size_t)b * total + i];
+  part[wv][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (wv != 0) return;
-  const int tap = i % kk;
-  const int ci = (i / kk) % 64;
-  const int co = i / (kk * 64);
+  const int tap = tap_major ? i / 4096 : i % kk;
+  const int ci = tap_major ? i % 64 : (i / kk) % 64;
+  const int co = tap_major ? (i / 64) % 64 : i / (kk * 64);
   if (co >= co_valid || ci >= ci_valid) return;
-  const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  const float s = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+                  ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
   float* dst = dw + ((size_t)(co0 + co) * cin_total + ci_dst0 + ci) * kk + tap;
   *dst = accumulate ? *dst + s : s;
 }
@@ -727,8 +743,8 @@ extern "C" int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void
   }
   if (rc) return rc;
   const int kk = ksize * ksize;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64 * kk), dim3(256), 0, st, workspace, dweight,
-                     n == 0 ? 0 : slabs, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64 * kk), dim3(512), 0, st, workspace, dweight,
+                     n == 0 ? 0 : slabs, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate, x6 ? 1 : 0);
   return eavsr::launch_status("conv_wgrad_reduce");
 }
 
