@@ -72,3 +72,36 @@ for ent in libs:
         names = ["requests issued", "loads landed + chunk 0 split", "first barrier", "k-steps", "epilogue issued", "stores acknowledged"]
         tot = sum(buf[i] for i in range(6))
         print(f"{ent[0]}: " + "  ".join(f"{names[i]} {buf[i] / nwg:.0f}" for i in range(6)) + f"  total {tot / nwg:.0f} ticks per workgroup (s_memtime: 100 MHz)")
+
+# in-step behaviour: a HIP graph of 120 dependent convolutions with 60 DIFFERENT weights (each launch's weight is cold in L2)
+NW = 60
+wts = [torch.randn(64, 64, 3, 3, device=dev) / 24 for _ in range(NW)]
+for ent in libs:
+    name, lib = ent[0], ent[1]
+    wps = []
+    for wt_ in wts:
+        wp_ = torch.empty(lib.eavsr_conv_weight_x6_bytes(3, 64, 64), device=dev, dtype=torch.uint8)
+        assert lib.eavsr_pack_conv_weight_x6(p(wt_), p(wp_), 3, 64, 64, None) == 0
+        wps.append(wp_)
+    bufs = [torch.randn(n, 64, h, w, device=dev), torch.empty(n, 64, h, w, device=dev)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for k in range(120):
+                d = NAT.ConvDesc()
+                d.src[0] = p(bufs[k & 1]); d.src_c[0] = 64; d.n_src = 1; d.ksize = 3; d.bias = p(b); d.out = p(bufs[(k + 1) & 1])
+                d.n, d.h, d.w, d.cin, d.cout = n, h, w, 64, 64
+                d.act = 1
+                assert lib.eavsr_conv3x3_f32x6s(C.byref(d), p(wps[k % NW]), C.c_void_p(s.cuda_stream)) == 0
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(10):
+            g.replay()
+        e1.record(s)
+        torch.cuda.synchronize()
+        print(f"{name}: graph of 120 dependent convolutions, 60 weights: {e0.elapsed_time(e1) * 1e3 / 1200:6.2f} us per launch", flush=True)
