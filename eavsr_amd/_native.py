@@ -95,6 +95,7 @@ SIGNATURES = {
     "eavsr_conv3x3_smallco_lite_f32": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_conv_weight_x6_bytes": (C.c_size_t, [i32, i32, i32]),
     "eavsr_pack_conv_weight_x6": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "eavsr_pack_conv_weight_x6_dgrad": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "eavsr_conv_f32x6": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "eavsr_ca_scale_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_ca_scale_mean_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -129,6 +130,7 @@ SIGNATURES = {
     "eavsr_dcnv2_col2im_f32": (C.c_int, [vp] * 7 + [i32, i32, i32, i32, i32, vp]),
     "eavsr_gconv3x3_fwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_gconv3x3_bwd_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, i32, vp]),
+    "eavsr_gconv3x3_bwd_acc_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, i32, i32, vp]),
     # 16-bit backbone
     "eavsr_conv_h16_tiles": (i32, [i32, i32]),
     "eavsr_pack_conv3x3_c64_h16": (C.c_int, [vp, vp, i32, vp]),

@@ -313,6 +313,7 @@ class _GConvFn(Function):
     def forward(ctx, x, weight, bias, cpg, act, slope):
         out = ops.gconv3x3(x, weight, bias, cpg, act, slope)
         ctx.meta = (cpg, act, slope)
+        ctx.params = [weight, bias]      # the caller's tensor objects (grad_sink keys on them)
         ctx.save_for_backward(x, weight, out)
         return out
 
@@ -321,6 +322,11 @@ class _GConvFn(Function):
         cpg, act, slope = ctx.meta
         x, weight, out = ctx.saved_tensors
         g = ops.act_bwd(dout.contiguous(), out, act, slope) if act is not None else dout.contiguous()
+        if ctx.params[1] is not None and all(ctx.needs_input_grad[1:3]) and grad_sink.eligible(ctx.params):
+            # the uses of the front end's weights across the frames add into one buffer (was: one ATen add per use and tensor)
+            bufs, acc = grad_sink._active.raw(ctx.params)
+            dx = ops.gconv3x3_bwd(g, x, weight, cpg, grads=tuple(bufs), accumulate=acc)[0]
+            return dx, None, None, None, None, None
         dx, dw, db = ops.gconv3x3_bwd(g, x, weight, cpg)
         return dx, dw, db, None, None, None
 
@@ -481,14 +487,14 @@ class _RcabFn(Function):
         else:
             dW2, db2 = ops.conv_wgrad(dr, [t], 3), ops.channel_sum(dr)
         # the ReLU's backward mask (t > 0) leaves in the epilogue of conv-2's input-gradient convolution
-        g1 = ops.conv2d(dr, _dgrad_weight([w2], 0, 64), None, act="relu_mask", residual=t)
+        g1 = ops.conv2d(dr, w2, None, act="relu_mask", residual=t, dgrad=True)
         # first convolution; the residual path's gradient d rides in its input-gradient convolution
         if sink is not None:
             sink.add_use(pw1, pb1, 3, g1, [x])
             dW1 = db1 = None
         else:
             dW1, db1 = ops.conv_wgrad(g1, [x], 3), ops.channel_sum(g1)
-        dx = ops.conv2d(g1, _dgrad_weight([w1], 0, 64), None, residual=d)
+        dx = ops.conv2d(g1, w1, None, residual=d, dgrad=True)
         return (dx, dW1, db1, dW2, db2) + tuple(dca)
 
 

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void gconv3x3_dgrad_kernel(const float* __rest
 // dw[o][j][tap] = sum_{n,y,x} g[n,o,y,x] x[n,o*cpg+j,y+ky-1,x+kx-1] ; db[o] = sum g   one workgroup per (o, j)
 __global__ __launch_bounds__(1024) void gconv3x3_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                               float* __restrict__ dw, float* __restrict__ db, int n,
-                                                              int co, int cpg, int h, int w) {
+                                                              int co, int cpg, int h, int w, int accumulate) {
   __shared__ float red[16][10];
   const int o = blockIdx.x / cpg, j = blockIdx.x - o * cpg;
   float acc[10];
@@ -202,8 +202,13 @@ __global__ __launch_bounds__(1024) void gconv3x3_wgrad_kernel(const float* __res
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
-    if (threadIdx.x < 9) dw[((size_t)o * cpg + j) * 9 + threadIdx.x] = v;
-    else if (j == 0 && db != nullptr) db[o] = v;
+    // accumulate: the uses of the weight across the frames of the recurrence add into one buffer (autograd.grad_sink)
+    if (threadIdx.x < 9) {
+      float* d = dw + ((size_t)o * cpg + j) * 9 + threadIdx.x;
+      *d = accumulate ? *d + v : v;
+    } else if (j == 0 && db != nullptr) {
+      db[o] = accumulate ? db[o] + v : v;
+    }
   }
 }
 
@@ -247,9 +252,18 @@ extern "C" int eavsr_gconv3x3_fwd_f32(const float* x, const float* weight, const
   return eavsr::launch_status("gconv3x3_fwd");
 }
 
+extern "C" int eavsr_gconv3x3_bwd_acc_f32(const float* g, const float* x, const float* weight, float* dx, float* dweight,
+                                          float* dbias, int32_t n, int32_t cout, int32_t cpg, int32_t h, int32_t w,
+                                          int32_t accumulate, void* stream);
 extern "C" int eavsr_gconv3x3_bwd_f32(const float* g, const float* x, const float* weight, float* dx, float* dweight,
                                       float* dbias, int32_t n, int32_t cout, int32_t cpg, int32_t h, int32_t w,
                                       void* stream) {
+  return eavsr_gconv3x3_bwd_acc_f32(g, x, weight, dx, dweight, dbias, n, cout, cpg, h, w, 0, stream);
+}
+
+extern "C" int eavsr_gconv3x3_bwd_acc_f32(const float* g, const float* x, const float* weight, float* dx, float* dweight,
+                                          float* dbias, int32_t n, int32_t cout, int32_t cpg, int32_t h, int32_t w,
+                                          int32_t accumulate, void* stream) {
   EAVSR_REQUIRE(g && x && weight && dx && dweight, -1, "gconv3x3_bwd: NULL pointer");
   EAVSR_REQUIRE(n >= 0 && cout > 0 && cpg > 0 && h > 0 && w > 0 && (long)n * cout * cpg <= 65535, -1,
                 "gconv3x3_bwd: bad dims");
@@ -257,6 +271,7 @@ extern "C" int eavsr_gconv3x3_bwd_f32(const float* g, const float* x, const floa
   hipStream_t st = eavsr::as_stream(stream);
   dim3 grid(eavsr::cdiv(w, 64), eavsr::cdiv(h, 4), n * cout * cpg), block(64, 4, 1);
   hipLaunchKernelGGL(gconv3x3_dgrad_kernel, grid, block, 0, st, g, weight, dx, cout, cpg, h, w);
-  hipLaunchKernelGGL(gconv3x3_wgrad_kernel, dim3(cout * cpg), dim3(1024), 0, st, g, x, dweight, dbias, n, cout, cpg, h, w);
+  hipLaunchKernelGGL(gconv3x3_wgrad_kernel, dim3(cout * cpg), dim3(1024), 0, st, g, x, dweight, dbias, n, cout, cpg, h, w,
+                     accumulate ? 1 : 0);
   return eavsr::launch_status("gconv3x3_bwd");
 }

@@ -375,8 +375,10 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
 
 // (cout, cin, KS, KS) fp32 -> [cot][chunk][k-step][plane][mt][lane] 16-byte elements: lane (r = lane & 31, g = lane >> 5) holds
 // A[row r][k = 8 g + j] = W[cot * 32 MT + mt * 32 + r][chunk * 8 + j][tap 2 s + g], j = 0..7, plane 0 / 1 / 2 = hi / mid / lo
+// tr: `wt` is the FORWARD weight (cin, cout, k, k) of the convolution whose input gradient this launch packs for -- transposed and
+// flipped on the fly: element (co, ci, tap) = wt[ci][co][kk - 1 - tap]
 __global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p, int cout, int cin, int kk, int mt_n, long total,
-                             int np = 3, int dt = 0) {
+                             int np = 3, int dt = 0, int tr = 0) {
   const int ksteps = (kk + 1) / 2;
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
@@ -397,7 +399,7 @@ __global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int ci = ch * 8 + 2 * c + u;
-      v[u] = (co < cout && tap < kk) ? wt[((size_t)co * cin + ci) * kk + tap] : 0.f;
+      v[u] = (co < cout && tap < kk) ? (tr ? wt[((size_t)ci * cout + co) * kk + (kk - 1 - tap)] : wt[((size_t)co * cin + ci) * kk + tap]) : 0.f;
     }
     if (np == 3) {
       unsigned h2, m2, l2;
@@ -481,6 +483,17 @@ extern "C" int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int3
   hipLaunchKernelGGL(pack7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
                      reinterpret_cast<u32x4*>(packed), cout, cin, ksize * ksize, mt_of(cout), total);
   return eavsr::launch_status("pack_conv_weight_x6");
+}
+
+extern "C" int eavsr_pack_conv_weight_x6_dgrad(const float* weight, void* packed, int32_t ksize, int32_t cout_w, int32_t cin_w, void* stream) {
+  EAVSR_REQUIRE(weight && packed, -1, "pack_conv_weight_x6_dgrad: NULL pointer");
+  EAVSR_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, -2, "pack_conv_weight_x6_dgrad: kernel size %d (3, 5 and 7 only)", ksize);
+  EAVSR_REQUIRE(cout_w > 0 && cin_w > 0 && cout_w % 8 == 0, -1, "pack_conv_weight_x6_dgrad: cout %d must be a multiple of 8", cout_w);
+  // the input-gradient convolution has cin_w output and cout_w input channels
+  const long total = (long)(eavsr_conv_weight_x6_bytes(ksize, cin_w, cout_w) / 16);
+  hipLaunchKernelGGL(pack7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
+                     reinterpret_cast<u32x4*>(packed), cin_w, cout_w, ksize * ksize, mt_of(cin_w), total, 3, 0, 1);
+  return eavsr::launch_status("pack_conv_weight_x6_dgrad");
 }
 
 extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,

@@ -327,19 +327,26 @@ CONV5_MODE = os.environ.get("EAVSR_CONV5", "bf16x6")
 _conv7_pack_cache = {}
 
 
-def _packed_conv_x6(weights: Sequence[Tensor]) -> Tensor:
-    """A-operand form of a 7x7 / 5x5 weight (eavsr_pack_conv_weight_x6); cached per weight objects and versions"""
-    key = tuple((id(w), w._version) for w in weights)
+def _packed_conv_x6(weights: Sequence[Tensor], dgrad: bool = False) -> Tensor:
+    """A-operand form of a 7x7 / 5x5 / 3x3 weight (eavsr_pack_conv_weight_x6); cached per weight objects and versions.
+    dgrad=True: the form of the INPUT-GRADIENT convolution of the (single) forward weight -- transposed and flipped by the pack
+    kernel itself (eavsr_pack_conv_weight_x6_dgrad), no materialised copy."""
+    key = tuple((id(w), w._version) for w in weights) + ((("dgrad", 0),) if dgrad else ())
     hit = _conv7_pack_cache.get(key)
     if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
         return hit[1]
     w = _chk(_cat_weights(weights).detach(), "weight")
     cout, cin, k = int(w.shape[0]), int(w.shape[1]), int(w.shape[-1])
-    packed = torch.empty(lib().eavsr_conv_weight_x6_bytes(k, cout, cin), device=w.device, dtype=torch.uint8)
-    with _DeviceOf(w):
-        N.check(lib().eavsr_pack_conv_weight_x6(_p(w), _p(packed), k, cout, cin, _stream(w)), "pack_conv_weight_x6")
+    if dgrad:
+        packed = torch.empty(lib().eavsr_conv_weight_x6_bytes(k, cin, cout), device=w.device, dtype=torch.uint8)
+        with _DeviceOf(w):
+            N.check(lib().eavsr_pack_conv_weight_x6_dgrad(_p(w), _p(packed), k, cout, cin, _stream(w)), "pack_conv_weight_x6_dgrad")
+    else:
+        packed = torch.empty(lib().eavsr_conv_weight_x6_bytes(k, cout, cin), device=w.device, dtype=torch.uint8)
+        with _DeviceOf(w):
+            N.check(lib().eavsr_pack_conv_weight_x6(_p(w), _p(packed), k, cout, cin, _stream(w)), "pack_conv_weight_x6")
     ids = {id(x) for x in weights}
-    for k_ in [k_ for k_ in _conv7_pack_cache if any(i in ids for i, _ in k_)]:
+    for k_ in [k_ for k_ in _conv7_pack_cache if (k_[-1] == ("dgrad", 0)) == dgrad and any(i in ids for i, _ in k_ if isinstance(i, int))]:
         _conv7_pack_cache.pop(k_, None)
     refs = tuple(weakref.ref(x, lambda _r, k_=key, c=_conv7_pack_cache: c.pop(k_, None)) for x in weights)
     _conv7_pack_cache[key] = (refs, packed)
@@ -505,13 +512,33 @@ def ca_fusable(x: Tensor, cout: int = 64) -> bool:
 FUSE_PIXEL_SHUFFLE = os.environ.get("EAVSR_FUSE_SHUFFLE", "1") == "1"
 
 
+_dgrad_w_cache = {}
+
+
+def dgrad_weight(w: Tensor) -> Tensor:
+    """(cin, cout, k, k) transposed and flipped copy of a forward weight: the weight of its input-gradient convolution; cached
+    per weight object and version"""
+    key = (id(w), w._version)
+    hit = _dgrad_w_cache.get(key)
+    if hit is not None and hit[0]() is w:
+        return hit[1]
+    wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()
+    for k_ in [k_ for k_ in _dgrad_w_cache if k_[0] == id(w)]:
+        _dgrad_w_cache.pop(k_, None)
+    _dgrad_w_cache[key] = (weakref.ref(w, lambda _r, k_=key, c=_dgrad_w_cache: c.pop(k_, None)), wt)
+    return wt
+
+
 def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence[Tensor]],
            bias: Union[None, Tensor, Sequence[Optional[Tensor]]] = None, act: Optional[str] = None,
            slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False,
            ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False, pixel_shuffle2: bool = False,
-           sigmoid_from: Optional[int] = None):
+           sigmoid_from: Optional[int] = None, dgrad: bool = False):
     """conv over the virtual channel-concatenation of `srcs`; `weight` may be a list of weights
     that are concatenated along cout (several heads in one launch).
+    dgrad=True: `weight` is ONE forward weight (cout_w, cin_w, k, k) and the call computes the input gradient of its stride-1
+    "same" convolution from srcs = dY (cout_w channels): the convolution with the transposed, flipped weight.  The small-launch
+    bf16x6 kernel packs that form straight from `weight`; every other route materialises it once per weight version.
     sigmoid_from=c: output channels >= c (a multiple of 8) leave through the sigmoid instead of `act` (the mask head of the
     predictor, networks.py:313-314) -- in the epilogue of the bf16x6 5x5 / 7x7 kernel, by torch on every other route.
     pixel_shuffle2=True returns F.pixel_shuffle(out, 2) -- written by the F(4x4,3x3) kernel's epilogue itself where that kernel
@@ -532,9 +559,20 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         if s.shape[0] != n or tuple(s.shape[2:]) != (h, w):
             raise ValueError("all sources must share n,h,w")
     cin = sum(int(s.shape[1]) for s in srcs)
-    cout = sum(int(x.shape[0]) for x in weights)
+    if dgrad:
+        if len(weights) != 1 or biases != [None] or chan_partial or ca is not None or pixel_shuffle2 or sigmoid_from is not None:
+            raise ValueError("dgrad: one forward weight, no bias / channel sums / prologue / shuffle / sigmoid")
+        if int(weights[0].shape[0]) != cin:
+            raise ValueError(f"dgrad: the forward weight has {int(weights[0].shape[0])} output channels, dY gives {cin}")
+        k_ = int(weights[0].shape[-1])
+        # only the small-launch bf16x6 kernel reads the forward weight in place (necessary conditions; the decision is below)
+        if not (CONV3_SMALL == "x6s" and CONV_MODE in ("winograd", "winograd4") and k_ == 3 and len(srcs) == 1 and cin == 64
+                and int(weights[0].shape[1]) not in (2, 3, 4, 6) and CONV3_H16 is None
+                and n * lib().eavsr_conv3x3_x6s_tiles(h, w) <= X6S_MAX_TILES):
+            return conv2d(srcs, dgrad_weight(weights[0]), None, act, slope, residual)
+    cout = sum(int(x.shape[0]) for x in weights) if not dgrad else int(weights[0].shape[1])
     k = int(weights[0].shape[-1])
-    if any(int(x.shape[1]) != cin for x in weights):
+    if not dgrad and any(int(x.shape[1]) != cin for x in weights):
         raise ValueError(f"weight expects {[int(x.shape[1]) for x in weights]} input channels, sources give {cin}")
     if pixel_shuffle2 and (cout % 4 or residual is not None or chan_partial or ca is not None):
         raise ValueError("pixel_shuffle2: cout % 4 == 0, no residual / channel sums / channel-attention prologue")
@@ -594,6 +632,8 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     use_x6s = (CONV3_SMALL == "x6s" and CONV_MODE in ("winograd", "winograd4") and k == 3 and len(srcs) == 1 and cin == 64
                and ca is None and not pixel_shuffle2 and not use_wino
                and n * lib().eavsr_conv3x3_x6s_tiles(h, w) <= X6S_MAX_TILES)
+    if dgrad and not use_x6s:      # (e.g. a large launch that the Winograd kernel takes)
+        weights, dgrad = [dgrad_weight(weights[0])], False
     wp = None if use_x6s else pack_cache.get(weights)      # (the x6s kernel has its own packed form)
     part = None
     if chan_partial:
@@ -638,7 +678,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     st = _stream(out)
     px = float(n) * h * w
     if use_x6s:
-        wq = _packed_conv_x6(weights)
+        wq = _packed_conv_x6(weights, dgrad=dgrad)
         _launch(f"conv3x3_{cin}to{cout}_x6s", 2.0 * cin * cout * 9 * px,
                 4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
                 lambda: lib().eavsr_conv3x3_f32x6s(C.byref(d), _p(wq), st), "conv3x3_f32x6s")
@@ -1630,14 +1670,23 @@ def gconv3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], cpg: int, act: O
     return out
 
 
-def gconv3x3_bwd(g: Tensor, x: Tensor, weight: Tensor, cpg: int):
+def gconv3x3_bwd(g: Tensor, x: Tensor, weight: Tensor, cpg: int, grads=None, accumulate: bool = False):
+    """grads=(dweight, dbias) buffers: written -- or, accumulate=True, added to -- in place (autograd.grad_sink)"""
     g, x, weight = _chk(g, "g"), _chk(x, "x"), _chk(weight.detach(), "weight")
     n, cout, h, w = g.shape
-    dx, dw = torch.empty_like(x), torch.empty_like(weight)
-    db = torch.empty(cout, device=g.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    if grads is None:
+        dw, db = torch.empty_like(weight), torch.empty(cout, device=g.device, dtype=torch.float32)
+        accumulate = False
+    else:
+        dw, db = grads
+        if (tuple(dw.shape) != tuple(weight.shape) or tuple(db.shape) != (cout,) or not dw.is_contiguous() or dw.dtype != torch.float32
+                or db.dtype != torch.float32 or dw.device != g.device or db.device != g.device):
+            raise ValueError("gconv3x3_bwd: grads = contiguous fp32 (dweight, dbias) of the parameters' shapes on g's device")
     st = _stream(g)
     _launch("gconv3x3_bwd", 36.0 * cpg * g.numel(), 4.0 * (2 * x.numel() + g.numel()), g,
-            lambda: lib().eavsr_gconv3x3_bwd_f32(_p(g), _p(x), _p(weight), _p(dx), _p(dw), _p(db), n, cout, cpg, h, w, st),
+            lambda: lib().eavsr_gconv3x3_bwd_acc_f32(_p(g), _p(x), _p(weight), _p(dx), _p(dw), _p(db), n, cout, cpg, h, w,
+                                                     int(bool(accumulate)), st),
             "gconv3x3_bwd")
     return dx, dw, db
 

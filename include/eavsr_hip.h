@@ -298,6 +298,11 @@ int eavsr_conv3x3_smallco_lite_f32(const float* x, const float* weight_packed, c
  * this library (eavsr_dcnv2_f32x9, eavsr_dcnv2_il_f32, eavsr_dcnv2_il2_f32, eavsr_conv3x3_f32x9).                            */
 size_t eavsr_conv_weight_x6_bytes(int32_t ksize, int32_t cout, int32_t cin);
 int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int32_t ksize, int32_t cout, int32_t cin, void* stream);
+/* The same packed form for the INPUT-GRADIENT convolution of a stride-1 "same" convolution with forward weight `weight`
+ * (cout_w, cin_w, k, k) (ABI 27): the transposed, flipped weight W'[ci][co][tap] = W[co][ci][k*k - 1 - tap] is read in place, no
+ * materialised copy (loss.backward() of every nn.Conv2d of RCABlock, models/networks.py:456-464; eavsrp_model.py:109-113).  The
+ * result packs a (cin_w output, cout_w input)-channel convolution: eavsr_conv_weight_x6_bytes(ksize, cin_w, cout_w) bytes. */
+int eavsr_pack_conv_weight_x6_dgrad(const float* weight, void* packed, int32_t ksize, int32_t cout_w, int32_t cin_w, void* stream);
 int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin, int32_t cout,
                      int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t sigmoid_from, void* stream);
 /* The 3x3 form for SMALL launches (ABI 27): 64 input channels, one source, the same exact bf16x6 arithmetic; the descriptor's bias,
@@ -477,6 +482,10 @@ int eavsr_gconv3x3_fwd_f32(const float* x, const float* weight, const float* bia
                            int32_t cout, int32_t cpg, int32_t h, int32_t w, int32_t act, float slope, void* stream);
 int eavsr_gconv3x3_bwd_f32(const float* g, const float* x, const float* weight, float* dx, float* dweight,
                            float* dbias, int32_t n, int32_t cout, int32_t cpg, int32_t h, int32_t w, void* stream);
+/* accumulate != 0: dweight / dbias are added to (the uses of the weight across the frames of the recurrence, ABI 27) */
+int eavsr_gconv3x3_bwd_acc_f32(const float* g, const float* x, const float* weight, float* dx, float* dweight,
+                               float* dbias, int32_t n, int32_t cout, int32_t cpg, int32_t h, int32_t w, int32_t accumulate,
+                               void* stream);
 
 /* ============================================================================================
  * 16-bit residual backbone (BASELINE.json configs[2] bf16 / configs[4] fp16; SURVEY.md 8a: a10, a11).

@@ -292,6 +292,27 @@ def test_conv3x3_small_launches_bf16x6_matches_fp64_and_the_fp32_kernel(ops, cud
         assert (outs["x6s"][r == 0] == 0).all()
 
 
+@pytest.mark.parametrize("case", [(64, 2, 96, 96), (40, 1, 19, 37), (64, 1, 180, 320), (6, 1, 24, 40)])
+def test_conv2d_dgrad_flag_reads_the_forward_weight_in_place(ops, cuda, case):
+    """conv2d(dY, W, dgrad=True) = the input gradient of conv(x, W): the small-launch bf16x6 kernel packs the transposed, flipped
+    weight straight from W (eavsr_pack_conv_weight_x6_dgrad) -- bit-identical to the same kernel on the materialised copy; large
+    launches and small channel counts materialise it (the other kernels' routes), same values as torch's conv_transpose."""
+    cin_w, n, h, w = case
+    dy = cases.randn(95, n, 64, h, w)
+    wt = cases.randn(96, 64, cin_w, 3, 3, scale=1.0 / 24)
+    r = torch.relu(cases.randn(97, n, cin_w, h, w))
+    ref = torch.nn.grad.conv2d_input((n, cin_w, h, w), wt.double(), dy.double(), padding=1)
+    gd, gw, gr = g(dy, cuda), g(wt, cuda), g(r, cuda)
+    for kw, want in ((dict(), ref), (dict(residual=gr), ref + r.double()),
+                     (dict(residual=gr, act="relu_mask"), torch.where(r > 0, ref, torch.zeros_like(ref)))):
+        got = ops.conv2d(gd, gw, None, dgrad=True, **kw)
+        mat = ops.conv2d(gd, ops.dgrad_weight(gw), None, **kw)
+        assert torch.equal(got, mat)
+        assert H.maxabs(got.cpu().double(), want) <= 2e-5 * max(1.0, want.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.conv2d(gd, gw, g(cases.randn(98, cin_w), cuda), dgrad=True)
+
+
 @pytest.mark.parametrize("k", [5, 7])
 @pytest.mark.parametrize("shape", [(8, 1, 1, 1, 1), (8, 33, 2, 3, 2), (16, 64, 1, 5, 200), (8, 5, 3, 2, 37), (40, 3, 0, 9, 9)])
 def test_conv_bf16x6_degenerate_shapes(ops, cuda, k, shape):

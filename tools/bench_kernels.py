@@ -88,5 +88,16 @@ if "h16b" in which:
             ops.conv3x3_c64_h16(t16, w33b, b, chan_partial=True)
         for _ in range(reps):
             ops.rcab_convs_h16(x16, w33, b, w33b, b, chan_partial=True)
+if "train" in which:
+    # the training step's two dominant kernels at configs[3]'s launch shapes: the crop-sized 3x3 64 -> 64 convolution (2 x 64 x 96 x 96)
+    # and the 3x3 weight gradient over the seven frames of a clip as segments of one launch
+    xt = r(2, 64, 96, 96)
+    for _ in range(reps):
+        ops.conv2d(xt, w33, b, act="relu")
+    dys = [r(2, 64, 96, 96) for _ in range(7)]
+    xs = [[r(2, 64, 96, 96)] for _ in range(7)]
+    dw = torch.empty(64, 64, 3, 3, device=dev)
+    for _ in range(reps):
+        ops.conv_wgrad_multi(dys, xs, 3, out=dw)
 torch.cuda.synchronize()
 print("done")
