@@ -101,6 +101,7 @@ SIGNATURES = {
     "eavsr_ca_scale_mean_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_scale_residual_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_ca_tail_f32": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_ca_tail_stats_f32": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_adapt_frontend_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_flow_level_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, vp]),
     "eavsr_affine_offsets_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
@@ -126,6 +127,7 @@ SIGNATURES = {
     "eavsr_conv_wgrad_blocks": (i32, [i32, i32, i32, i32]),
     "eavsr_conv_wgrad_f32": (C.c_int, [vp, vp, vp, vp] + [i32] * 11 + [vp]),
     "eavsr_conv_wgrad_multi_f32": (C.c_int, [vp, vp, i32, vp, vp] + [i32] * 11 + [vp]),
+    "eavsr_conv_wgrad_bias_multi_f32": (C.c_int, [vp, vp, i32, vp, vp, vp] + [i32] * 11 + [vp]),
     "eavsr_dcnv2_im2col_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_col2im_f32": (C.c_int, [vp] * 7 + [i32, i32, i32, i32, i32, vp]),
     "eavsr_gconv3x3_fwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),

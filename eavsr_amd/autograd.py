@@ -97,9 +97,8 @@ class grad_sink:
         if not pend:
             return
         acc = e["written"]
-        ops.conv_wgrad_multi([g for g, _ in pend], [ss for _, ss in pend], e["k"], out=e["dW"], accumulate=acc)
-        if e["db"] is not None:
-            ops.channel_sum_multi([g for g, _ in pend], out=e["db"], accumulate=acc)
+        # (the bias gradient rides in the weight-gradient launch: the 3x3 kernel stages dY anyway)
+        ops.conv_wgrad_multi([g for g, _ in pend], [ss for _, ss in pend], e["k"], out=e["dW"], accumulate=acc, bias_out=e["db"])
         e["written"] = True
         e["pending"] = []
 
@@ -462,10 +461,12 @@ class _RcabFn(Function):
         n, c, h, w = x.shape
         t = ops.conv2d([x], [w1], [b1], act="relu")
         r, partial = ops.conv2d([t], [w2], [b2], chan_partial=True)
-        scale, mean = ops.ca_scale(partial, h * w, wa, ba, wb, bb, with_mean=True)
+        # the tail as ONE launch (every workgroup redoes the 64 -> 4 -> 64 MLP of its sample from the per-tile sums: 9 KB at a crop;
+        # in the one-stream training graph the launch it saves is a pure gain -- unlike the two-stream inference step)
+        out, scale, mean = ops.ca_tail(r, partial, wa, ba, wb, bb, x, with_stats=True)
         ctx.save_for_backward(x, t, r, mean, scale, w1, w2, wa, ba, wb, bb)
         ctx.params = ([w1], [b1], [w2], [b2], [wa, ba, wb, bb])      # the caller's tensor objects (grad_sink keys on them)
-        return ops.scale_residual(r, scale, x)
+        return out
 
     @staticmethod
     def backward(ctx, d):

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
                                                             int tiles, float inv_hw, const float* __restrict__ w1,
                                                             const float* __restrict__ b1, const float* __restrict__ w2,
                                                             const float* __restrict__ b2, const float* __restrict__ x,
-                                                            float* __restrict__ out, int c, int cr, int hw4, int slice) {
+                                                            float* __restrict__ out, int c, int cr, int hw4, int slice,
+                                                            float* __restrict__ scale_out, float* __restrict__ mean_out) {
   extern __shared__ float sm[];  // part[Q*c] then mean[c] then hidden[cr] then scale[c]
   const int Q = CA_THREADS / c;  // the grouping of ca_scale_kernel (1024 logical threads), whatever this kernel's width
   float* part = sm;
@@ -150,6 +151,12 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
     s_scale[ch] = 1.f / (1.f + expf(-v));
   }
   __syncthreads();
+  // (training: the backward of CALayer needs the attention and the channel means -- written once per sample)
+  if (blockIdx.x == 0 && scale_out != nullptr)
+    for (int ch = tid; ch < c; ch += CT_THREADS) {
+      scale_out[(size_t)bn * c + ch] = s_scale[ch];
+      if (mean_out != nullptr) mean_out[(size_t)bn * c + ch] = mean[ch];
+    }
   // 2. out = r * scale + x over the slice: flat piece f -> channel f / len, column f % len (kept incrementally)
   const int p0 = blockIdx.x * slice, len = min(slice, hw4 - p0);
   const int total = len * c;
@@ -209,9 +216,18 @@ extern "C" int eavsr_scale_residual_f32(const float* r, const float* scale, cons
   return eavsr::launch_status("scale_residual");
 }
 
+extern "C" int eavsr_ca_tail_stats_f32(const float* r, const float* chan_partial, int32_t tiles, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, const float* x, float* out, float* scale_out,
+                                       float* mean_out, int32_t n, int32_t c, int32_t cr, int32_t hw, void* stream);
 extern "C" int eavsr_ca_tail_f32(const float* r, const float* chan_partial, int32_t tiles, const float* w1, const float* b1,
                                  const float* w2, const float* b2, const float* x, float* out, int32_t n, int32_t c,
                                  int32_t cr, int32_t hw, void* stream) {
+  return eavsr_ca_tail_stats_f32(r, chan_partial, tiles, w1, b1, w2, b2, x, out, nullptr, nullptr, n, c, cr, hw, stream);
+}
+
+extern "C" int eavsr_ca_tail_stats_f32(const float* r, const float* chan_partial, int32_t tiles, const float* w1, const float* b1,
+                                       const float* w2, const float* b2, const float* x, float* out, float* scale_out,
+                                       float* mean_out, int32_t n, int32_t c, int32_t cr, int32_t hw, void* stream) {
   EAVSR_REQUIRE(r && chan_partial && w1 && b1 && w2 && b2 && x && out, -1, "ca_tail: NULL pointer");
   EAVSR_REQUIRE(n >= 0 && c > 0 && cr > 0 && tiles > 0 && hw > 0 && n <= 65535, -1, "ca_tail: bad dims");
   EAVSR_REQUIRE(c <= 256 && cr <= 256, -2, "ca_tail: c=%d / cr=%d unsupported (<= 256)", c, cr);
@@ -226,6 +242,7 @@ extern "C" int eavsr_ca_tail_f32(const float* r, const float* chan_partial, int3
   const int bx = eavsr::cdiv(hw4, slice);
   const int Q = CA_THREADS / c;
   hipLaunchKernelGGL(ca_tail_kernel, dim3(bx, n), dim3(CT_THREADS), (size_t)(Q * c + c + cr + c) * sizeof(float),
-                     eavsr::as_stream(stream), r, chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, x, out, c, cr, hw4, slice);
+                     eavsr::as_stream(stream), r, chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, x, out, c, cr, hw4, slice,
+                     scale_out, mean_out);
   return eavsr::launch_status("ca_tail");
 }

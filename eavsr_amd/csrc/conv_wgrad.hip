@@ -29,6 +29,7 @@ struct WgradArgs {
   const float* dyv[WG_MAX_SEG];   // (n, cout_total, h, w) each, this launch uses channels co0 .. co0+63
   const float* xv[WG_MAX_SEG];    // (n, cin_src, h, w) each,   this launch uses channels ci0 .. ci0+63
   float* ws;         // [blocks][64][64][KK]
+  float* ws_bias;    // [blocks][64] per-workgroup sums of dY over its tiles (the bias gradient), or NULL; conv_wgrad3_x6_kernel only
   int n, h, w, cout_total, co0, co_valid, cin_src, ci0, ci_valid, tiles_x, tiles_y, num_tiles;   // n: images per segment
 };
 
@@ -434,7 +435,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_x6_kernel(WgradArgs a) {
     vh[0] = x0 > 0 ? wx_ld(r_x, vh_, (unsigned)x0 * 4u - 4u) : 0.f;
     vh[1] = x0 + TW < w ? wx_ld(r_x, vh_, (unsigned)x0 * 4u + TW * 4u) : 0.f;
   };
+  float bsum = 0.f;      // this thread's share of sum(dY) of channel `chn` (the bias gradient rides along: dY is staged here anyway)
   auto stage = [&]() __attribute__((always_inline)) {
+    if (ct == 0 && a.ws_bias != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bsum += (va[i][0] + va[i][1]) + (va[i][2] + va[i][3]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       unsigned h0, m0, l0, h1, m1, l1;
@@ -562,6 +568,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_x6_kernel(WgradArgs a) {
   for (int tap = 0; tap < KK; ++tap) asm volatile("" ::"v"(acc[tap]));
   return;
 #endif
+  if (ct == 0 && a.ws_bias != nullptr) {      // eight lanes per channel (the quads of a row), then the slab's 32 channels of this quadrant
+    float v = bsum;
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    if (q8 == 0) a.ws_bias[(size_t)blockIdx.x * 64 + 32 * mt + chn] = v;
+  }
   // Three taps per round (48 KB of LDS, two barriers); the slab is TAP-MAJOR, ws[blk][tap][co][ci], so that a half-wave stores
   // 32 consecutive input channels (the [co][ci][tap] form of the fp32 kernels is a 36-byte stride per lane: nine partial passes
   // over every line; 10 us of a 27 us one-segment launch together with nine rounds of barriers).
@@ -595,9 +608,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3_x6_kernel(WgradArgs a) {
 // in wave order: deterministic.  tap_major: the slab is [tap][co][ci] (the bf16x6 3x3 kernel), otherwise [co][ci][tap].
 __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int blocks, int kk, int co0, int co_valid, int ci_dst0,
-                                                           int ci_valid, int cin_total, int accumulate, int tap_major) {
+                                                           int ci_valid, int cin_total, int accumulate, int tap_major,
+                                                           const float* __restrict__ ws_bias, float* __restrict__ dbias) {
   __shared__ float part[8][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if ((int)blockIdx.x == 64 * kk) {      // the extra workgroup: dbias[co0 + co] (+)= sum_blk ws_bias[blk][co], same order
+    float s = 0.f;
+    for (int b = wv; b < blocks; b += 8) s += ws_bias[(size_t)b * 64 + lane];
+    part[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && lane < co_valid) {
+      const float t = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) +
+                      ((part[4][lane] + part[5][lane]) + (part[6][lane] + part[7][lane]));
+      dbias[co0 + lane] = accumulate ? dbias[co0 + lane] + t : t;
+    }
+    return;
+  }
   const int i = blockIdx.x * 64 + lane;
   const int total = 64 * 64 * kk;   // a multiple of 64
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -693,10 +719,24 @@ extern "C" int32_t eavsr_conv_wgrad_blocks(int32_t n, int32_t h, int32_t w, int3
   return (int32_t)(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
 }
 
+extern "C" int eavsr_channel_sum_multi_f32(const void* const* a_list, int32_t nseg, float* out, int32_t n, int32_t c, int32_t hw,
+                                           int32_t accumulate, void* stream);
+extern "C" int eavsr_conv_wgrad_bias_multi_f32(const void* const* dy_list, const void* const* x_list, int32_t nseg, float* dweight,
+                                               float* dbias, float* workspace, int32_t n, int32_t h, int32_t w, int32_t cout_total,
+                                               int32_t co0, int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0,
+                                               int32_t ksize, int32_t accumulate, void* stream);
 extern "C" int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void* const* x_list, int32_t nseg, float* dweight,
                                           float* workspace, int32_t n, int32_t h, int32_t w, int32_t cout_total, int32_t co0,
                                           int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,
                                           int32_t accumulate, void* stream) {
+  return eavsr_conv_wgrad_bias_multi_f32(dy_list, x_list, nseg, dweight, nullptr, workspace, n, h, w, cout_total, co0, cin_src, ci0,
+                                         cin_total, ci_dst0, ksize, accumulate, stream);
+}
+
+extern "C" int eavsr_conv_wgrad_bias_multi_f32(const void* const* dy_list, const void* const* x_list, int32_t nseg, float* dweight,
+                                               float* dbias, float* workspace, int32_t n, int32_t h, int32_t w, int32_t cout_total,
+                                               int32_t co0, int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0,
+                                               int32_t ksize, int32_t accumulate, void* stream) {
   EAVSR_REQUIRE(dy_list && x_list && dweight && workspace, -1, "conv_wgrad: NULL pointer");
   EAVSR_REQUIRE(nseg >= 1 && nseg <= WG_MAX_SEG, -1, "conv_wgrad: %d segments (1..%d)", nseg, WG_MAX_SEG);
   EAVSR_REQUIRE(ksize == 1 || ksize == 3 || ksize == 5, -2, "conv_wgrad: kernel size %d unsupported (1, 3, 5)", ksize);
@@ -710,6 +750,7 @@ extern "C" int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void
     EAVSR_REQUIRE(a.dyv[s] && a.xv[s], -1, "conv_wgrad: NULL segment pointer");
   }
   a.ws = workspace;
+  a.ws_bias = nullptr;
   a.n = n; a.h = h; a.w = w;
   a.cout_total = cout_total; a.co0 = co0; a.co_valid = cout_total - co0 < 64 ? cout_total - co0 : 64;
   a.cin_src = cin_src; a.ci0 = ci0; a.ci_valid = cin_src - ci0 < 64 ? cin_src - ci0 : 64;
@@ -726,8 +767,10 @@ extern "C" int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void
   bool x6 = ksize == 3 && n > 0 && w % 4 == 0 && (long)h * w * 128 < (1L << 31) && wgrad3_x6_enabled();
   for (int s = 0; x6 && s < nseg; ++s)
     x6 = ((reinterpret_cast<uintptr_t>(a.dyv[s]) | reinterpret_cast<uintptr_t>(a.xv[s])) & 15) == 0;
+  const int kk = ksize * ksize;
   if (x6) {
     WgradArgs b = a;
+    if (dbias != nullptr) b.ws_bias = workspace + (size_t)blocks * 64 * 64 * kk;      // behind the slabs (the caller sized it)
     b.tiles_y = eavsr::cdiv(h, Wx6Cfg::TH);
     EAVSR_REQUIRE((long)b.tiles_x * b.tiles_y * n * nseg < (1L << 31), -1, "conv_wgrad: too many tiles");
     b.num_tiles = b.tiles_x * b.tiles_y * n * nseg;
@@ -742,10 +785,16 @@ extern "C" int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void
     }
   }
   if (rc) return rc;
-  const int kk = ksize * ksize;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64 * kk), dim3(512), 0, st, workspace, dweight,
-                     n == 0 ? 0 : slabs, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate, x6 ? 1 : 0);
-  return eavsr::launch_status("conv_wgrad_reduce");
+  const bool bias_in_kernel = x6 && dbias != nullptr;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64 * kk + (bias_in_kernel ? 1 : 0)), dim3(512), 0, st, workspace, dweight,
+                     n == 0 ? 0 : slabs, kk, co0, a.co_valid, ci_dst0, a.ci_valid, cin_total, accumulate, x6 ? 1 : 0,
+                     bias_in_kernel ? workspace + (size_t)blocks * 64 * 64 * kk : nullptr, dbias);
+  rc = eavsr::launch_status("conv_wgrad_reduce");
+  if (rc) return rc;
+  // every other kernel: the bias gradient of ALL output channels as its own launch, once (with the first 64-channel block)
+  if (dbias != nullptr && !bias_in_kernel && co0 == 0)
+    return eavsr_channel_sum_multi_f32(dy_list, nseg, dbias, n, cout_total, h * w, accumulate, stream);
+  return 0;
 }
 
 extern "C" int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float* workspace,

@@ -1331,25 +1331,32 @@ def ca_scale(partial: Tensor, hw: int, w1: Tensor, b1: Tensor, w2: Tensor, b2: T
     return (scale, mean) if with_mean else scale
 
 
-def ca_tail(r: Tensor, partial: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, x: Tensor) -> Tensor:
+def ca_tail(r: Tensor, partial: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, x: Tensor, with_stats: bool = False):
     """the RCAB tail in one launch: r * sigmoid(W2 relu(W1 mean_hw(r) + b1) + b2) + x with mean_hw(r) from the conv's per-tile
-    channel sums `partial` (n, tiles, c); falls back to ca_scale + scale_residual where the fused kernel's alignment rules fail"""
+    channel sums `partial` (n, tiles, c); falls back to ca_scale + scale_residual where the fused kernel's alignment rules fail.
+    with_stats=True also returns the attention (n, c) and the channel means (n, c) (the backward of CALayer needs them):
+    (out, scale, mean)."""
     r, x, partial = _chk(r, "r"), _chk(x, "x"), _chk(partial, "partial")
     n, c, h, w = r.shape
     if x.shape != r.shape or partial.shape[0] != n or partial.shape[2] != c:
         raise ValueError("ca_tail: shape mismatch")
     hw = h * w
     if hw % 4 or (r.data_ptr() | x.data_ptr()) % 16 or c > 256:
+        if with_stats:
+            scale, mean = ca_scale(partial, hw, w1, b1, w2, b2, with_mean=True)
+            return scale_residual(r, scale, x), scale, mean
         return scale_residual(r, ca_scale(partial, hw, w1, b1, w2, b2), x)
     tiles = int(partial.shape[1])
     cr = int(w1.shape[0])
     w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
     out = torch.empty_like(r)
+    scale = torch.empty((n, c), device=r.device, dtype=torch.float32) if with_stats else None
+    mean = torch.empty((n, c), device=r.device, dtype=torch.float32) if with_stats else None
     st = _stream(r)
     _launch("ca_tail", 2.0 * r.numel(), 12.0 * r.numel(), r,
-            lambda: lib().eavsr_ca_tail_f32(_p(r), _p(partial), tiles, _p(w1), _p(b1), _p(w2), _p(b2), _p(x), _p(out), n, c, cr,
-                                            hw, st), "ca_tail")
-    return out
+            lambda: lib().eavsr_ca_tail_stats_f32(_p(r), _p(partial), tiles, _p(w1), _p(b1), _p(w2), _p(b2), _p(x), _p(out),
+                                                  _p(scale), _p(mean), n, c, cr, hw, st), "ca_tail")
+    return (out, scale, mean) if with_stats else out
 
 
 def scale_residual(r: Tensor, scale: Tensor, x: Tensor) -> Tensor:
@@ -1570,11 +1577,13 @@ def _ptr_array(tensors):
 
 
 def conv_wgrad_multi(dys: Sequence[Tensor], srcs_list: Sequence[Sequence[Tensor]], ksize: int, out: Tensor,
-                     accumulate: bool = False) -> Tensor:
+                     accumulate: bool = False, bias_out: Optional[Tensor] = None) -> Tensor:
     """`conv_wgrad` over several USES of one weight in one launch per (source, 64-channel block): dys[s] / srcs_list[s] are
     the (dY, sources) pairs of use s, all of the same shapes (the frames of the recurrence: eavsrp_model.py:271-324).  The K
     dimension of the weight-gradient GEMM becomes pixels x uses -- a 2 x 96 x 96 training crop has 72 tiles per use for 256
-    CUs -- and the per-use accumulation into `out` becomes one slab reduction.  At most WGRAD_MAX_SEGMENTS uses per call."""
+    CUs -- and the per-use accumulation into `out` becomes one slab reduction.  At most WGRAD_MAX_SEGMENTS uses per call.
+    bias_out (cout,): the bias gradient sum(dY) is written (or, accumulate=True, added) there as well -- by the bf16x6 3x3 kernel
+    itself, which stages dY anyway, by a channel-sum launch otherwise (eavsr_conv_wgrad_bias_multi_f32)."""
     nseg = len(dys)
     if not 1 <= nseg <= WGRAD_MAX_SEGMENTS or len(srcs_list) != nseg:
         raise ValueError(f"conv_wgrad_multi: 1..{WGRAD_MAX_SEGMENTS} segments")
@@ -1594,7 +1603,10 @@ def conv_wgrad_multi(dys: Sequence[Tensor], srcs_list: Sequence[Sequence[Tensor]
     blocks = lib().eavsr_conv_wgrad_blocks(n * nseg, h, w, ksize)
     if blocks <= 0:
         raise NotImplementedError(f"conv_wgrad: kernel size {ksize}")
-    ws = torch.empty(blocks * 64 * 64 * ksize * ksize, device=dw.device, dtype=torch.float32)
+    if bias_out is not None and (tuple(bias_out.shape) != (cout,) or not bias_out.is_contiguous() or bias_out.dtype != torch.float32
+                                 or bias_out.device != dw.device):
+        raise ValueError("conv_wgrad_multi: bias_out must be a contiguous fp32 (cout,) tensor on dy's device")
+    ws = torch.empty(blocks * (64 * 64 * ksize * ksize + 64), device=dw.device, dtype=torch.float32)
     st = _stream(dw)
     dyl = _ptr_array(dys)
     base = 0
@@ -1603,10 +1615,11 @@ def conv_wgrad_multi(dys: Sequence[Tensor], srcs_list: Sequence[Sequence[Tensor]
         xl = _ptr_array([ss[si] for ss in srcs_list])
         for ci0 in range(0, cs, 64):
             for co0 in range(0, cout, 64):
+                db = bias_out if (si == 0 and ci0 == 0) else None      # once per 64-channel block of outputs
                 _launch(f"conv_wgrad{ksize}x{ksize}", 2.0 * min(64, cout - co0) * min(64, cs - ci0) * ksize * ksize * n * nseg * h * w,
                         4.0 * n * nseg * h * w * 128, dw,
-                        lambda xl=xl, cs=cs, ci0=ci0, co0=co0, base=base: lib().eavsr_conv_wgrad_multi_f32(
-                            dyl, xl, nseg, _p(dw), _p(ws), n, h, w, cout, co0, cs, ci0, cin, base + ci0, ksize, acc, st),
+                        lambda xl=xl, cs=cs, ci0=ci0, co0=co0, base=base, db=db: lib().eavsr_conv_wgrad_bias_multi_f32(
+                            dyl, xl, nseg, _p(dw), _p(db), _p(ws), n, h, w, cout, co0, cs, ci0, cin, base + ci0, ksize, acc, st),
                         "conv_wgrad")
         base += cs
     return dw

@@ -342,6 +342,11 @@ int eavsr_scale_residual_f32(const float* r, const float* scale, const float* x,
 int eavsr_ca_tail_f32(const float* r, const float* chan_partial, int32_t tiles, const float* w1, const float* b1,
                       const float* w2, const float* b2, const float* x, float* out, int32_t n, int32_t c, int32_t cr,
                       int32_t hw, void* stream);
+/* The same launch also writing the attention scale_out (n, c) and, when mean_out != NULL, the channel means (n, c) -- what the
+ * backward of CALayer needs (training step, ABI 27); scale_out == NULL: eavsr_ca_tail_f32. */
+int eavsr_ca_tail_stats_f32(const float* r, const float* chan_partial, int32_t tiles, const float* w1, const float* b1,
+                            const float* w2, const float* b2, const float* x, float* out, float* scale_out, float* mean_out,
+                            int32_t n, int32_t c, int32_t cr, int32_t hw, void* stream);
 
 /* ---- a3 / a6 front end ----------------------------------------------------------------------
  * AdaptBlock2_3x3 / AdaptBlockOffset `concat` + `concat2` (models/networks.py:290-291,300 and
@@ -465,6 +470,14 @@ int eavsr_conv_wgrad_multi_f32(const void* const* dy_list, const void* const* x_
                                float* workspace, int32_t n, int32_t h, int32_t w, int32_t cout_total, int32_t co0,
                                int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,
                                int32_t accumulate, void* stream);
+/* The same with the BIAS gradient riding along (ABI 27): dbias (cout_total,) or NULL.  dbias[co0 .. co0 + 63] (+)= sum over
+ * segments, images and pixels of dy -- inside the bf16x6 3x3 kernel (which stages dY anyway); every other kernel launches
+ * eavsr_channel_sum_multi_f32 over ALL channels with the co0 == 0 call.  Pass dbias with ONE (source, ci0) per co0 block.
+ * workspace: eavsr_conv_wgrad_blocks(n * nseg, h, w, ksize) * (64*64*ksize*ksize + 64) floats. */
+int eavsr_conv_wgrad_bias_multi_f32(const void* const* dy_list, const void* const* x_list, int32_t nseg, float* dweight,
+                                    float* dbias, float* workspace, int32_t n, int32_t h, int32_t w, int32_t cout_total,
+                                    int32_t co0, int32_t cin_src, int32_t ci0, int32_t cin_total, int32_t ci_dst0, int32_t ksize,
+                                    int32_t accumulate, void* stream);
 
 /* DCNv2 backward samplers (the two GEMMs run on eavsr_conv_wgrad_f32 / eavsr_conv2d_f32 with k = 1):
  * columns (n, c*9, h, w) = im2col(x, offset, mask);  from dcolumns: dx (pre-zeroed, atomics; NULL = skip),

@@ -541,6 +541,13 @@ def test_conv_wgrad_over_several_uses_in_one_launch(cuda, k, nseg, shape):
     ops.conv_wgrad_multi(gd[:1], [[ga[0], gb[0]]], k, out=out, accumulate=True)       # (+)= one more use
     want1 = want + torch.nn.grad.conv2d_weight(torch.cat([xa[0], xb[0]], 1).double(), (cout, c + 24, k, k), dys[0].double(), padding=k // 2)
     assert H.maxabs(out.cpu().double(), want1) <= 2e-5 * scale
+    db2 = torch.full((cout,), 7.0, device=cuda)      # the bias gradient riding in the weight-gradient launch (ABI 27)
+    out2 = torch.empty_like(out)
+    ops.conv_wgrad_multi(gd, [[a, b] for a, b in zip(ga, gb)], k, out=out2, bias_out=db2)
+    assert H.maxabs(out2.cpu().double(), want) <= 2e-5 * scale
+    assert H.maxabs(db2.cpu().double(), want_b) <= 1e-5 * max(1.0, want_b.abs().max().item()) + 1e-4
+    ops.conv_wgrad_multi(gd[:2], [[ga[0], gb[0]], [ga[1], gb[1]]], k, out=out2, bias_out=db2, accumulate=True)
+    assert H.maxabs(db2.cpu().double(), want_b + dys[0].double().sum(dim=(0, 2, 3)) + dys[1].double().sum(dim=(0, 2, 3))) <= 1e-3
     db = torch.empty(cout, device=cuda)
     ops.channel_sum_multi(gd, out=db)
     assert H.maxabs(db.cpu().double(), want_b) <= 1e-5 * max(1.0, want_b.abs().max().item()) + 1e-4
