@@ -127,6 +127,7 @@ SIGNATURES = {
     "eavsr_conv_wgrad_blocks": (i32, [i32, i32, i32, i32]),
     "eavsr_conv_wgrad_f32": (C.c_int, [vp, vp, vp, vp] + [i32] * 11 + [vp]),
     "eavsr_conv_wgrad_multi_f32": (C.c_int, [vp, vp, i32, vp, vp] + [i32] * 11 + [vp]),
+    "eavsr_conv_wgrad_span_f32": (C.c_int, [vp, vp, vp, vp] + [i32] * 9 + [vp]),
     "eavsr_conv_wgrad_bias_multi_f32": (C.c_int, [vp, vp, i32, vp, vp, vp] + [i32] * 11 + [vp]),
     "eavsr_dcnv2_im2col_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_col2im_f32": (C.c_int, [vp] * 7 + [i32, i32, i32, i32, i32, vp]),

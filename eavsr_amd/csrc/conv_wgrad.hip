@@ -61,6 +61,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int l31 = lane & 31, half = lane >> 5;
   const int h = a.h, w = a.w;
   const size_t plane = (size_t)h * w;
+  // blockIdx.y: the 64-channel block of the source this workgroup takes (eavsr_conv_wgrad_span_f32: the nine blocks of DCNv2's
+  // 576-channel column tensor as ONE launch instead of nine); 0 for every other caller
+  const int a_ci0 = a.ci0 + 64 * (int)blockIdx.y;
+  const int a_ci_valid = min(a.cin_src - a_ci0, 64);
+  const size_t slab = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
 
   for (int pass = 0; pass < Cfg::PASSES; ++pass) {
     // this wave's output tiles of the pass: t = pass*40 + wave + 8*i ; (mt, ct, tap) = (t&1, (t>>1)&1, t>>2)
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
       constexpr int BATCH = 16;
       const int seg = bn / a.n, bl = bn - seg * a.n;      // wave-uniform
       const char* dyb = reinterpret_cast<const char*>(a.dyv[seg] + ((size_t)bl * a.cout_total + a.co0) * plane);
-      const char* xb = reinterpret_cast<const char*>(a.xv[seg] + ((size_t)bl * a.cin_src + a.ci0) * plane);
+      const char* xb = reinterpret_cast<const char*>(a.xv[seg] + ((size_t)bl * a.cin_src + a_ci0) * plane);
       __syncthreads();  // previous tile's MFMAs are done with the LDS tiles
       // dY tile: 64 channels x PX pixels (zero beyond the image / beyond co_valid)
 #pragma unroll 1
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
           const int ci = e / (IH * IW), rem = e - ci * (IH * IW);
           const int r = rem / IW, c = rem - r * IW;
           const int gy = y0 - PAD + r, gx = x0 - PAD + c;
-          const bool ok = ci < a.ci_valid && gy >= 0 && gy < h && gx >= 0 && gx < w;
-          const unsigned off = ((unsigned)min(ci, a.ci_valid - 1) * (unsigned)plane +
+          const bool ok = ci < a_ci_valid && gy >= 0 && gy < h && gx >= 0 && gx < w;
+          const unsigned off = ((unsigned)min(ci, a_ci_valid - 1) * (unsigned)plane +
                                 (unsigned)(min(max(gy, 0), h - 1) * w + min(max(gx, 0), w - 1))) * 4u;
           const float v = *reinterpret_cast<const float*>(xb + off);
           tv_[i] = ok ? v : 0.f;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          a.ws[(((size_t)blockIdx.x * 64 + co) * 64 + ci) * KK + tap] = acc[i][r];
+          a.ws[((slab * 64 + co) * 64 + ci) * KK + tap] = acc[i][r];
         }
       }
     }
@@ -626,6 +631,10 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restri
   }
   const int i = blockIdx.x * 64 + lane;
   const int total = 64 * 64 * kk;   // a multiple of 64
+  // blockIdx.y: the 64-channel source block (eavsr_conv_wgrad_span_f32); its slabs follow the previous block's
+  ws += (size_t)blockIdx.y * blocks * total;
+  ci_dst0 += 64 * (int)blockIdx.y;
+  ci_valid = min(ci_valid - 64 * (int)blockIdx.y, 64);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int b = wv;
   for (; b + 24 < blocks; b += 32) {
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(512) void wgrad_reduce_kernel(const float* __restri
 }
 
 template <int KS>
-int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
+int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st, int ci_blocks = 1) {
   using Cfg = WgCfg<KS>;
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
@@ -663,7 +672,7 @@ int launch_wgrad(const WgradArgs& a, int blocks, hipStream_t st) {
     eavsr::set_error("conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  hipLaunchKernelGGL(conv_wgrad_kernel<KS>, dim3(blocks), dim3(512), Cfg::LDS_BYTES, st, a);
+  hipLaunchKernelGGL(conv_wgrad_kernel<KS>, dim3(blocks, ci_blocks), dim3(512), Cfg::LDS_BYTES, st, a);
   return eavsr::launch_status("conv_wgrad");
 }
 
@@ -795,6 +804,36 @@ extern "C" int eavsr_conv_wgrad_bias_multi_f32(const void* const* dy_list, const
   if (dbias != nullptr && !bias_in_kernel && co0 == 0)
     return eavsr_channel_sum_multi_f32(dy_list, nseg, dbias, n, cout_total, h * w, accumulate, stream);
   return 0;
+}
+
+// ksize 1 over a span of 64-channel source blocks in ONE launch (+ one reduction): DCNv2's weight gradient is the 1x1 weight gradient
+// of dY against the 576-channel column tensor (backward_dcn.hip) -- nine launches and nine reductions of ~20 us each per call before
+extern "C" int eavsr_conv_wgrad_span_f32(const float* dy, const float* x, float* dweight, float* workspace, int32_t n, int32_t h,
+                                         int32_t w, int32_t cout_total, int32_t co0, int32_t cin_src, int32_t cin_total,
+                                         int32_t ci_dst0, int32_t accumulate, void* stream) {
+  EAVSR_REQUIRE(dy && x && dweight && workspace, -1, "conv_wgrad_span: NULL pointer");
+  EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && cout_total > 0 && cin_src > 0 && cin_total > 0, -1, "conv_wgrad_span: bad dims");
+  EAVSR_REQUIRE(co0 >= 0 && co0 < cout_total && ci_dst0 >= 0 && ci_dst0 + cin_src <= cin_total, -1,
+                "conv_wgrad_span: channel offsets out of range");
+  const int ci_blocks = eavsr::cdiv(cin_src, 64);
+  EAVSR_REQUIRE(ci_blocks <= 1024, -1, "conv_wgrad_span: %d source channels", cin_src);
+  WgradArgs a;
+  for (int s = 0; s < WG_MAX_SEG; ++s) { a.dyv[s] = dy; a.xv[s] = x; }
+  a.ws = workspace; a.ws_bias = nullptr;
+  a.n = n; a.h = h; a.w = w;
+  a.cout_total = cout_total; a.co0 = co0; a.co_valid = cout_total - co0 < 64 ? cout_total - co0 : 64;
+  a.cin_src = cin_src; a.ci0 = 0; a.ci_valid = cin_src < 64 ? cin_src : 64;
+  a.tiles_x = eavsr::cdiv(w, 32);
+  a.tiles_y = eavsr::cdiv(h, 8);
+  EAVSR_REQUIRE((long)a.tiles_x * a.tiles_y * n < (1L << 31), -1, "conv_wgrad_span: too many tiles");
+  a.num_tiles = a.tiles_x * a.tiles_y * n;
+  const int blocks = eavsr_conv_wgrad_blocks(n, h, w, 1);
+  hipStream_t st = eavsr::as_stream(stream);
+  const int rc = launch_wgrad<1>(a, blocks, st, ci_blocks);
+  if (rc) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64, ci_blocks), dim3(512), 0, st, workspace, dweight, n == 0 ? 0 : blocks, 1, co0,
+                     a.co_valid, ci_dst0, cin_src, cin_total, accumulate, 0, nullptr, nullptr);
+  return eavsr::launch_status("conv_wgrad_reduce");
 }
 
 extern "C" int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float* workspace,

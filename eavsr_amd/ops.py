@@ -1552,8 +1552,20 @@ def conv_wgrad(dy: Tensor, srcs: Sequence[Tensor], ksize: int, out: Optional[Ten
     blocks = lib().eavsr_conv_wgrad_blocks(n, h, w, ksize)
     if blocks <= 0:
         raise NotImplementedError(f"conv_wgrad: kernel size {ksize}")
-    ws = torch.empty(blocks * 64 * 64 * ksize * ksize, device=dy.device, dtype=torch.float32)
     st = _stream(dy)
+    if ksize == 1 and max(int(s.shape[1]) for s in srcs) > 64:
+        # every 64-channel block of a source in ONE launch + one reduction (DCNv2's 576-channel column tensor: nine of each before)
+        ws = torch.empty(blocks * 64 * 64 * max((int(s.shape[1]) + 63) // 64 for s in srcs), device=dy.device, dtype=torch.float32)
+        base = 0
+        for s in srcs:
+            cs = int(s.shape[1])
+            for co0 in range(0, cout, 64):
+                _launch("conv_wgrad1x1", 2.0 * min(64, cout - co0) * cs * n * h * w, 4.0 * n * h * w * (64 + cs), dy,
+                        lambda s=s, cs=cs, co0=co0, base=base: lib().eavsr_conv_wgrad_span_f32(
+                            _p(dy), _p(s), _p(dw), _p(ws), n, h, w, cout, co0, cs, cin, base, acc, st), "conv_wgrad_span")
+            base += cs
+        return dw
+    ws = torch.empty(blocks * 64 * 64 * ksize * ksize, device=dy.device, dtype=torch.float32)
     base = 0
     for s in srcs:
         cs = int(s.shape[1])

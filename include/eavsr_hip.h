@@ -457,6 +457,12 @@ int32_t eavsr_conv_wgrad_blocks(int32_t n, int32_t h, int32_t w, int32_t ksize);
 int eavsr_conv_wgrad_f32(const float* dy, const float* x, float* dweight, float* workspace, int32_t n, int32_t h,
                          int32_t w, int32_t cout_total, int32_t co0, int32_t cin_src, int32_t ci0,
                          int32_t cin_total, int32_t ci_dst0, int32_t ksize, int32_t accumulate, void* stream);
+/* ksize 1 over ALL 64-channel blocks of one source in one launch + one reduction (ABI 27): dweight[co0+co][ci_dst0 + ci] (+)=
+ * sum dy[.., co0+co, ..] x[.., ci, ..] for ci = 0 .. cin_src-1.  DCNv2's weight gradient = this against the 576-channel column
+ * tensor of eavsr_dcnv2_im2col_f32.  workspace: eavsr_conv_wgrad_blocks(n,h,w,1) * ceil(cin_src / 64) * 64*64 floats. */
+int eavsr_conv_wgrad_span_f32(const float* dy, const float* x, float* dweight, float* workspace, int32_t n, int32_t h, int32_t w,
+                              int32_t cout_total, int32_t co0, int32_t cin_src, int32_t cin_total, int32_t ci_dst0,
+                              int32_t accumulate, void* stream);
 /* The same over up to 8 SEGMENTS in one launch (ABI 26): dy_list[s] / x_list[s] are HOST arrays of device pointers to nseg (dY, X)
  * pairs of identical shapes -- the uses of one weight across the frames of the recurrence (models/eavsrp_model.py:271-324: the
  * same backbone / alignment weights at every time step), whose gradients autograd would compute and sum one use at a time
