@@ -272,11 +272,29 @@ def flow_warp(x, flow, padding_mode="zeros", flow2=None, flow_layout="nchw", int
 
 
 # ------------------------------------------------------------------------------------------ DCNv2
+_dcn_wt_cache = {}
+
+
+def _dcn_wt(weight: Tensor) -> Tensor:
+    """(cin * 9, cout, 1, 1): the DCNv2 weight as the 1x1 convolution that maps dOut to the column gradients; once per weight version"""
+    key = (id(weight), weight._version)
+    hit = _dcn_wt_cache.get(key)
+    if hit is not None and hit[0]() is weight:
+        return hit[1]
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    wt = weight.detach().reshape(cout, cin * 9).t().contiguous().view(cin * 9, cout, 1, 1)
+    for k_ in [k_ for k_ in _dcn_wt_cache if k_[0] == id(weight)]:
+        _dcn_wt_cache.pop(k_, None)
+    _dcn_wt_cache[key] = (weakref.ref(weight, lambda _r, k_=key, c=_dcn_wt_cache: c.pop(k_, None)), wt)
+    return wt
+
+
 class _DcnFn(Function):
     @staticmethod
     def forward(ctx, x, offset, mask, weight, bias, dg):
         ctx.dg = dg
         ctx.has_bias = bias is not None
+        ctx.params = [weight] + ([bias] if bias is not None else [])      # the caller's tensor objects (grad_sink keys on them)
         ctx.save_for_backward(x, offset, mask, weight)
         return ops.modulated_deform_conv2d(x, offset, mask, weight, bias, 1, 1, 1, 1, dg)
 
@@ -287,11 +305,19 @@ class _DcnFn(Function):
         dout = dout.contiguous()
         cout, cin = weight.shape[0], weight.shape[1]
         col = ops.dcnv2_im2col(x, offset, mask, dg)                              # (n, cin*9, h, w)
-        dW = ops.conv_wgrad(dout, [col], 1).view(cout, cin, 3, 3) if ctx.needs_input_grad[3] else None
-        wt = weight.reshape(cout, cin * 9).t().contiguous().view(cin * 9, cout, 1, 1)
-        dcol = ops.conv2d(dout, wt, None)                                        # W^T . dOut
+        need_w, need_b = ctx.needs_input_grad[3], ctx.has_bias and ctx.needs_input_grad[4]
+        dW = db = None
+        if need_w and (need_b or not ctx.has_bias) and grad_sink.eligible(ctx.params):
+            # the uses of the weight across the frames add into one buffer (was: one ATen add per use and tensor)
+            bufs, acc = grad_sink._active.raw(ctx.params)
+            ops.conv_wgrad(dout, [col], 1, out=bufs[0].view(cout, cin * 9, 1, 1), accumulate=acc)
+            if ctx.has_bias:
+                ops.channel_sum(dout, out=bufs[1], accumulate=acc)
+        else:
+            dW = ops.conv_wgrad(dout, [col], 1).view(cout, cin, 3, 3) if need_w else None
+            db = ops.channel_sum(dout) if need_b else None
+        dcol = ops.conv2d(dout, _dcn_wt(weight), None)                           # W^T . dOut
         dx, doff, dmask = ops.dcnv2_col2im(x, offset, mask, dcol, dg, need_dx=ctx.needs_input_grad[0])
-        db = ops.channel_sum(dout) if ctx.has_bias and ctx.needs_input_grad[4] else None
         return dx, doff, dmask, dW, db, None
 
 
