@@ -22,17 +22,20 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 // per-(n,c) reduction over the plane: out[nc] = sum_hw a (* b).  One workgroup per (n,c).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                        float* __restrict__ out, int hw, float scale) {
-  __shared__ float red[4];
+// blockDim.x = 256 or 1024 (planes of >= 4,096 pixels: a 96 x 96 training crop is 2,304 float4 per plane -- nine dependent
+// round trips per thread of 256, one and a fraction per thread of 1,024; the launch is latency, not bandwidth)
+__global__ __launch_bounds__(1024) void plane_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, int hw, float scale) {
+  __shared__ float red[16];
   const size_t base = (size_t)blockIdx.x * hw;
+  const int nt = blockDim.x;
   float s0 = 0.f, s1 = 0.f;
   if ((hw & 3) == 0) {   // whole float4 groups, 16-byte aligned planes: two independent load streams per thread
     const float4* a4 = reinterpret_cast<const float4*>(a + base);
     const float4* b4 = b ? reinterpret_cast<const float4*>(b + base) : nullptr;
     const int q = hw >> 2;
-    for (int i = threadIdx.x; i < q; i += 512) {
-      const int j = i + 256;
+    for (int i = threadIdx.x; i < q; i += 2 * nt) {
+      const int j = i + nt;
       const float4 x0 = a4[i], x1 = j < q ? a4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       if (b4) {
         const float4 y0 = b4[i], y1 = j < q ? b4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -44,15 +47,19 @@ __global__ __launch_bounds__(256) void plane_sum_kernel(const float* __restrict_
       }
     }
   } else if (b != nullptr) {
-    for (int i = threadIdx.x; i < hw; i += 256) s0 += a[base + i] * b[base + i];
+    for (int i = threadIdx.x; i < hw; i += nt) s0 += a[base + i] * b[base + i];
   } else {
-    for (int i = threadIdx.x; i < hw; i += 256) s0 += a[base + i];
+    for (int i = threadIdx.x; i < hw; i += nt) s0 += a[base + i];
   }
   float s = s0 + s1;
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2] + red[3]) * scale;
+  if (threadIdx.x == 0) {
+    float t = (red[0] + red[1]) + red[2] + red[3];
+    for (int k = 4; k < (nt >> 6); ++k) t += red[k];
+    out[blockIdx.x] = t * scale;
+  }
 }
 
 // per-channel reduction over batch and plane (bias gradients): out[c] = sum_seg sum_n sum_hw a_seg[n,c,hw].  One workgroup of
@@ -266,15 +273,43 @@ __global__ __launch_bounds__(256) void rcab_tail_bwd_kernel(RcabBwdArgs a) {
         sh[1] = dm * a.inv_hw;
       }
     }
+    // the plane's first RB_PRE float4 per thread are requested BEFORE the barrier (they do not depend on the MLP that wave 0 is
+    // still computing), every pass issues all of its loads before its first store (d and dr may alias as far as the compiler knows:
+    // load / store / load chains were nine dependent round trips per thread at a 96 x 96 crop)
+    constexpr int RB_PRE = 9;
+    const size_t base = (size_t)blockIdx.x * a.hw;
+    const bool vec = (a.hw & 3) == 0;
+    const int q = a.hw >> 2;
+    const float4* d4 = reinterpret_cast<const float4*>(a.d + base);
+    float4 pre[RB_PRE];
+    if (vec) {
+#pragma unroll
+      for (int u = 0; u < RB_PRE; ++u) {
+        const int i = tid + u * 256;
+        pre[u] = i < q ? d4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     __syncthreads();
     const float sc = sh[0], add = sh[1];
-    const size_t base = (size_t)blockIdx.x * a.hw;
-    if ((a.hw & 3) == 0) {
-      const float4* d4 = reinterpret_cast<const float4*>(a.d + base);
+    if (vec) {
       float4* o4 = reinterpret_cast<float4*>(a.dr + base);
-      for (int i = tid; i < (a.hw >> 2); i += 256) {
-        const float4 v = d4[i];
-        o4[i] = make_float4(v.x * sc + add, v.y * sc + add, v.z * sc + add, v.w * sc + add);
+#pragma unroll
+      for (int u = 0; u < RB_PRE; ++u) {
+        const int i = tid + u * 256;
+        if (i < q) o4[i] = make_float4(pre[u].x * sc + add, pre[u].y * sc + add, pre[u].z * sc + add, pre[u].w * sc + add);
+      }
+      for (int i0 = RB_PRE * 256; i0 < q; i0 += 4 * 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + tid + u * 256;
+          v[u] = i < q ? d4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + tid + u * 256;
+          if (i < q) o4[i] = make_float4(v[u].x * sc + add, v[u].y * sc + add, v[u].z * sc + add, v[u].w * sc + add);
+        }
       }
     } else {
       for (int i = tid; i < a.hw; i += 256) a.dr[base + i] = a.d[base + i] * sc + add;
@@ -484,7 +519,7 @@ extern "C" int eavsr_plane_sum_f32(const float* a, const float* b, float* out, i
   EAVSR_REQUIRE(a && out, -1, "plane_sum: NULL pointer");
   EAVSR_REQUIRE(nc >= 0 && hw > 0, -1, "plane_sum: bad dims");
   if (nc == 0) return 0;
-  hipLaunchKernelGGL(plane_sum_kernel, dim3(nc), dim3(256), 0, eavsr::as_stream(stream), a, b, out, hw, scale);
+  hipLaunchKernelGGL(plane_sum_kernel, dim3(nc), dim3(hw >= 4096 ? 1024 : 256), 0, eavsr::as_stream(stream), a, b, out, hw, scale);
   return eavsr::launch_status("plane_sum");
 }
 

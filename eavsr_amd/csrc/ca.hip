@@ -165,6 +165,32 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
   f32x4* o4 = reinterpret_cast<f32x4*>(out) + (size_t)bn * c * hw4 + p0;
   int ch = tid / len, col = tid - ch * len;
   const int dch = CT_THREADS / len, dcol = CT_THREADS - dch * len;
+  if (scale_out != nullptr) {
+    // the training step's form (one stream, nothing to co-reside with): four pieces per thread in flight instead of one
+    for (int f = tid; f < total; f += 4 * CT_THREADS) {
+      f32x4 a[4], b[4];
+      size_t o[4];
+      float sv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = f + u * CT_THREADS < total;
+        o[u] = ok ? (size_t)ch * hw4 + col : 0;
+        sv[u] = ok ? s_scale[ch] : 0.f;
+        a[u] = r4[o[u]];
+        b[u] = x4[o[u]];
+        ch += dch; col += dcol;
+        if (col >= len) { col -= len; ++ch; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (f + u * CT_THREADS < total) {
+          f32x4 v;
+          v[0] = a[u][0] * sv[u] + b[u][0]; v[1] = a[u][1] * sv[u] + b[u][1]; v[2] = a[u][2] * sv[u] + b[u][2]; v[3] = a[u][3] * sv[u] + b[u][3];
+          o4[o[u]] = v;
+        }
+    }
+    return;
+  }
   for (int f = tid; f < total; f += CT_THREADS) {
     const size_t o = (size_t)ch * hw4 + col;
     const f32x4 a = r4[o], b = x4[o];
