@@ -12,6 +12,8 @@ warm-up runs before the capture.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 
@@ -138,9 +140,15 @@ class GraphedTrainStep:
         self.static_lr = model.data_lr_seq.clone()
         self.static_hr = model.data_hr_seq.clone()
         opt = model.optimizer_EAVSRP
-        self._capturable_before = [g.get("capturable", False) for g in opt.param_groups]
-        for g in opt.param_groups:                   # Adam keeps `step` on the device and never reads it back
+        self._capturable_before = [(g.get("capturable", False), g.get("fused", None), g.get("foreach", None)) for g in opt.param_groups]
+        # Adam keeps `step` on the device and never reads it back (capturable), and runs as torch's FUSED multi-tensor kernel: the
+        # default (foreach) capturable form with a device-tensor learning rate divides two 0-dim tensors PER PARAMETER -- 2,432 launches
+        # of 4 us in a 196 ms step (profiles/r05_rocprof_summary_train.txt before this change).  EAVSR_ADAM_FUSED=0: A/B switch.
+        self._fused = os.environ.get("EAVSR_ADAM_FUSED", "1") == "1"
+        for g in opt.param_groups:
             g["capturable"] = True
+            if self._fused:
+                g["fused"], g["foreach"] = True, False
         for st in opt.state.values():
             if "step" in st and not st["step"].is_cuda:
                 st["step"] = st["step"].to(dev, torch.float32)
@@ -185,8 +193,10 @@ class GraphedTrainStep:
 
     def close(self):
         """Give the optimizer back its pre-capture flags (`capturable`) and drop the graph."""
-        for g, c in zip(self.model.optimizer_EAVSRP.param_groups, self._capturable_before):
+        for g, (c, fu, fe) in zip(self.model.optimizer_EAVSRP.param_groups, self._capturable_before):
             g["capturable"] = c
+            if self._fused:
+                g["fused"], g["foreach"] = fu, fe
         self.graph = None
         self._grads = []
 
