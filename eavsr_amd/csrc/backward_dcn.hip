@@ -36,6 +36,7 @@ __device__ __forceinline__ Samp make_samp(float py, float px, int h, int w) {
 }
 
 // columns[n][c*9 + k][px] = bilinear(x[n,c], p + tap_k + offset) * mask      one thread per (n, g, k, px)
+template <int CPG>      // > 0: channels per deformable group at compile time (the channel loop unrolls: 4 CPG loads in flight)
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                          const float* __restrict__ mask, float* __restrict__ col,
                                                          int c, int h, int w, int dg) {
@@ -43,12 +44,13 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= hw) return;
   const int g = blockIdx.y / 9, k = blockIdx.y % 9, bn = blockIdx.z;
-  const int cpg = c / dg;
+  const int cpg = CPG > 0 ? CPG : c / dg;
   const int gy = p / w, gx = p - gy * w;
   const float oy = offset[((size_t)bn * dg * 18 + g * 18 + 2 * k) * hw + p];
   const float ox = offset[((size_t)bn * dg * 18 + g * 18 + 2 * k + 1) * hw + p];
   const float m = mask[((size_t)bn * dg * 9 + g * 9 + k) * hw + p];
   const Samp s = make_samp((float)(gy - 1 + k / 3) + oy, (float)(gx - 1 + k % 3) + ox, h, w);
+#pragma unroll
   for (int cc = 0; cc < cpg; ++cc) {
     const int ch = g * cpg + cc;
     const float* q = x + ((size_t)bn * c + ch) * hw;
@@ -61,6 +63,9 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 }
 
 // from dcolumns: dx (atomics), doffset, dmask                                  one thread per (n, g, k, px)
+// CPG > 0: the channels per deformable group as a compile-time constant (8 in the model) -- the channel loop unrolls and its
+// 5 CPG loads are all requested before the first use (the runtime loop was CPG dependent round trips per thread)
+template <int CPG>
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                          const float* __restrict__ mask, const float* __restrict__ dcol,
                                                          float* __restrict__ dx, float* __restrict__ doffset,
@@ -69,29 +74,57 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= hw) return;
   const int g = blockIdx.y / 9, k = blockIdx.y % 9, bn = blockIdx.z;
-  const int cpg = c / dg;
+  const int cpg = CPG > 0 ? CPG : c / dg;
   const int gy = p / w, gx = p - gy * w;
   const size_t oi = ((size_t)bn * dg * 18 + g * 18 + 2 * k) * hw + p;
   const size_t mi = ((size_t)bn * dg * 9 + g * 9 + k) * hw + p;
   const float oy = offset[oi], ox = offset[oi + hw], m = mask[mi];
   const Samp s = make_samp((float)(gy - 1 + k / 3) + oy, (float)(gx - 1 + k % 3) + ox, h, w);
   float gm = 0.f, gpy = 0.f, gpx = 0.f;
-  for (int cc = 0; cc < cpg; ++cc) {
-    const int ch = g * cpg + cc;
-    const float dc = dcol[((size_t)bn * c * 9 + (size_t)ch * 9 + k) * hw + p];
-    const float* q = x + ((size_t)bn * c + ch) * hw;
-    const float a1 = s.v1 ? q[s.i1] : 0.f, a2 = s.v2 ? q[s.i2] : 0.f, a3 = s.v3 ? q[s.i3] : 0.f, a4 = s.v4 ? q[s.i4] : 0.f;
-    const float val = s.hh * s.hw * a1 + s.hh * s.lw * a2 + s.lh * s.hw * a3 + s.lh * s.lw * a4;
-    gm += dc * val;
-    const float dv = dc * m;
-    gpy += dv * ((a3 - a1) * s.hw + (a4 - a2) * s.lw);
-    gpx += dv * ((a2 - a1) * s.hh + (a4 - a3) * s.lh);
-    if (dx != nullptr) {
-      float* dq = dx + ((size_t)bn * c + ch) * hw;
-      if (s.v1) atomicAdd(dq + s.i1, dv * s.w1);
-      if (s.v2) atomicAdd(dq + s.i2, dv * s.w2);
-      if (s.v3) atomicAdd(dq + s.i3, dv * s.w3);
-      if (s.v4) atomicAdd(dq + s.i4, dv * s.w4);
+  if constexpr (CPG > 0) {
+    float dcv[CPG], a1[CPG], a2[CPG], a3[CPG], a4[CPG];
+#pragma unroll
+    for (int cc = 0; cc < CPG; ++cc) {      // (clamped indices: every load is in range; validity is applied to the values)
+      const int ch = g * CPG + cc;
+      const float* q = x + ((size_t)bn * c + ch) * hw;
+      dcv[cc] = dcol[((size_t)bn * c * 9 + (size_t)ch * 9 + k) * hw + p];
+      a1[cc] = q[s.i1]; a2[cc] = q[s.i2]; a3[cc] = q[s.i3]; a4[cc] = q[s.i4];
+    }
+#pragma unroll
+    for (int cc = 0; cc < CPG; ++cc) {
+      const float b1 = s.v1 ? a1[cc] : 0.f, b2 = s.v2 ? a2[cc] : 0.f, b3 = s.v3 ? a3[cc] : 0.f, b4 = s.v4 ? a4[cc] : 0.f;
+      const float dc = dcv[cc];
+      const float val = s.hh * s.hw * b1 + s.hh * s.lw * b2 + s.lh * s.hw * b3 + s.lh * s.lw * b4;
+      gm += dc * val;
+      const float dv = dc * m;
+      gpy += dv * ((b3 - b1) * s.hw + (b4 - b2) * s.lw);
+      gpx += dv * ((b2 - b1) * s.hh + (b4 - b3) * s.lh);
+      if (dx != nullptr) {
+        float* dq = dx + ((size_t)bn * c + g * CPG + cc) * hw;
+        if (s.v1) atomicAdd(dq + s.i1, dv * s.w1);
+        if (s.v2) atomicAdd(dq + s.i2, dv * s.w2);
+        if (s.v3) atomicAdd(dq + s.i3, dv * s.w3);
+        if (s.v4) atomicAdd(dq + s.i4, dv * s.w4);
+      }
+    }
+  } else {
+    for (int cc = 0; cc < cpg; ++cc) {
+      const int ch = g * cpg + cc;
+      const float dc = dcol[((size_t)bn * c * 9 + (size_t)ch * 9 + k) * hw + p];
+      const float* q = x + ((size_t)bn * c + ch) * hw;
+      const float a1 = s.v1 ? q[s.i1] : 0.f, a2 = s.v2 ? q[s.i2] : 0.f, a3 = s.v3 ? q[s.i3] : 0.f, a4 = s.v4 ? q[s.i4] : 0.f;
+      const float val = s.hh * s.hw * a1 + s.hh * s.lw * a2 + s.lh * s.hw * a3 + s.lh * s.lw * a4;
+      gm += dc * val;
+      const float dv = dc * m;
+      gpy += dv * ((a3 - a1) * s.hw + (a4 - a2) * s.lw);
+      gpx += dv * ((a2 - a1) * s.hh + (a4 - a3) * s.lh);
+      if (dx != nullptr) {
+        float* dq = dx + ((size_t)bn * c + ch) * hw;
+        if (s.v1) atomicAdd(dq + s.i1, dv * s.w1);
+        if (s.v2) atomicAdd(dq + s.i2, dv * s.w2);
+        if (s.v3) atomicAdd(dq + s.i3, dv * s.w3);
+        if (s.v4) atomicAdd(dq + s.i4, dv * s.w4);
+      }
     }
   }
   doffset[oi] = s.in ? gpy : 0.f;
@@ -221,8 +254,12 @@ extern "C" int eavsr_dcnv2_im2col_f32(const float* x, const float* offset, const
                     deform_groups * 9 <= 65535, -1, "dcnv2_im2col: bad dims");
   if (n == 0) return 0;
   dim3 grid(eavsr::cdiv(h * w, 256), deform_groups * 9, n);
-  hipLaunchKernelGGL(dcn_im2col_kernel, grid, dim3(256), 0, eavsr::as_stream(stream), x, offset, mask, columns, c, h, w,
-                     deform_groups);
+  if (c / deform_groups == 8)
+    hipLaunchKernelGGL(dcn_im2col_kernel<8>, grid, dim3(256), 0, eavsr::as_stream(stream), x, offset, mask, columns, c, h, w,
+                       deform_groups);
+  else
+    hipLaunchKernelGGL(dcn_im2col_kernel<0>, grid, dim3(256), 0, eavsr::as_stream(stream), x, offset, mask, columns, c, h, w,
+                       deform_groups);
   return eavsr::launch_status("dcnv2_im2col");
 }
 
@@ -234,8 +271,12 @@ extern "C" int eavsr_dcnv2_col2im_f32(const float* x, const float* offset, const
                     deform_groups * 9 <= 65535, -1, "dcnv2_col2im: bad dims");
   if (n == 0) return 0;
   dim3 grid(eavsr::cdiv(h * w, 256), deform_groups * 9, n);
-  hipLaunchKernelGGL(dcn_col2im_kernel, grid, dim3(256), 0, eavsr::as_stream(stream), x, offset, mask, dcolumns, dx,
-                     doffset, dmask, c, h, w, deform_groups);
+  if (c / deform_groups == 8)
+    hipLaunchKernelGGL(dcn_col2im_kernel<8>, grid, dim3(256), 0, eavsr::as_stream(stream), x, offset, mask, dcolumns, dx,
+                       doffset, dmask, c, h, w, deform_groups);
+  else
+    hipLaunchKernelGGL(dcn_col2im_kernel<0>, grid, dim3(256), 0, eavsr::as_stream(stream), x, offset, mask, dcolumns, dx,
+                       doffset, dmask, c, h, w, deform_groups);
   return eavsr::launch_status("dcnv2_col2im");
 }
 
