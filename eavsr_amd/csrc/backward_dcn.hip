@@ -205,23 +205,33 @@ __global__ __launch_bounds__(1024) void gconv3x3_wgrad_kernel(const float* __res
   for (int bn = 0; bn < n; ++bn) {
     const float* gq = g + ((size_t)bn * co + o) * hw;
     const float* xq = x + ((size_t)bn * co * cpg + (size_t)o * cpg + j) * hw;
-    for (int p = threadIdx.x; p < hw; p += 1024) {
-      const int py = p / w, px = p - py * w;
-      const float gv = gq[p];
-      float xv[9];
-      bool ok[9];
+    // two pixels per pass: twenty loads in flight per thread (a 96 x 96 crop is nine passes of one pixel: nine round trips)
+    for (int p0 = threadIdx.x; p0 < hw; p0 += 2048) {
+      float gv[2], xv[2][9];
+      bool ok[2][9];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int u = 0; u < 2; ++u) {
+        const int p = p0 + u * 1024;
+        const bool in = p < hw;
+        const int pc = in ? p : 0;
+        const int py = pc / w, px = pc - py * w;
+        gv[u] = in ? gq[pc] : 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {      // clamped addresses, all loads first (nine conditional loads were nine round trips)
-          const int yy = py + ky - 1, xx = px + kx - 1;
-          ok[ky * 3 + kx] = yy >= 0 && yy < h && xx >= 0 && xx < w;
-          xv[ky * 3 + kx] = xq[(size_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
-        }
-      acc[9] += gv;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int k = 0; k < 9; ++k)
-        if (ok[k]) acc[k] += gv * xv[k];
+          for (int kx = 0; kx < 3; ++kx) {      // clamped addresses, all loads first (nine conditional loads were nine round trips)
+            const int yy = py + ky - 1, xx = px + kx - 1;
+            ok[u][ky * 3 + kx] = in && yy >= 0 && yy < h && xx >= 0 && xx < w;
+            xv[u][ky * 3 + kx] = xq[(size_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)];
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {      // (pixel p0 before pixel p0 + 1024: the order of the one-pixel loop)
+        acc[9] += gv[u];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          if (ok[u][k]) acc[k] += gv[u] * xv[u][k];
+      }
     }
   }
 #pragma unroll
