@@ -142,6 +142,9 @@ SIGNATURES = {
     "eavsr_conv5x5_c64_h16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv_h16_partial_rows": (i32, [i32, i32, i32]),
     "eavsr_conv3x3_c64_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "eavsr_conv3x3_c64_h16_res": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_ca_scale_pre_ws_floats": (C.c_int64, [i32]),
+    "eavsr_ca_scale_pre_h16": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_c64_h16_act": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "eavsr_rcab_convs_h16": (C.c_int, [vp] * 7 + [i32] * 4 + [vp]),
     "eavsr_rcab_h16_partial_rows": (i32, [i32, i32, i32]),

@@ -203,7 +203,173 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The attention of an RCAB BEFORE its second convolution runs (16-bit modes, round 5).  r = conv2(t) + b2 is linear in t, so the
+// channel means of r -- all the attention needs (networks.py:444-447) -- follow from sums of t:
+//   sum_o r[co][o] = hw b2[co] + sum_{ci, ky, kx} W2[co][ci][ky][kx] S[ci][ky][kx],
+//   S[ci][ky][kx] = sum of t[ci] over the pixels p whose output pixel p - (ky - 1, kx - 1) lies in the image
+//                 = T - R(ky) - C(kx) + X(ky, kx)      (zero padding by inclusion / exclusion)
+// with T the plane sum (the first convolution's epilogue already leaves it as per-tile channel sums), R(0) / R(2) the sums of the
+// last / first image row, C(0) / C(2) of the last / first column, X the corner pixel both exclude (R(1) = C(1) = 0).  The second
+// convolution can then apply x + scale * r in its own epilogue (eavsr_conv3x3_c64_h16_res) and scale_residual_h16 -- three
+// 128-byte-per-pixel streams per RCAB, 8 % / 13 % of the configs[2] / [4] step -- disappears.  W2 is rounded to the 16-bit type
+// here as the convolution's packed weights are; t is the 16-bit tensor the convolution reads.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CP_SEGS = 8;      // segments per border line (workgroups of the border-sum launch: 4 x CP_SEGS per sample)
+
+template <bool BF16> __device__ __forceinline__ float cp_from_h16(unsigned short v) {
+  if (BF16) return __builtin_bit_cast(float, (unsigned)v << 16);
+  return (float)__builtin_bit_cast(_Float16, v);
+}
+template <bool BF16> __device__ __forceinline__ float cp_round_h16(float v) {
+  if (BF16) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const unsigned r = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;      // round to nearest even (finite inputs)
+    return __builtin_bit_cast(float, r);
+  }
+  return (float)(_Float16)v;
+}
+
+// out[((bn * 4 + b) * CP_SEGS + s) * 64 + ch] = sum over segment s of border line b (0 top row, 1 bottom row, 2 left column,
+// 3 right column) of t[bn][..][ch].  256 threads = 64 channels x 4 pixel lanes; a pixel's 64 channels are 128 contiguous bytes.
+template <bool BF16>
+__global__ __launch_bounds__(256) void h16_border_sums_kernel(const unsigned short* __restrict__ t, float* __restrict__ out, int h, int w) {
+  __shared__ float red[4][64];
+  const int ch = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int sgm = blockIdx.x, b = blockIdx.y, bn = blockIdx.z;
+  const int len = b < 2 ? w : h;
+  const int lo = (int)((long)len * sgm / CP_SEGS), hi = (int)((long)len * (sgm + 1) / CP_SEGS);
+  const size_t base = (size_t)bn * h * w;
+  const size_t stride = b < 2 ? 1 : (size_t)w;                                      // pixels between consecutive elements of the line
+  const size_t org = b == 0 ? 0 : b == 1 ? (size_t)(h - 1) * w : b == 2 ? 0 : (size_t)(w - 1);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = lo + pl;
+  for (; i + 12 < hi; i += 16) {
+    const float v0 = cp_from_h16<BF16>(t[(base + org + (size_t)i * stride) * 64 + ch]);
+    const float v1 = cp_from_h16<BF16>(t[(base + org + (size_t)(i + 4) * stride) * 64 + ch]);
+    const float v2 = cp_from_h16<BF16>(t[(base + org + (size_t)(i + 8) * stride) * 64 + ch]);
+    const float v3 = cp_from_h16<BF16>(t[(base + org + (size_t)(i + 12) * stride) * 64 + ch]);
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; i < hi; i += 4) s0 += cp_from_h16<BF16>(t[(base + org + (size_t)i * stride) * 64 + ch]);
+  red[pl][ch] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (pl == 0) out[(((size_t)bn * 4 + b) * CP_SEGS + sgm) * 64 + ch] = (red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch]);
+}
+
+// one workgroup of 1024 threads per sample, 64 channels
+template <bool BF16>
+__global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restrict__ partial, int rows, const float* __restrict__ border,
+                                                            const unsigned short* __restrict__ t, int h, int w,
+                                                            const float* __restrict__ wc, const float* __restrict__ bc,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            float* __restrict__ scale, int cr) {
+  constexpr int C = 64, Q = 1024 / C;
+  __shared__ float part[Q * C];
+  __shared__ float T[C], B[4][C], X[4][C], S[9][C], mean[C], hid[C];
+  const int bn = blockIdx.x, tid = threadIdx.x;
+  {      // the plane sums of t from the first convolution's per-tile (or per-workgroup) channel sums: ca_scale_kernel's reduction
+    const int q = tid / C, ch = tid - q * C;
+    const float* p = partial + (size_t)bn * rows * C + ch;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = q;
+    for (; r + 15 * Q < rows; r += 16 * Q) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = p[(size_t)(r + j * Q) * C];
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+    }
+    for (; r + 3 * Q < rows; r += 4 * Q) {
+      const float v0 = p[(size_t)r * C], v1 = p[(size_t)(r + Q) * C], v2 = p[(size_t)(r + 2 * Q) * C], v3 = p[(size_t)(r + 3 * Q) * C];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; r < rows; r += Q) s0 += p[(size_t)r * C];
+    part[q * C + ch] = (s0 + s1) + (s2 + s3);
+  }
+  if (tid < 4 * C) {      // border lines: the segments of the border-sum launch, in order
+    const int b = tid >> 6, ch = tid & 63;
+    const float* p = border + (((size_t)bn * 4 + b) * CP_SEGS) * C + ch;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < CP_SEGS; ++k) v += p[k * C];
+    B[b][ch] = v;
+  } else if (tid < 8 * C) {      // corners: 0 = (0, 0), 1 = (0, w - 1), 2 = (h - 1, 0), 3 = (h - 1, w - 1)
+    const int k = (tid >> 6) - 4, ch = tid & 63;
+    const size_t px = (size_t)bn * h * w + (size_t)((k >> 1) ? h - 1 : 0) * w + ((k & 1) ? w - 1 : 0);
+    X[k][ch] = cp_from_h16<BF16>(t[px * C + ch]);
+  }
+  __syncthreads();
+  if (tid < C) {
+    float v = 0.f;
+    for (int k = 0; k < Q; ++k) v += part[k * C + tid];
+    T[tid] = v;
+  }
+  __syncthreads();
+  if (tid < 9 * C) {      // S[tap][ci] = T - R(ky) - C(kx) + X(ky, kx)
+    const int tap = tid >> 6, ci = tid & 63, ky = tap / 3, kx = tap - 3 * ky;
+    const float R = ky == 0 ? B[1][ci] : ky == 2 ? B[0][ci] : 0.f;      // ky = 0 excludes the LAST row, ky = 2 the first
+    const float Cc = kx == 0 ? B[3][ci] : kx == 2 ? B[2][ci] : 0.f;
+    const float Xc = (ky == 1 || kx == 1) ? 0.f : X[(ky == 0 ? 2 : 0) + (kx == 0 ? 1 : 0)][ci];
+    S[tap][ci] = (T[ci] - R) - Cc + Xc;
+  }
+  __syncthreads();
+  {      // mean of r: 64 outputs x 576 products, 16 threads per output (one shuffle tree inside 16 consecutive lanes)
+    const int co = tid >> 4, pt = tid & 15;
+    const float* wr = wc + (size_t)co * 576;
+    float v = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < 36; ++i) {
+      const int k = pt + 16 * i;      // k = ci * 9 + tap (the weight's own order)
+      const int ci = k / 9, tap = k - 9 * ci;
+      v += cp_round_h16<BF16>(wr[k]) * S[tap][ci];
+    }
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    if (pt == 0) mean[co] = (bc ? bc[co] : 0.f) + v / ((float)h * (float)w);
+  }
+  __syncthreads();
+  if (tid < cr) {
+    float v = b1[tid];
+    for (int k = 0; k < C; ++k) v += w1[tid * C + k] * mean[k];
+    hid[tid] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  if (tid < C) {
+    float v = b2[tid];
+    for (int j = 0; j < cr; ++j) v += w2[tid * cr + j] * hid[j];
+    scale[(size_t)bn * C + tid] = 1.f / (1.f + expf(-v));
+  }
+}
+
 }  // namespace
+
+extern "C" int64_t eavsr_ca_scale_pre_ws_floats(int32_t n) { return n > 0 ? (int64_t)n * 4 * CP_SEGS * 64 : 0; }
+
+extern "C" int eavsr_ca_scale_pre_h16(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight,
+                                      const float* conv_bias, const float* w1, const float* b1, const float* w2, const float* b2,
+                                      float* scale, float* workspace, int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype,
+                                      void* stream) {
+  EAVSR_REQUIRE(t && chan_partial && conv_weight && w1 && b1 && w2 && b2 && scale && workspace, -1, "ca_scale_pre: NULL pointer");
+  EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "ca_scale_pre: dtype %d (1 = f16, 2 = bf16)", dtype);
+  EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && rows > 0 && cr > 0 && cr <= 64 && n <= 65535, -1, "ca_scale_pre: bad dims");
+  if (n == 0) return 0;
+  hipStream_t st = eavsr::as_stream(stream);
+  const unsigned short* t16 = reinterpret_cast<const unsigned short*>(t);
+  if (dtype == 2) {
+    hipLaunchKernelGGL(h16_border_sums_kernel<true>, dim3(CP_SEGS, 4, n), dim3(256), 0, st, t16, workspace, h, w);
+    hipLaunchKernelGGL(ca_scale_pre_kernel<true>, dim3(n), dim3(1024), 0, st, chan_partial, rows, workspace, t16, h, w, conv_weight,
+                       conv_bias, w1, b1, w2, b2, scale, cr);
+  } else {
+    hipLaunchKernelGGL(h16_border_sums_kernel<false>, dim3(CP_SEGS, 4, n), dim3(256), 0, st, t16, workspace, h, w);
+    hipLaunchKernelGGL(ca_scale_pre_kernel<false>, dim3(n), dim3(1024), 0, st, chan_partial, rows, workspace, t16, h, w, conv_weight,
+                       conv_bias, w1, b1, w2, b2, scale, cr);
+  }
+  return eavsr::launch_status("ca_scale_pre");
+}
 
 extern "C" int eavsr_ca_scale_mean_f32(const float* chan_partial, int32_t tiles, int32_t hw, const float* w1,
                                        const float* b1, const float* w2, const float* b2, float* scale, float* mean_out,

@@ -67,6 +67,11 @@ struct H16Args {
   int sum_rows;       // 0: chan_partial holds one row per tile; > 0: one row per (workgroup, wave group) and sample (2 x gridDim.x rows per
                       // sample), the sums of that group's tiles of the sample added up in the kernel -- large images, where the ONE
                       // workgroup of ca_scale would otherwise read thousands of per-tile rows
+  // RCABlock's tail inside the second convolution's epilogue (round 5): out = res_x + res_scale[n][co] * (conv + bias), rounded once.
+  // The attention res_scale is known BEFORE this launch: the channel means of this convolution's output are a linear function of
+  // border-corrected channel sums of its INPUT (eavsr_ca_scale_pre_h16, csrc/ca.hip).  NULL: the plain epilogues.
+  const void* res_x;         // (n, h, w, 64) 16-bit: the block's input (the skip path)
+  const float* res_scale;    // (n, 64) fp32
   int ps;             // 1: conv 64 -> 256 + PixelShuffle(2) as four 64 -> 64 slices (blockIdx.y = 2 dy + dx): slice k holds the output
                       // channels 4 c + k of the reference weight as its channel c, and its pixel (y, x) is output pixel (2 y + dy, 2 x + dx)
 };
@@ -245,9 +250,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
           for (int qd = 0; qd < 4; ++qd) bq4[m][qd] = *reinterpret_cast<const f32x4*>(s_bias + m * 32 + 8 * qd + 4 * half);
         // the activation and the channel sums are launch constants: four straight-line variants (the sums alone are ~450 of the
         // ~900 vector instructions of a general epilogue, as many issue cycles as the tile's MFMAs)
-        auto epilogue = [&](auto sums_c, auto act_c) __attribute__((always_inline)) {
+        auto epilogue = [&](auto sums_c, auto act_c, auto res_c) __attribute__((always_inline)) {
           constexpr bool SUMS = decltype(sums_c)::value;
           constexpr int ACT = decltype(act_c)::value;
+          constexpr bool RES = decltype(res_c)::value;
+          // RES: this lane's 32 attention values and the 2 x 8 eight-byte pieces of the skip tensor it adds to, all requested
+          // before the first use (they are older than the phase's stores: the vmcnt(8) at its end still counts exactly those)
+          f32x4 sq4[2][4];
+          unsigned xq[2][2][4][2];
+          if (RES) {
+            const float* sp = a.res_scale + (size_t)bn * 64 + 4 * half;
+            const char* xb_ = reinterpret_cast<const char*>(a.res_x) + (size_t)bn * h * w * 128 + (4 * half) * 2;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) sq4[m][qd] = *reinterpret_cast<const f32x4*>(sp + m * 32 + 8 * qd);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              const int gy = ty * HT_H + 2 * w4 + r, gx = tx * HT_W + l31;
+              const bool ok = gy < h && gx < w;
+              const char* xrow = xb_ + ((size_t)(ok ? gy : 0) * w + (ok ? gx : 0)) * 128;
+#pragma unroll
+              for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                  const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(xrow + (m * 32 + 8 * qd) * 2);
+                  xq[r][m][qd][0] = xv[0];
+                  xq[r][m][qd][1] = xv[1];
+                }
+            }
+          }
           float csum[2][16];
           if (SUMS) {
 #pragma unroll
@@ -277,6 +310,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
                     float v = acc[r][m][4 * qd + e] + bq4[m][qd][e];
+                    if (RES) {
+                      const unsigned short xs_ = (unsigned short)(xq[r][m][qd][e >> 1] >> (16 * (e & 1)));
+                      v = fmaf(v, sq4[m][qd][e], from_h16<BF16>(xs_));
+                    }
                     if (ACT == 1) v = fmaxf(v, 0.f);
                     if (ACT == 2) v = fmaxf(v, v * slope);
                     pk[e] = to_h16<BF16>(v);
@@ -326,8 +363,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         using A0 = std::integral_constant<int, 0>;
         using A1 = std::integral_constant<int, 1>;
         using A2 = std::integral_constant<int, 2>;
-        if (a.chan_partial) { if (a.act == 1) epilogue(T_{}, A1{}); else epilogue(T_{}, A0{}); }      // (the sums exist for the RCAB's second conv: no LeakyReLU form)
-        else { if (a.act == 1) epilogue(F_{}, A1{}); else if (a.act == 2) epilogue(F_{}, A2{}); else epilogue(F_{}, A0{}); }
+        if (a.res_x) epilogue(F_{}, A0{}, T_{});
+        else if (a.chan_partial) { if (a.act == 1) epilogue(T_{}, A1{}, F_{}); else epilogue(T_{}, A0{}, F_{}); }      // (the sums: no LeakyReLU form)
+        else { if (a.act == 1) epilogue(F_{}, A1{}, F_{}); else if (a.act == 2) epilogue(F_{}, A2{}, F_{}); else epilogue(F_{}, A0{}, F_{}); }
         H16_STAMP(4);     // channel sums
       }
     } else if (q >= 1) {
@@ -651,7 +689,15 @@ extern "C" int eavsr_pack_conv3x3_c64_h16(const float* weight, void* packed, int
 }
 
 static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, const float* bias, void* out, float* chan_partial,
-                                  int32_t n, int32_t h, int32_t w, int32_t act, float slope, int32_t ps, int32_t dtype, void* stream);
+                                  int32_t n, int32_t h, int32_t w, int32_t act, float slope, int32_t ps, int32_t dtype, void* stream,
+                                  const void* res_x = nullptr, const float* res_scale = nullptr);
+
+extern "C" int eavsr_conv3x3_c64_h16_res(const void* x, const void* weight_packed, const float* bias, void* out, const void* res_x,
+                                         const float* res_scale, int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream) {
+  EAVSR_REQUIRE(res_x && res_scale, -1, "conv3x3_c64_h16_res: NULL pointer");
+  EAVSR_REQUIRE((((uintptr_t)res_x | (uintptr_t)res_scale) & 15) == 0, -1, "conv3x3_c64_h16_res: res_x / res_scale must be 16-byte aligned");
+  return conv3x3_c64_h16_launch(x, weight_packed, bias, out, nullptr, n, h, w, 0, 0.f, 0, dtype, stream, res_x, res_scale);
+}
 
 extern "C" int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float* bias, void* out,
                                      float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t relu,
@@ -668,7 +714,8 @@ extern "C" int eavsr_conv3x3_c64_h16_act(const void* x, const void* weight_packe
 }
 
 static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, const float* bias, void* out, float* chan_partial,
-                                  int32_t n, int32_t h, int32_t w, int32_t act, float slope, int32_t ps, int32_t dtype, void* stream) {
+                                  int32_t n, int32_t h, int32_t w, int32_t act, float slope, int32_t ps, int32_t dtype, void* stream,
+                                  const void* res_x, const float* res_scale) {
   EAVSR_REQUIRE(x && weight_packed && out, -1, "conv3x3_c64_h16: NULL pointer");
   EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "conv3x3_c64_h16: dtype %d (1 = f16, 2 = bf16)", dtype);
   EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0, -1, "conv3x3_c64_h16: bad dims");
@@ -677,6 +724,7 @@ static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, cons
   if (n == 0) return 0;
   H16Args a;
   a.x = x; a.wp = weight_packed; a.bias = bias; a.out = out; a.chan_partial = chan_partial;
+  a.res_x = res_x; a.res_scale = res_scale;
   a.n = n; a.h = h; a.w = w;
   a.tiles_x = eavsr::cdiv(w, HT_W);
   a.tiles_y = eavsr::cdiv(h, HT_H);

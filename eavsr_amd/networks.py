@@ -403,6 +403,17 @@ RCAB_H16_FUSED = _os.environ.get("EAVSR_RCAB_H16_FUSED", "0") == "1"
 def set_rcab_h16_fused(on: bool) -> None:
     global RCAB_H16_FUSED
     RCAB_H16_FUSED = bool(on)
+
+
+# The RCAB's attention computed BEFORE its second convolution and the tail `res * y + x` folded into that convolution's epilogue
+# (16-bit modes; csrc/ca.hip eavsr_ca_scale_pre_h16 + eavsr_conv3x3_c64_h16_res): no scale_residual_h16 launch -- three 128-byte-
+# per-pixel streams per RCAB.  EAVSR_RCAB_H16_PRE=0 keeps conv, conv, ca_scale, scale_residual (A/B switch).
+RCAB_H16_PRE = _os.environ.get("EAVSR_RCAB_H16_PRE", "1") == "1"
+
+
+def set_rcab_h16_pre(on: bool) -> None:
+    global RCAB_H16_PRE
+    RCAB_H16_PRE = bool(on)
 if BACKBONE_DTYPE is not None:
     ops.set_conv3_h16(BACKBONE_DTYPE)
 
@@ -453,6 +464,14 @@ class RCAGroup(nn.Module):
             c1, c2 = blk.res[0], blk.res[2]
             if RCAB_H16_FUSED and ops.rcab_convs_h16_preferred(xs):      # conv -> ReLU -> conv as ONE launch (csrc/rcab_h16.hip)
                 r, partial = ops.rcab_convs_h16(xs, c1.weight, c1.bias, c2.weight, c2.bias, chan_partial=True)
+            elif RCAB_H16_PRE:
+                # the attention BEFORE the second convolution (its output's channel means are linear in sums of its input), the
+                # tail `res * y + x` as that convolution's epilogue: no scale_residual launch (csrc/ca.hip, ops.ca_scale_pre_h16)
+                t, tpart = ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True, chan_partial=True)
+                du_a, du_b = blk.ca.conv_du[0], blk.ca.conv_du[2]
+                scale = ops.ca_scale_pre_h16(t, tpart, c2.weight, c2.bias, du_a.weight, du_a.bias, du_b.weight, du_b.bias)
+                xs = ops.conv3x3_c64_h16_res(t, c2.weight, c2.bias, xs, scale)
+                continue
             else:
                 t = ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True)
                 r, partial = ops.conv3x3_c64_h16(t, c2.weight, c2.bias, chan_partial=True)

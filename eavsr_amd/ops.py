@@ -1809,6 +1809,48 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
     return (out, part) if chan_partial else out
 
 
+def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Optional[Tensor], w1: Tensor, b1: Tensor,
+                     w2: Tensor, b2: Tensor) -> Tensor:
+    """The attention of an RCAB (CALayer, networks.py:444-447) BEFORE its second convolution runs: t = the 16-bit NHWC input of
+    that convolution, partial = the per-tile channel sums of t from conv3x3_c64_h16(.., relu=True, chan_partial=True),
+    conv_weight / conv_bias = the second convolution's parameters.  (n, 64) fp32 for conv3x3_c64_h16(.., skip=, scale=)."""
+    t, partial = _chk_h16(t, "t"), _chk(partial, "partial")
+    n, h, w, c = t.shape
+    if c != 64 or tuple(conv_weight.shape) != (64, 64, 3, 3) or partial.shape[0] != n or partial.shape[2] != 64:
+        raise ValueError("ca_scale_pre_h16: 64 channels, a (64, 64, 3, 3) convolution, partial (n, rows, 64)")
+    code = h16_code(t.dtype)
+    cw = _chk(conv_weight.detach(), "conv_weight")
+    cb = None if conv_bias is None else _chk(conv_bias.detach(), "conv_bias")
+    w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
+    cr = int(w1.shape[0])
+    scale = torch.empty((n, 64), device=t.device, dtype=torch.float32)
+    ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
+    st = _stream(t)
+    _launch("ca_scale_pre_h16", 0.0, 4.0 * partial.numel(), t,
+            lambda: lib().eavsr_ca_scale_pre_h16(_p(t), _p(partial), int(partial.shape[1]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2),
+                                                 _p(scale), _p(ws), n, h, w, cr, code, st), "ca_scale_pre_h16")
+    return scale
+
+
+def conv3x3_c64_h16_res(x: Tensor, weight: Tensor, bias: Optional[Tensor], skip: Tensor, scale: Tensor) -> Tensor:
+    """skip + scale[n, co] * (conv3x3(x) + bias), rounded once: the RCAB's second convolution with its tail as the epilogue
+    (networks.py:461-464); x, skip 16-bit NHWC (n,h,w,64), scale (n, 64) fp32 from ca_scale_pre_h16"""
+    x, skip, scale = _chk_h16(x, "x"), _chk_h16(skip, "skip"), _chk(scale, "scale")
+    n, h, w, c = x.shape
+    if c != 64 or skip.shape != x.shape or skip.dtype != x.dtype or tuple(scale.shape) != (n, 64):
+        raise ValueError("conv3x3_c64_h16_res: x / skip (n,h,w,64) of one 16-bit type, scale (n, 64)")
+    code = h16_code(x.dtype)
+    wp = _packed_h16(weight, code)
+    b = None if bias is None else _chk(bias.detach(), "bias")
+    out = torch.empty_like(x)
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch("conv3x3_64to64_h16", 2.0 * 64 * 64 * 9 * px, 3.0 * px * 128, x,
+            lambda: lib().eavsr_conv3x3_c64_h16_res(_p(x), _p(wp), _p(b), _p(out), _p(skip), _p(scale), n, h, w, code, st),
+            "conv3x3_c64_h16_res")
+    return out
+
+
 # The one-launch RCAB convolutions stream their weights per tile (11.5 us per tile whatever the launch); the resident-weights
 # kernel amortises its weight load and prologue over a workgroup's tiles (7.1 us per tile and convolution at 4 tiles per
 # workgroup, 5 us at 8).  Measured (tools/gpu_rcab_h16_time.py): 4 x 256 x 256 (4 tiles per workgroup) 49.7 us against 52.3 for the two

@@ -524,6 +524,21 @@ int32_t eavsr_conv_h16_partial_rows(int32_t n, int32_t h, int32_t w);
 int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float* bias, void* out,
                           float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t relu, int32_t dtype,
                           void* stream);
+/* RCABlock's tail inside its second convolution (ABI 27): out = res_x + res_scale[n][co] * (conv(x) + bias), rounded once to the
+ * 16-bit type -- `res * y + x` of models/networks.py:463-464 without a launch of its own.  res_scale (n, 64) fp32 comes from
+ * eavsr_ca_scale_pre_h16 BEFORE this launch: the channel means of a convolution's output are a linear function of border-corrected
+ * channel sums of its input.  res_x: the block's input, (n, h, w, 64) 16-bit. */
+int eavsr_conv3x3_c64_h16_res(const void* x, const void* weight_packed, const float* bias, void* out, const void* res_x,
+                              const float* res_scale, int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
+/* scale[n][co] = sigmoid(W2 relu(W1 mean_hw(conv(t) + conv_bias) + b1) + b2) (CALayer, models/networks.py:444-447) from the per-tile
+ * channel sums of t that eavsr_conv3x3_c64_h16(.., relu, chan_partial) left (rows = eavsr_conv_h16_partial_rows) and the border rows
+ * / columns / corners of t (16-bit NHWC), WITHOUT running the convolution: sum_o conv(t)[co][o] = sum W[co][ci][ky][kx] (T[ci] -
+ * R(ky) - C(kx) + X(ky,kx)).  conv_weight (64, 64, 3, 3) fp32 is rounded to `dtype` as the convolution's packed weights are.
+ * workspace: eavsr_ca_scale_pre_ws_floats(n) floats.  Two launches (border sums, then one workgroup per sample). */
+int64_t eavsr_ca_scale_pre_ws_floats(int32_t n);
+int eavsr_ca_scale_pre_h16(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight, const float* conv_bias,
+                           const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,
+                           int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream);
 /* The upsampling tail in the 16-bit modes (models/eavsrp_model.py:343-360; eavsrpx2_model.py likewise).
  * eavsr_conv3x3_c64_h16_act: out = act(conv3x3(x) + bias), act = EAVSR_ACT_NONE | RELU | LRELU(slope) -- conv_hr (:355-357) with
  *   pixel_shuffle2 = 0.  pixel_shuffle2 = 1: the 64 -> 256 convolution + nn.PixelShuffle(2) + activation of upsample1 / upsample2

@@ -203,6 +203,18 @@ def test_rcagroup_16bit_backbone_vs_fp32_oracle(ops, cuda, dt):
         Nw.set_backbone_dtype(None)
     rel = H.maxabs(out, ref) / ref.abs().max().item()
     assert rel <= (4e-2 if dt == "bf16" else 6e-3), rel
+    # the default computes each RCAB's attention before its second convolution (ops.ca_scale_pre_h16); the four-launch form agrees
+    try:
+        Nw.set_backbone_dtype(dt)
+        Nw.set_rcab_h16_pre(False)
+        with torch.no_grad(), ops.profile() as prof:
+            out0 = grp(x.to(cuda)).cpu()
+        assert "scale_residual_h16" in set(prof.summary())
+    finally:
+        Nw.set_rcab_h16_pre(True)
+        Nw.set_backbone_dtype(None)
+    assert H.maxabs(out0, out) <= 8 * EPS[dt] * ref.abs().max().item()
+    assert H.maxabs(out0, ref) / ref.abs().max().item() <= (4e-2 if dt == "bf16" else 6e-3)
     # the same group with each RCAB's two convolutions as ONE launch (csrc/rcab_h16.hip, opt-in): same r, channel sums by another
     # summation tree -- the group output may differ by a 16-bit rounding flip here and there, never by more
     try:
@@ -329,6 +341,40 @@ def test_multiadstn_16bit_alignment_vs_reference_golden(ops, cuda, dt):
     assert "conv5x5_64to120_h16" in names and "conv5x5_64to120_wino" not in names, names     # the heads ran in 16 bits too
     rel = H.maxabs(out, gold["out"]) / gold["out"].abs().max().item()
     assert rel <= (2e-2 if dt == "bf16" else 3e-3), rel
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(1, 8, 32), (2, 19, 37), (1, 45, 80), (3, 7, 5), (2, 1, 40), (1, 33, 1), (1, 1, 1), (2, 256, 256), (1, 540, 960)])
+def test_rcab_attention_before_the_second_convolution(ops, cuda, dt, shape):
+    """eavsr_ca_scale_pre_h16 + eavsr_conv3x3_c64_h16_res (round 5): the attention of an RCAB (CALayer, networks.py:444-447) from
+    border-corrected channel sums of the second convolution's INPUT -- sum_o conv(t)[co][o] = sum W (T - R(ky) - C(kx) + X) -- must
+    equal the attention computed from the convolution's OUTPUT (ca_scale on its channel sums), and `x + scale * conv(t)` in the
+    convolution's epilogue must equal scale_residual_h16 of the separately stored r up to one 16-bit rounding (r is no longer
+    rounded before the product).  Single rows / columns / pixels (where the excluded border lines coincide), ragged tiles,
+    several samples, the per-workgroup row layout of the sums (540 x 960)."""
+    n, h, w = shape
+    x = cases.randn(41, n, 64, h, w).to(DT[dt])
+    xh = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    w1, w2 = cases.randn(42, 64, 64, 3, 3, scale=1.0 / 24.0).to(cuda), cases.randn(43, 64, 64, 3, 3, scale=1.0 / 24.0).to(cuda)
+    b1, b2 = cases.randn(44, 64, scale=0.1).to(cuda), cases.randn(45, 64, scale=0.1).to(cuda)
+    a_w, a_b = cases.randn(46, 4, 64, scale=0.5).to(cuda), cases.randn(47, 4, scale=0.1).to(cuda)
+    c_w, c_b = cases.randn(48, 64, 4, scale=0.5).to(cuda), cases.randn(49, 64, scale=0.1).to(cuda)
+    # the four-launch form
+    t = ops.conv3x3_c64_h16(xh, w1, b1, relu=True)
+    r, rpart = ops.conv3x3_c64_h16(t, w2, b2, chan_partial=True)
+    scale_post = ops.ca_scale(rpart, h * w, a_w, a_b, c_w, c_b)
+    y_post = ops.scale_residual_h16(r, scale_post, xh)
+    # attention first, tail in the second convolution
+    t2, tpart = ops.conv3x3_c64_h16(xh, w1, b1, relu=True, chan_partial=True)
+    assert torch.equal(t2, t)
+    scale_pre = ops.ca_scale_pre_h16(t2, tpart, w2, b2, a_w, a_b, c_w, c_b)
+    y_pre = ops.conv3x3_c64_h16_res(t2, w2, b2, xh, scale_pre)
+    # the means behind the two attentions: fp32 sums of the same products in another order (+ r's rounding in the old form)
+    assert H.maxabs(scale_pre.cpu(), scale_post.cpu()) <= (3e-3 if dt == "bf16" else 5e-4)
+    ref = xh.float() + r.float() * scale_post[:, None, None, :]      # what the old form rounds
+    tol = EPS[dt] * 2.0 * max(1.0, ref.abs().max().item())
+    assert H.maxabs(y_pre.float().cpu(), ref.cpu()) <= tol
+    assert H.maxabs(y_pre.float().cpu(), y_post.float().cpu()) <= tol
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
