@@ -117,7 +117,10 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4& a, const f32x4& b, const f
 // A memory phase first requests the group's next patch (its stage was consumed in the phase before), then runs the epilogue under
 // that latency, straight from the accumulators (8-byte stores, channel sums by DPP adds): staging the outputs through the patch
 // stage put the whole patch round trip (2+ us) at the END of every phase and the schedule was no faster than the old one.
-template <bool BF16>
+// RESK: the instantiation with the RCAB tail in the epilogue (a.res_x / a.res_scale) -- a kernel of its own so that its registers
+// do not weigh on the plain one (as one kernel with a run-time switch the patch offsets went to scratch and every patch request
+// waited for the previous one: s_waitcnt vmcnt(0) in front of each)
+template <bool BF16, bool RESK>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_w = smem;                                  // resident weights
@@ -162,17 +165,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
 
   // per-lane source offset of this wave's 11 patch pieces relative to the patch origin (tile-invariant): interior tiles need one
   // add per piece instead of the division / bounds / swizzle arithmetic
-  unsigned rel_off[11];
-#pragma unroll
-  for (int i = 0; i < 11; ++i) {
-    const int e = (i * 4 + w4) * 64 + lane;
+  // (RESK recomputes them per tile instead: its sixteen skip-tensor registers are live while the patch is requested, and with the
+  //  offsets resident one of them went to scratch -- a scratch reload + vmcnt(0) in front of the last patch piece)
+  auto rel_off_of = [&](int i, int lane_) __attribute__((always_inline)) {
+    const int e = (i * 4 + w4) * 64 + lane_;
     const int pp = e >> 3, sb = e & 7;
     const int r = pp / HP_W, c = pp - r * HP_W;
-    rel_off[i] = (unsigned)((r * w + c) * 128 + ((sb ^ ((c >> 1) & 7)) << 4));
+    return (unsigned)((r * w + c) * 128 + ((sb ^ ((c >> 1) & 7)) << 4));
+  };
+  unsigned rel_off[11];
+  if constexpr (!RESK) {
+#pragma unroll
+    for (int i = 0; i < 11; ++i) rel_off[i] = rel_off_of(i, lane);
   }
   const bool tail_lane = ((10 * 4 + w4) * 64 + lane) >> 3 < HP_PIX;   // the last piece is partial
 
   f32x16 acc[2][2];   // [row][m]
+  // RESK: the sample's 64 attention values go to LDS at the start of a tile's compute phase (the group's channel-sum slots, unused
+  // in this mode).  The sixteen eight-byte pieces of the skip tensor that this lane's tile adds to are requested at the very START
+  // of the memory phase, BEFORE the next tile's patch: a wave's requests return in order, so behind the patch (whose round trip
+  // is the 5 us the phase lasts) they stalled the epilogue for that long; in front of it their ~2 us hide in the phase's slack.
+  // (Holding them across the MFMAs instead spilled the patch offsets to scratch, with a vmcnt(0) in front of every patch request.)
+  unsigned xq[2][2][4][2];
   float run = 0.f;     // sum_rows mode, wave 0 of a group: this group's channel sums of sample run_bn so far (lane = channel)
   int run_bn = -1;
   auto flush_rows = [&](int upto_bn) __attribute__((always_inline)) {      // rows of samples run_bn (the sums) .. upto_bn - 1 (zeros)
@@ -190,6 +204,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
     bool stores_behind_dma = false;
     if (q >= 0 && (q & 1) == 0) {
       // ================================================================== memory phase =======================================
+      if constexpr (RESK) {
+        if (j >= 1 && j - 1 < cnt_g) {
+          int bn, ty, tx;
+          tile_at(j - 1, bn, ty, tx);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int gy = ty * HT_H + 2 * w4 + r, gx = tx * HT_W + l31;
+            const bool ok = gy < h && gx < w;
+            const char* xrow = reinterpret_cast<const char*>(a.res_x) + (size_t)bn * h * w * 128 + (4 * half) * 2 +
+                               ((size_t)(ok ? gy : 0) * w + (ok ? gx : 0)) * 128;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) {
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(xrow + (m * 32 + 8 * qd) * 2);
+                xq[r][m][qd][0] = xv[0];
+                xq[r][m][qd][1] = xv[1];
+              }
+          }
+          __builtin_amdgcn_sched_barrier(0);      // (the requests stay in front of the patch's)
+        }
+      }
       if (j < cnt_g) {
         // ---- the patch of tile j FIRST (the stage was consumed in the last phase; its latency hides under the epilogue below):
         // slot e -> pixel e >> 3, stored block e & 7 holds the logical block (e & 7) ^ swz(col); slots outside the image are
@@ -200,12 +237,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)bn * h * w * 128;
         if (y0 >= 0 && x0 >= 0 && y0 + HP_H <= h && x0 + HP_W <= w) {      // interior tile (wave-uniform): no zero fills
           const char* org = xb + ((size_t)y0 * w + x0) * 128;
+          int lane_o = lane;      // RESK: an opaque copy per tile, so that the offsets below are not hoisted back out of the tile loop
+          if constexpr (RESK) asm volatile("" : "+v"(lane_o));
 #pragma unroll
           for (int i = 0; i < 11; ++i) {
             const int seg = i * 4 + w4;
 #ifndef EAVSR_H16_EXP_NO_DMA
             if (seg < HP_SEGS && (i < 10 || tail_lane))
-              __builtin_amdgcn_global_load_lds((gptr_t)(org + rel_off[i]), (lptr_t)(pst + seg * 1024), 16, 0, 0);
+              __builtin_amdgcn_global_load_lds((gptr_t)(org + (RESK ? rel_off_of(i, lane_o) : rel_off[i])), (lptr_t)(pst + seg * 1024), 16, 0, 0);
 #endif
           }
         } else {
@@ -254,32 +293,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
           constexpr bool SUMS = decltype(sums_c)::value;
           constexpr int ACT = decltype(act_c)::value;
           constexpr bool RES = decltype(res_c)::value;
-          // RES: this lane's 32 attention values and the 2 x 8 eight-byte pieces of the skip tensor it adds to, all requested
-          // before the first use (they are older than the phase's stores: the vmcnt(8) at its end still counts exactly those)
           f32x4 sq4[2][4];
-          unsigned xq[2][2][4][2];
           if (RES) {
-            const float* sp = a.res_scale + (size_t)bn * 64 + 4 * half;
-            const char* xb_ = reinterpret_cast<const char*>(a.res_x) + (size_t)bn * h * w * 128 + (4 * half) * 2;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-              for (int qd = 0; qd < 4; ++qd) sq4[m][qd] = *reinterpret_cast<const f32x4*>(sp + m * 32 + 8 * qd);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              const int gy = ty * HT_H + 2 * w4 + r, gx = tx * HT_W + l31;
-              const bool ok = gy < h && gx < w;
-              const char* xrow = xb_ + ((size_t)(ok ? gy : 0) * w + (ok ? gx : 0)) * 128;
-#pragma unroll
-              for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                  const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(xrow + (m * 32 + 8 * qd) * 2);
-                  xq[r][m][qd][0] = xv[0];
-                  xq[r][m][qd][1] = xv[1];
-                }
-            }
+              for (int qd = 0; qd < 4; ++qd) sq4[m][qd] = *reinterpret_cast<const f32x4*>(s_red + grp * 256 + m * 32 + 8 * qd + 4 * half);
           }
           float csum[2][16];
           if (SUMS) {
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         using A0 = std::integral_constant<int, 0>;
         using A1 = std::integral_constant<int, 1>;
         using A2 = std::integral_constant<int, 2>;
-        if (a.res_x) epilogue(F_{}, A0{}, T_{});
+        if constexpr (RESK) epilogue(F_{}, A0{}, T_{});
         else if (a.chan_partial) { if (a.act == 1) epilogue(T_{}, A1{}, F_{}); else epilogue(T_{}, A0{}, F_{}); }      // (the sums: no LeakyReLU form)
         else { if (a.act == 1) epilogue(F_{}, A1{}, F_{}); else if (a.act == 2) epilogue(F_{}, A2{}, F_{}); else epilogue(F_{}, A0{}, F_{}); }
         H16_STAMP(4);     // channel sums
@@ -388,6 +407,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         }
       }
       if (j < cnt_g) {
+        if constexpr (RESK) {
+          int bn, ty, tx;
+          tile_at(j, bn, ty, tx);
+          if (w4 == 0) s_red[grp * 256 + lane] = a.res_scale[(size_t)bn * 64 + lane];
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -634,7 +658,7 @@ __global__ void pack_weight_h16_kernel(const float* __restrict__ w, unsigned sho
   p[i] = to_h16<BF16>(w[((size_t)co * 64 + ci) * 9 + tap]);
 }
 
-template <bool BF16>
+template <bool BF16, bool RESK = false>
 int launch_conv_h16(const H16Args& a, int blocks, int slices, hipStream_t st) {
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
@@ -642,14 +666,14 @@ int launch_conv_h16(const H16Args& a, int blocks, int slices, hipStream_t st) {
   static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
   hipError_t& attr_err = attr_err_pd[dev_];
   std::call_once(once, [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_h16_kernel<BF16>),
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_h16_kernel<BF16, RESK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv3x3_c64_h16: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  hipLaunchKernelGGL(conv3x3_c64_h16_kernel<BF16>, dim3(blocks, slices), dim3(512), H_LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv3x3_c64_h16_kernel<BF16, RESK>), dim3(blocks, slices), dim3(512), H_LDS_BYTES, st, a);
   return eavsr::launch_status("conv3x3_c64_h16");
 }
 
@@ -738,6 +762,9 @@ static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, cons
   }
   const int per = ps ? 64 : 256;                      // persistent: one workgroup per CU (four slices: 64 each)
   const int blocks = tiles < per ? (int)tiles : per;
+  if (res_x != nullptr)
+    return dtype == 2 ? launch_conv_h16<true, true>(a, blocks, 1, eavsr::as_stream(stream))
+                      : launch_conv_h16<false, true>(a, blocks, 1, eavsr::as_stream(stream));
   return dtype == 2 ? launch_conv_h16<true>(a, blocks, ps ? 4 : 1, eavsr::as_stream(stream))
                     : launch_conv_h16<false>(a, blocks, ps ? 4 : 1, eavsr::as_stream(stream));
 }
