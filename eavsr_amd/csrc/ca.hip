@@ -269,6 +269,14 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
   __shared__ float part[Q * C];
   __shared__ float T[C], B[4][C], X[4][C], S[9][C], mean[C], hid[C];
   const int bn = blockIdx.x, tid = threadIdx.x;
+  // every parameter this thread will need, requested now (each was a round trip of its own behind a barrier)
+  const float bc_v = bc ? bc[tid >> 4] : 0.f;
+  const int hj = tid >> 6;                                   // hidden unit of this wave (cr <= 16 of them in one pass)
+  const float w1_v = hj < cr ? w1[hj * C + (tid & 63)] : 0.f, b1_v = hj < cr ? b1[hj] : 0.f;
+  float w2_v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) w2_v[j] = (tid < C && j < cr) ? w2[tid * cr + j] : 0.f;
+  const float b2_v = tid < C ? b2[tid] : 0.f;
   {      // the plane sums of t from the first convolution's per-tile (or per-workgroup) channel sums: ca_scale_kernel's reduction
     const int q = tid / C, ch = tid - q * C;
     const float* p = partial + (size_t)bn * rows * C + ch;
@@ -300,6 +308,15 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
     const size_t px = (size_t)bn * h * w + (size_t)((k >> 1) ? h - 1 : 0) * w + ((k & 1) ? w - 1 : 0);
     X[k][ch] = cp_from_h16<BF16>(t[px * C + ch]);
   }
+  // this thread's 36 weights of the contraction below as nine 16-byte requests, issued BEHIND the sums' requests (a wave's requests
+  // return in order) and in flight across the next three barriers (as 36 dependent dwords in front of their use they were nine L2
+  // round trips of the one workgroup the whole GPU waits for: 11.6 us per launch at 540 x 960)
+  f32x4 wq[9];
+  {
+    const f32x4* wr4 = reinterpret_cast<const f32x4*>(wc + (size_t)(tid >> 4) * 576) + (tid & 15);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wq[i] = wr4[16 * i];
+  }
   __syncthreads();
   if (tid < C) {
     float v = 0.f;
@@ -317,30 +334,35 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
   __syncthreads();
   {      // mean of r: 64 outputs x 576 products, 16 threads per output (one shuffle tree inside 16 consecutive lanes)
     const int co = tid >> 4, pt = tid & 15;
-    const float* wr = wc + (size_t)co * 576;
     float v = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < 36; ++i) {
-      const int k = pt + 16 * i;      // k = ci * 9 + tap (the weight's own order)
-      const int ci = k / 9, tap = k - 9 * ci;
-      v += cp_round_h16<BF16>(wr[k]) * S[tap][ci];
-    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 4 * (pt + 16 * i) + e;      // k = ci * 9 + tap (the weight's own order)
+        const int ci = k / 9, tap = k - 9 * ci;
+        v += cp_round_h16<BF16>(wq[i][e]) * S[tap][ci];
+      }
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
     v += __shfl_xor(v, 4);
     v += __shfl_xor(v, 8);
-    if (pt == 0) mean[co] = (bc ? bc[co] : 0.f) + v / ((float)h * (float)w);
+    if (pt == 0) mean[co] = bc_v + v / ((float)h * (float)w);
   }
   __syncthreads();
-  if (tid < cr) {
-    float v = b1[tid];
-    for (int k = 0; k < C; ++k) v += w1[tid * C + k] * mean[k];
-    hid[tid] = fmaxf(v, 0.f);
+  // hidden unit j by wave j, wave j + 16, ..: one request per lane and a shuffle tree (four threads walking 64 dependent products each
+  // were most of what was left of the launch)
+  if (hj < cr) {
+    float v = w1_v * mean[tid & 63];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((tid & 63) == 0) hid[hj] = fmaxf(v + b1_v, 0.f);
   }
   __syncthreads();
   if (tid < C) {
-    float v = b2[tid];
-    for (int j = 0; j < cr; ++j) v += w2[tid * cr + j] * hid[j];
+    float v = b2_v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += j < cr ? w2_v[j] * hid[j] : 0.f;
     scale[(size_t)bn * C + tid] = 1.f / (1.f + expf(-v));
   }
 }
@@ -355,7 +377,7 @@ extern "C" int eavsr_ca_scale_pre_h16(const void* t, const float* chan_partial, 
                                       void* stream) {
   EAVSR_REQUIRE(t && chan_partial && conv_weight && w1 && b1 && w2 && b2 && scale && workspace, -1, "ca_scale_pre: NULL pointer");
   EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "ca_scale_pre: dtype %d (1 = f16, 2 = bf16)", dtype);
-  EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && rows > 0 && cr > 0 && cr <= 64 && n <= 65535, -1, "ca_scale_pre: bad dims");
+  EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && rows > 0 && cr > 0 && cr <= 8 && n <= 65535, -1, "ca_scale_pre: bad dims (1..8 hidden units)");
   if (n == 0) return 0;
   hipStream_t st = eavsr::as_stream(stream);
   const unsigned short* t16 = reinterpret_cast<const unsigned short*>(t);

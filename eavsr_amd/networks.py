@@ -464,7 +464,7 @@ class RCAGroup(nn.Module):
             c1, c2 = blk.res[0], blk.res[2]
             if RCAB_H16_FUSED and ops.rcab_convs_h16_preferred(xs):      # conv -> ReLU -> conv as ONE launch (csrc/rcab_h16.hip)
                 r, partial = ops.rcab_convs_h16(xs, c1.weight, c1.bias, c2.weight, c2.bias, chan_partial=True)
-            elif RCAB_H16_PRE:
+            elif RCAB_H16_PRE and int(blk.ca.conv_du[0].weight.shape[0]) <= 8:      # (the kernel's hidden-unit bound)
                 # the attention BEFORE the second convolution (its output's channel means are linear in sums of its input), the
                 # tail `res * y + x` as that convolution's epilogue: no scale_residual launch (csrc/ca.hip, ops.ca_scale_pre_h16)
                 t, tpart = ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True, chan_partial=True)
