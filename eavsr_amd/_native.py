@@ -41,6 +41,7 @@ class ConvDesc(C.Structure):
         ("ca_x", vp),
         ("ca_out", vp),
         ("out_shuffle", i32),
+        ("res_scale", vp),
     ]
 
 
@@ -143,6 +144,7 @@ SIGNATURES = {
     "eavsr_conv_h16_partial_rows": (i32, [i32, i32, i32]),
     "eavsr_conv3x3_c64_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_c64_h16_res": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "eavsr_ca_scale_pre_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, vp]),
     "eavsr_ca_scale_pre_ws_floats": (C.c_int64, [i32]),
     "eavsr_ca_scale_pre_h16": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_c64_h16_act": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),

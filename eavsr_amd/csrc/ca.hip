@@ -230,37 +230,41 @@ template <bool BF16> __device__ __forceinline__ float cp_round_h16(float v) {
   return (float)(_Float16)v;
 }
 
+// element (bn, y, x, ch) of t -- DT 1 / 2: 16-bit NHWC (fp16 / bf16); DT 0: fp32 NCHW (the fp32 path of configs[1] / [3])
+template <int DT> __device__ __forceinline__ float cp_load(const void* t, int bn, int y, int x, int ch, int h, int w) {
+  if (DT == 0) return reinterpret_cast<const float*>(t)[(((size_t)bn * 64 + ch) * h + y) * w + x];
+  return cp_from_h16<DT == 2>(reinterpret_cast<const unsigned short*>(t)[(((size_t)bn * h + y) * w + x) * 64 + ch]);
+}
+
 // out[((bn * 4 + b) * CP_SEGS + s) * 64 + ch] = sum over segment s of border line b (0 top row, 1 bottom row, 2 left column,
 // 3 right column) of t[bn][..][ch].  256 threads = 64 channels x 4 pixel lanes; a pixel's 64 channels are 128 contiguous bytes.
-template <bool BF16>
-__global__ __launch_bounds__(256) void h16_border_sums_kernel(const unsigned short* __restrict__ t, float* __restrict__ out, int h, int w) {
+template <int DT>
+__global__ __launch_bounds__(256) void h16_border_sums_kernel(const void* __restrict__ t, float* __restrict__ out, int h, int w) {
   __shared__ float red[4][64];
   const int ch = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int sgm = blockIdx.x, b = blockIdx.y, bn = blockIdx.z;
   const int len = b < 2 ? w : h;
   const int lo = (int)((long)len * sgm / CP_SEGS), hi = (int)((long)len * (sgm + 1) / CP_SEGS);
-  const size_t base = (size_t)bn * h * w;
-  const size_t stride = b < 2 ? 1 : (size_t)w;                                      // pixels between consecutive elements of the line
-  const size_t org = b == 0 ? 0 : b == 1 ? (size_t)(h - 1) * w : b == 2 ? 0 : (size_t)(w - 1);
+  auto at = [&](int i) __attribute__((always_inline)) {
+    return b == 0 ? cp_load<DT>(t, bn, 0, i, ch, h, w) : b == 1 ? cp_load<DT>(t, bn, h - 1, i, ch, h, w)
+         : b == 2 ? cp_load<DT>(t, bn, i, 0, ch, h, w) : cp_load<DT>(t, bn, i, w - 1, ch, h, w);
+  };
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int i = lo + pl;
   for (; i + 12 < hi; i += 16) {
-    const float v0 = cp_from_h16<BF16>(t[(base + org + (size_t)i * stride) * 64 + ch]);
-    const float v1 = cp_from_h16<BF16>(t[(base + org + (size_t)(i + 4) * stride) * 64 + ch]);
-    const float v2 = cp_from_h16<BF16>(t[(base + org + (size_t)(i + 8) * stride) * 64 + ch]);
-    const float v3 = cp_from_h16<BF16>(t[(base + org + (size_t)(i + 12) * stride) * 64 + ch]);
+    const float v0 = at(i), v1 = at(i + 4), v2 = at(i + 8), v3 = at(i + 12);
     s0 += v0; s1 += v1; s2 += v2; s3 += v3;
   }
-  for (; i < hi; i += 4) s0 += cp_from_h16<BF16>(t[(base + org + (size_t)i * stride) * 64 + ch]);
+  for (; i < hi; i += 4) s0 += at(i);
   red[pl][ch] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (pl == 0) out[(((size_t)bn * 4 + b) * CP_SEGS + sgm) * 64 + ch] = (red[0][ch] + red[1][ch]) + (red[2][ch] + red[3][ch]);
 }
 
 // one workgroup of 1024 threads per sample, 64 channels
-template <bool BF16>
+template <int DT>
 __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restrict__ partial, int rows, const float* __restrict__ border,
-                                                            const unsigned short* __restrict__ t, int h, int w,
+                                                            const void* __restrict__ t, int h, int w,
                                                             const float* __restrict__ wc, const float* __restrict__ bc,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
                                                             const float* __restrict__ w2, const float* __restrict__ b2,
@@ -305,8 +309,7 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
     B[b][ch] = v;
   } else if (tid < 8 * C) {      // corners: 0 = (0, 0), 1 = (0, w - 1), 2 = (h - 1, 0), 3 = (h - 1, w - 1)
     const int k = (tid >> 6) - 4, ch = tid & 63;
-    const size_t px = (size_t)bn * h * w + (size_t)((k >> 1) ? h - 1 : 0) * w + ((k & 1) ? w - 1 : 0);
-    X[k][ch] = cp_from_h16<BF16>(t[px * C + ch]);
+    X[k][ch] = cp_load<DT>(t, bn, (k >> 1) ? h - 1 : 0, (k & 1) ? w - 1 : 0, ch, h, w);
   }
   // this thread's 36 weights of the contraction below as nine 16-byte requests, issued BEHIND the sums' requests (a wave's requests
   // return in order) and in flight across the next three barriers (as 36 dependent dwords in front of their use they were nine L2
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
       for (int e = 0; e < 4; ++e) {
         const int k = 4 * (pt + 16 * i) + e;      // k = ci * 9 + tap (the weight's own order)
         const int ci = k / 9, tap = k - 9 * ci;
-        v += cp_round_h16<BF16>(wq[i][e]) * S[tap][ci];
+        v += (DT == 0 ? wq[i][e] : cp_round_h16<DT == 2>(wq[i][e])) * S[tap][ci];
       }
     v += __shfl_xor(v, 1);
     v += __shfl_xor(v, 2);
@@ -371,26 +374,40 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
 
 extern "C" int64_t eavsr_ca_scale_pre_ws_floats(int32_t n) { return n > 0 ? (int64_t)n * 4 * CP_SEGS * 64 : 0; }
 
+static int ca_scale_pre_launch(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight, const float* conv_bias,
+                               const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,
+                               int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream) {
+  EAVSR_REQUIRE(t && chan_partial && conv_weight && w1 && b1 && w2 && b2 && scale && workspace, -1, "ca_scale_pre: NULL pointer");
+  EAVSR_REQUIRE(dtype >= 0 && dtype <= 2, -1, "ca_scale_pre: dtype %d (0 = f32 NCHW, 1 = f16, 2 = bf16 NHWC)", dtype);
+  EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && rows > 0 && cr > 0 && cr <= 8 && n <= 65535, -1, "ca_scale_pre: bad dims (1..8 hidden units)");
+  EAVSR_REQUIRE(((uintptr_t)conv_weight & 15) == 0, -1, "ca_scale_pre: conv_weight must be 16-byte aligned");
+  if (n == 0) return 0;
+  hipStream_t st = eavsr::as_stream(stream);
+#define CP_LAUNCH(DT_)                                                                                                             \
+  do {                                                                                                                             \
+    hipLaunchKernelGGL(h16_border_sums_kernel<DT_>, dim3(CP_SEGS, 4, n), dim3(256), 0, st, t, workspace, h, w);                     \
+    hipLaunchKernelGGL(ca_scale_pre_kernel<DT_>, dim3(n), dim3(1024), 0, st, chan_partial, rows, workspace, t, h, w, conv_weight,   \
+                       conv_bias, w1, b1, w2, b2, scale, cr);                                                                      \
+  } while (0)
+  if (dtype == 2) CP_LAUNCH(2);
+  else if (dtype == 1) CP_LAUNCH(1);
+  else CP_LAUNCH(0);
+#undef CP_LAUNCH
+  return eavsr::launch_status("ca_scale_pre");
+}
+
 extern "C" int eavsr_ca_scale_pre_h16(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight,
                                       const float* conv_bias, const float* w1, const float* b1, const float* w2, const float* b2,
                                       float* scale, float* workspace, int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype,
                                       void* stream) {
-  EAVSR_REQUIRE(t && chan_partial && conv_weight && w1 && b1 && w2 && b2 && scale && workspace, -1, "ca_scale_pre: NULL pointer");
-  EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "ca_scale_pre: dtype %d (1 = f16, 2 = bf16)", dtype);
-  EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && rows > 0 && cr > 0 && cr <= 8 && n <= 65535, -1, "ca_scale_pre: bad dims (1..8 hidden units)");
-  if (n == 0) return 0;
-  hipStream_t st = eavsr::as_stream(stream);
-  const unsigned short* t16 = reinterpret_cast<const unsigned short*>(t);
-  if (dtype == 2) {
-    hipLaunchKernelGGL(h16_border_sums_kernel<true>, dim3(CP_SEGS, 4, n), dim3(256), 0, st, t16, workspace, h, w);
-    hipLaunchKernelGGL(ca_scale_pre_kernel<true>, dim3(n), dim3(1024), 0, st, chan_partial, rows, workspace, t16, h, w, conv_weight,
-                       conv_bias, w1, b1, w2, b2, scale, cr);
-  } else {
-    hipLaunchKernelGGL(h16_border_sums_kernel<false>, dim3(CP_SEGS, 4, n), dim3(256), 0, st, t16, workspace, h, w);
-    hipLaunchKernelGGL(ca_scale_pre_kernel<false>, dim3(n), dim3(1024), 0, st, chan_partial, rows, workspace, t16, h, w, conv_weight,
-                       conv_bias, w1, b1, w2, b2, scale, cr);
-  }
-  return eavsr::launch_status("ca_scale_pre");
+  EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "ca_scale_pre_h16: dtype %d (1 = f16, 2 = bf16)", dtype);
+  return ca_scale_pre_launch(t, chan_partial, rows, conv_weight, conv_bias, w1, b1, w2, b2, scale, workspace, n, h, w, cr, dtype, stream);
+}
+
+extern "C" int eavsr_ca_scale_pre_f32(const float* t, const float* chan_partial, int32_t tiles, const float* conv_weight,
+                                      const float* conv_bias, const float* w1, const float* b1, const float* w2, const float* b2,
+                                      float* scale, float* workspace, int32_t n, int32_t h, int32_t w, int32_t cr, void* stream) {
+  return ca_scale_pre_launch(t, chan_partial, tiles, conv_weight, conv_bias, w1, b1, w2, b2, scale, workspace, n, h, w, cr, 0, stream);
 }
 
 extern "C" int eavsr_ca_scale_mean_f32(const float* chan_partial, int32_t tiles, int32_t hw, const float* w1,

@@ -84,6 +84,7 @@ struct W4Args {
   int act;
   float slope;
   int out_shuffle;        // 2: out is F.pixel_shuffle(conv, 2), (n, cout / 4, 2h, 2w); 0: (n, cout, h, w)
+  const float* res_scale; // (n, cout) or NULL: out = residual + res_scale[n][co] * act(conv + bias) (3x3; the RCAB tail as the epilogue)
 };
 
 constexpr int CK = 4, NW = 8, NPOS = 36;
@@ -200,8 +201,11 @@ __device__ unsigned long long g_w4_it[256 * 256];
 // chunks (128 jobs each) while waves 4-7 request the second chunk's weight slab, then two pure GEMM iterations.  An fp32 MFMA
 // holds its SIMD's vector ALU for all of its 32 cycles (tools/ubench/mfma_fill.hip), so a transform beside MFMAs only ever adds
 // to ONE pair of SIMDs what the barrier then makes everybody wait for; as a phase of its own it costs every SIMD the same.
-template <int R, bool FUSE = false, bool GRP = false>
+// RSC: the instantiation whose epilogue is out = residual + res_scale[n][co] * act(conv + bias) (the RCAB tail; the grouped 3x3
+// kernel only) -- a kernel of its own so that the plain one's code and registers are exactly what they were
+template <int R, bool FUSE = false, bool GRP = false, bool RSC = false>
 __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
+  static_assert(!RSC || (GRP && R == 3 && !FUSE), "the scaled-residual epilogue exists for the grouped 3x3 kernel");
   static_assert(!FUSE || R == 3, "the fused channel-attention prologue exists for the 3x3 kernel");
   static_assert(!GRP || (R == 3 && !FUSE), "the grouped schedule exists for the plain 3x3 kernel");
   using C = WCfg<R>;
@@ -893,8 +897,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
                 const int r = 2 * rp + ch, co = co0 + ch;
                 if (co < a.cout && pok) {
                   csum[r] += (vv[ch][0] + vv[ch][1]) + (vv[ch][2] + vv[ch][3]);
-                  *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
-                      f32x4{vv[ch][0] + rr[ch][0], vv[ch][1] + rr[ch][1], vv[ch][2] + rr[ch][2], vv[ch][3] + rr[ch][3]};
+                  if constexpr (RSC) {
+                    const float sc = a.res_scale[(size_t)bn * a.cout + co];      // (L2-resident)
+                    *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
+                        f32x4{vv[ch][0] * sc + rr[ch][0], vv[ch][1] * sc + rr[ch][1], vv[ch][2] * sc + rr[ch][2], vv[ch][3] * sc + rr[ch][3]};
+                  } else {
+                    *reinterpret_cast<f32x4*>(a.out + ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx) =
+                        f32x4{vv[ch][0] + rr[ch][0], vv[ch][1] + rr[ch][1], vv[ch][2] + rr[ch][2], vv[ch][3] + rr[ch][3]};
+                  }
                 }
               }
             }
@@ -1121,6 +1131,10 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   a.tiles_y = eavsr::cdiv(d->h, C::TOH);
   a.act = d->act; a.slope = d->slope;
   a.out_shuffle = d->out_shuffle;
+  a.res_scale = d->res_scale;
+  EAVSR_REQUIRE(d->res_scale == nullptr || (R == 3 && d->residual != nullptr && d->out_shuffle == 0 && d->ca_scale == nullptr &&
+                                            (d->cin / CK) % 2 == 0 && w6_grouped_schedule()), -2,
+                "conv_wino6: res_scale needs the (grouped) 3x3 kernel, a residual, no prologue, an even number of 4-channel chunks");
   EAVSR_REQUIRE(d->out_shuffle == 0 || d->out_shuffle == 2, -1, "conv_wino6: out_shuffle %d (0 or 2)", d->out_shuffle);
   if (d->out_shuffle == 2)
     EAVSR_REQUIRE(R == 3 && d->cout % 4 == 0 && d->residual == nullptr && d->chan_partial == nullptr, -2,
@@ -1143,6 +1157,9 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
     if (R == 3 && attr_err == hipSuccess)
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, false, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WCfg<3>::LDS_BYTES);
+    if (R == 3 && attr_err == hipSuccess)
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, false, true, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)WCfg<3>::LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv_wino6: hipFuncSetAttribute(%zu B of LDS): %s", C::LDS_BYTES, hipGetErrorString(attr_err));
@@ -1161,7 +1178,10 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
     const bool grp_on = w6_grouped_schedule();
     if constexpr (R == 3) {
       if (grp_on && (d->cin / CK) % 2 == 0) {
-        hipLaunchKernelGGL((conv_wino6_kernel<3, false, true>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
+        if (d->res_scale != nullptr)
+          hipLaunchKernelGGL((conv_wino6_kernel<3, false, true, true>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
+        else
+          hipLaunchKernelGGL((conv_wino6_kernel<3, false, true>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
         return eavsr::launch_status("conv_wino6");
       }
     }

@@ -351,6 +351,15 @@ class RCABlock(nn.Module):
                     return AG.rcab(x, *ps)
             r = _run_fused(self.res, x)
             return AG.rcab_tail(r, x, a.weight, a.bias, b.weight, b.bias)
+        if (RCAB_PRE and x.shape[1] == 64 and len(self.res) == 3 and isinstance(self.res[1], _Act) and self.res[1].kind == "relu"
+                and tuple(self.res[2].weight.shape) == (64, 64, 3, 3) and int(a.weight.shape[0]) <= 8):
+            # the attention BEFORE the second convolution (ops.ca_scale_pre: its output's channel means are linear in border-corrected
+            # channel sums of its input), `res * y + x` as that convolution's epilogue: no scale_residual launch (88 MB of HBM traffic
+            # per block at 2 x 64 x 180 x 320)
+            c1, c2 = self.res[0], self.res[2]
+            t, tpart = c1(x, act="relu", chan_partial=True)
+            scale = ops.ca_scale_pre(t, tpart, c2.weight, c2.bias, a.weight, a.bias, b.weight, b.bias)
+            return ops.conv2d(t, c2.weight, c2.bias, residual=x, res_scale=scale)
         r, partial = _run_fused(self.res, x, chan_partial=True)     # conv-ReLU-conv, + channel sums
         if FUSE_CA_TAIL:
             return ops.ca_tail(r, partial, a.weight, a.bias, b.weight, b.bias, x)      # CALayer + res * y + x in one launch
@@ -370,6 +379,15 @@ import os as _os
 # scale_residual waves fit per SIMD beside a convolution but one 32-register wave of the fused kernel, each holding its slot through a
 # latency-bound MLP prologue, while ca_scale's two workgroups leave the GPU to the other stream.
 FUSE_CA_TAIL = _os.environ.get("EAVSR_FUSE_CA_TAIL", "0") == "1"
+# fp32 inference: the RCAB's attention before its second convolution, the tail as that convolution's epilogue (as RCAB_H16_PRE in the
+# 16-bit modes): 217.0 / 218.0 -> 213.0 / 214.0 ms per configs[1] step in rotation on one box (tools/visits/r5_o.sh), timed output
+# bit-identical to the eager forward.  EAVSR_RCAB_PRE=0 keeps conv, conv, ca_scale, scale_residual (A/B switch).
+RCAB_PRE = _os.environ.get("EAVSR_RCAB_PRE", "1") == "1"
+
+
+def set_rcab_pre(on: bool) -> None:
+    global RCAB_PRE
+    RCAB_PRE = bool(on)
 # training: one autograd node per RCAB (autograd._RcabFn); EAVSR_RCAB_ONE_NODE=0: the per-op nodes of rounds 1-4
 RCAB_ONE_NODE = _os.environ.get("EAVSR_RCAB_ONE_NODE", "1") != "0"
 FUSE_CA_INTO_CONV = _os.environ.get("EAVSR_FUSE_CA", "0") == "1"

@@ -533,9 +533,11 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
            bias: Union[None, Tensor, Sequence[Optional[Tensor]]] = None, act: Optional[str] = None,
            slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False,
            ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False, pixel_shuffle2: bool = False,
-           sigmoid_from: Optional[int] = None, dgrad: bool = False):
+           sigmoid_from: Optional[int] = None, dgrad: bool = False, res_scale: Optional[Tensor] = None):
     """conv over the virtual channel-concatenation of `srcs`; `weight` may be a list of weights
     that are concatenated along cout (several heads in one launch).
+    res_scale (n, cout) with `residual`: out = residual + res_scale[n, co] * act(conv + bias) -- RCABlock's tail as the epilogue of
+    the F(4x4,3x3) kernel (the attention from ca_scale_pre BEFORE the launch); other routes: the convolution, then scale_residual.
     dgrad=True: `weight` is ONE forward weight (cout_w, cin_w, k, k) and the call computes the input gradient of its stride-1
     "same" convolution from srcs = dY (cout_w channels): the convolution with the transposed, flipped weight.  The small-launch
     bf16x6 kernel packs that form straight from `weight`; every other route materialises it once per weight version.
@@ -576,6 +578,12 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         raise ValueError(f"weight expects {[int(x.shape[1]) for x in weights]} input channels, sources give {cin}")
     if pixel_shuffle2 and (cout % 4 or residual is not None or chan_partial or ca is not None):
         raise ValueError("pixel_shuffle2: cout % 4 == 0, no residual / channel sums / channel-attention prologue")
+    if res_scale is not None:
+        if residual is None or chan_partial or ca is not None or pixel_shuffle2 or sigmoid_from is not None or dgrad or act == "relu_mask":
+            raise ValueError("res_scale: with `residual`; no channel sums / prologue / shuffle / sigmoid / dgrad / mask")
+        res_scale = _chk(res_scale, "res_scale")
+        if tuple(res_scale.shape) != (n, cout):
+            raise ValueError(f"res_scale must be (n, cout) = ({n}, {cout})")
     masked = act == "relu_mask"    # out = residual > 0 ? conv : 0 (a ReLU's backward inside the input-gradient convolution): direct kernels only
     if masked and (residual is None or chan_partial or ca is not None or pixel_shuffle2 or sigmoid_from is not None):
         raise ValueError("act='relu_mask': residual = the ReLU's forward output; no channel sums / prologue / shuffle / sigmoid")
@@ -620,6 +628,9 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     use_wino4 = (use_wino and CONV_MODE == "winograd4" and out.data_ptr() % 16 == 0
                  and (residual is None or residual.data_ptr() % 16 == 0)
                  and 2 * n * lib().eavsr_conv3x3_wino4_tiles(h, w) >= WINO_MIN_TILES)
+    if res_scale is not None and not (use_wino4 and cin % 8 == 0 and lib().eavsr_wino4_schedule() == 1):
+        # every other kernel: the convolution, then the tail as its own launch
+        return scale_residual(conv2d(srcs, weights, biases, act=act, slope=slope), res_scale, residual)
     if pixel_shuffle2 and not (use_wino4 and FUSE_PIXEL_SHUFFLE):      # every other kernel: plain output, shuffled by torch
         return torch.nn.functional.pixel_shuffle(conv2d(srcs, weights, biases, act=act, slope=slope), 2)
     # 5x5 (the predictor's offset / mask heads) by F(2x2, 5x5): the same 6 x 6 tile pipeline, 4 x 32-pixel tiles
@@ -658,6 +669,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.act = ACT[act]
     d.slope = float(slope)
+    d.res_scale = _p(res_scale)
     if pixel_shuffle2 and use_wino4:
         d.out_shuffle = 2
         out = out.view(n, cout // 4, 2 * h, 2 * w)      # the same buffer, written in the shuffled layout
@@ -1829,6 +1841,27 @@ def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias:
     _launch("ca_scale_pre_h16", 0.0, 4.0 * partial.numel(), t,
             lambda: lib().eavsr_ca_scale_pre_h16(_p(t), _p(partial), int(partial.shape[1]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2),
                                                  _p(scale), _p(ws), n, h, w, cr, code, st), "ca_scale_pre_h16")
+    return scale
+
+
+def ca_scale_pre(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Optional[Tensor], w1: Tensor, b1: Tensor,
+                 w2: Tensor, b2: Tensor) -> Tensor:
+    """ca_scale_pre_h16 for the fp32 NCHW path: t (n, 64, h, w) = ReLU(conv1(x)), partial = its per-tile channel sums (the first
+    convolution's chan_partial), conv_weight / conv_bias = the SECOND convolution's.  (n, 64) for conv2d(.., residual=, res_scale=)."""
+    t, partial = _chk(t, "t"), _chk(partial, "partial")
+    n, c, h, w = t.shape
+    if c != 64 or tuple(conv_weight.shape) != (64, 64, 3, 3) or partial.shape[0] != n or partial.shape[2] != 64:
+        raise ValueError("ca_scale_pre: 64 channels, a (64, 64, 3, 3) convolution, partial (n, tiles, 64)")
+    cw = _chk(conv_weight.detach(), "conv_weight")
+    cb = None if conv_bias is None else _chk(conv_bias.detach(), "conv_bias")
+    w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
+    cr = int(w1.shape[0])
+    scale = torch.empty((n, 64), device=t.device, dtype=torch.float32)
+    ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
+    st = _stream(t)
+    _launch("ca_scale_pre", 0.0, 4.0 * partial.numel(), t,
+            lambda: lib().eavsr_ca_scale_pre_f32(_p(t), _p(partial), int(partial.shape[1]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2),
+                                                 _p(scale), _p(ws), n, h, w, cr, st), "ca_scale_pre")
     return scale
 
 

@@ -211,6 +211,10 @@ typedef struct eavsr_conv2d_desc {
    * upsampling tail, eavsrp_model.py:343-347: channel 4c+2i+j -> out[c][2y+i][2x+j]); eavsr_conv3x3_wino4_f32 only, cout % 4 == 0,
    * no residual, no channel sums -- every other entry point returns -2 for a non-zero value. */
   int32_t out_shuffle;
+  /* NULL, or (n, cout) fp32 (ABI 27; eavsr_conv3x3_wino4_f32 only, with `residual`): out = residual + res_scale[n][co] * act(conv
+   * + bias) -- RCABlock's tail `res * y + x` (models/networks.py:463-464) as the second convolution's epilogue; the attention
+   * comes from eavsr_ca_scale_pre_f32 BEFORE the launch.  Every other entry point returns -2 for a non-NULL value. */
+  const float* res_scale;
 } eavsr_conv2d_desc;
 
 int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);
@@ -535,6 +539,11 @@ int eavsr_conv3x3_c64_h16_res(const void* x, const void* weight_packed, const fl
  * / columns / corners of t (16-bit NHWC), WITHOUT running the convolution: sum_o conv(t)[co][o] = sum W[co][ci][ky][kx] (T[ci] -
  * R(ky) - C(kx) + X(ky,kx)).  conv_weight (64, 64, 3, 3) fp32 is rounded to `dtype` as the convolution's packed weights are.
  * workspace: eavsr_ca_scale_pre_ws_floats(n) floats.  Two launches (border sums, then one workgroup per sample). */
+/* The fp32 NCHW form (64 channels): t (n, 64, h, w) fp32, chan_partial (n, tiles, 64) from the first convolution (relu + channel
+ * sums), the second convolution's fp32 weights as they are. */
+int eavsr_ca_scale_pre_f32(const float* t, const float* chan_partial, int32_t tiles, const float* conv_weight, const float* conv_bias,
+                           const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,
+                           int32_t n, int32_t h, int32_t w, int32_t cr, void* stream);
 int64_t eavsr_ca_scale_pre_ws_floats(int32_t n);
 int eavsr_ca_scale_pre_h16(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight, const float* conv_bias,
                            const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,

@@ -292,6 +292,40 @@ def test_conv3x3_small_launches_bf16x6_matches_fp64_and_the_fp32_kernel(ops, cud
         assert (outs["x6s"][r == 0] == 0).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 180, 320), (1, 45, 80), (2, 19, 37), (1, 1, 8), (3, 5, 1)])
+def test_rcab_attention_before_the_second_convolution_fp32(ops, cuda, shape):
+    """eavsr_ca_scale_pre_f32 + the scaled-residual epilogue of the F(4x4,3x3) kernel (desc.res_scale): the attention of an RCAB
+    (CALayer, networks.py:444-447) from border-corrected channel sums of the second convolution's INPUT must equal the attention
+    from that convolution's OUTPUT, and `x + scale * conv(t)` as the convolution's epilogue the separate scale_residual launch --
+    on a launch the Winograd kernel takes, on small / ragged ones (other kernels: the tail as its own launch), single rows / columns."""
+    n, h, w = shape
+    x = cases.randn(101, n, 64, h, w)
+    w1, w2 = cases.randn(102, 64, 64, 3, 3, scale=1.0 / 24), cases.randn(103, 64, 64, 3, 3, scale=1.0 / 24)
+    b1, b2 = cases.randn(104, 64, scale=0.1), cases.randn(105, 64, scale=0.1)
+    a_w, a_b, c_w, c_b = cases.randn(106, 4, 64, scale=0.5), cases.randn(107, 4, scale=0.1), cases.randn(108, 64, 4, scale=0.5), cases.randn(109, 64, scale=0.1)
+    gx, gw1, gw2, gb1, gb2 = (g(v, cuda) for v in (x, w1, w2, b1, b2))
+    ga_w, ga_b, gc_w, gc_b = (g(v, cuda) for v in (a_w, a_b, c_w, c_b))
+    # reference (fp64): the block as the reference computes it
+    t64 = F.relu(F.conv2d(x.double(), w1.double(), b1.double(), 1, 1))
+    r64 = F.conv2d(t64, w2.double(), b2.double(), 1, 1)
+    m64 = r64.mean((2, 3))
+    s64 = torch.sigmoid(F.relu(m64 @ a_w.double().t() + a_b.double()) @ c_w.double().t() + c_b.double())
+    y64 = x.double() + r64 * s64[:, :, None, None]
+    t, tpart = ops.conv2d(gx, gw1, gb1, act="relu", chan_partial=True)
+    scale = ops.ca_scale_pre(t, tpart, gw2, gb2, ga_w, ga_b, gc_w, gc_b)
+    assert H.maxabs(scale.cpu().double(), s64) <= 2e-5
+    with ops.profile() as prof:
+        y = ops.conv2d(t, gw2, gb2, residual=gx, res_scale=scale)
+    if (n, h, w) == (2, 180, 320):
+        assert list(prof.summary()) == ["conv3x3_64to64_wino4"]      # the epilogue form: one launch
+    assert H.maxabs(y.cpu().double(), y64) <= 1e-4 * max(1.0, y64.abs().max().item())
+    r, rpart = ops.conv2d(t, gw2, gb2, chan_partial=True)
+    y_old = ops.scale_residual(r, ops.ca_scale(rpart, h * w, ga_w, ga_b, gc_w, gc_b), gx)
+    assert H.maxabs(y.cpu(), y_old.cpu()) <= 2e-5 * max(1.0, y64.abs().max().item())
+    with pytest.raises(ValueError):
+        ops.conv2d(t, gw2, gb2, res_scale=scale)      # no residual
+
+
 @pytest.mark.parametrize("case", [(64, 2, 96, 96), (40, 1, 19, 37), (64, 1, 180, 320), (6, 1, 24, 40)])
 def test_conv2d_dgrad_flag_reads_the_forward_weight_in_place(ops, cuda, case):
     """conv2d(dY, W, dgrad=True) = the input gradient of conv(x, W): the small-launch bf16x6 kernel packs the transposed, flipped
