@@ -199,8 +199,11 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
         usable = usable_cores()
         cands = sorted({c for c in (8, 16, 32, 64, 128, usable) if c <= usable})
         best = None
+        # the probe runs the FULL-SIZE frames of the workload (two of them: torch's CPU kernels thread over pixels, and a 64 x 96
+        # crop said nothing about how a 180 x 320 convolution scales -- VERDICT r5 weak 11); larger workloads keep the crop
+        pf, ph, pw = (2, full_h, full_w) if full_h * full_w <= 180 * 320 else (min(frames, 7), crop_h, crop_w)
         for c in cands:      # ascending; stop as soon as more threads are clearly slower (saves the slow candidates' minutes)
-            secs_p, _ = _run_cpu_child(preset, min(frames, 7), crop_h, crop_w, c, 1, 40.0, timeout_s=60, scale=scale)
+            secs_p, _ = _run_cpu_child(preset, pf, ph, pw, c, 1, 40.0, timeout_s=60, scale=scale)
             if len(secs_p) >= 2:
                 probe += f"{c}: {secs_p[-1]:.1f} s; "
                 if best is None or secs_p[-1] < best[1]:
@@ -213,7 +216,7 @@ def cpu_baseline(preset, frames, full_h, full_w, crop_h, crop_w, runs=3, budget=
                 if best is not None:
                     break
         cores = best[0] if best else min(usable, 32)
-        probe = f" (thread count chosen by a probe on a {crop_h}x{crop_w} clip over {usable} usable cores -- {probe.rstrip('; ')})"
+        probe = f" (thread count chosen by a probe on a {pf} x {ph}x{pw} clip over {usable} usable cores -- {probe.rstrip('; ')})"
     base = {"unit": "frames/s", "cores": cores, "kind": "port"}
     if frames * full_h * full_w > 2_500_000:
         # a clip this large (configs[4]: 15 x 540 x 960) needs minutes per run on the host: a BOUNDED sample instead -- all frames
@@ -861,6 +864,12 @@ def main():
             if "offset_stats" in dcn_entry:
                 ns["workload_offsets_px"] = {k: dcn_entry["offset_stats"].get(k) for k in ("mean_norm", "max_abs", "frac_outside_lds_window")}
             line["roofline"]["north_star"] = ns
+            # ... and once more where a record that keeps only the top-level keys of `roofline` still carries it (VERDICT r5 item 4:
+            # the driver's BENCH record drops nested roofline keys and keeps `config` whole)
+            line["config"]["dcnv2_hbm"] = (f"{1e3 * ns['avg_ms']:.1f} us = {ns['frac']:.3f} of 8 TB/s on {ns.get('bytes_per_px', 1376)} B/px "
+                                           f"({ns['kernel']}, {ns['launch_shape']}, {ns['calls']} launches, HIP events in this run)")
+            if "frac_at_sigma_px" in ns:
+                line["config"]["dcnv2_hbm_at_sigma_px"] = ns["frac_at_sigma_px"]
         line["kernels"] = [e for e in (dcn_entry, entry("flow_warp_pair", "hbm"), entry("flow_warp", "hbm"),
                                        entry("adapt_frontend", "hbm"), entry("affine_offsets", "hbm"),
                                        entry("scale_residual", "hbm"), entry("conv5x5_64to120_wino", "mfma"),
@@ -881,6 +890,23 @@ def main():
                     line["roofline"]["traffic"] = tr.get(dom_name)
                 for e in line["kernels"]:
                     e["traffic"] = tr.get(e["kernel"])
+            except Exception:
+                pass
+
+    if rank == 0:
+        # the N = 1 step time of the last committed profile visit: a SCALE record (N = 2, 4, 8; weak scaling, so every rank's step
+        # should take this long) can be sanity-checked against it without a second run
+        import glob as _glob
+        import re as _re
+        cands = sorted((p_ for p_ in _glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_line.json"))),
+                       key=lambda p_: int(_re.search(r"r(\d+)_bench_line", p_).group(1)))
+        if cands and args.config == 1 and args.backbone_dtype == "fp32":
+            try:
+                ref_line = json.load(open(cands[-1]))
+                line["expected_n1_ms"] = {"ms_per_step": ref_line["ms_per_step"], "value": ref_line["value"],
+                                          "source": os.path.relpath(cands[-1], ROOT),
+                                          "note": "N = 1 on one MI355X at the commit of that profile visit; weak scaling: per-rank step time "
+                                                  "at N > 1 should equal it (per_rank_ms), value should be N x this value"}
             except Exception:
                 pass
 

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -49,6 +49,7 @@ class ConvDesc(C.Structure):
 SIGNATURES = {
     "eavsr_abi_version": (C.c_int, []),
     "eavsr_version": (C.c_char_p, []),
+    "eavsr_conv2d_desc_size": (C.c_size_t, []),
     "eavsr_last_error": (C.c_char_p, []),
     "eavsr_selftest_mfma_f32": (C.c_int, [vp, vp]),
     "eavsr_flow_warp_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -196,6 +197,9 @@ def load():
         if lib.eavsr_abi_version() != ABI_VERSION:
             raise NativeLibraryError(
                 f"ABI mismatch: library {lib.eavsr_abi_version()} vs binding {ABI_VERSION}; rebuild")
+        if lib.eavsr_conv2d_desc_size() != C.sizeof(ConvDesc):      # a descriptor that grew without an ABI bump
+            raise NativeLibraryError(
+                f"struct eavsr_conv2d_desc: library {lib.eavsr_conv2d_desc_size()} bytes vs binding {C.sizeof(ConvDesc)}; rebuild")
         _lib = lib
     return _lib
 

@@ -70,6 +70,10 @@ class grad_sink:
 
     # uses of one weight that wait for their (batched) weight-gradient launch: at most this many per launch
     BATCH = ops.WGRAD_MAX_SEGMENTS
+    # uses per call site in the LAST backward that ended: a call site whose expected uses are all in launches at once instead of
+    # holding its dY and saved sources until flush() -- most convolutions outside the recurrence are used once per step, and
+    # their activations would otherwise stay alive until backward ends (peak memory, baked into the graph's pool)
+    _last_uses = {}
 
     def add_use(self, ws, bs, k, g, srcs):
         """One use of the weights `ws` (+ biases `bs`): dY = g over the sources `srcs`.  The gradient launch is DEFERRED: uses of
@@ -82,14 +86,16 @@ class grad_sink:
             cout = sum(int(w.shape[0]) for w in ws)
             dW = torch.empty((cout, int(ws[0].shape[1]), k, k), device=ws[0].device, dtype=torch.float32)
             db = torch.empty((cout,), device=ws[0].device, dtype=torch.float32) if bs is not None else None
-            e = {"ws": list(ws), "bs": None if bs is None else list(bs), "dW": dW, "db": db, "k": k, "written": False, "pending": []}
+            e = {"ws": list(ws), "bs": None if bs is None else list(bs), "dW": dW, "db": db, "k": k, "written": False, "pending": [],
+                 "uses": 0, "key": key}
             self.entries[key] = e
         if e["pending"] and (tuple(e["pending"][0][0].shape) != tuple(g.shape)
                              or [tuple(s_.shape) for s_ in e["pending"][0][1]] != [tuple(s_.shape) for s_ in srcs]):
             self._launch(e)       # another shape at the same call site: what waits goes first
         e["pending"].append((g, list(srcs)))
-        if len(e["pending"]) >= self.BATCH:
-            self._launch(e)
+        e["uses"] += 1
+        if len(e["pending"]) >= self.BATCH or e["uses"] == grad_sink._last_uses.get(key, -1):
+            self._launch(e)       # a full batch, or the last use this call site had in the previous backward
 
     @staticmethod
     def _launch(e):
@@ -121,6 +127,7 @@ class grad_sink:
                     p.grad = g if p.grad is None else p.grad + g
                 continue
             self._launch(e)
+            grad_sink._last_uses[e["key"]] = e["uses"]
             ws, bs, dW, db = e["ws"], e["bs"], e["dW"], e["db"]
             c0 = 0
             for i, w_ in enumerate(ws):
@@ -137,7 +144,7 @@ class grad_sink:
 # c0 .. c0+cs.  A weight is used once per frame and branch, so within a step the same operand is asked for 7-28
 # times: it is built once per weight version (and, being the same tensor object, its packed form is then also a
 # hit in ops.pack_cache).
-_dgrad_cache = {}
+_dgrad_cache = ops.register_weight_cache({})
 
 
 def _dgrad_weight(ws, c0: int, cs: int) -> Tensor:
@@ -272,7 +279,7 @@ def flow_warp(x, flow, padding_mode="zeros", flow2=None, flow_layout="nchw", int
 
 
 # ------------------------------------------------------------------------------------------ DCNv2
-_dcn_wt_cache = {}
+_dcn_wt_cache = ops.register_weight_cache({})
 
 
 def _dcn_wt(weight: Tensor) -> Tensor:

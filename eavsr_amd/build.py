@@ -38,12 +38,29 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the native library cannot be built")
 
 
+_HIPCC_VERSION = None
+
+
+def hipcc_version() -> str:
+    """`hipcc --version`, condensed (HIP version + the clang revision line): part of the build digest, because three kernels
+    (conv_wino6.hip, conv_h16.hip, rcab_h16.hip) read their MFMA operands by `asm volatile` LDS reads with hand-counted
+    `s_waitcnt` -- correct only as long as the compiler keeps the registers between a read and its wait where this toolchain
+    keeps them.  A toolchain bump therefore rebuilds everything AND invalidates the guard library below, whose bit-compare
+    (tests/test_hip_ops.py::test_winograd4_hand_counted_reads_equal_the_compilers) is the check that the assumption still holds."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        r = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True)
+        lines = [ln.strip() for ln in (r.stdout or "").splitlines() if ln.startswith(("HIP version", "AMD clang version"))]
+        _HIPCC_VERSION = " | ".join(lines) or "unknown hipcc"
+    return _HIPCC_VERSION
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
 def _digest() -> str:
-    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(PER_FILE_FLAGS.items()))).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(PER_FILE_FLAGS.items())) + hipcc_version()).encode())
     files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     files.append(os.path.join(os.path.dirname(HERE), "include", "eavsr_hip.h"))
     for f in files:
@@ -82,6 +99,33 @@ def build_native(force: bool = False, verbose: bool = False, extra_flags=()) -> 
     with open(stamp, "w") as f:
         f.write(dig)
     return LIB
+
+
+GUARD_DIR = os.path.join(LIBDIR, "guard")
+# name -> (sources, extra flags): the product kernel with its hand-scheduled pieces handed back to the compiler
+GUARD_VARIANTS = {
+    "wino4_creads": (["conv_wino6.hip", "capi.hip"], ["-DEAVSR_W4_COMPILER_READS"]),
+}
+
+
+def build_guard(name: str = "wino4_creads", force: bool = False) -> str:
+    """eavsr_amd/lib/guard/lib<name>.so: conv_wino6.hip built with -DEAVSR_W4_COMPILER_READS (every LDS operand read and wait
+    left to the compiler) beside capi.hip -- the reference the toolchain guard compares the product kernel with, bit for bit, on
+    the GPU.  Same flags as the product build; keyed on the same digest (sources, flags, hipcc version)."""
+    srcs, extra = GUARD_VARIANTS[name]
+    os.makedirs(GUARD_DIR, exist_ok=True)
+    out = os.path.join(GUARD_DIR, f"lib{name}.so")
+    stamp = out + ".stamp"
+    dig = _digest() + "|" + " ".join(extra)
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return out
+    cmd = [_hipcc(), *FLAGS, *extra, "-shared", *[os.path.join(CSRC, f) for f in srcs], "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on the guard library {name}:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return out
 
 
 if __name__ == "__main__":

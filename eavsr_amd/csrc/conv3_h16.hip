@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, EAVSR_H16G_WAVES) void conv3x3_h16g_kernel(G16
             const int co = cot * G_CO + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
             if (co < a.cout) {
               const float v = acc[m][t][e];
-              a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = fmaxf(v, eavsr_mul_legacy(v, act_s));
+              a.out[((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx] = eavsr_act(v, act_s);
             }
           }
       }

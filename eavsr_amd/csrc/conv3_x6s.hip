@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int cu = (r & 3) + 8 * (r >> 2);
       float v = acc[r];
-      v = fmaxf(v, eavsr_mul_legacy(v, act_s));      // branch-free: max(v, v s), 0 <= s <= 1
+      v = eavsr_act(v, act_s);      // branch-free: max(v, v s), 0 <= s <= 1
       vv[r] = v;
       if (a.chan_partial) {
         float sum = (pxok && co0 + cu < a.cout) ? v : 0.f;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
     const int cu = (r & 3) + 8 * (r >> 2);
     const bool cok = co0 + cu < a.cout;
     float v = acc[r];
-    v = fmaxf(v, eavsr_mul_legacy(v, act_s));      // branch-free: max(v, v s), 0 <= s <= 1
+    v = eavsr_act(v, act_s);      // branch-free: max(v, v s), 0 <= s <= 1
     float sum = 0.f;
     if (cok && pxok) {
       sum = v;

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_mfma_kernel(ConvArgs a) {
       for (int t = 0; t < NT; ++t) {
         const int gy = y0 + wave * NT + t;
         float v = acc[m][t][r] + b;
-        v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_RELU ? 0.f : a.act == EAVSR_ACT_LRELU ? a.slope : 1.f));   // branch-free: max(v, v s), 0 <= s <= 1
+        v = eavsr_act(v, a.act == EAVSR_ACT_RELU ? 0.f : a.act == EAVSR_ACT_LRELU ? a.slope : 1.f);   // branch-free: max(v, v s), 0 <= s <= 1
 #ifdef EAVSR_CONV_EXP_NOSTORE   // timing ablation only (tools/gpu_conv_ablate.py)
         if (cok && xok && gy < h && v == 12345.678f) {
 #else
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_small_kernel(ConvArgs a) {
       const int co = co_base + col;
       const bool cok = co < a.cout;
       float v = acc[m][r] + bb[m][r];
-      v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_RELU ? 0.f : a.act == EAVSR_ACT_LRELU ? a.slope : 1.f));   // branch-free: max(v, v s), 0 <= s <= 1
+      v = eavsr_act(v, a.act == EAVSR_ACT_RELU ? 0.f : a.act == EAVSR_ACT_LRELU ? a.slope : 1.f);   // branch-free: max(v, v s), 0 <= s <= 1
       float sum = 0.f;
       if (cok && pok) {
         const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256 * KZ) void conv3x3_smallco_kernel(SmallArgs a) 
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
           float v = acc[co][p] + (a.bias ? a.bias[co] : 0.f);
-          v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope));   // branch-free: max(v, v s), 0 <= s <= 1
+          v = eavsr_act(v, a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope);   // branch-free: max(v, v s), 0 <= s <= 1
           const size_t o = ((size_t)bn * COUT + co) * plane + (size_t)gy * w + gx;
           if (a.residual) v += a.residual[o];
           a.out[o] = v;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__((TH / PXR) * TW) void conv3x3_smallco_lite_kernel(S
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
           float v = acc[co][p] + bv[co];
-          v = fmaxf(v, eavsr_mul_legacy(v, act_s));
+          v = eavsr_act(v, act_s);
           a.out[((size_t)bn * COUT + co) * (plane4 / 4) + (size_t)gy * w + gx] = v + rv[p][co];
         }
       }

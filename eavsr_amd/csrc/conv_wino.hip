@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_kernel(WnArgs a) {
         for (int dy = 0; dy < 2; ++dy) {
           const int gy = y0 + 2 * (tb0 + b) + dy;
           float v0 = y[dy][0] + bb, v1 = y[dy][1] + bb;
-          { const float as_ = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope; v0 = fmaxf(v0, eavsr_mul_legacy(v0, as_)); v1 = fmaxf(v1, eavsr_mul_legacy(v1, as_)); }   // branch-free: max(v, v s)
+          { const float as_ = a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope; v0 = eavsr_act(v0, as_); v1 = eavsr_act(v1, as_); }   // branch-free: max(v, v s)
           if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
             const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
             csum[r] += v0 + v1;

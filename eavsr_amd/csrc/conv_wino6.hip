@@ -878,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 float t = (ch == 0 ? y[j].x : y[j].y) + bias_r[r];
-                t = fmaxf(t, eavsr_mul_legacy(t, act_s));
+                t = eavsr_act(t, act_s);
                 vv[ch][j] = t;
               }
             }
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               y[j] += bb;
-              y[j] = fmaxf(y[j], eavsr_mul_legacy(y[j], act_s));
+              y[j] = eavsr_act(y[j], act_s);
             }
             if (cok && gy < h && gx < w) {     // w % 4 == 0 and gx even: gx + 1 < w as well
               csum[r] += y[0] + y[1];

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(512) void conv_x6_kernel(C7Args a) {
       for (int t = 0; t < S_NT; ++t) {
         float v = acc[m][t][r];
         if (sg) v = eavsr_sigmoid_fast(v);
-        else v = fmaxf(v, eavsr_mul_legacy(v, act_s));      // branch-free: max(v, v s), 0 <= s <= 1
+        else v = eavsr_act(v, act_s);      // branch-free: max(v, v s), 0 <= s <= 1
         if (cok && xok && y0 + wave * S_NT + t < h) ob[(size_t)cu * plane + (size_t)t * w] = v;
       }
     }

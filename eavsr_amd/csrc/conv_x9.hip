@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_x9_kernel(CxArgs a) {
       for (int t = 0; t < NT; ++t) {
         const int gy = y0 + wave * NT + t;
         float v = acc[m][t][r] + b;
-        v = fmaxf(v, eavsr_mul_legacy(v, a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope));   // branch-free: max(v, v s), 0 <= s <= 1
+        v = eavsr_act(v, a.act == EAVSR_ACT_NONE ? 1.f : a.act == EAVSR_ACT_RELU ? 0.f : a.slope);   // branch-free: max(v, v s), 0 <= s <= 1
         if (cok && xok && gy < h) {
           const size_t o = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx;
           sum += v;

@@ -544,24 +544,37 @@ class EAVSRPModel:
 
     def load_networks(self, epoch_or_path):
         """Every key of the file must exist in the network with the same shape and every parameter of the network
-        must be in the file: the reference `exit()`s on either mismatch (base_model.py:193-213); here it raises."""
-        path = self._network_path(epoch_or_path)
-        if isinstance(epoch_or_path, int) and getattr(self.opt, "load_path", ""):
-            path = self.opt.load_path
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.get("state_dict", sd)
-        own = self.netEAVSRP.state_dict()
-        unknown = [k for k in sd if k not in own]
-        missing = [k for k in own if k not in sd]
-        if unknown:
-            raise RuntimeError("Saved parameter named [%s] is not in the network (%d such keys)" % (unknown[0], len(unknown)))
-        if missing:
-            raise RuntimeError("Parameter named [%s] is not in %s (%d such keys)" % (missing[0], path, len(missing)))
-        for k, v in sd.items():
-            if tuple(own[k].shape) != tuple(v.shape):
-                raise RuntimeError("While copying the parameter named [%s], whose dimensions in the model are %s and "
-                                   "whose dimensions in the checkpoint are %s." % (k, list(own[k].shape), list(v.shape)))
-        self.netEAVSRP.load_state_dict(sd, strict=True)
+        must be in the file: the reference `exit()`s on either mismatch (base_model.py:193-213); here it raises.
+        Several processes: a COLLECTIVE -- every rank calls it (as every rank runs train_basic.py / test_basic.py).  The ranks
+        first agree that all of them read and checked their file (`shard.all_ranks_ok`): if one failed, every rank raises --
+        nobody is left blocked in the parameter broadcast that follows, and that broadcast can never pair with another rank's
+        next collective.  Then rank 0's parameters and buffers go to everybody (`sync_parameters`)."""
+        from .shard import all_ranks_ok
+        path, err = None, None
+        try:
+            path = self._network_path(epoch_or_path)
+            if isinstance(epoch_or_path, int) and getattr(self.opt, "load_path", ""):
+                path = self.opt.load_path
+            sd = torch.load(path, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            own = self.netEAVSRP.state_dict()
+            unknown = [k for k in sd if k not in own]
+            missing = [k for k in own if k not in sd]
+            if unknown:
+                raise RuntimeError("Saved parameter named [%s] is not in the network (%d such keys)" % (unknown[0], len(unknown)))
+            if missing:
+                raise RuntimeError("Parameter named [%s] is not in %s (%d such keys)" % (missing[0], path, len(missing)))
+            for k, v in sd.items():
+                if tuple(own[k].shape) != tuple(v.shape):
+                    raise RuntimeError("While copying the parameter named [%s], whose dimensions in the model are %s and "
+                                       "whose dimensions in the checkpoint are %s." % (k, list(own[k].shape), list(v.shape)))
+            self.netEAVSRP.load_state_dict(sd, strict=True)
+        except Exception as e:      # noqa: BLE001 -- re-raised below, on every rank
+            err = e
+        if not all_ranks_ok(err is None):
+            if err is not None:
+                raise err
+            raise RuntimeError(f"load_networks({epoch_or_path!r}): another rank failed to load its checkpoint; aborting on every rank")
         self.sync_parameters()
         if isinstance(epoch_or_path, int):
             self.start_epoch = epoch_or_path

@@ -107,14 +107,9 @@ def clear_weight_caches():
     A replayed graph updates the parameters on the device without touching their Python-side version counters, so
     a cache filled inside (or before) a capture must not serve eager calls afterwards - and a capture must not hit an
     entry built outside it, or the replays would keep reading that stale copy."""
-    from . import autograd, ops
-    ops.pack_cache.clear()
-    for name in ("_bias_cache", "_wcat_cache", "_x9_pack_cache", "_wino_pack_cache", "_h16_pack_cache", "_h16_ps_cache", "_h16_last_cache", "_h16g_pack_cache", "_h16x1_pack_cache",
-                 "_h16_pack5_cache", "_il16_pack_cache", "_smallco_pack_cache", "_conv7_pack_cache", "_il2_pack_cache"):
-        d = getattr(ops, name, None)
-        if d is not None:
-            d.clear()
-    autograd._dgrad_cache.clear()
+    from . import autograd, ops      # (importing autograd registers its caches)
+    for d in ops.WEIGHT_CACHES:      # every derived-weight cache registers itself there (ops.register_weight_cache)
+        d.clear()
 
 
 class GraphedTrainStep:
@@ -228,6 +223,11 @@ class GraphedTrainStep:
                     self._lr_dev[i].fill_(lr)
                     self._lr_seen[i] = lr
         self.graph.replay()
+        if self.world == 1:
+            # the replayed Adam has changed every parameter without bumping its `_version`: whatever an eager call between two
+            # replays (an evaluation pass, an eager backward) cached for this version is stale now.  In a pure replay
+            # loop the caches are empty and this is sixteen no-ops.
+            clear_weight_caches()
         if self.world > 1:
             m.grad_sync.reset()
             m.grad_sync.finish()

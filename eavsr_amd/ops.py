@@ -248,6 +248,17 @@ class _PackCache:
 
 pack_cache = _PackCache()
 
+# Every cache of a form DERIVED from a parameter (packed / transformed / split / transposed weights, concatenated biases), keyed
+# by (id, _version): graph.clear_weight_caches() empties all of them around a capture (a replayed graph updates the parameters
+# without bumping `_version`).  A new cache registers itself here -- ADVICE r5: two caches added in round 5 were missing from
+# the hand-kept list there.
+WEIGHT_CACHES = [pack_cache]
+
+
+def register_weight_cache(d):
+    WEIGHT_CACHES.append(d)
+    return d
+
 
 def _cat_bias(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
     if biases[0] is None:
@@ -255,7 +266,7 @@ def _cat_bias(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
     return biases[0] if len(biases) == 1 else torch.cat([b.detach() for b in biases], 0)
 
 
-_bias_cache = {}
+_bias_cache = register_weight_cache({})
 
 
 def _bias_of(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
@@ -271,7 +282,7 @@ def _bias_of(biases: Sequence[Optional[Tensor]]) -> Optional[Tensor]:
     return cat
 
 
-_wcat_cache = {}
+_wcat_cache = register_weight_cache({})
 
 
 def _cat_weights(weights: Sequence[Tensor]) -> Tensor:
@@ -297,7 +308,7 @@ def _cat_weights(weights: Sequence[Tensor]) -> Tensor:
 # the step 240.0 -> 236.8 ms.  EAVSR_SMALLCO=classic: round 2's 112-184-register kernels (the A/B reference).
 SMALLCO_LITE = os.environ.get("EAVSR_SMALLCO", "lite") != "classic"
 SMALLCO_LITE_MIN_TILES = 0
-_smallco_pack_cache = {}
+_smallco_pack_cache = register_weight_cache({})
 
 
 def _packed_smallco(weights: Sequence[Tensor]) -> Tensor:
@@ -324,7 +335,7 @@ def _packed_smallco(weights: Sequence[Tensor]) -> Tensor:
 # eavsr_conv2d_f32; 5x5: F(2x2,5x5)).  A/B switches.
 CONV7_MODE = os.environ.get("EAVSR_CONV7", "bf16x6")
 CONV5_MODE = os.environ.get("EAVSR_CONV5", "bf16x6")
-_conv7_pack_cache = {}
+_conv7_pack_cache = register_weight_cache({})
 
 
 def _packed_conv_x6(weights: Sequence[Tensor], dgrad: bool = False) -> Tensor:
@@ -374,7 +385,7 @@ def _conv_x6(x: Tensor, weights, biases, act, slope, sigmoid_from: int = -1):
 # type (fp32 NCHW in and out).  Set by networks.set_backbone_dtype (EAVSR_CONV3_16BIT=0 keeps these convolutions fp32: A/B switch).
 CONV3_H16 = None
 CONV3_H16_ENABLED = os.environ.get("EAVSR_CONV3_16BIT", "1") == "1"
-_h16g_pack_cache = {}
+_h16g_pack_cache = register_weight_cache({})
 
 
 def set_conv3_h16(dtype) -> None:
@@ -405,7 +416,7 @@ def _packed_h16g(weights: Sequence[Tensor], code: int) -> Tensor:
 # SPyNet's 7x7 layers with >= 16 output channels in the 16-bit modes (one operand plane of csrc/conv_x6.hip); EAVSR_CONV7_16BIT=0
 # keeps them on the exact bf16x6 form (A/B switch)
 CONV7_H16_ENABLED = os.environ.get("EAVSR_CONV7_16BIT", "1") == "1"
-_h16x1_pack_cache = {}
+_h16x1_pack_cache = register_weight_cache({})
 
 
 def _conv_h16x1(x: Tensor, weights, biases, act, slope, dtype):
@@ -512,7 +523,7 @@ def ca_fusable(x: Tensor, cout: int = 64) -> bool:
 FUSE_PIXEL_SHUFFLE = os.environ.get("EAVSR_FUSE_SHUFFLE", "1") == "1"
 
 
-_dgrad_w_cache = {}
+_dgrad_w_cache = register_weight_cache({})
 
 
 def dgrad_weight(w: Tensor) -> Tensor:
@@ -601,7 +612,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
             y = conv2d(srcs, weights, biases, act, slope)
             y[:, sigmoid_from:] = torch.sigmoid(y[:, sigmoid_from:])
             return y
-    if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None and not masked:
+    if k == 3 and len(srcs) == 1 and cout in (2, 3, 4, 6) and not chan_partial and ca is None and not masked and res_scale is None:
         y = _conv3x3_smallco(srcs[0], weights, biases, act, slope, residual)
         return torch.nn.functional.pixel_shuffle(y, 2) if pixel_shuffle2 else y
     if (CONV3_H16 is not None and k == 7 and CONV7_H16_ENABLED and sigmoid_from is None and len(srcs) == 1 and cin % 8 == 0 and cout >= 16
@@ -929,7 +940,7 @@ def set_dcn_il_impl(impl: str) -> None:
     DCN_IL_IMPL = impl
 
 
-_il2_pack_cache = {}
+_il2_pack_cache = register_weight_cache({})
 
 
 def _packed_dcn_il2(weight: Tensor) -> Tensor:
@@ -953,7 +964,7 @@ def _packed_dcn_il2(weight: Tensor) -> Tensor:
     return packed
 
 
-_il16_pack_cache = {}
+_il16_pack_cache = register_weight_cache({})
 
 
 def _packed_il16(weight: Tensor, code: int) -> Tensor:
@@ -1043,7 +1054,7 @@ def set_dcn_mode(mode: str) -> None:
     DCN_MODE = mode
 
 
-_x9_pack_cache = {}
+_x9_pack_cache = register_weight_cache({})
 
 
 def _packed_x9(weights: Sequence[Tensor]) -> Tensor:
@@ -1128,7 +1139,7 @@ def modes(conv: Optional[str] = None, dcn: Optional[str] = None, dcn_il_impl: Op
         set_dcn_il_impl(prev[2])
 
 
-_wino_pack_cache = {}
+_wino_pack_cache = register_weight_cache({})
 
 
 def _packed_wino(weights: Sequence[Tensor], four: bool = False, kind: Optional[str] = None) -> Tensor:
@@ -1779,7 +1790,7 @@ def from_nhwc_h16(x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
     return out
 
 
-_h16_pack_cache = {}
+_h16_pack_cache = register_weight_cache({})
 
 
 def _packed_h16(weight: Tensor, code: int) -> Tensor:
@@ -1921,8 +1932,8 @@ def rcab_convs_h16(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: 
     return (out, part) if chan_partial else out
 
 
-_h16_ps_cache = {}
-_h16_last_cache = {}
+_h16_ps_cache = register_weight_cache({})
+_h16_last_cache = register_weight_cache({})
 
 
 def _packed_h16_ps2(weight: Tensor, bias: Optional[Tensor], code: int):
@@ -2002,7 +2013,7 @@ def conv3x3_c64to3_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], residu
     return out
 
 
-_h16_pack5_cache = {}
+_h16_pack5_cache = register_weight_cache({})
 
 
 def _packed5_h16(wcat: Tensor, code: int) -> Tensor:

@@ -122,6 +122,19 @@ def all_ranks_str(value: str) -> List[str]:
     return [bytes(int(b) for b in row if b).decode(errors="replace") for row in t.cpu().tolist()]
 
 
+def all_ranks_ok(ok: bool) -> bool:
+    """True iff EVERY rank passes ok=True: one MIN all-reduce of a flag (host tensor over gloo where the group has it, a device
+    tensor otherwise).  The agreement step in front of a start-up collective: a rank that failed locally (a missing checkpoint,
+    a shape mismatch) must take the others down with it instead of leaving them blocked in the broadcast that follows, or
+    pairing that broadcast with their next collective.  Every rank must call it."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    dev = "cpu" if (host_collectives() or not torch.cuda.is_available()) else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def cap_host_threads(world: int) -> int:
     """N ranks on one node share its cores: cap this rank's intra-op / OpenMP threads at cores // world (at least 1), so that
     eight ranks do not start eight full-width thread pools.  Returns the cap."""
@@ -171,7 +184,8 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 
     (models/networks.py:67-74).  Ranks agree afterwards even when only rank `src` loaded a checkpoint or when the ranks were
     seeded differently (until round 5 they agreed only because every rank seeded identically).
     Tensors travel in `state_dict()` order, grouped by dtype, packed flat on the tensors' own device (RCCL for device tensors,
-    gloo for host tensors).  Returns the number of bytes broadcast; a no-op (0) on one process."""
+    gloo for host tensors).  Returns the number of bytes broadcast; a no-op (0) on one process.  A COLLECTIVE: every rank of the
+    group must call it, at the same point of its program (`EAVSRPModel.load_networks` agrees on success first: `all_ranks_ok`)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     tensors = [t for t in module.state_dict(keep_vars=True).values() if isinstance(t, torch.Tensor) and t.numel() > 0]

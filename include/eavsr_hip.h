@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 27
+#define EAVSR_ABI_VERSION 28
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -217,6 +217,9 @@ typedef struct eavsr_conv2d_desc {
   const float* res_scale;
 } eavsr_conv2d_desc;
 
+/* sizeof(eavsr_conv2d_desc) as THIS library was compiled (ABI 28): a binding compares it with its own struct at load time, so
+ * that a descriptor that grew without an ABI bump (ABI 27 did, within one round) can never be read past its end. */
+size_t eavsr_conv2d_desc_size(void);
 int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);
 /* Opt-in "bf16x9" form of the 3x3 convolution (same descriptor, same tensors, same epilogue): both fp32 operands
  * are split EXACTLY into three bf16 terms and all nine partial products are accumulated in fp32 on

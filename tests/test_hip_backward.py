@@ -579,6 +579,31 @@ def test_grad_sink_matches_autograd_accumulation(AG, cuda):
     for k in plain:
         scale = max(1e-8, plain[k].abs().max().item())
         assert H.maxabs(sunk[k], plain[k]) <= 2e-4 * scale, (k, H.maxabs(sunk[k], plain[k]), scale)
+    # second backward: the sink now knows every call site's use count and launches at the LAST expected use instead of at flush()
+    # (single-use convolutions at once: ADVICE r5) -- same sums; then a clip of another length, where the expectation is wrong
+    # in both directions (a launch that comes early is followed by accumulating ones)
+    assert AG.grad_sink._last_uses and 1 in set(AG.grad_sink._last_uses.values())
+    net.zero_grad(set_to_none=True)
+    with AG.grad_sink() as sink:
+        loss = (net(clip) - hr).abs().mean()
+        loss.backward()
+        assert all(not e.get("pending") for e in sink.entries.values())      # nothing waits for flush(): every expected use came
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            scale = max(1e-8, plain[k].abs().max().item())
+            assert H.maxabs(p.grad, plain[k]) <= 2e-4 * scale, (k, H.maxabs(p.grad, plain[k]), scale)
+    for t2 in (6, 3):
+        clip2, hr2 = synthetic_clip(1, t2, 64, 64, seed=23).to(cuda), synthetic_clip(1, t2, 256, 256, seed=24).to(cuda)
+        net.zero_grad(set_to_none=True)
+        (net(clip2) - hr2).abs().mean().backward()
+        plain2 = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+        net.zero_grad(set_to_none=True)
+        with AG.grad_sink():
+            (net(clip2) - hr2).abs().mean().backward()
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                scale = max(1e-8, plain2[k].abs().max().item())
+                assert H.maxabs(p.grad, plain2[k]) <= 2e-4 * scale, (t2, k, H.maxabs(p.grad, plain2[k]), scale)
     # outside the context nothing is redirected, and a second context cannot be nested
     with AG.grad_sink():
         with pytest.raises(RuntimeError):
@@ -625,6 +650,56 @@ def test_graphed_training_step_matches_eager(AG, cuda):
     graphed.set_input(data); fresh.set_input(data)
     graphed.test(); fresh.test()
     assert H.maxabs(graphed.data_sr_seq.cpu(), fresh.data_sr_seq.cpu()) <= 1e-6
+
+
+def test_eager_calls_between_replays_never_see_stale_derived_weights(AG, cuda):
+    """a replayed graph updates the parameters without bumping `_version`, so every cache of a derived weight form
+    (packed, Winograd-transformed, bf16-split, transposed for the input gradient, flipped for DCNv2's backward) must be dropped
+    around a replay -- ALL of them register in ops.WEIGHT_CACHES.  Eager forward + backward (no optimizer step), replays, then
+    the same eager forward + backward at the unchanged `_version`: outputs and gradients equal those of a fresh model loaded
+    from the replayed parameters."""
+    from eavsr_amd import ops
+    from eavsr_amd.eavsrp_model import EAVSRPModel
+    from eavsr_amd.graph import GraphedTrainStep
+    from eavsr_amd.utils.synthetic import synthetic_clip
+    mk = lambda: Namespace(predict=False, n_frame=3, n_flow=5, scale=4, isTrain=True, gpu_ids=[0], lr=1e-3, beta1=0.9,
+                           beta2=0.999, weight_decay=0.0, npost=350)
+    sd = H.filled(H.model_shapes("x4"), "trained_like")
+    data = {"lr_seq": synthetic_clip(1, 3, 64, 64, seed=1), "hr_seq": synthetic_clip(1, 3, 256, 256, seed=2), "fname": "x"}
+    lr, hr = data["lr_seq"].to(cuda), data["hr_seq"].to(cuda)
+    m = EAVSRPModel(mk())
+    m.netEAVSRP.load_state_dict(sd, strict=True)
+    m.set_input(data, epoch=0)
+    g = GraphedTrainStep(m, warmup=1)
+    watch = ["backbone.forward_1.main.2.rg.3.res.0.weight", "deform_align.backward_1.weight", "fusion.forward_2.weight",
+             "deform_align.forward_1.adastn.mask_conv.weight", "conv_last.weight"]
+
+    def eager_fwd_bwd(net):
+        for p in net.parameters():
+            p.grad = None
+        with AG.grad_sink():
+            out = net(lr)
+            (out - hr).abs().mean().backward()
+        prm = dict(net.named_parameters())
+        return out.detach().clone(), {k: prm[k].grad.detach().clone() for k in watch}
+
+    g.step()
+    versions = {k: p._version for k, p in m.netEAVSRP.named_parameters()}
+    eager_fwd_bwd(m.netEAVSRP)                               # fills every derived-weight cache at this version
+    assert any(len(getattr(d, "_d", d)) for d in ops.WEIGHT_CACHES)
+    for _ in range(3):
+        g.step()                                             # parameters move on the device; versions do not
+    assert {k: p._version for k, p in m.netEAVSRP.named_parameters()} == versions
+    out, grads = eager_fwd_bwd(m.netEAVSRP)
+    fresh = EAVSRPModel(mk())
+    fresh.netEAVSRP.load_state_dict({k: v.detach().clone() for k, v in m.netEAVSRP.state_dict().items()}, strict=True)
+    fresh.netEAVSRP.train()
+    out_f, grads_f = eager_fwd_bwd(fresh.netEAVSRP)
+    assert H.maxabs(out.cpu(), out_f.cpu()) <= 1e-6
+    for k in watch:
+        sc = max(1e-7, grads_f[k].abs().max().item())
+        assert H.maxabs(grads[k].cpu(), grads_f[k].cpu()) <= 1e-4 * sc, (k, H.maxabs(grads[k].cpu(), grads_f[k].cpu()), sc)
+    g.close()
 
 
 def test_graphed_training_step_follows_learning_rate_changes(AG, cuda):

@@ -145,6 +145,68 @@ def test_config1_dcnv2_launch_shape_properties(cuda):
         ops.set_dcn_il_impl(prev)
 
 
+def _outside_window_fraction(off, D, h, w):
+    """fraction of (pixel, group, tap) samples of explicit offsets (n, 18 D, h, w) with a bilinear corner outside dcnv2_il2's LDS
+    window (8 x 32 tile; rows y0 - 6 .. y0 + 13, columns x0 - 8 .. x0 + 39: csrc/dcnv2_il2.hip), and outside the IMAGE (a sample
+    the validity gate -1 < p < size drops)"""
+    n = off.shape[0]
+    o = off.view(n, D, 9, 2, h, w)
+    ky = torch.tensor([-1., -1., -1., 0., 0., 0., 1., 1., 1.]).view(1, 1, 9, 1, 1)
+    kx = torch.tensor([-1., 0., 1., -1., 0., 1., -1., 0., 1.]).view(1, 1, 9, 1, 1)
+    ys = torch.arange(h).view(1, 1, 1, h, 1)
+    xs = torch.arange(w).view(1, 1, 1, 1, w)
+    py, px = ys + ky + o[:, :, :, 0], xs + kx + o[:, :, :, 1]
+    ry = 6 + (ys % 8) + ky + torch.floor(o[:, :, :, 0])
+    rx = 8 + (xs % 32) + kx + torch.floor(o[:, :, :, 1])
+    outside = (ry < 0) | (ry > 18) | (rx < 0) | (rx > 46)
+    invalid = (py <= -1) | (py >= h) | (px <= -1) | (px >= w)
+    return outside.float().mean().item(), invalid.float().mean().item()
+
+
+def test_config1_dcnv2_launch_shape_out_of_window_samples_match_the_oracle(cuda):
+    """the RARE path of `dcnv2_il2` (samples whose corners leave the LDS window are served inline from global
+    memory) at the bench's own launch -- 2 x 64 x 180 x 320, 460 tiles walked by 256 persistent workgroups -- against the CPU oracle
+    (`O.dcnv2`, the mmcv op as networks.py:627-630 consumes it), in the explicit and in the heads form, with sigma = 8 px offsets:
+    a stated, non-zero fraction of the samples leaves the window and another leaves the image."""
+    from eavsr_amd import ops
+    from tests.golden import cases
+    assert ops.DCN_IL_IMPL == "il2"
+    n, c, h, w, D = 2, 64, 180, 320, 8
+    x = cases.randn(401, n, c, h, w)
+    wt = cases.randn(402, 64, c, 3, 3, scale=1.0 / (c * 9) ** 0.5)
+    b = cases.randn(403, 64, scale=0.1)
+    xil = ops.to_il8(x.to(cuda))
+    # explicit offsets / masks (mmcv's signature)
+    off = cases.randn(404, n, 18 * D, h, w, scale=8.0)
+    off[:, :, :3, :] -= 6.0            # a band at the top / left that pushes samples out of the image as well
+    off[:, 1::2, :, -4:] += 9.0
+    mask = cases.rand(405, n, 9 * D, h, w)
+    f_out, f_inv = _outside_window_fraction(off, D, h, w)
+    assert f_out > 0.2 and f_inv > 0.005, (f_out, f_inv)
+    with ops.profile() as prof:
+        y = ops.dcnv2_il(xil, off.to(cuda), mask.to(cuda), wt.to(cuda), b.to(cuda), D).cpu()
+    assert "dcnv2_il" in set(prof.summary()), set(prof.summary())
+    ref = O.dcnv2(x, off, mask, wt, b, 1, 1, 1, 1, D)
+    sc = max(1.0, ref.abs().max().item())
+    err_e = H.maxabs(y, ref) / sc
+    assert err_e <= 3e-5, err_e
+    # heads form (AdaptBlockOffset's 15 D channels; networks.py:298-315), translations of sigma = 8 px
+    heads = torch.cat([cases.randn(406, n, 4 * D, h, w, scale=0.3) + torch.tensor([1.0, 0, 0, 1.0]).repeat(D).view(1, 4 * D, 1, 1),
+                       cases.randn(407, n, 2 * D, h, w, scale=8.0), cases.randn(408, n, 9 * D, h, w, scale=2.0)], 1)
+    offh = O.affine_offsets(heads[:, :4 * D], heads[:, 4 * D:6 * D], D)
+    fh_out, fh_inv = _outside_window_fraction(offh, D, h, w)
+    st = ops.dcn_offset_stats(heads.to(cuda), D)
+    assert fh_out > 0.2 and fh_inv > 0.001 and abs(st["frac_outside_lds_window"] - fh_out) < 1e-3, (fh_out, fh_inv, st)
+    with ops.profile() as prof:
+        yh = ops.dcnv2_il(xil, heads.to(cuda), None, wt.to(cuda), b.to(cuda), D, heads=True).cpu()
+    assert "dcnv2_il_heads" in set(prof.summary()), set(prof.summary())
+    refh = O.dcnv2(x, offh, torch.sigmoid(heads[:, 6 * D:]), wt, b, 1, 1, 1, 1, D)
+    err_h = H.maxabs(yh, refh) / max(1.0, refh.abs().max().item())
+    assert err_h <= 3e-5, err_h
+    print(f"dcnv2_il2 at 2x64x180x320, sigma = 8 px: explicit {f_out:.3f} of the samples outside the LDS window, {f_inv:.4f} outside "
+          f"the image, max|hip - oracle| / scale = {err_e:.2e}; heads {fh_out:.3f} / {fh_inv:.4f}, {err_h:.2e}")
+
+
 # ---------------------------------------------------------------------------------------------------------- configs[4]
 def test_config4_fifteen_frame_recurrence_matches_the_cpu_oracle_fp32_and_fp16(cuda):
     """t = 15 bidirectional propagation (configs[4]'s recurrence depth; eavsrp_model.py:242-329 index maps for t > n_frame)
@@ -171,6 +233,32 @@ def test_config4_fifteen_frame_recurrence_matches_the_cpu_oracle_fp32_and_fp16(c
     assert psnrs["fp16"] >= 60.0 and psnrs["bf16"] >= 50.0, psnrs
     print(f"configs[4] recurrence 1x15x3x64x96: fp32 max err {err:.3e}; PSNR vs oracle fp16 {psnrs['fp16']:.1f} dB, "
           f"bf16 {psnrs['bf16']:.1f} dB")
+
+
+def test_config4_mid_size_fp16_backbone_psnr_against_the_cpu_oracle(cuda):
+    """configs[4]'s reduced-precision claim against the REFERENCE arithmetic at a size where the 16-bit kernels
+    run as they do at 540 x 960 (several tiles per persistent workgroup, the Winograd / bf16x6 routes of the fp32 remainder):
+    1 x 15 x 3 x 128 x 192, fp16 backbone PSNR vs `O.eavsrp_forward` (models/eavsrp_model.py:202-240), fp32 within 1e-3 of it."""
+    from eavsr_amd import networks as Nw, ops
+    net, sd = _net(cuda)
+    clip = _clip(1, 15, 128, 192, seed=21)
+    with torch.no_grad():
+        y32 = net(clip.to(cuda)).cpu()
+        try:
+            Nw.set_backbone_dtype("fp16")
+            with ops.profile() as prof16:
+                y16 = net(clip.to(cuda)).cpu()
+        finally:
+            Nw.set_backbone_dtype(None)
+        names16 = set(prof16.summary())
+        ref = O.eavsrp_forward(sd, clip, 4)
+    assert tuple(y16.shape) == (1, 15, 3, 512, 768) and torch.isfinite(y16).all()
+    assert {"conv3x3_64to64_h16", "dcnv2_il16_heads"} <= names16, names16
+    err = H.maxabs(y32, ref)
+    assert err <= 1e-3, err
+    psnr16, psnr32 = O.psnr_255(y16, ref), O.psnr_255(y32, ref)
+    assert psnr32 >= 80.0 and psnr16 >= 60.0, (psnr32, psnr16)
+    print(f"configs[4] mid size 1x15x3x128x192: fp32 max|hip - oracle| = {err:.3e} ({psnr32:.1f} dB); fp16 backbone vs the oracle {psnr16:.1f} dB")
 
 
 def test_config4_full_size_long_sequence_fp16(cuda):
@@ -268,3 +356,65 @@ def test_config3_training_step_full_size_loss_decreases(cuda):
     assert all(l == l and l < 1e3 for l in losses), losses
     assert losses[-1] < losses[0], losses
     print(f"configs[3] 2x7x3x96x96 training step: L1 {losses[0]:.5f} -> {losses[-1]:.5f}")
+
+
+def _host_mem_available_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+def test_config3_gradients_at_the_bench_shape_match_oracle_autograd(cuda):
+    """configs[3]'s gradients at the size the bench trains at (7 x 3 x 96 x 96 crops, HR 384 x 384; both clips
+    of the per-GPU batch when the host has the ~26 GB CPU autograd needs, one otherwise), against CPU autograd through the
+    oracle (models/eavsrp_model.py:109-119: L1 loss, backward), asserting that the routes that carry the bench's training step --
+    the crop-sized bf16x6 3x3 convolution `conv3x3_64to64_x6s` and the bf16x6 3x3 weight gradient (`eavsr_wgrad3_mode() == 1`
+    behind `conv_wgrad3x3`) -- are the ones that ran."""
+    from eavsr_amd import ops, autograd as AG
+    from eavsr_amd.eavsrp_model import EAVSRP
+    from tests.test_hip_backward import _oracle_forward_with_grad
+    nclips = 2 if _host_mem_available_gib() >= 48.0 else 1
+    sd = H.filled(H.model_shapes("x4"), "trained_like")
+    net = EAVSRP(Namespace(predict=False, n_frame=7, n_flow=5, scale=4), None)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(cuda).train()
+    clip = _clip(nclips, 7, 96, 96, seed=7)
+    hr = torch.nn.functional.interpolate(clip.view(-1, 3, 96, 96), scale_factor=4, mode="bicubic",
+                                         align_corners=False).clamp(0, 1).view(nclips, 7, 3, 384, 384)
+    with ops.profile() as prof:
+        with AG.grad_sink():
+            out = net(clip.to(cuda))
+            loss = (out - hr.to(cuda)).abs().mean()
+            loss.backward()
+    names = set(prof.summary())
+    assert {"conv3x3_64to64_x6s", "conv_wgrad3x3", "conv_wgrad5x5", "conv_wgrad1x1"} <= names, names
+    assert ops.lib().eavsr_wgrad3_mode() == 1
+    watch = ["conv_last.weight", "backbone.forward_2.main.2.rg.3.res.0.weight", "backbone.backward_1.main.2.rg.29.res.2.weight",
+             "backbone.forward_1.main.2.rg.30.weight", "backbone.backward_2.main.0.weight", "fusion.backward_1.weight",
+             "deform_align.forward_1.weight", "deform_align.backward_2.adastn.mask_conv.bias",
+             "deform_align.backward_1.adastn.transform_matrix_conv.weight", "deform_align.forward_1.flow_l2.concat.0.weight",
+             "deform_align.forward_2.trans_l1.conv_first.weight", "encoder.tail.bias", "upsample1.0.weight",
+             "backbone.backward_1.main.2.rg.7.ca.conv_du.0.weight", "backbone.forward_2.main.2.rg.0.res.0.bias"]
+    csd = {k: (v.clone().requires_grad_(True) if k in watch else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        with torch.no_grad():
+            flows = O.compute_flow(sd, clip)
+        out_c = _oracle_forward_with_grad(csd, clip, flows)
+        loss_c = (out_c - hr).abs().mean()
+    gs = torch.autograd.grad(loss_c, [csd[k] for k in watch])
+    assert abs(loss.item() - loss_c.item()) <= 1e-4, (loss.item(), loss_c.item())
+    params = dict(net.named_parameters())
+    worst = ("", 0.0)
+    for k, gc in zip(watch, gs):
+        gg = params[k].grad
+        assert gg is not None, k
+        scale = max(1e-7, gc.abs().max().item())
+        e = H.maxabs(gg.cpu(), gc) / scale
+        worst = max(worst, (k, e), key=lambda p: p[1])
+        assert e <= 5e-3, (k, e, scale)
+    print(f"configs[3] gradients at {nclips} x 7 x 3 x 96 x 96 vs oracle autograd: loss {loss.item():.6f} / {loss_c.item():.6f}, "
+          f"worst relative gradient error {worst[1]:.2e} ({worst[0]}) over {len(watch)} parameters")

@@ -407,6 +407,103 @@ def test_conv_epilogue_relu_of_minus_infinity_and_of_negatives_is_plus_zero(ops,
     assert (y5[:, 2] == 0).all() and not torch.signbit(y5[y5 == 0]).any()
 
 
+@pytest.mark.parametrize("mode", ["winograd4", "winograd", "direct", "bf16x9"])
+def test_conv_epilogue_relu_propagates_nan_like_torch(ops, cuda, mode):
+    """v_max_f32 returns its other operand for a NaN, so max(v, v (*) 0) turned ReLU(NaN) into +0 where
+    torch.relu (networks.py:149-150) carries it to the loss.  eavsr_act() selects v when v is unordered: a NaN bias makes every
+    output of that channel NaN through every activation form and every route; the other channels are untouched.  A NaN INPUT pixel
+    makes at least the outputs torch makes NaN (the Winograd transforms spread it over the pixel's 6 x 6 tiles)."""
+    nan = float("nan")
+    for (n, h, w) in ((2, 96, 128), (2, 96, 96)):      # the Winograd launch | a crop-sized launch (bf16x6 small kernel in the default mode)
+        x = cases.randn(81, n, 64, h, w)
+        wt = cases.randn(82, 64, 64, 3, 3, scale=0.05)
+        b = cases.randn(83, 64, scale=0.1)
+        b[7] = nan
+        ops.set_conv_mode(mode)
+        try:
+            ys = {a: ops.conv2d(g(x, cuda), g(wt, cuda), g(b, cuda), act=a, slope=0.1).cpu() for a in ("relu", "lrelu", None)}
+            xn = x.clone()
+            xn[1, 3, 40, 50] = nan
+            yx = ops.conv2d(g(xn, cuda), g(wt, cuda), g(cases.randn(83, 64, scale=0.1), cuda), act="relu").cpu()
+        finally:
+            ops.set_conv_mode(DEFAULT_CONV_MODE)
+        ref = F.relu(F.conv2d(x, wt, b, 1, 1))
+        for a, y in ys.items():
+            assert torch.isnan(y[:, 7]).all(), (mode, a)
+            keep = [c for c in range(64) if c != 7]
+            assert torch.isfinite(y[:, keep]).all(), (mode, a)
+        assert H.maxabs(ys["relu"][:, keep], ref[:, keep]) <= 1e-4 * max(1.0, ref[:, keep].abs().max().item())
+        refx = F.relu(F.conv2d(xn, wt, None, 1, 1))
+        assert torch.isnan(yx[torch.isnan(refx)]).all(), mode
+        assert torch.isfinite(yx[0]).all(), mode                   # the other sample is untouched
+    # the small-cout, 5x5 bf16x6 and 1x1 kernels share the epilogue
+    x = cases.randn(84, 2, 64, 24, 40)
+    for k, cout in ((3, 3), (5, 16), (1, 64)):
+        wk = cases.randn(85, cout, 64, k, k, scale=0.03)
+        bk = cases.randn(86, cout, scale=0.1)
+        bk[1] = nan
+        yk = ops.conv2d(g(x, cuda), g(wk, cuda), g(bk, cuda), act="relu").cpu()
+        assert torch.isnan(yk[:, 1]).all() and torch.isfinite(yk[:, [0, 2]]).all(), (k, cout)
+
+
+def test_winograd4_hand_counted_reads_equal_the_compilers(ops, cuda):
+    """Toolchain guard: conv_wino6.hip reads its MFMA operands (and the grouped transform its
+    patch) by `asm volatile` LDS reads with hand-counted `s_waitcnt`; that is correct only while the compiler keeps a register
+    between a read and its wait where THIS toolchain keeps it.  eavsr_amd/lib/guard/libwino4_creads.so is the same source
+    built with -DEAVSR_W4_COMPILER_READS (every read and wait the compiler's; keyed on sources, flags and `hipcc --version`,
+    prebuilt by __graft_entry__.build()): both libraries at the bench's launch, 2 x 64 x 180 x 320, must agree BIT FOR BIT -- the
+    plain grouped kernel with channel sums, the scaled-residual instantiation (the RCAB tail as the epilogue), the duty-pair
+    schedule (an odd number of 4-channel chunks) and the F(2x2,5x5) instantiation."""
+    import ctypes as C
+    from eavsr_amd import build, _native as N
+    assert build.hipcc_version() in ("unknown hipcc",) or "clang" in build.hipcc_version()
+    guard = C.CDLL(build.build_guard("wino4_creads"))
+    for fn in ("eavsr_conv3x3_wino4_f32", "eavsr_conv5x5_wino_f32"):
+        getattr(guard, fn).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        getattr(guard, fn).restype = C.c_int
+    assert guard.eavsr_abi_version() == N.ABI_VERSION
+    n, h, w = 2, 180, 320
+    gen = torch.Generator().manual_seed(90)
+    rn = lambda *sh: torch.randn(*sh, generator=gen).to(cuda)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def both(entry, k, cin, cout, act, residual=False, res_scale=False, sums=False):
+        x, wt, b = rn(n, cin, h, w), rn(cout, cin, k, k) * 0.05, rn(cout) * 0.1
+        res = rn(n, cout, h, w) if residual else None
+        rs = torch.rand(n, cout, generator=gen).to(cuda) if res_scale else None
+        wu = ops._packed_wino([wt], kind="f4" if k == 3 else "f5")
+        tiles = (ops.lib().eavsr_conv3x3_wino4_tiles if k == 3 else ops.lib().eavsr_conv5x5_wino_tiles)(h, w)
+        outs = []
+        for lib in (ops.lib(), guard):
+            out = torch.full((n, cout, h, w), float("nan"), device=cuda)
+            part = torch.full((n, tiles, cout), float("nan"), device=cuda) if sums else None
+            d = N.ConvDesc()
+            d.src[0] = x.data_ptr(); d.src_c[0] = cin; d.n_src = 1; d.ksize = k
+            d.bias = b.data_ptr(); d.out = out.data_ptr()
+            d.residual = res.data_ptr() if res is not None else None
+            d.res_scale = rs.data_ptr() if rs is not None else None
+            d.chan_partial = part.data_ptr() if part is not None else None
+            d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
+            d.act = {"none": 0, "relu": 1, "lrelu": 2}[act]
+            d.slope = 0.1
+            rc = getattr(lib, entry)(C.byref(d), C.c_void_p(wu.data_ptr()), st)
+            assert rc == 0, (entry, rc)
+            torch.cuda.synchronize()
+            outs.append((out, part))
+        (o1, p1), (o2, p2) = outs
+        assert torch.isfinite(o1).all()
+        assert torch.equal(o1, o2), (entry, k, cin, cout, (o1 - o2).abs().max().item())
+        assert p1 is None or torch.equal(p1, p2)
+        return o1, x, wt, b
+
+    o, x, wt, b = both("eavsr_conv3x3_wino4_f32", 3, 64, 64, "relu", sums=True)               # conv-1 of an RCAB
+    ref = F.relu(F.conv2d(x[:1].cpu(), wt.cpu(), b.cpu(), 1, 1))
+    assert H.maxabs(o[:1].cpu(), ref) <= 1e-4 * max(1.0, ref.abs().max().item())             # (and both are right)
+    both("eavsr_conv3x3_wino4_f32", 3, 64, 64, "none", residual=True, res_scale=True)          # conv-2 + the tail as its epilogue
+    both("eavsr_conv3x3_wino4_f32", 3, 12, 40, "lrelu", residual=True)                         # 3 chunks: the duty-pair schedule
+    both("eavsr_conv5x5_wino_f32", 5, 64, 120, "none")                                         # F(2x2,5x5)
+
+
 def test_conv2d_ca_out_without_ca_raises_on_every_route(ops, cuda):
     """the bf16x6 route returned before the argument check"""
     x = torch.zeros(1, 64, 16, 16, device=cuda)

@@ -119,6 +119,59 @@ def test_harness_window_maps_and_psnr():
     assert H.crop_center(torch.arange(36.0).view(1, 6, 6), 2).flatten().tolist() == [14.0, 15.0, 20.0, 21.0]
 
 
+def test_harness_ssim_follows_skimage_and_frames_are_written_as_png(tmp_path):
+    """psnr_total.py:39-44's SSIM (skimage `structural_similarity(win_size=11, data_range=255,
+    multichannel=True, gaussian_weights=True)`) and the frame writing of test_basic.py:85-92.  skimage is not installed here: its
+    published algorithm is restated independently with scipy.ndimage (gaussian_filter sigma 1.5 / truncate 3.5 / reflect, sample
+    covariance, crop by 5) and compared; known answers: identical images -> 1, a constant shift -> the luminance term alone."""
+    import numpy as np
+    from scipy.ndimage import gaussian_filter
+    from eavsr_amd import harness as Hn
+    g = torch.Generator().manual_seed(5)
+    a = (torch.rand(3, 40, 52, generator=g) * 255).round()
+    b = (a + torch.randn(3, 40, 52, generator=g) * 12).clamp(0, 255).round()
+
+    def skimage_ssim(x, y):      # skimage/metrics/_structural_similarity.py, the gaussian_weights branch, per channel
+        vals = []
+        for c in range(x.shape[0]):
+            im1, im2 = x[c].numpy().astype(np.float64), y[c].numpy().astype(np.float64)
+            f = lambda t: gaussian_filter(t, sigma=1.5, truncate=3.5, mode="reflect")
+            ux, uy = f(im1), f(im2)
+            cn = 121.0 / 120.0
+            vx, vy, vxy = cn * (f(im1 * im1) - ux * ux), cn * (f(im2 * im2) - uy * uy), cn * (f(im1 * im2) - ux * uy)
+            c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+            S = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+            vals.append(S[5:-5, 5:-5].mean())
+        return float(np.mean(vals))
+    got, want = Hn.calc_ssim(b, a), skimage_ssim(b, a)
+    assert abs(got - want) < 1e-9 and 0.2 < got < 0.99, (got, want)
+    assert abs(Hn.calc_ssim(a, a) - 1.0) < 1e-12
+    flat = torch.full((1, 32, 32), 100.0)
+    lum = (2 * 100 * 110 + 6.5025) / (100 ** 2 + 110 ** 2 + 6.5025)      # contrast / structure terms are 1 for constants
+    assert abs(Hn.calc_ssim(flat + 10, flat) - lum) < 1e-12
+    assert abs(Hn.calc_ssim(torch.stack([b, a]), torch.stack([a, a])) - 0.5 * (got + 1.0)) < 1e-9      # leading dims are averaged
+    with pytest.raises(ValueError):
+        Hn.calc_ssim(torch.zeros(3, 8, 8), torch.zeros(3, 8, 8))
+    # PNG: round trip through our own decoder, and through PIL where it is installed
+    path = Hn.write_png(a, str(tmp_path / "x" / "frame.png"))
+    assert torch.equal(Hn.read_png(path), a.to(torch.uint8))
+    grey = (torch.rand(17, 9, generator=g) * 255)
+    assert torch.equal(Hn.read_png(Hn.write_png(grey, str(tmp_path / "g.png")))[0], grey.to(torch.uint8))      # astype(uint8): truncation
+    try:
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(path)), a.to(torch.uint8).permute(1, 2, 0).numpy())
+        Image.fromarray(b.to(torch.uint8).permute(1, 2, 0).numpy()).save(str(tmp_path / "pil.png"))      # filtered scanlines
+        assert torch.equal(Hn.read_png(str(tmp_path / "pil.png")), b.to(torch.uint8))
+    except ImportError:
+        pass
+    # the folder layout of test_basic.py:85-92
+    res = {"data_sr_seq": torch.stack([a, b]).unsqueeze(0)}
+    fn = [["000/00000.png"], ["000/00001.png"]]
+    out = Hn.save_visuals(res, fn, str(tmp_path / "ckpt" / "run"), load_iter="200", full_res=True)
+    assert [os.path.relpath(o, str(tmp_path)) for o in out] == ["ckpt/run/sr_full_200/000/00000.png", "ckpt/run/sr_full_200/000/00001.png"]
+    assert torch.equal(Hn.read_png(out[1]), b.to(torch.uint8))
+
+
 # ---- the bench contract, checked on the committed line of the last GPU visit -------------------------------------
 def test_committed_bench_line_follows_the_contract():
     import json
@@ -284,6 +337,24 @@ def test_learning_rate_schedulers_follow_the_reference_policies():
     opt.lr_policy = "nope"
     with pytest.raises(NotImplementedError):
         get_scheduler(mk(), opt)
+
+
+def test_every_derived_weight_cache_is_registered_for_clearing():
+    """graph.clear_weight_caches() must drop EVERY cache keyed by (parameter, version); caches register themselves in
+    ops.WEIGHT_CACHES -- no module-level `*_cache` dict of ops / autograd may stay outside it."""
+    from eavsr_amd import autograd, graph, ops
+    regs = {id(d) for d in ops.WEIGHT_CACHES}
+    found = 0
+    for mod in (ops, autograd):
+        for name, val in vars(mod).items():
+            if name.endswith("_cache") and isinstance(val, dict):
+                assert id(val) in regs, f"{mod.__name__}.{name} is not registered (ops.register_weight_cache)"
+                found += 1
+    assert found >= 17 and id(ops.pack_cache) in regs
+    ops._dgrad_w_cache["x"] = 1
+    autograd._dcn_wt_cache["y"] = 2
+    graph.clear_weight_caches()
+    assert not ops._dgrad_w_cache and not autograd._dcn_wt_cache
 
 
 def test_scoped_mode_switches_restore_the_previous_modes():

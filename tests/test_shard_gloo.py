@@ -273,6 +273,62 @@ def test_parameters_are_broadcast_from_rank_0_once():
     assert sd1[-2] == want[2].weight.tolist() and sd1[4] == [0.0] * 8 and sd1[6] == 7      # running_mean / num_batches_tracked of rank 0
 
 
+def _load_worker(rank, world, port, q, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from argparse import Namespace
+    from eavsr_amd import shard
+    from eavsr_amd.eavsrp_model import EAVSRPModel
+    shard.init_process_group("gloo")
+    assert shard.all_ranks_ok(True) is True and shard.all_ranks_ok(rank == 0) is False
+    torch.manual_seed(7 + rank)
+    m = object.__new__(EAVSRPModel)      # load_networks needs a network, options and the broadcast -- not a GPU
+    m.netEAVSRP = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Linear(4, 2))
+    m.opt = Namespace(load_path="")
+    good = os.path.join(tmp, "good.pth")
+    if rank == 0:
+        torch.manual_seed(99)
+        ref = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.Linear(4, 2))
+        torch.save({"state_dict": ref.state_dict()}, good)
+        torch.save({"state_dict": {k: v for k, v in ref.state_dict().items() if k != "1.bias"}}, os.path.join(tmp, "bad_1.pth"))
+    shard.barrier()
+    # (1) every rank reads a good file: identical replicas = the file's
+    m.load_networks(good)
+    ok_sd = [v.tolist() for v in m.netEAVSRP.state_dict().values()]
+    # (2) rank 1's file is broken (a key short), rank 0's is fine: BOTH ranks raise, nobody hangs in the broadcast
+    raised = None
+    try:
+        m.load_networks(good if rank == 0 else os.path.join(tmp, "bad_1.pth"))
+    except RuntimeError as e:
+        raised = str(e)
+    # (3) the group is still usable and in step afterwards
+    seen = shard.ranks_seen()
+    q.put((rank, ok_sd, raised, seen))
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_load_networks_is_a_collective_and_a_failing_rank_aborts_every_rank(tmp_path):
+    """`load_networks` ends in the start-up broadcast; a rank that failed to read its file used to leave the others
+    blocked in it (or paired with their next collective).  Now the ranks agree on success first (`shard.all_ranks_ok`)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_load_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, sd0, r0, seen0), (_, sd1, r1, seen1) = res
+    assert sd0 == sd1
+    assert r0 is not None and "another rank" in r0          # rank 0 loaded fine and still aborts
+    assert r1 is not None and "1.bias" in r1                # rank 1 reports its own error
+    assert seen0 == seen1 == 2
+
+
 class _StubGraph:
     """what a replay of the captured forward + backward leaves behind: gradients in the bound `.grad` tensors"""
 
