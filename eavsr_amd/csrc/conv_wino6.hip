@@ -68,6 +68,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __attribute__((aligned(16))) float g_wino4_zero[4];   // source of the zero-padding DMA lanes
 
+// Buffer addressing for the grouped kernel's epilogue (round 6; as csrc/dcnv2_il2.hip since round 5): a 128-bit resource per
+// (image, 64-channel block) of `out` / `residual`, ONE per-lane 32-bit offset register per tile, a scalar offset per (channel,
+// row) computed at the use.  The hardware's range check replaces the exec-mask regions: a lane right of the image holds W6_OOB
+// (its loads return zeros, its stores are dropped), a lane whose channel is >= cout lies beyond the resource's extent.
+typedef __amdgpu_buffer_rsrc_t w6_rsrc;
+constexpr unsigned W6_OOB = 0x80000000u;      // beyond every extent the launcher accepts (64 channels x plane x 4 B < 2^31)
+__device__ __forceinline__ w6_rsrc w6_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 w6_ld4(w6_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void w6_st4(w6_rsrc r, unsigned voff, unsigned soff, f32x4 v) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
+}
+
 struct W4Args {
   const float* src[5];
   int src_c[5];
@@ -834,7 +851,126 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile (tg, l15)] for every xi ----
     {
       float csum[4] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (R == 3) {
+      constexpr bool fast_done = GRP;
+      if constexpr (GRP) {
+       {
+        // ---- grouped kernel (round 6): the same output transform, bias, activation and sums in ~half the instructions.  The
+        // epilogue of a one-tile workgroup is exposed whole (230 tiles on 256 CUs) and it is bound by instruction ISSUE: ~1,250
+        // vector instructions per wave and tile in the round-5 form (64-bit address arithmetic and an exec-mask region per
+        // store / residual load, bias + activation + sums value by value, zero-filled residual registers) against the ~260
+        // packed operations of the transform itself.  Here: buffer stores / loads (one lane offset per tile, scalar offsets,
+        // range-checked edges), the bias as packed pairs, a three-instruction activation, packed channel sums, the residual's
+        // rows requested one channel pair ahead.
+        const int gx = x0 + 4 * l15;
+        const int gy0 = y0 + 4 * tg;                                  // wave-uniform
+        const int rows = h - gy0;                                     // rows of this wave's tile row inside the image (may be <= 0)
+        const int cblk = a.cout - cot * 64 < 64 ? a.cout - cot * 64 : 64;
+        const size_t img_off = ((size_t)bn * a.cout + (size_t)cot * 64) * plane;
+        const unsigned blk_bytes = (unsigned)((size_t)cblk * plane * sizeof(float));
+        const w6_rsrc r_out = w6_make_rsrc(a.out + img_off, blk_bytes);
+        const bool has_res = a.residual != nullptr;
+        const w6_rsrc r_res = w6_make_rsrc(has_res ? a.residual + img_off : a.out + img_off, blk_bytes);
+        const unsigned lane_off = gx < w ? (unsigned)((((size_t)(cb * 16 + 4 * kq)) * plane + (size_t)gy0 * w + gx) * sizeof(float)) : W6_OOB;
+        const unsigned plane_b = (unsigned)(plane * sizeof(float)), row_b = (unsigned)(w * sizeof(float));
+        // F.pixel_shuffle(out, 2) written directly (eavsrp_model.py:343-347): channel co = 4 c' + 2 i + j goes to out'[c'][2 y + i][2 x + j].
+        // This lane's four channels are ONE c' = co >> 2 with (i, j) = (rp, ch); its four pixels x .. x + 3 of the pair (ch = 0, 1)
+        // become the eight adjacent floats 2 x .. 2 x + 7 of row 2 y + rp: two 16-byte stores.  Same resource (the image's 64-channel
+        // block = 16 shuffled planes of 4 h w), another lane offset.
+        const bool shuf = a.out_shuffle == 2;
+        const unsigned lane_off_ps = gx < w ? (unsigned)((((size_t)(cb * 4 + kq)) * 4 * plane + (size_t)(2 * gy0) * (2 * w) + 2 * gx) * sizeof(float)) : W6_OOB;
+        const bool has_act = a.act != EAVSR_ACT_NONE;
+        // The plain instantiation is branch-free in what it computes: a residual that is not there is sixteen zero registers (never
+        // loaded), a scale that is not there is 1, the channel sums are always accumulated (and dropped at the end), the
+        // activation is the select form with s = 1 for "none" -- runtime flags here came out as per-VALUE branches and selects.
+        // The scaled-residual instantiation (the RCAB's second convolution: no activation in the reference, networks.py:461-464)
+        // skips the activation by ONE uniform branch per step.
+        float sc4[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (RSC) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = cot * 64 + cb * 16 + 4 * kq + r;
+            sc4[r] = co < a.cout ? a.res_scale[(size_t)bn * a.cout + co] : 0.f;      // (L2-resident)
+          }
+        }
+        // the residual rows are requested ONE (channel pair, row) step ahead of their use, two steps' worth of registers
+        f32x4 rr[2][2] = {{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}};      // [step & 1][ch]
+        auto load_rr = [&](int step) __attribute__((always_inline)) {      // step = 4 rp + dy
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch)
+            rr[step & 1][ch] = w6_ld4(r_res, lane_off, (unsigned)(2 * (step >> 2) + ch) * plane_b + (unsigned)(step & 3) * row_b);
+        };
+        if (has_res) load_rr(0);
+        f32x2 cs2[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+          const f32x2 b2 = f32x2{bias_r[2 * rp], bias_r[2 * rp + 1]};
+#pragma unroll
+          for (int dy = 0; dy < 4; ++dy) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int step = 4 * rp + dy;
+            if (has_res && step < 7) load_rr(step + 1);
+            f32x2 sq[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {      // row dy of A^T m, column q of the 6 x 6 block (two channels per packed operation)
+              f32x2 m[6];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[w6_slot(i, q)][2 * rp], acc[w6_slot(i, q)][2 * rp + 1]};
+              if (dy == 0) sq[q] = m[0] + (m[1] + m[2]) + (m[3] + m[4]);
+              else if (dy == 1) sq[q] = (m[1] - m[2]) + 2.f * (m[3] - m[4]);
+              else if (dy == 2) sq[q] = (m[1] + m[2]) + 4.f * (m[3] + m[4]);
+              else sq[q] = ((m[1] - m[2]) + 8.f * (m[3] - m[4])) + m[5];
+            }
+            const f32x2 p1 = sq[1] + sq[2], p2 = sq[1] - sq[2], p3 = sq[3] + sq[4], p4 = sq[3] - sq[4];
+            f32x2 y[4];
+            y[0] = (sq[0] + p1 + p3) + b2;
+            y[1] = (p2 + 2.f * p4) + b2;
+            y[2] = (p1 + 4.f * p3) + b2;
+            y[3] = ((p2 + 8.f * p4) + sq[5]) + b2;
+            f32x4 vc[2];
+            if (!RSC || has_act) {
+#pragma unroll
+              for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vc[ch][j] = eavsr_act(ch == 0 ? y[j].x : y[j].y, act_s);
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vc[ch][j] = ch == 0 ? y[j].x : y[j].y;
+            }
+            if (!RSC && shuf) {      // (no residual, no channel sums: the launcher checks)
+              if (dy < rows) {
+                const unsigned so = (unsigned)(2 * dy + rp) * (2 * row_b);
+                w6_st4(r_out, lane_off_ps, so, f32x4{vc[0][0], vc[1][0], vc[0][1], vc[1][1]});
+                w6_st4(r_out, lane_off_ps, so + 16u, f32x4{vc[0][2], vc[1][2], vc[0][3], vc[1][3]});
+              }
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < 2; ++ch) {
+                const int r = 2 * rp + ch;
+                const f32x4 v = vc[ch];
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(v[j], sc4[r], rr[step & 1][ch][j]);
+                if (dy < rows) {      // wave-uniform: this row of the tile lies inside the image
+                  if constexpr (!RSC) cs2[r] += f32x2{v[0], v[1]} + f32x2{v[2], v[3]};
+                  w6_st4(r_out, lane_off, (unsigned)r * plane_b + (unsigned)dy * row_b, o);
+                }
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = cot * 64 + cb * 16 + 4 * kq + r;
+          // (columns right of the image and channels >= cout are excluded here, rows below it above)
+          csum[r] = (co < a.cout && gx < w) ? cs2[r].x + cs2[r].y : 0.f;
+        }
+       }
+      }
+      if constexpr (fast_done) {
+        // (nothing left: the grouped kernel's epilogue above)
+      } else if constexpr (R == 3) {
         const int gx = x0 + 4 * l15;   // 16 lanes x float4 = one 256-byte row segment
         // Two output channels at a time as packed fp32 pairs (r = 2 rp, 2 rp + 1 are adjacent accumulator registers), one
         // output row at a time (registers): half the vector instructions of a channel-by-channel transform - the epilogue
@@ -1142,6 +1278,8 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   const long blocks = (long)a.tiles_x * a.tiles_y * d->n;
   EAVSR_REQUIRE(blocks < (1L << 31), -1, "conv_wino6: too many tiles");
   EAVSR_REQUIRE((long)d->h * d->w * 16 < (1L << 31), -1, "conv_wino6: image plane too large for 32-bit tile offsets");
+  EAVSR_REQUIRE(R != 3 || (long)d->h * d->w * 64 * 4 < (1L << 31), -1,
+                "conv_wino6: image plane too large for the epilogue's 32-bit offsets (64 channels x h x w x 4 bytes must be < 2 GiB)");
   constexpr size_t LDS_FUSE = C::LDS_BYTES + 2 * C::IN_PAD * sizeof(float);
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();

@@ -50,8 +50,7 @@ class GraphedForward:
         # the captured launches read the derived weight forms (packed / Winograd-transformed) that the warm-up left in the
         # per-parameter caches: hold them, so that clearing or refreshing a cache cannot free memory the graph still uses
         from . import ops
-        self._weights_alive = [dict(ops.pack_cache._d)] + [dict(getattr(ops, n)) for n in (
-            "_bias_cache", "_wcat_cache", "_x9_pack_cache", "_wino_pack_cache", "_h16_pack_cache", "_h16_ps_cache", "_h16_last_cache", "_h16g_pack_cache", "_h16x1_pack_cache", "_h16_pack5_cache", "_il16_pack_cache", "_smallco_pack_cache", "_conv7_pack_cache", "_il2_pack_cache") if hasattr(ops, n)]
+        self._weights_alive = [dict(getattr(d, "_d", d)) for d in ops.WEIGHT_CACHES]
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype or x.device != self.static_in.device:
@@ -74,7 +73,25 @@ class StreamedForward:
     the host would become the bound.  Results are bit-identical to the single-stream forward (same kernels per clip).
     """
 
-    def __init__(self, module, example: torch.Tensor, groups: int = 2, warmup: int = 2):
+    # Start-up skew between the streams, microseconds per stream index (stream g waits g x skew behind a device-side delay before
+    # its replay).  Both sub-batches run the SAME program; started together they stay in phase -- both in an alignment step
+    # (small streaming kernels that cannot fill the chip) at the same time, then both in the 62 convolutions of a backbone call,
+    # which serialise on the CUs (one 132 KB-LDS workgroup each) -- so the alignment steps are exposed twenty-eight times per
+    # forward.  Half a backbone call out of phase, one stream's alignment runs under the other's convolutions.  DESIGN.md 3.5.
+    SKEW_US = float(os.environ.get("EAVSR_STREAM_SKEW_US", "0"))
+
+    def __init__(self, module, example: torch.Tensor, groups: int = 2, warmup: int = 2, skew_us: float | None = None):
+        self.skew_us = self.SKEW_US if skew_us is None else float(skew_us)
+        self._ticks_per_us = 0.0
+        if self.skew_us > 0:      # what one tick of torch's spin kernel lasts on this device, measured once
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(1_000_000)
+            torch.cuda.synchronize(example.device)
+            e0.record()
+            torch.cuda._sleep(20_000_000)
+            e1.record()
+            torch.cuda.synchronize(example.device)
+            self._ticks_per_us = 20_000_000 / max(1e-3, e0.elapsed_time(e1) * 1e3)
         n = example.shape[0]
         if groups < 1 or n % groups:
             raise ValueError(f"{n} clips do not split into {groups} equal groups")
@@ -95,6 +112,8 @@ class StreamedForward:
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 part.static_in.copy_(x[g * self.per:(g + 1) * self.per])
+                if g and self.skew_us > 0:
+                    torch.cuda._sleep(int(self.skew_us * g * self._ticks_per_us))
                 part.graph.replay()
                 self.static_out[g * self.per:(g + 1) * self.per].copy_(part.static_out)
         for st in self.streams:
