@@ -80,9 +80,15 @@ __device__ __forceinline__ w6_rsrc w6_make_rsrc(const void* base, unsigned bytes
 __device__ __forceinline__ f32x4 w6_ld4(w6_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-__device__ __forceinline__ void w6_st4(w6_rsrc r, unsigned voff, unsigned soff, f32x4 v) {
+// The store's offset goes through the VECTOR offset (one v_add per store), never through the scalar one.  A 128-bit buffer store
+// reads its data registers over the cycles after it issues, and a vector instruction that rewrites them too early corrupts the
+// store.  The compiler pads that hazard -- except for stores with a REGISTER scalar offset, which older parts exempt; gfx950 does
+// not honour the exemption: with `soffset` in a register the next channel's results landed in the previous channel's rows for the
+// last lanes of each row segment, run-dependent (found by tools/dbg/rsc_diff.py against the round-5 library; one wait state,
+// DESIGN.md 3.2).  With an immediate scalar offset the hazard recogniser does its job.
+__device__ __forceinline__ void w6_st4(w6_rsrc r, unsigned voff, unsigned off, f32x4 v) {
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff + off, 0, 0);
 }
 
 struct W4Args {

@@ -17,9 +17,17 @@ torch.manual_seed(0)
 wt = torch.randn(64, 64, 3, 3, device=dev) * 0.05
 b = torch.randn(64, device=dev) * 0.1
 out = []
+# FORM: relu (default) | sums (ReLU + per-tile channel sums: conv-1 of an RCAB) | rsc (residual + res_scale: conv-2 with the tail as
+# its epilogue) | res (plain residual)
+form = os.environ.get("FORM", "relu")
 for n in (2, 4):
     x = torch.randn(n, 64, h, w, device=dev)
-    call = lambda: ops.conv2d(x, wt, b, act="relu")
+    res = torch.randn(n, 64, h, w, device=dev)
+    rs = torch.rand(n, 64, device=dev)
+    call = {"relu": lambda: ops.conv2d(x, wt, b, act="relu"),
+            "sums": lambda: ops.conv2d(x, wt, b, act="relu", chan_partial=True)[0],
+            "rsc": lambda: ops.conv2d(x, wt, b, residual=res, res_scale=rs),
+            "res": lambda: ops.conv2d(x, wt, b, residual=res)}[form]
     for _ in range(5):
         y = call()
     torch.cuda.synchronize()
@@ -34,4 +42,4 @@ for n in (2, 4):
         ts.append(e0.elapsed_time(e1) * 1e3 / inner)
     ts.sort()
     out.append(f"n={n} {ts[len(ts) // 2]:6.1f} us ({ts[0]:.1f}..{ts[-1]:.1f}) bits {hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest()[:10]}")
-print(f"{os.path.basename(os.environ.get('EAVSR_LIB_PATH', 'libeavsr_hip.so')):24s} " + "   ".join(out), flush=True)
+print(f"{os.path.basename(os.environ.get('EAVSR_LIB_PATH', 'libeavsr_hip.so')):24s} {form:5s} " + "   ".join(out), flush=True)
