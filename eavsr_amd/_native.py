@@ -50,6 +50,7 @@ SIGNATURES = {
     "eavsr_abi_version": (C.c_int, []),
     "eavsr_version": (C.c_char_p, []),
     "eavsr_conv2d_desc_size": (C.c_size_t, []),
+    "eavsr_lab_build": (C.c_int, []),
     "eavsr_last_error": (C.c_char_p, []),
     "eavsr_selftest_mfma_f32": (C.c_int, [vp, vp]),
     "eavsr_flow_warp_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -58,10 +59,8 @@ SIGNATURES = {
     "eavsr_dcnv2_generic_f32": (C.c_int, [vp] * 6 + [i32] * 15 + [vp]),
     "eavsr_dcn_weight_x9_bytes": (C.c_int64, [i32, i32]),
     "eavsr_pack_dcn_weight_x9": (C.c_int, [vp, vp, i32, i32, vp]),
-    "eavsr_dcnv2_f32x9": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_nchw_to_il8_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_il_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "eavsr_dcnv2_ws_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcn_weight_il2_bytes": (C.c_int64, [i32, i32]),
     "eavsr_pack_dcn_weight_il2": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_dcnv2_il2_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -71,11 +70,6 @@ SIGNATURES = {
     "eavsr_dcnv2_il16": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_wino4_schedule": (C.c_int, []),
     "eavsr_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), vp]),
-    "eavsr_conv3x3_f32x9": (C.c_int, [vp, vp, vp]),
-    "eavsr_wino_weight_elems": (C.c_int64, [i32, i32]),
-    "eavsr_pack_conv_weight_wino": (C.c_int, [vp, vp, i32, i32, vp]),
-    "eavsr_conv3x3_wino_tiles": (i32, [i32, i32]),
-    "eavsr_conv3x3_wino_f32": (C.c_int, [vp, vp, vp]),
     "eavsr_wino4_weight_elems": (C.c_int64, [i32, i32]),
     "eavsr_pack_conv_weight_wino4": (C.c_int, [vp, vp, i32, i32, vp]),
     "eavsr_conv3x3_wino4_tiles": (i32, [i32, i32]),
@@ -105,7 +99,6 @@ SIGNATURES = {
     "eavsr_ca_tail_f32": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_ca_tail_stats_f32": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_adapt_frontend_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "eavsr_flow_level_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, vp]),
     "eavsr_affine_offsets_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_resize_bilinear_ac_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "eavsr_pyramid_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
@@ -149,8 +142,6 @@ SIGNATURES = {
     "eavsr_ca_scale_pre_ws_floats": (C.c_int64, [i32]),
     "eavsr_ca_scale_pre_h16": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_c64_h16_act": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
-    "eavsr_rcab_convs_h16": (C.c_int, [vp] * 7 + [i32] * 4 + [vp]),
-    "eavsr_rcab_h16_partial_rows": (i32, [i32, i32, i32]),
     "eavsr_conv3x3_c64to3_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_h16g_weight_bytes": (C.c_int64, [i32, i32]),
     "eavsr_pack_conv3x3_h16g": (C.c_int, [vp, vp, i32, i32, i32, vp]),
@@ -161,6 +152,21 @@ SIGNATURES = {
     "eavsr_nchw_f32_to_nhwc_h16": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_nhwc_h16_to_nchw_f32": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_scale_residual_h16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+}
+
+# Entry points of the LAB build only (`python -m eavsr_amd.build --lab`; the header's EXPERIMENTAL section): bound when the
+# library exports them, absent from a default build (ops raises LabBuildRequired for the modes that need them).
+LAB_SIGNATURES = {
+    "eavsr_conv3x3_f32x9": (C.c_int, [vp, vp, vp]),
+    "eavsr_dcnv2_f32x9": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_dcnv2_ws_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "eavsr_wino_weight_elems": (C.c_int64, [i32, i32]),
+    "eavsr_pack_conv_weight_wino": (C.c_int, [vp, vp, i32, i32, vp]),
+    "eavsr_conv3x3_wino_tiles": (i32, [i32, i32]),
+    "eavsr_conv3x3_wino_f32": (C.c_int, [vp, vp, vp]),
+    "eavsr_flow_level_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, vp]),
+    "eavsr_rcab_h16_partial_rows": (i32, [i32, i32, i32]),
+    "eavsr_rcab_convs_h16": (C.c_int, [vp] * 7 + [i32] * 4 + [vp]),
 }
 
 _lock = threading.Lock()
@@ -200,8 +206,21 @@ def load():
         if lib.eavsr_conv2d_desc_size() != C.sizeof(ConvDesc):      # a descriptor that grew without an ABI bump
             raise NativeLibraryError(
                 f"struct eavsr_conv2d_desc: library {lib.eavsr_conv2d_desc_size()} bytes vs binding {C.sizeof(ConvDesc)}; rebuild")
+        if lib.eavsr_lab_build():
+            for name, (res, args) in LAB_SIGNATURES.items():
+                try:
+                    fn = getattr(lib, name)
+                except AttributeError as e:
+                    raise NativeLibraryError(f"{LIB_PATH} says it is a lab build but does not export {name}") from e
+                fn.restype = res
+                fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def lab_build() -> bool:
+    """True when the loaded library is the lab build (the retired schedules are there)"""
+    return bool(load().eavsr_lab_build())
 
 
 def check(code: int, what: str):

@@ -1,6 +1,8 @@
 """Build libeavsr_hip.so in-tree with hipcc for gfx950 (no GPU needed: hipcc cross-compiles).
 
-    python -m eavsr_amd.build [--force] [--verbose]
+    python -m eavsr_amd.build [--force] [--verbose] [--lab]
+
+--lab (or EAVSR_BUILD_LAB=1) also compiles the retired schedules kept for A/B measurements (LAB_SOURCES below).
 
 The shared object lands in eavsr_amd/lib/ (git-ignored, but it travels with gpurun snapshots).
 """
@@ -55,13 +57,27 @@ def hipcc_version() -> str:
     return _HIPCC_VERSION
 
 
-def sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+# Product and lab.  The DEFAULT build holds what the default path and the documented modes use.  Schedules that
+# were built, measured and retired -- kept because their A/B figures are quoted in DESIGN.md / docs/history -- compile only with
+# `python -m eavsr_amd.build --lab` (-DEAVSR_LAB=1): whole files below, and the `#if EAVSR_LAB` pieces of predictor.hip (one kernel
+# per pyramid level), conv_wino6.hip (channel-attention prologue inside the F(4x4,3x3) kernel) and dcnv2_x9.hip (the round-1 NCHW
+# DCNv2 with nine partial products; its weight packing stays: eavsr_dcnv2_il_f32 reads the same slabs).  The header groups the entry
+# points the same way; ops.py raises LabBuildRequired for a lab-only mode on a default build; lab tests skip.
+LAB_SOURCES = {
+    "dcnv2_ws.hip",      # wave-specialised DCNv2 schedule (round 2): not faster at the alignment's offsets
+    "conv_x9.hip",       # direct 3x3 convolution with all nine bf16 partial products
+    "conv_wino.hip",     # Winograd F(2x2,3x3): 15 % slower end to end than F(4x4,3x3) (round 1)
+    "rcab_h16.hip",      # conv -> ReLU -> conv of a 16-bit RCAB as one launch: bit-identical, slower in the step (round 5)
+}
 
 
-def _digest() -> str:
-    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(PER_FILE_FLAGS.items())) + hipcc_version()).encode())
-    files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+def sources(lab: bool = False):
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (lab or f not in LAB_SOURCES))
+
+
+def _digest(lab: bool = False) -> str:
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(PER_FILE_FLAGS.items())) + hipcc_version() + ("|lab" if lab else "")).encode())
+    files = sources(lab) + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
     files.append(os.path.join(os.path.dirname(HERE), "include", "eavsr_hip.h"))
     for f in files:
         with open(f, "rb") as fh:
@@ -70,13 +86,22 @@ def _digest() -> str:
     return h.hexdigest()
 
 
-def build_native(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+def lab_requested() -> bool:
+    """EAVSR_BUILD_LAB=1 makes every build of this process (the one `import eavsr_amd` triggers included) a lab build"""
+    return os.environ.get("EAVSR_BUILD_LAB", "0") == "1"
+
+
+def build_native(force: bool = False, verbose: bool = False, extra_flags=(), lab=None) -> str:
+    lab = lab_requested() if lab is None else bool(lab)
     os.makedirs(OBJDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.stamp")
-    dig = _digest() + "|" + " ".join(extra_flags)
+    dig = _digest(lab) + "|" + " ".join(extra_flags)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = _hipcc()
+    extra_flags = (*extra_flags, f"-DEAVSR_LAB={1 if lab else 0}")
+    for f in os.listdir(OBJDIR):      # objects of sources that are not part of this flavour must not be linked
+        os.remove(os.path.join(OBJDIR, f))
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
@@ -91,7 +116,7 @@ def build_native(force: bool = False, verbose: bool = False, extra_flags=()) -> 
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, sources()))
+        objs = list(ex.map(compile_one, sources(lab)))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -117,6 +142,7 @@ def build_guard(name: str = "wino4_creads", force: bool = False) -> str:
     out = os.path.join(GUARD_DIR, f"lib{name}.so")
     stamp = out + ".stamp"
     dig = _digest() + "|" + " ".join(extra)
+    extra = [*extra, "-DEAVSR_LAB=0"]
     if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
         return out
     cmd = [_hipcc(), *FLAGS, *extra, "-shared", *[os.path.join(CSRC, f) for f in srcs], "-o", out]
@@ -129,4 +155,4 @@ def build_guard(name: str = "wino4_creads", force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_native(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build_native(force="--force" in sys.argv, verbose="--verbose" in sys.argv, lab=("--lab" in sys.argv) or lab_requested()))

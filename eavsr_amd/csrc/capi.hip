@@ -32,6 +32,7 @@ extern "C" int eavsr_abi_version(void) { return EAVSR_ABI_VERSION; }
 extern "C" const char* eavsr_version(void) { return "eavsr-hip 0.1.0 gfx950"; }
 extern "C" const char* eavsr_last_error(void) { return eavsr::g_err; }
 extern "C" size_t eavsr_conv2d_desc_size(void) { return sizeof(eavsr_conv2d_desc); }
+extern "C" int eavsr_lab_build(void) { return EAVSR_LAB; }
 
 // ---------------------------------------------------------------------------------------------
 // MFMA layout self-test.  One wave computes D(32x32) = A(32x2) . B(2x32) with the operand map

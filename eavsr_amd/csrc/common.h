@@ -8,6 +8,12 @@
 
 #include "../../include/eavsr_hip.h"
 
+// 0: the product build (default).  1: `python -m eavsr_amd.build --lab` -- also the retired schedules kept for A/B measurements
+// (eavsr_amd/build.py LAB_SOURCES and the `#if EAVSR_LAB` pieces of predictor.hip / conv_wino6.hip; the header's experimental section)
+#ifndef EAVSR_LAB
+#define EAVSR_LAB 0
+#endif
+
 namespace eavsr {
 
 // thread-local error string behind eavsr_last_error()

@@ -77,6 +77,7 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
   lo = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
 }
 
+#if EAVSR_LAB      // the round-1 NCHW kernel with all nine partial products: lab build only; the weight packing below is shared with eavsr_dcnv2_il_f32
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void dcnv2_x9_kernel(X9Args a) {
   }
 }
 
+#endif  // EAVSR_LAB
 // weight (cout, cin, 3, 3) fp32 -> [cot][group][step][plane][mt][lane] 16-byte elements: lane (m = lane & 31,
 // kgrp = lane >> 5) holds row co = 64 cot + 32 mt + m, k = channels 8 g .. 8 g + 7 of tap 2 s + kgrp
 __global__ void pack_x9_kernel(const float* __restrict__ wt, unsigned* __restrict__ out, int cout, int cin, long total) {
@@ -430,6 +432,7 @@ extern "C" int eavsr_pack_dcn_weight_x9(const float* weight, void* packed, int32
   return eavsr::launch_status("pack_dcn_weight_x9");
 }
 
+#if EAVSR_LAB
 extern "C" int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask, const void* weight_x9,
                                  const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w,
                                  int32_t cout, int32_t deform_groups, void* stream) {
@@ -466,3 +469,4 @@ extern "C" int eavsr_dcnv2_f32x9(const float* x, const float* offset, const floa
   hipLaunchKernelGGL(dcnv2_x9_kernel, grid, dim3(512), XLDS_BYTES, eavsr::as_stream(stream), a);
   return eavsr::launch_status("dcnv2_f32x9");
 }
+#endif  // EAVSR_LAB

@@ -276,6 +276,7 @@ extern "C" int eavsr_affine_offsets_f32(const float* heads, float* offset, float
   return eavsr::launch_status("affine_offsets");
 }
 
+#if EAVSR_LAB      // one kernel per pyramid level: built, correct, not faster (docs/history 4g) -- lab build only
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -549,3 +550,4 @@ extern "C" int eavsr_flow_level_f32(const float* x, const float* h_hr, const flo
                      w_heads, b_heads, w_trans, b_trans, out, c, h, w, tiles_x, tiles_y);
   return eavsr::launch_status("flow_level");
 }
+#endif  // EAVSR_LAB

@@ -402,6 +402,8 @@ FUSE_FLOW_LEVEL = _os.environ.get("EAVSR_FUSE_LEVEL", "0") == "1"
 
 def set_fuse_flow_level(on: bool) -> None:
     global FUSE_FLOW_LEVEL
+    if on:
+        ops.require_lab("the one-kernel-per-pyramid-level form (eavsr_flow_level_f32)")
     FUSE_FLOW_LEVEL = bool(on)
 
 
@@ -420,6 +422,8 @@ RCAB_H16_FUSED = _os.environ.get("EAVSR_RCAB_H16_FUSED", "0") == "1"
 
 def set_rcab_h16_fused(on: bool) -> None:
     global RCAB_H16_FUSED
+    if on:
+        ops.require_lab("the one-launch 16-bit RCAB (eavsr_rcab_convs_h16)")
     RCAB_H16_FUSED = bool(on)
 
 

@@ -62,6 +62,26 @@ def lib():
     return N.load()
 
 
+class LabBuildRequired(RuntimeError):
+    """A mode / op that exists only in the lab build of the library (`python -m eavsr_amd.build --lab`): the retired schedules
+    kept for A/B measurements (eavsr_amd/build.py LAB_SOURCES; the EXPERIMENTAL section of include/eavsr_hip.h)."""
+
+
+def lab_available() -> bool:
+    return N.lab_build()
+
+
+def require_lab(what: str) -> None:
+    if not lab_available():
+        raise LabBuildRequired(f"{what} is part of the lab build only: rebuild with `python -m eavsr_amd.build --lab` "
+                               "(the default library holds the product path and its documented modes)")
+
+
+def _wino_tiles(h: int, w: int) -> int:
+    """8 x 32-pixel tiles of an image (the granularity the Winograd gates count in; eavsr_conv3x3_wino_tiles of the lab build)"""
+    return ((h + 7) // 8) * ((w + 31) // 32)
+
+
 # ------------------------------------------------------------------------------------------
 # optional per-launch timing (HIP events on the launch stream); off unless `with profile():`
 # ------------------------------------------------------------------------------------------
@@ -504,9 +524,9 @@ def _conv3x3_smallco(x: Tensor, weights, biases, act, slope, residual):
 # dense conv  (nn.Conv2d, stride 1, "same" padding)
 # ------------------------------------------------------------------------------------------
 def _wino_fusable(x: Tensor) -> bool:
-    return (CONV_MODE in ("winograd", "winograd4") and x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[1] % 8 == 0 and x.shape[1] <= 256
+    return (lab_available() and CONV_MODE in ("winograd", "winograd4") and x.dim() == 4 and x.shape[3] % 4 == 0 and x.shape[1] % 8 == 0 and x.shape[1] <= 256
             and x.is_contiguous() and x.data_ptr() % 16 == 0
-            and int(x.shape[0]) * lib().eavsr_conv3x3_wino_tiles(int(x.shape[2]), int(x.shape[3])) >= WINO_MIN_TILES)
+            and int(x.shape[0]) * _wino_tiles(int(x.shape[2]), int(x.shape[3])) >= WINO_MIN_TILES)
 
 
 def ca_fusable(x: Tensor, cout: int = 64) -> bool:
@@ -632,14 +652,19 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     out = torch.empty((n, cout, h, w), device=srcs[0].device, dtype=torch.float32)
     base_ok = (k == 3 and w % 4 == 0 and all(int(s_.shape[1]) % 8 == 0 and s_.data_ptr() % 16 == 0 for s_ in srcs))
     x9_ok = base_ok and ca is None and not masked
+    if CONV_MODE in ("winograd", "bf16x9"):      # (set through the environment: set_conv_mode() checks at the call)
+        require_lab(f"conv mode {CONV_MODE!r}")
+    lab = lab_available()
     use_wino = (CONV_MODE in ("winograd", "winograd4") and base_ok and not masked
-                and n * lib().eavsr_conv3x3_wino_tiles(h, w) >= WINO_MIN_TILES
-                and (ca is None or (len(srcs) == 1 and cin <= 256 and ca[1].data_ptr() % 16 == 0)))
+                and n * _wino_tiles(h, w) >= WINO_MIN_TILES
+                and (ca is None or (lab and len(srcs) == 1 and cin <= 256 and ca[1].data_ptr() % 16 == 0)))
     # F(4x4, 3x3): same 512-pixel-per-workgroup granularity (8 x 64), no fused channel-attention prologue
     use_wino4 = (use_wino and CONV_MODE == "winograd4" and out.data_ptr() % 16 == 0
                  and (residual is None or residual.data_ptr() % 16 == 0)
                  and 2 * n * lib().eavsr_conv3x3_wino4_tiles(h, w) >= WINO_MIN_TILES)
-    if res_scale is not None and not (use_wino4 and cin % 8 == 0 and lib().eavsr_wino4_schedule() == 1):
+    if use_wino and not use_wino4 and not lab:
+        use_wino = False      # default build: F(2x2,3x3) is a lab kernel -- what F(4x4,3x3) does not take runs the direct kernel
+    if res_scale is not None and not (use_wino4 and cin % 8 == 0 and lib().eavsr_wino4_schedule() >= 1):
         # every other kernel: the convolution, then the tail as its own launch
         return scale_residual(conv2d(srcs, weights, biases, act=act, slope=slope), res_scale, residual)
     if pixel_shuffle2 and not (use_wino4 and FUSE_PIXEL_SHUFFLE):      # every other kernel: plain output, shuffled by torch
@@ -659,7 +684,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     wp = None if use_x6s else pack_cache.get(weights)      # (the x6s kernel has its own packed form)
     part = None
     if chan_partial:
-        tiles = (lib().eavsr_conv3x3_x6s_tiles(h, w) if use_x6s else lib().eavsr_conv5x5_wino_tiles(h, w) if use_wino5 else lib().eavsr_conv3x3_wino4_tiles(h, w) if use_wino4 else lib().eavsr_conv3x3_wino_tiles(h, w) if use_wino
+        tiles = (lib().eavsr_conv3x3_x6s_tiles(h, w) if use_x6s else lib().eavsr_conv5x5_wino_tiles(h, w) if use_wino5 else lib().eavsr_conv3x3_wino4_tiles(h, w) if use_wino4 else _wino_tiles(h, w) if use_wino
                  else lib().eavsr_conv2d_tiles(n, h, w, k))
         part = torch.empty((n, tiles, cout), device=out.device, dtype=torch.float32)
     if residual is not None:
@@ -800,6 +825,8 @@ def modulated_deform_conv2d(input: Tensor, offset: Tensor, mask: Tensor, weight:
         # generic callers hold an NCHW tensor: one conversion pass to the IL8 layout, then the hot-path kernel (inside
         # MultiAdSTN the warp before the call writes IL8 itself and the predictor heads are passed instead of offset / mask)
         return dcnv2_il(to_il8(x), offset, mask, weight, b, deform_groups, nprod=int(DCN_MODE[2]), heads=False)
+    if DCN_MODE == "bf16x9":
+        require_lab("dcn mode 'bf16x9'")
     if DCN_MODE == "bf16x9" and w % 4 == 0 and x.data_ptr() % 16 == 0:
         wx = _packed_dcn_x9(weight)
         _launch("dcnv2_x9", flops, nbytes, x,
@@ -865,7 +892,9 @@ def dcnv2_il(x_il8: Tensor, offset_or_heads: Tensor, mask: Optional[Tensor], wei
     px = float(n) * h * w
     # algorithmic bytes of the DCNv2 op as SURVEY 8d defines them (input + 27 D offset/mask + output); in heads mode the
     # kernel itself moves (cin + 15 D + cout) floats per pixel
-    fn = {"ws": lib().eavsr_dcnv2_ws_f32, "il": lib().eavsr_dcnv2_il_f32, "il2": lib().eavsr_dcnv2_il2_f32}[impl]
+    if impl == "ws":
+        require_lab("the wave-specialised DCNv2 schedule 'ws'")
+    fn = getattr(lib(), {"ws": "eavsr_dcnv2_ws_f32", "il": "eavsr_dcnv2_il_f32", "il2": "eavsr_dcnv2_il2_f32"}[impl])
     _launch("dcnv2_il" + ("_heads" if heads else ""), 2.0 * cin * 9 * cout * px, 4.0 * px * (cin + 27 * D + cout), out,
             lambda: fn(_p(x_il8), _p(oh), _p(mask), _p(wx), _p(b), _p(out), n, cin, h, w, cout, D,
                        int(nprod), (2 if mask_activated else 1) if heads else 0, st), "dcnv2_il")
@@ -937,6 +966,8 @@ def set_dcn_il_impl(impl: str) -> None:
     global DCN_IL_IMPL
     if impl not in ("il", "ws", "il2"):
         raise ValueError(f"dcn il impl {impl!r}: 'il', 'il2' or 'ws'")
+    if impl == "ws":
+        require_lab("the wave-specialised DCNv2 schedule 'ws'")
     DCN_IL_IMPL = impl
 
 
@@ -1051,6 +1082,8 @@ def set_dcn_mode(mode: str) -> None:
     global DCN_MODE
     if mode not in ("native", "bf16x9", "il6", "il9"):
         raise ValueError(f"dcn mode {mode!r}: 'native', 'bf16x9', 'il6' or 'il9'")
+    if mode == "bf16x9":
+        require_lab("dcn mode 'bf16x9' (the round-1 NCHW kernel with nine partial products)")
     DCN_MODE = mode
 
 
@@ -1115,7 +1148,10 @@ WINO_MIN_TILES = int(os.environ.get("EAVSR_WINO_MIN_TILES", "192"))   # 8 x 32-p
 
 def set_conv_mode(mode: str) -> None:
     global CONV_MODE
-    CONV_MODE = _norm_conv_mode(mode)
+    mode = _norm_conv_mode(mode)
+    if mode in ("winograd", "bf16x9"):      # F(2x2,3x3) and the nine-product direct kernel: retired schedules
+        require_lab(f"conv mode {mode!r}")
+    CONV_MODE = mode
 
 
 @contextlib.contextmanager
@@ -1146,6 +1182,8 @@ def _packed_wino(weights: Sequence[Tensor], four: bool = False, kind: Optional[s
     """G g G^T of a conv weight (or of several stacked along cout); kind "f2" = F(2x2, 3x3), "f4" = F(4x4, 3x3),
     "f5" = F(2x2, 5x5); cached per weight objects and versions."""
     kind = kind or ("f4" if four else "f2")
+    if kind == "f2":
+        require_lab("Winograd F(2x2,3x3)")
     key = tuple((id(w), w._version) for w in weights) + ((kind, 0),)
     hit = _wino_pack_cache.get(key)
     if hit is not None and all(r() is w for r, w in zip(hit[0], weights)):
@@ -1158,8 +1196,8 @@ def _packed_wino(weights: Sequence[Tensor], four: bool = False, kind: Optional[s
         raise NotImplementedError(f"winograd weight shape {tuple(w.shape)} unsupported")
     packed = torch.empty(elems, device=w.device, dtype=torch.float32)
     with _DeviceOf(w):
-        fn = {"f2": lib().eavsr_pack_conv_weight_wino, "f4": lib().eavsr_pack_conv_weight_wino4,
-              "f5": lib().eavsr_pack_conv_weight_wino5x5}[kind]
+        fn = getattr(lib(), {"f2": "eavsr_pack_conv_weight_wino", "f4": "eavsr_pack_conv_weight_wino4",
+                             "f5": "eavsr_pack_conv_weight_wino5x5"}[kind])
         N.check(fn(_p(w), _p(packed), cout, cin, _stream(w)), "pack_conv_weight_wino")
     ids = {id(x) for x in weights}
     for k in [k for k in _wino_pack_cache if k[-1] == (kind, 0) and any(i in ids for i, _ in k[:-1])]:
@@ -1192,6 +1230,7 @@ def flow_level(x: Tensor, h_hr: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: 
                head_bs: Sequence[Tensor], wt: Tensor, bt: Tensor) -> Tensor:
     """TransOffsetworelu(AdaptBlock2_3x3(x, h_hr)) as one kernel (networks.py:334-348 + 566-571): (n,c,h,w) x 2 -> (n,2,h,w).
     head_ws / head_bs: [transform_matrix_conv, translation_conv] parameters (4 + 2 output channels)."""
+    require_lab("ops.flow_level (one kernel per pyramid level)")
     x, h_hr = _chk(x, "x"), _chk(h_hr, "h_hr")
     if x.shape != h_hr.shape:
         raise ValueError("x and h_hr must have the same shape")
@@ -1912,6 +1951,7 @@ def rcab_convs_h16(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: 
     """r = conv3x3(ReLU(conv3x3(x))) of one RCAB (networks.py:461-462) as ONE launch on 16-bit NHWC tensors
     (csrc/rcab_h16.hip: streamed weights, the intermediate lives in LDS); with `chan_partial` also the channel sums of r for the
     channel attention, in the row layout of conv3x3_c64_h16."""
+    require_lab("ops.rcab_convs_h16 (conv -> ReLU -> conv of a 16-bit RCAB as one launch)")
     x = _chk_h16(x, "x")
     n, h, w, c = x.shape
     if c != 64:

@@ -55,6 +55,8 @@ int eavsr_abi_version(void);
 const char* eavsr_version(void);
 /* message of the last failing call on the calling thread ("" if none) */
 const char* eavsr_last_error(void);
+/* 0: the product build (every entry point above the EXPERIMENTAL section); 1: the lab build (ABI 28) */
+int eavsr_lab_build(void);
 
 /* Verifies on the device that v_mfma_f32_32x32x2_f32 has the operand / accumulator lane layout the
  * kernels assume (asymmetric integer data).  scratch: >= 8192 floats of device memory.  The result
@@ -80,15 +82,6 @@ int eavsr_flow_warp_f32(const float* x, const float* flow, const float* flow2, f
 int eavsr_flow_warp_pair_f32(const float* xa, const float* xb, const float* flow, const float* flow2, float* outa,
                              float* outb, int32_t n, int32_t c, int32_t h, int32_t w, int32_t outb_il8, void* stream);
 
-/* One pyramid level of MultiAdSTN's residual-flow refinement as ONE kernel (networks.py:604-619): AdaptBlock2_3x3
- * (front end `concat` + `concat2`, the 3x3 heads transform_matrix_conv (4) ++ translation_conv (2), the affine -> 18 offsets
- * expansion, networks.py:334-348) followed by TransOffsetworelu's 3x3 conv 18 -> 2 (networks.py:566-571).
- * x, h_hr (n, c, h, w); w1 (2c,1,3,3) b1 (2c); w2 (c,2,3,3) b2 (c); w_heads (6, c, 3, 3) b_heads (6); w_trans (2, 18, 3, 3)
- * b_trans (2); out (n, 2, h, w).  Replaces eavsr_adapt_frontend_f32 + eavsr_conv3x3_smallco_f32 (64 -> 6) +
- * eavsr_affine_offsets_f32 + eavsr_conv3x3_smallco_f32 (18 -> 2) and their three HBM round trips. */
-int eavsr_flow_level_f32(const float* x, const float* h_hr, const float* w1, const float* b1, const float* w2,
-                         const float* b2, const float* w_heads, const float* b_heads, const float* w_trans,
-                         const float* b_trans, float* out, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 
 /* ---- a7: DCNv2 ------------------------------------------------------------------------------
  * replaces mmcv.ops.modulated_deform_conv2d as called at models/networks.py:627-630 (module
@@ -108,13 +101,10 @@ int eavsr_dcnv2_f32(const float* x, const float* offset, const float* mask,
  * products are accumulated in fp32 -- no operand is rounded; only the accumulation order differs from the fma
  * chain of eavsr_dcnv2_f32.  weight_x9: eavsr_dcn_weight_x9_bytes(cout, cin) bytes written by
  * eavsr_pack_dcn_weight_x9 from weight(cout,cin,3,3).  Additionally requires w % 4 == 0 and a 16-byte aligned x
- * (returns -2 otherwise: call eavsr_dcnv2_f32).  Opt-in; the reference-facing wrappers default to eavsr_dcnv2_f32. */
+ * (returns -2 otherwise: call eavsr_dcnv2_f32).  The packed slabs are what eavsr_dcnv2_il_f32 reads; the NCHW kernel itself
+ * (eavsr_dcnv2_f32x9) is in the EXPERIMENTAL section at the end of this header (lab build only). */
 int64_t eavsr_dcn_weight_x9_bytes(int32_t cout, int32_t cin);
 int eavsr_pack_dcn_weight_x9(const float* weight, void* weight_x9, int32_t cout, int32_t cin, void* stream);
-int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask,
-                      const void* weight_x9, const float* bias, float* out,
-                      int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
-                      int32_t deform_groups, void* stream);
 
 /* Round-2 hot-path form of the same operation (csrc/dcnv2_il.hip).  Differences from eavsr_dcnv2_f32x9:
  *   x_il8   the sampled feature map in "IL8" layout [n][cin/8][h][w][8] (the 8 channels of a deformable group interleaved
@@ -131,12 +121,6 @@ int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask,
  * weight_x9 from eavsr_pack_dcn_weight_x9.  Requires (cin/dg) % 8 == 0, 16-byte aligned x_il8; any h, w. */
 int eavsr_nchw_to_il8_f32(const float* x, float* out_il8, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 int eavsr_dcnv2_il_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
-                       const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
-                       int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
-/* The same operation, arguments and arithmetic as eavsr_dcnv2_il_f32, scheduled wave-specialised (csrc/dcnv2_ws.hip): four
- * sampler waves (positions, LDS gathers, blend, 3-way bf16 split -> LDS stage) and four contractor waves (MFMAs, LDS-DMA,
- * stores) per workgroup, so that the two waves of a SIMD use different issue ports. */
-int eavsr_dcnv2_ws_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
                        const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
                        int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
 
@@ -221,29 +205,11 @@ typedef struct eavsr_conv2d_desc {
  * that a descriptor that grew without an ABI bump (ABI 27 did, within one round) can never be read past its end. */
 size_t eavsr_conv2d_desc_size(void);
 int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);
-/* Opt-in "bf16x9" form of the 3x3 convolution (same descriptor, same tensors, same epilogue): both fp32 operands
- * are split EXACTLY into three bf16 terms and all nine partial products are accumulated in fp32 on
- * v_mfma_f32_32x32x16_bf16 (see eavsr_dcnv2_f32x9).  weight_x9 comes from eavsr_pack_dcn_weight_x9 on the
- * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  Requires ksize 3, w % 4 == 0, 16-byte aligned sources
- * with channels % 8 == 0, no fused channel-attention prologue, and a problem size that runs 32-row tiles
- * (eavsr_conv2d_tile_rows); returns -2 otherwise and the caller uses eavsr_conv2d_f32.                          */
-int eavsr_conv3x3_f32x9(const eavsr_conv2d_desc* desc, const void* weight_x9, void* stream);
-/* The 3x3 convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores (same descriptor, tensors and epilogue;
- * 2.25x fewer multiplications; fp32 arithmetic throughout, as cuDNN / MIOpen run fp32 3x3 convolutions by default).
- * weight_wino: eavsr_wino_weight_elems(cout, cin) floats written by eavsr_pack_conv_weight_wino from the
- * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  8 x 32-pixel tiles: chan_partial has
- * eavsr_conv3x3_wino_tiles(h, w) rows per sample.  Requires ksize 3, w % 4 == 0, 16-byte aligned sources with
- * channels % 8 == 0; the fused channel-attention prologue (ca_scale / ca_x / ca_out of the descriptor) is applied in
- * the input transform and needs a single source with cin <= 256.  Returns -2 otherwise (call eavsr_conv2d_f32).  */
-int64_t eavsr_wino_weight_elems(int32_t cout, int32_t cin);
-int eavsr_pack_conv_weight_wino(const float* weight, float* weight_wino, int32_t cout, int32_t cin, void* stream);
-int32_t eavsr_conv3x3_wino_tiles(int32_t h, int32_t w);
-int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* desc, const float* weight_wino, void* stream);
 
 /* The same convolution by Winograd F(4x4, 3x3): 36 transform-domain GEMMs per 6x6 input tile, 4x fewer
  * multiplications than the direct sum (1.78x fewer than F(2x2, 3x3)), fp32 throughout; the larger transform costs
- * accuracy (~1e-5 of the output scale against ~4e-7).  Same descriptor, epilogue and requirements as
- * eavsr_conv3x3_wino_f32 except: sources a multiple of 4 channels, out / residual / ca_x / ca_out 16-byte aligned,
+ * accuracy (~1e-5 of the output scale against ~4e-7).  Same descriptor and epilogue as eavsr_conv2d_f32 (desc->weight_packed is
+ * ignored); requires ksize 3, w % 4 == 0, 16-byte aligned sources of a multiple of 4 channels, out / residual 16-byte aligned,
  * chan_partial has eavsr_conv3x3_wino4_tiles(h, w) rows per sample (8 x 64-pixel tiles).  The fused channel-attention
  * prologue (ca_scale, ca_x, optional ca_out: input = src[0] * ca_scale[n, c] + ca_x, single source) is applied in the
  * input transform.  weight_wino4: eavsr_wino4_weight_elems(cout, cin) floats from eavsr_pack_conv_weight_wino4. */
@@ -562,15 +528,6 @@ int eavsr_ca_scale_pre_h16(const void* t, const float* chan_partial, int32_t row
  *   .permute(3, 4, 1, 0, 2)); fp32 accumulation, out fp32 NCHW (n, 3, h, w) = conv + bias + residual (nullable: the bilinear skip). */
 int eavsr_conv3x3_c64_h16_act(const void* x, const void* weight_packed, const float* bias, void* out, int32_t n, int32_t h,
                               int32_t w, int32_t act, float slope, int32_t pixel_shuffle2, int32_t dtype, void* stream);
-/* conv3x3 -> ReLU -> conv3x3 of one RCAB (RCABlock.forward, models/networks.py:461-462, mode 'CRC') as ONE launch in the 16-bit
- * modes (ABI 26): r = conv2(ReLU(conv1(x) + bias1)) + bias2 on 16-bit NHWC tensors, both weights in the packed form of
- * eavsr_pack_conv3x3_c64_h16, the intermediate rounded to 16 bits in LDS (never in HBM) and zero outside the image (the second
- * convolution's own padding).  r is bit-identical to two eavsr_conv3x3_c64_h16 launches.  chan_partial (nullable): (n,
- * eavsr_rcab_h16_partial_rows(n, h, w), 64) fp32, one row per workgroup of the launch and sample (zeros where a workgroup has no
- * tile of the sample); the rows of a sample add up to the channel sums of r over its pixels. */
-int32_t eavsr_rcab_h16_partial_rows(int32_t n, int32_t h, int32_t w);
-int eavsr_rcab_convs_h16(const void* x, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2,
-                         void* out, float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
 int eavsr_conv3x3_c64to3_h16(const void* x, const void* weight, const float* bias, const float* residual, float* out,
                              int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
 /* Generic 3x3 convolution of the 16-bit modes (csrc/conv3_h16.hip): same descriptor as eavsr_conv2d_f32 (fp32 NCHW sources as a
@@ -607,6 +564,67 @@ int eavsr_nhwc_h16_to_nchw_f32(const void* in, const float* residual, float* out
 /* NHWC 16-bit RCAB tail: out = r * scale[n,c] + x  (scale fp32) */
 int eavsr_scale_residual_h16(const void* r, const float* scale, const void* x, void* out, int32_t n,
                              int32_t c, int32_t hw, int32_t dtype, void* stream);
+
+/* ============================================================================================
+ * EXPERIMENTAL -- exported by the LAB build only (`python -m eavsr_amd.build --lab`, -DEAVSR_LAB=1; eavsr_lab_build() == 1).
+ * Schedules that were built, measured against the stable ones above and retired; kept because DESIGN.md / docs/history quote
+ * their A/B figures.  Same boundary contract; no stability promise; a default build does not contain them.
+ * (Also lab-only, without an entry point of its own: the channel-attention prologue of eavsr_conv3x3_wino4_f32 -- desc.ca_scale
+ * with that entry point returns -2 on a default build.)
+ * ============================================================================================ */
+/* One pyramid level of MultiAdSTN's residual-flow refinement as ONE kernel (networks.py:604-619): AdaptBlock2_3x3
+ * (front end `concat` + `concat2`, the 3x3 heads transform_matrix_conv (4) ++ translation_conv (2), the affine -> 18 offsets
+ * expansion, networks.py:334-348) followed by TransOffsetworelu's 3x3 conv 18 -> 2 (networks.py:566-571).
+ * x, h_hr (n, c, h, w); w1 (2c,1,3,3) b1 (2c); w2 (c,2,3,3) b2 (c); w_heads (6, c, 3, 3) b_heads (6); w_trans (2, 18, 3, 3)
+ * b_trans (2); out (n, 2, h, w).  Replaces eavsr_adapt_frontend_f32 + eavsr_conv3x3_smallco_f32 (64 -> 6) +
+ * eavsr_affine_offsets_f32 + eavsr_conv3x3_smallco_f32 (18 -> 2) and their three HBM round trips. */
+int eavsr_flow_level_f32(const float* x, const float* h_hr, const float* w1, const float* b1, const float* w2,
+                         const float* b2, const float* w_heads, const float* b_heads, const float* w_trans,
+                         const float* b_trans, float* out, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+
+/* The round-1 NCHW DCNv2 with all nine bf16 partial products (csrc/dcnv2_x9.hip): arguments of eavsr_dcnv2_f32, weight_x9 from
+ * eavsr_pack_dcn_weight_x9 (stable: eavsr_dcnv2_il_f32 reads the same slabs); w % 4 == 0, 16-byte aligned x, else -2. */
+int eavsr_dcnv2_f32x9(const float* x, const float* offset, const float* mask,
+                      const void* weight_x9, const float* bias, float* out,
+                      int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                      int32_t deform_groups, void* stream);
+
+/* The same operation, arguments and arithmetic as eavsr_dcnv2_il_f32, scheduled wave-specialised (csrc/dcnv2_ws.hip): four
+ * sampler waves (positions, LDS gathers, blend, 3-way bf16 split -> LDS stage) and four contractor waves (MFMAs, LDS-DMA,
+ * stores) per workgroup, so that the two waves of a SIMD use different issue ports. */
+int eavsr_dcnv2_ws_f32(const float* x_il8, const float* offset_or_heads, const float* mask, const void* weight_x9,
+                       const float* bias, float* out, int32_t n, int32_t cin, int32_t h, int32_t w, int32_t cout,
+                       int32_t deform_groups, int32_t nprod, int32_t heads, void* stream);
+
+/* Opt-in "bf16x9" form of the 3x3 convolution (same descriptor, same tensors, same epilogue): both fp32 operands
+ * are split EXACTLY into three bf16 terms and all nine partial products are accumulated in fp32 on
+ * v_mfma_f32_32x32x16_bf16 (see eavsr_dcnv2_f32x9).  weight_x9 comes from eavsr_pack_dcn_weight_x9 on the
+ * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  Requires ksize 3, w % 4 == 0, 16-byte aligned sources
+ * with channels % 8 == 0, no fused channel-attention prologue, and a problem size that runs 32-row tiles
+ * (eavsr_conv2d_tile_rows); returns -2 otherwise and the caller uses eavsr_conv2d_f32.                          */
+int eavsr_conv3x3_f32x9(const eavsr_conv2d_desc* desc, const void* weight_x9, void* stream);
+
+/* The 3x3 convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores (same descriptor, tensors and epilogue;
+ * 2.25x fewer multiplications; fp32 arithmetic throughout, as cuDNN / MIOpen run fp32 3x3 convolutions by default).
+ * weight_wino: eavsr_wino_weight_elems(cout, cin) floats written by eavsr_pack_conv_weight_wino from the
+ * (cout, cin, 3, 3) weight (desc->weight_packed is ignored).  8 x 32-pixel tiles: chan_partial has
+ * eavsr_conv3x3_wino_tiles(h, w) rows per sample.  Requires ksize 3, w % 4 == 0, 16-byte aligned sources with
+ * channels % 8 == 0; the fused channel-attention prologue (ca_scale / ca_x / ca_out of the descriptor) is applied in
+ * the input transform and needs a single source with cin <= 256.  Returns -2 otherwise (call eavsr_conv2d_f32).  */
+int64_t eavsr_wino_weight_elems(int32_t cout, int32_t cin);
+int eavsr_pack_conv_weight_wino(const float* weight, float* weight_wino, int32_t cout, int32_t cin, void* stream);
+int32_t eavsr_conv3x3_wino_tiles(int32_t h, int32_t w);
+int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* desc, const float* weight_wino, void* stream);
+
+/* conv3x3 -> ReLU -> conv3x3 of one RCAB (RCABlock.forward, models/networks.py:461-462, mode 'CRC') as ONE launch in the 16-bit
+ * modes (ABI 26): r = conv2(ReLU(conv1(x) + bias1)) + bias2 on 16-bit NHWC tensors, both weights in the packed form of
+ * eavsr_pack_conv3x3_c64_h16, the intermediate rounded to 16 bits in LDS (never in HBM) and zero outside the image (the second
+ * convolution's own padding).  r is bit-identical to two eavsr_conv3x3_c64_h16 launches.  chan_partial (nullable): (n,
+ * eavsr_rcab_h16_partial_rows(n, h, w), 64) fp32, one row per workgroup of the launch and sample (zeros where a workgroup has no
+ * tile of the sample); the rows of a sample add up to the channel sums of r over its pixels. */
+int32_t eavsr_rcab_h16_partial_rows(int32_t n, int32_t h, int32_t w);
+int eavsr_rcab_convs_h16(const void* x, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2,
+                         void* out, float* chan_partial, int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than ~20 s on 8 CPU cores")
 
 
+def _lab_only_to_skip(outcome):
+    """A test (or one of its fixtures) that asks for a retired schedule -- F(2x2,3x3), the nine-product kernels, the
+    wave-specialised DCNv2, one kernel per pyramid level, the one-launch 16-bit RCAB, the prologue inside the Winograd kernel --
+    raises ops.LabBuildRequired on the default (product) library: that is a SKIP here and a run with the lab library
+    (`python -m eavsr_amd.build --lab`, then `pytest -m gpu`) executes it.  VERDICT r5 item 7."""
+    if outcome.excinfo is not None and outcome.excinfo[0].__name__ == "LabBuildRequired":
+        try:
+            pytest.skip(f"lab build only: {outcome.excinfo[1]}")
+        except pytest.skip.Exception:
+            outcome.force_exception(sys.exc_info()[1])
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_setup(item):
+    _lab_only_to_skip((yield))
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    _lab_only_to_skip((yield))
+
+
 @pytest.fixture(scope="session")
 def cuda():
     import torch

@@ -217,17 +217,18 @@ def test_rcagroup_16bit_backbone_vs_fp32_oracle(ops, cuda, dt):
     assert H.maxabs(out0, ref) / ref.abs().max().item() <= (4e-2 if dt == "bf16" else 6e-3)
     # the same group with each RCAB's two convolutions as ONE launch (csrc/rcab_h16.hip, opt-in): same r, channel sums by another
     # summation tree -- the group output may differ by a 16-bit rounding flip here and there, never by more
-    try:
-        Nw.set_backbone_dtype(dt)
-        Nw.set_rcab_h16_fused(True)
-        with torch.no_grad(), ops.profile() as prof:
-            out1 = grp(x.to(cuda)).cpu()
-        assert "rcab_convs_h16" in set(prof.summary())
-    finally:
-        Nw.set_rcab_h16_fused(False)
-        Nw.set_backbone_dtype(None)
-    assert H.maxabs(out1, out) <= 4 * EPS[dt] * ref.abs().max().item()
-    assert H.maxabs(out1, ref) / ref.abs().max().item() <= (4e-2 if dt == "bf16" else 6e-3)
+    if ops.lab_available():      # (a retired schedule: lab build only)
+        try:
+            Nw.set_backbone_dtype(dt)
+            Nw.set_rcab_h16_fused(True)
+            with torch.no_grad(), ops.profile() as prof:
+                out1 = grp(x.to(cuda)).cpu()
+            assert "rcab_convs_h16" in set(prof.summary())
+        finally:
+            Nw.set_rcab_h16_fused(False)
+            Nw.set_backbone_dtype(None)
+        assert H.maxabs(out1, out) <= 4 * EPS[dt] * ref.abs().max().item()
+        assert H.maxabs(out1, ref) / ref.abs().max().item() <= (4e-2 if dt == "bf16" else 6e-3)
     with torch.no_grad():
         exact = grp(x.to(cuda)).cpu()          # back to the exact fp32 path
     assert H.maxabs(exact, ref) <= 2e-5 * max(1.0, ref.abs().max().item())

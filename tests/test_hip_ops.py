@@ -916,6 +916,7 @@ def test_conv5x5_winograd_vs_torch_cpu(conv_wino4, cuda, case):
 def test_conv3x3_winograd4_fused_channel_attention_prologue(conv_wino4, cuda):
     """conv(r * scale + x) with the side output of the effective input, applied in the F(4x4, 3x3) input transform;
     ragged size (tiles cut by the image edge), several tiles per workgroup, with and without side output / residual"""
+    conv_wino4.require_lab("the channel-attention prologue inside the F(4x4,3x3) kernel")
     n, c, h, w = 10, 64, 133, 156
     r, x = cases.randn(1, n, c, h, w), cases.randn(2, n, c, h, w)
     scale = cases.rand(3, n, c)
@@ -965,7 +966,8 @@ def test_conv3x3_winograd4_error_against_fp64_and_fallbacks(ops, cuda):
         r, xx, sc = cases.randn(5, n, 64, h, w), cases.randn(6, n, 64, h, w), cases.rand(7, n, 64)
         with ops.profile() as prof:
             out = ops.conv2d(g(r, cuda), g(wt, cuda), None, ca=(g(sc, cuda), g(xx, cuda)))
-        assert list(prof.summary()) == ["conv3x3_64to64_wino4_ca"]
+        # the prologue inside the Winograd kernel is a lab instantiation; the default build folds it into the direct kernel
+        assert list(prof.summary()) == ["conv3x3_64to64_wino4_ca" if ops.lab_available() else "conv3x3_64to64_ca"]
         ref = F.conv2d(r * sc.view(n, 64, 1, 1) + xx, wt, None, 1, 1)
         assert H.maxabs(out.cpu(), ref) <= 6e-5 * max(1.0, ref.abs().max().item())
     finally:

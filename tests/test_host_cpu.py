@@ -18,11 +18,26 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     build.build_native()
     lib = _native.load()
     header = open(os.path.join(ROOT, "include", "eavsr_hip.h")).read()
-    declared = set(re.findall(r"\b(eavsr_[a-z0-9_]+)\s*\(", header))
-    declared -= {"eavsr_conv2d_desc"}
+    stable_part, lab_part = header.split(" * EXPERIMENTAL -- exported by the LAB build only")
+    find = lambda text: set(re.findall(r"^(?:int|int32_t|int64_t|size_t|const char\*)\s+(eavsr_[a-z0-9_]+)\s*\(", text, flags=re.M))
+    declared, declared_lab = find(stable_part), find(lab_part)
+    # the header's two sections are exactly the binding's two tables ...
     assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    assert declared_lab == set(_native.LAB_SIGNATURES), declared_lab ^ set(_native.LAB_SIGNATURES)
+    # ... and the DEFAULT build (what build() makes and the GPU box runs) exports exactly the stable section: product, not notebook
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (eavsr_[a-z0-9_]+)$", nm, flags=re.M))
+    assert lib.eavsr_lab_build() == 0 and not _native.lab_build()
+    assert exported == declared, exported ^ declared
+    assert not (exported & declared_lab)
     for name in declared:
         assert hasattr(lib, name), name
+    from eavsr_amd import ops
+    with pytest.raises(ops.LabBuildRequired):
+        ops.set_conv_mode("bf16x9")
+    with pytest.raises(ops.LabBuildRequired):
+        ops.set_dcn_il_impl("ws")
     assert lib.eavsr_abi_version() == _native.ABI_VERSION
     assert b"gfx950" in lib.eavsr_version()
     # pure host helpers (no device work)
@@ -361,16 +376,20 @@ def test_scoped_mode_switches_restore_the_previous_modes():
     """`ops.modes(...)` / `networks.backbone_dtype(...)`: scoped kernel selection that never leaks (also on an exception)."""
     from eavsr_amd import networks as Nw, ops
     before = (ops.CONV_MODE, ops.DCN_MODE, ops.DCN_IL_IMPL, Nw.BACKBONE_DTYPE)
-    with ops.modes(conv="direct", dcn="native", dcn_il_impl="ws"):
-        assert (ops.CONV_MODE, ops.DCN_MODE, ops.DCN_IL_IMPL) == ("direct", "native", "ws")
+    with ops.modes(conv="direct", dcn="native", dcn_il_impl="il"):
+        assert (ops.CONV_MODE, ops.DCN_MODE, ops.DCN_IL_IMPL) == ("direct", "native", "il")
         with ops.modes(dcn="il9"):
             assert (ops.CONV_MODE, ops.DCN_MODE) == ("direct", "il9")
         assert ops.DCN_MODE == "native"
     assert (ops.CONV_MODE, ops.DCN_MODE, ops.DCN_IL_IMPL) == before[:3]
     with pytest.raises(ValueError):
-        with ops.modes(conv="winograd"):
+        with ops.modes(conv="direct"):
             raise ValueError("boom")
     assert ops.CONV_MODE == before[0]
+    with pytest.raises(ops.LabBuildRequired):      # a lab-only mode on the default build: refused, nothing left behind
+        with ops.modes(dcn="native", conv="winograd"):
+            pass
+    assert (ops.CONV_MODE, ops.DCN_MODE) == before[:2]
     with pytest.raises(ValueError):
         with ops.modes(dcn="no-such-mode"):
             pass
