@@ -50,29 +50,17 @@
 #include <cstdlib>
 #include <cstring>
 
-#ifndef EAVSR_W4_DEFAULT_SCHED
-#define EAVSR_W4_DEFAULT_SCHED 1
-#endif
-
 namespace {
 
-// Schedule of the 3x3 kernel (an even number of 4-channel chunks; read once): 1 = grouped (round 3: transform phases of two chunks,
-// pure GEMM iterations), 2 = duty pair with the transform interleaved into the duty waves' GEMM steps (round 6), 0 = round 2's duty
-// pair (transform as a block).  EAVSR_W4_SCHED=grp | di | duty selects; EAVSR_W4_GRP=0 still means "duty" (older A/B scripts).
-static int w6_schedule() {
+// the grouped schedule is the default; EAVSR_W4_GRP=0 keeps the duty-pair schedule (A/B switch), read once
+static bool w6_grouped_schedule() {
 #ifdef EAVSR_W4_NOGRP      // diagnostic builds (tools/build_wino4_diag.sh)
-  return 0;
+  return false;
 #else
-  static const int sched = [] {
-    const char* e = getenv("EAVSR_W4_SCHED");
-    if (e != nullptr) return !strcmp(e, "di") ? 2 : !strcmp(e, "duty") ? 0 : 1;
-    const char* g = getenv("EAVSR_W4_GRP");
-    return (g == nullptr || atoi(g) != 0) ? EAVSR_W4_DEFAULT_SCHED : 0;
-  }();
-  return sched;
+  static const bool on = [] { const char* e = getenv("EAVSR_W4_GRP"); return e == nullptr || atoi(e) != 0; }();
+  return on;
 #endif
 }
-static bool w6_grouped_schedule() { return w6_schedule() != 0; }      // (the schedules that have the scaled-residual epilogue)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -238,21 +226,11 @@ __device__ unsigned long long g_w4_it[256 * 256];
 // to ONE pair of SIMDs what the barrier then makes everybody wait for; as a phase of its own it costs every SIMD the same.
 // RSC: the instantiation whose epilogue is out = residual + res_scale[n][co] * act(conv + bias) (the RCAB tail; the grouped 3x3
 // kernel only) -- a kernel of its own so that the plain one's code and registers are exactly what they were
-// DI ("duty, interleaved"; round 6; 3x3 without the fused prologue): the duty-pair schedule -- the wave pair (it & 3) transforms chunk
-// it + 1 during iteration it, one barrier per chunk, no transform phase -- with the transform cut into slices that sit BETWEEN the
-// duty waves' own GEMM steps: its LDS reads go out behind step 0 / 1 and are covered by the GEMM's own counted waits (the counter
-// is in order: by the wait of step 4 everything but the newest six operand reads has landed), the column pass rides steps 5-7, a
-// row of the row pass + its three V stores steps 8-13.  Round 2's duty pair ran the transform as a BLOCK in front of its 36 MFMAs
-// (LDS round trip -> 112 vector instructions -> stores -> MFMAs: a 4,950-cycle chain beside 2,304 cycles of MFMAs per SIMD); the
-// grouped schedule made it a phase of its own (1,950 cycles per pair of chunks with the matrix pipe idle).  Here a duty wave's SIMD
-// pays the transform's ISSUE time only (fp32 MFMAs hold the vector ALU, so ~112 x 4-5 cycles are added to 2,304), every SIMD is
-// on duty every second iteration, and no LDS stage is added.
-template <int R, bool FUSE = false, bool GRP = false, bool RSC = false, bool DI = false>
+template <int R, bool FUSE = false, bool GRP = false, bool RSC = false>
 __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
-  static_assert(!RSC || ((GRP || DI) && R == 3 && !FUSE), "the scaled-residual epilogue exists for the grouped / interleaved 3x3 kernels");
+  static_assert(!RSC || (GRP && R == 3 && !FUSE), "the scaled-residual epilogue exists for the grouped 3x3 kernel");
   static_assert(!FUSE || R == 3, "the fused channel-attention prologue exists for the 3x3 kernel");
   static_assert(!GRP || (R == 3 && !FUSE), "the grouped schedule exists for the plain 3x3 kernel");
-  static_assert(!DI || (R == 3 && !FUSE && !GRP), "the interleaved duty schedule exists for the plain 3x3 kernel");
   using C = WCfg<R>;
   constexpr int M = C::M, PADR = C::PADR, TOH = C::TOH, TOW = C::TOW, IH = C::IH, IW = C::IW, IN_ELEMS = C::IN_ELEMS;
   constexpr int IN_SEGS = C::IN_SEGS, IN_PAD = C::IN_PAD, IN_IT = C::IN_IT;
@@ -719,22 +697,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       }
     };
 #ifndef EAVSR_W4_UREGS
-    if constexpr (!DI) duty_transform();
+    duty_transform();
 #if defined(EAVSR_W4_DUTY_NO_U) && !defined(EAVSR_W4_SPREAD)
-    if constexpr (!DI) {
-      if (!dma_late && on_duty) issue_dma();
-    }
+    if (!dma_late && on_duty) issue_dma();
 #endif
 #endif
-    // DI: the transform of chunk it + 1 as slices between this wave's GEMM steps (W4_T below); a duty wave of the early half
-    // requests its patch pieces in the middle of the GEMM, like the late half
-    const bool do_t = DI && on_duty && it + 1 < total_iters;
-    const bool dma_mid = dma_late || (DI && on_duty);
-    [[maybe_unused]] f32x4 tq[2];
-    [[maybe_unused]] f32x2 te[2], td[6];
-    [[maybe_unused]] const float* tpp = smem + ((it + 1) & 1) * IN_PAD + kq * (IH * IW) + (M * tg) * IW + 4 * l15;
-    [[maybe_unused]] float* tvd = s_v + ((it + 1) & 1) * V_ELEMS + kq * 64 + 2 * ((tg * 16 + l15) ^ ((kq & 1) << 4));
-    [[maybe_unused]] float* tsc = smem + C::LDS_FLOATS + (wave & 1) * (18 * 128) + 2 * lane;      // this duty wave's scratch
     // ---- the 36 GEMM steps of this wave: M_xi[co, t] += sum over the chunk's 4 channels U_xi[co, c] V_xi[c, t]
     // U and V hold the positions in PAIRS ([xi / 2][c][column][xi & 1], column ^ 16 (c & 1)): one ds_read_b64 per operand
     // and two positions - ds_read_b64 moves 256 B/clk against 128 for ds_read_b32 (whose 32 banks would also put the two
@@ -757,70 +724,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     // reads of the later steps may be outstanding.
     {
       const unsigned ua_l = (unsigned)(unsigned long long)(lptr_t)ua, vb_l = (unsigned)(unsigned long long)(lptr_t)vb;
-      [[maybe_unused]] const unsigned tpp_l = (unsigned)(unsigned long long)(lptr_t)tpp;
-      [[maybe_unused]] const unsigned tsc_l = (unsigned)(unsigned long long)(lptr_t)tsc;
       // (macros, not generic lambdas: clang rejects captured variables as asm operands inside one)
 #define W4_RD(I)                                                                                                     \
   do {                                                                                                               \
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(av[(I) % (AHEAD + 1)]) : "v"(ua_l), "n"((I) * (CK * 128) * 4)); \
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bv[(I) % (AHEAD + 1)]) : "v"(vb_l), "n"((I) * (CK * 64) * 4));  \
-  } while (0)
-      // ---- DI: slice I of the duty waves' transform, in two passes through a per-wave LDS scratch (18 pair slots x 64 lanes x 8 B) so
-      // that at most two input rows / one column pair are in registers (a one-pass form keeps all 36 values of a job + its
-      // outputs live between slices: +85 registers beside 144 accumulators, spilled).  Pass 1, steps 0-7: row r of the 6 x 6 patch
-      // (one b128 + two b32 reads at step r) goes through the ROW pass at step r + 2 -> three packed pairs into the scratch.
-      // Pass 2, steps 8-14: the six pairs of a pair column come back (a wave's LDS operations execute in order: no wait between
-      // its own store and load), go through the COLUMN pass (in1d, packed) and land in V.  (B^T d) B and B^T (d B) differ in
-      // rounding order only.)  Waits: the slices' reads are inline assembly like the operand reads; a slice waits until only the
-      // operand reads issued at the top of its own step may be outstanding.
-#define W4_TROW(SET, Rr)                                                                                                    \
-  do {                                                                                                                      \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tq[SET]) : "v"(tpp_l), "n"(((Rr) * IW + 4) * 4));                  \
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(te[SET].x) : "v"(tpp_l), "n"(((Rr) * IW + 3) * 4));                 \
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(te[SET].y) : "v"(tpp_l), "n"(((Rr) * IW + 8) * 4));                 \
-  } while (0)
-#define W4_TWAIT(I, ...)                                                                                                    \
-  do {                                                                                                                      \
-    if constexpr ((I) + AHEAD < NSTEP) asm volatile("s_waitcnt lgkmcnt(2)" : __VA_ARGS__);                                  \
-    else asm volatile("s_waitcnt lgkmcnt(0)" : __VA_ARGS__);                                                                \
-  } while (0)
-#define W4_T(I)                                                                                                             \
-  do {                                                                                                                      \
-    if constexpr (DI && R == 3) {                                                                                           \
-      if (do_t) {                                                                                                           \
-        if constexpr ((I) >= 2 && (I) <= 7) {      /* row pass of row I - 2 */                                              \
-          constexpr int r_ = (I) - 2, set_ = r_ & 1;                                                                        \
-          W4_TWAIT(I, "+v"(tq[set_]), "+v"(te[set_]));                                                                      \
-          const f32x2 x12_ = f32x2{tq[set_][0], tq[set_][1]}, x34_ = f32x2{tq[set_][2], tq[set_][3]};                       \
-          f32x2 o12_, o34_;                                                                                                 \
-          const f32x2 ba_ = x34_ - 4.f * x12_;                                                                              \
-          const f32x2 ec_ = x34_ - x12_;                                                                                    \
-          asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(o12_) : "v"(ba_));                  \
-          asm("v_pk_fma_f32 %0, %1, 2.0, %1 op_sel:[0,0,1] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(o34_) : "v"(ec_));        \
-          const f32x2 o05_ = f32x2{4.f * te[set_].x + (x34_.y - 5.f * x12_.y), 4.f * x12_.x + (te[set_].y - 5.f * x34_.x)};  \
-          *reinterpret_cast<f32x2*>(tsc + (r_ * 3 + 0) * 128) = o12_;                                                       \
-          *reinterpret_cast<f32x2*>(tsc + (r_ * 3 + 1) * 128) = o34_;                                                       \
-          *reinterpret_cast<f32x2*>(tsc + (r_ * 3 + 2) * 128) = o05_;                                                       \
-        }                                                                                                                   \
-        if constexpr ((I) <= 5) W4_TROW((I) & 1, I);      /* request row I */                                               \
-        if constexpr ((I) == 10 || (I) == 12 || (I) == 14) {      /* column pass of pair column (I - 10) / 2 */             \
-          constexpr int p_ = ((I) - 10) / 2;                                                                                \
-          W4_TWAIT(I, "+v"(td[0]), "+v"(td[1]), "+v"(td[2]), "+v"(td[3]), "+v"(td[4]), "+v"(td[5]));                        \
-          f32x2 to_[6];                                                                                                     \
-          in1d(td, to_);                                                                                                    \
-          for (int i_ = 0; i_ < 6; ++i_) *reinterpret_cast<f32x2*>(tvd + (i_ * 3 + p_) * (CK * 64)) = to_[i_];              \
-        }                                                                                                                   \
-        if constexpr ((I) == 8 || (I) == 10 || (I) == 12) {      /* request pair column (I - 8) / 2 */                      \
-          constexpr int p_ = ((I) - 8) / 2;                                                                                 \
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(td[0]) : "v"(tsc_l), "n"(((0 * 3 + p_) * 128) * 4));           \
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(td[1]) : "v"(tsc_l), "n"(((1 * 3 + p_) * 128) * 4));           \
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(td[2]) : "v"(tsc_l), "n"(((2 * 3 + p_) * 128) * 4));           \
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(td[3]) : "v"(tsc_l), "n"(((3 * 3 + p_) * 128) * 4));           \
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(td[4]) : "v"(tsc_l), "n"(((4 * 3 + p_) * 128) * 4));           \
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(td[5]) : "v"(tsc_l), "n"(((5 * 3 + p_) * 128) * 4));           \
-        }                                                                                                                   \
-      }                                                                                                                     \
-    }                                                                                                                       \
   } while (0)
 #define W4_S(I)                                                                                                      \
   do {                                                                                                               \
@@ -828,7 +736,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     if constexpr ((I) == NSTEP / 2) {                                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
       W4_IT(5);                                                                                                      \
-      if (dma_mid) issue_dma();                                                                                      \
+      if (dma_late) issue_dma();                                                                                     \
       W4_IT(6);                                                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
     }                                                                                                                \
@@ -837,7 +745,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(av[cur_]), "+v"(bv[cur_]) : "n"(2 * later_));                        \
     acc[2 * (I)] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur_].x, bv[cur_].x, acc[2 * (I)], 0, 0, 0);              \
     acc[2 * (I) + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur_].y, bv[cur_].y, acc[2 * (I) + 1], 0, 0, 0);      \
-    W4_T(I);                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);      /* the MFMAs stay between their wait and the next step's reads */        \
   } while (0)
       static_assert(AHEAD >= 1 && AHEAD <= 3 && NSTEP == 18, "the steps below are written out for 18 steps, up to 3 ahead");
@@ -847,9 +754,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
       W4_S(0); W4_S(1); W4_S(2); W4_S(3); W4_S(4); W4_S(5); W4_S(6); W4_S(7); W4_S(8);
       W4_S(9); W4_S(10); W4_S(11); W4_S(12); W4_S(13); W4_S(14); W4_S(15); W4_S(16); W4_S(17);
 #undef W4_S
-#undef W4_T
-#undef W4_TWAIT
-#undef W4_TROW
 #undef W4_RD
     }
 #else
@@ -953,8 +857,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
     // ---- epilogue, all in registers: lane (kq, l15) holds M_xi[co = 16 cb + 4 kq + r][tile (tg, l15)] for every xi ----
     {
       float csum[4] = {0.f, 0.f, 0.f, 0.f};
-      constexpr bool fast_done = GRP || DI;
-      if constexpr (GRP || DI) {
+      constexpr bool fast_done = GRP;
+      if constexpr (GRP) {
        {
         // ---- grouped kernel (round 6): the same output transform, bias, activation and sums in ~half the instructions.  The
         // epilogue of a one-tile workgroup is exposed whole (230 tiles on 256 CUs) and it is bound by instruction ISSUE: ~1,250
@@ -1387,7 +1291,6 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   EAVSR_REQUIRE(R != 3 || (long)d->h * d->w * 64 * 4 < (1L << 31), -1,
                 "conv_wino6: image plane too large for the epilogue's 32-bit offsets (64 channels x h x w x 4 bytes must be < 2 GiB)");
   [[maybe_unused]] constexpr size_t LDS_FUSE = C::LDS_BYTES + 2 * C::IN_PAD * sizeof(float);
-  [[maybe_unused]] constexpr size_t LDS_DI = C::LDS_BYTES + 2 * 18 * 128 * sizeof(float);      // + the two duty waves' transform scratch
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
   std::once_flag& once = once_pd.flag[dev_];
@@ -1407,12 +1310,6 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
     if (R == 3 && attr_err == hipSuccess)
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, false, true, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WCfg<3>::LDS_BYTES);
-    if (R == 3 && attr_err == hipSuccess)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, false, false, false, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WCfg<3>::LDS_BYTES + 2 * 18 * 128 * sizeof(float)));
-    if (R == 3 && attr_err == hipSuccess)
-      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino6_kernel<3, false, false, true, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WCfg<3>::LDS_BYTES + 2 * 18 * 128 * sizeof(float)));
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv_wino6: hipFuncSetAttribute(%zu B of LDS): %s", C::LDS_BYTES, hipGetErrorString(attr_err));
@@ -1430,19 +1327,13 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   } else {
     // the grouped schedule (transform phases of two chunks, pure GEMM iterations): 3x3, an even number of 4-channel chunks;
     // EAVSR_W4_GRP=0 keeps the duty-pair schedule (A/B switch)
-    const int sched = w6_schedule();
+    const bool grp_on = w6_grouped_schedule();
     if constexpr (R == 3) {
-      if (sched != 0 && (d->cin / CK) % 2 == 0) {
-        if (sched == 2) {
-          if (d->res_scale != nullptr)
-            hipLaunchKernelGGL((conv_wino6_kernel<3, false, false, true, true>), grid, dim3(64 * NW), LDS_DI, eavsr::as_stream(stream), a);
-          else
-            hipLaunchKernelGGL((conv_wino6_kernel<3, false, false, false, true>), grid, dim3(64 * NW), LDS_DI, eavsr::as_stream(stream), a);
-        } else if (d->res_scale != nullptr) {
+      if (grp_on && (d->cin / CK) % 2 == 0) {
+        if (d->res_scale != nullptr)
           hipLaunchKernelGGL((conv_wino6_kernel<3, false, true, true>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
-        } else {
+        else
           hipLaunchKernelGGL((conv_wino6_kernel<3, false, true>), grid, dim3(64 * NW), C::LDS_BYTES, eavsr::as_stream(stream), a);
-        }
         return eavsr::launch_status("conv_wino6");
       }
     }
@@ -1474,4 +1365,4 @@ extern "C" int eavsr_conv5x5_wino_f32(const eavsr_conv2d_desc* d, const float* w
   return launch_wino6<5>(d, weight_wino5x5, stream);
 }
 
-extern "C" int eavsr_wino4_schedule(void) { return w6_schedule(); }
+extern "C" int eavsr_wino4_schedule(void) { return w6_grouped_schedule() ? 1 : 0; }
