@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256) void h16_border_sums_kernel(const void* __rest
 // one workgroup of 1024 threads per sample, 64 channels
 template <int DT>
 __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restrict__ partial, int rows, const float* __restrict__ border,
+                                                            int p_rows, int p_cols, int p_stride,
                                                             const void* __restrict__ t, int h, int w,
                                                             const float* __restrict__ wc, const float* __restrict__ bc,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
                                                             float* __restrict__ scale, int cr) {
   constexpr int C = 64, Q = 1024 / C;
   __shared__ float part[Q * C];
-  __shared__ float T[C], B[4][C], X[4][C], S[9][C], mean[C], hid[C];
+  __shared__ float T[C], B[4][C], Bq[4][4][C], X[4][C], S[9][C], mean[C], hid[C];
   const int bn = blockIdx.x, tid = threadIdx.x;
   // every parameter this thread will need, requested now (each was a round trip of its own behind a barrier)
   const float bc_v = bc ? bc[tid >> 4] : 0.f;
@@ -300,15 +301,34 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
     for (; r < rows; r += Q) s0 += p[(size_t)r * C];
     part[q * C + ch] = (s0 + s1) + (s2 + s3);
   }
-  if (tid < 4 * C) {      // border lines: the segments of the border-sum launch, in order
-    const int b = tid >> 6, ch = tid & 63;
-    const float* p = border + (((size_t)bn * 4 + b) * CP_SEGS) * C + ch;
-    float v = 0.f;
+  // border lines: the pieces of border b (0 top row, 1 bottom row: p_rows pieces; 2 left column, 3 right column: p_cols pieces) -- the
+  // segments of the border-sum launch, or what the first convolution's epilogue left per border tile (round 6) -- added in a fixed
+  // order: thread (quarter qg, border b, channel ch) takes the pieces k = qg, qg + 4, .. with eight requests in flight, the four
+  // quarters meet in LDS
+  {
+    // (quarter and border are the same for a whole wave: the bounds below are scalar branches, a request that no lane needs is
+    // not issued -- sixteen exec-masked requests per wave cost the one memory pipe of the CU 2 us)
+    const int qg = __builtin_amdgcn_readfirstlane(tid >> 8), b = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), ch = tid & 63;
+    const int cnt = b < 2 ? p_rows : p_cols;
+    const float* p = border + (((size_t)bn * 4 + b) * p_stride) * C + ch;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = qg; k < cnt; k += 64) {      // sixteen predicated requests at once: one round trip for up to 64 pieces per border
+      float v[16];
 #pragma unroll
-    for (int k = 0; k < CP_SEGS; ++k) v += p[k * C];
-    B[b][ch] = v;
-  } else if (tid < 8 * C) {      // corners: 0 = (0, 0), 1 = (0, w - 1), 2 = (h - 1, 0), 3 = (h - 1, w - 1)
-    const int k = (tid >> 6) - 4, ch = tid & 63;
+      for (int j = 0; j < 16; ++j) {
+        v[j] = 0.f;
+        if (k + 4 * j < cnt) v[j] = p[(size_t)(k + 4 * j) * C];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        s0 += v[j] + v[j + 1];
+        s1 += v[j + 2] + v[j + 3];
+      }
+    }
+    Bq[qg][b][ch] = s0 + s1;
+  }
+  if (tid < 4 * C) {      // corners: 0 = (0, 0), 1 = (0, w - 1), 2 = (h - 1, 0), 3 = (h - 1, w - 1)
+    const int k = tid >> 6, ch = tid & 63;
     X[k][ch] = cp_load<DT>(t, bn, (k >> 1) ? h - 1 : 0, (k & 1) ? w - 1 : 0, ch, h, w);
   }
   // this thread's 36 weights of the contraction below as nine 16-byte requests, issued BEHIND the sums' requests (a wave's requests
@@ -325,6 +345,9 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
     float v = 0.f;
     for (int k = 0; k < Q; ++k) v += part[k * C + tid];
     T[tid] = v;
+  } else if (tid >= 4 * C && tid < 8 * C) {
+    const int b = (tid >> 6) - 4, ch = tid & 63;
+    B[b][ch] = (Bq[0][b][ch] + Bq[1][b][ch]) + (Bq[2][b][ch] + Bq[3][b][ch]);
   }
   __syncthreads();
   if (tid < 9 * C) {      // S[tap][ci] = T - R(ky) - C(kx) + X(ky, kx)
@@ -374,10 +397,15 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
 
 extern "C" int64_t eavsr_ca_scale_pre_ws_floats(int32_t n) { return n > 0 ? (int64_t)n * 4 * CP_SEGS * 64 : 0; }
 
+// pieces == nullptr: the border lines are summed by a launch of h16_border_sums_kernel into `workspace`; otherwise `pieces` holds what
+// the first convolution's epilogue left ([n][4][p_stride][64], p_rows / p_cols pieces per row / column border) and there is ONE launch
 static int ca_scale_pre_launch(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight, const float* conv_bias,
                                const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,
-                               int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream) {
-  EAVSR_REQUIRE(t && chan_partial && conv_weight && w1 && b1 && w2 && b2 && scale && workspace, -1, "ca_scale_pre: NULL pointer");
+                               int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream,
+                               const float* pieces = nullptr, int32_t p_rows = 0, int32_t p_cols = 0, int32_t p_stride = 0) {
+  EAVSR_REQUIRE(t && chan_partial && conv_weight && w1 && b1 && w2 && b2 && scale && (workspace || pieces), -1, "ca_scale_pre: NULL pointer");
+  EAVSR_REQUIRE(pieces == nullptr || (p_rows > 0 && p_cols > 0 && p_stride >= p_rows && p_stride >= p_cols), -1,
+                "ca_scale_pre: border pieces need 0 < p_rows, p_cols <= p_stride");
   EAVSR_REQUIRE(dtype >= 0 && dtype <= 2, -1, "ca_scale_pre: dtype %d (0 = f32 NCHW, 1 = f16, 2 = bf16 NHWC)", dtype);
   EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && rows > 0 && cr > 0 && cr <= 8 && n <= 65535, -1, "ca_scale_pre: bad dims (1..8 hidden units)");
   EAVSR_REQUIRE(((uintptr_t)conv_weight & 15) == 0, -1, "ca_scale_pre: conv_weight must be 16-byte aligned");
@@ -385,9 +413,14 @@ static int ca_scale_pre_launch(const void* t, const float* chan_partial, int32_t
   hipStream_t st = eavsr::as_stream(stream);
 #define CP_LAUNCH(DT_)                                                                                                             \
   do {                                                                                                                             \
-    hipLaunchKernelGGL(h16_border_sums_kernel<DT_>, dim3(CP_SEGS, 4, n), dim3(256), 0, st, t, workspace, h, w);                     \
-    hipLaunchKernelGGL(ca_scale_pre_kernel<DT_>, dim3(n), dim3(1024), 0, st, chan_partial, rows, workspace, t, h, w, conv_weight,   \
-                       conv_bias, w1, b1, w2, b2, scale, cr);                                                                      \
+    if (pieces == nullptr) {                                                                                                      \
+      hipLaunchKernelGGL(h16_border_sums_kernel<DT_>, dim3(CP_SEGS, 4, n), dim3(256), 0, st, t, workspace, h, w);                   \
+      hipLaunchKernelGGL(ca_scale_pre_kernel<DT_>, dim3(n), dim3(1024), 0, st, chan_partial, rows, workspace, CP_SEGS, CP_SEGS,     \
+                         CP_SEGS, t, h, w, conv_weight, conv_bias, w1, b1, w2, b2, scale, cr);                                     \
+    } else {                                                                                                                       \
+      hipLaunchKernelGGL(ca_scale_pre_kernel<DT_>, dim3(n), dim3(1024), 0, st, chan_partial, rows, pieces, p_rows, p_cols,          \
+                         p_stride, t, h, w, conv_weight, conv_bias, w1, b1, w2, b2, scale, cr);                                    \
+    }                                                                                                                              \
   } while (0)
   if (dtype == 2) CP_LAUNCH(2);
   else if (dtype == 1) CP_LAUNCH(1);
@@ -476,4 +509,17 @@ extern "C" int eavsr_ca_tail_stats_f32(const float* r, const float* chan_partial
                      eavsr::as_stream(stream), r, chan_partial, tiles, 1.0f / (float)hw, w1, b1, w2, b2, x, out, c, cr, hw4, slice,
                      scale_out, mean_out);
   return eavsr::launch_status("ca_tail");
+}
+
+// The same attention with the border lines of t taken from the pieces the FIRST convolution's epilogue wrote (round 6: eavsr_conv2d_desc
+// .border_pieces; eavsr_conv3x3_c64_h16_b): ONE launch per RCAB instead of two on its dependent chain.  pieces: [n][4][p_stride][64]
+// fp32, border 0 / 1 = top / bottom row (p_rows pieces), 2 / 3 = left / right column (p_cols pieces); dtype 0 = fp32 NCHW t, 1 / 2 =
+// fp16 / bf16 NHWC t (the four corner pixels are still read from t).
+extern "C" int eavsr_ca_scale_pre_pieces(const void* t, const float* chan_partial, int32_t rows, const float* pieces, int32_t p_rows,
+                                         int32_t p_cols, int32_t p_stride, const float* conv_weight, const float* conv_bias,
+                                         const float* w1, const float* b1, const float* w2, const float* b2, float* scale, int32_t n,
+                                         int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream) {
+  EAVSR_REQUIRE(pieces != nullptr, -1, "ca_scale_pre_pieces: NULL pieces");
+  return ca_scale_pre_launch(t, chan_partial, rows, conv_weight, conv_bias, w1, b1, w2, b2, scale, nullptr, n, h, w, cr, dtype, stream,
+                             pieces, p_rows, p_cols, p_stride);
 }

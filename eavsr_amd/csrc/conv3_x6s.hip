@@ -481,7 +481,7 @@ extern "C" int eavsr_conv3x3_f32x6s(const eavsr_conv2d_desc* d, const void* weig
   EAVSR_REQUIRE(d->n >= 0 && d->cout > 0 && d->h > 0 && d->w > 0, -1, "conv3x3_f32x6s: bad dims");
   if (d->n == 0) return 0;
   EAVSR_REQUIRE(d->src[0] && d->out, -1, "conv3x3_f32x6s: NULL pointer");
-  EAVSR_REQUIRE(d->ca_scale == nullptr && d->ca_x == nullptr && d->ca_out == nullptr && d->out_shuffle == 0 && d->res_scale == nullptr, -2,
+  EAVSR_REQUIRE(d->ca_scale == nullptr && d->ca_x == nullptr && d->ca_out == nullptr && d->out_shuffle == 0 && d->res_scale == nullptr && d->border_pieces == nullptr, -2,
                 "conv3x3_f32x6s: no channel-attention prologue, no pixel-shuffle store");
   EAVSR_REQUIRE(d->act >= 0 && d->act <= EAVSR_ACT_RELU_MASK, -1, "conv3x3_f32x6s: act %d", d->act);
   EAVSR_REQUIRE(d->act != EAVSR_ACT_LRELU || (d->slope >= 0.f && d->slope <= 1.f), -2,

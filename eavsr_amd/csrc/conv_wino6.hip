@@ -108,6 +108,8 @@ struct W4Args {
   float slope;
   int out_shuffle;        // 2: out is F.pixel_shuffle(conv, 2), (n, cout / 4, 2h, 2w); 0: (n, cout, h, w)
   const float* res_scale; // (n, cout) or NULL: out = residual + res_scale[n][co] * act(conv + bias) (3x3; the RCAB tail as the epilogue)
+  float* border;          // NULL, or [n][4][border_stride][64]: sums of the OUTPUT's four border lines per border tile (desc.border_pieces)
+  int border_stride;
 };
 
 constexpr int CK = 4, NW = 8, NPOS = 36;
@@ -907,6 +909,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
         };
         if (has_res) load_rr(0);
         f32x2 cs2[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+        // desc.border_pieces (round 6): the sums of the OUTPUT's border lines that fall into this tile -- what eavsr_ca_scale_pre needs
+        // beside the plane sums to know the NEXT convolution's channel means before it runs -- as a by-product of the epilogue (was: a
+        // launch of its own on every RCAB's dependent chain).  Row 0 / h - 1 of the image: this wave's row dy of the 4-pixel blocks,
+        // summed over its 16 lanes; column 0 / w - 1: pixel 0 / 3 of one lane's block, summed over the wave's rows.
+        const bool b_tile = !RSC && a.border != nullptr && (y0 == 0 || y0 + TOH >= h || x0 == 0 || x0 + TOW >= w);
+        float btop[4] = {0.f, 0.f, 0.f, 0.f}, bbot[4] = {0.f, 0.f, 0.f, 0.f}, blft[4] = {0.f, 0.f, 0.f, 0.f}, brgt[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rp = 0; rp < 2; ++rp) {
           const f32x2 b2 = f32x2{bias_r[2 * rp], bias_r[2 * rp + 1]};
@@ -959,7 +967,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(v[j], sc4[r], rr[step & 1][ch][j]);
                 if (dy < rows) {      // wave-uniform: this row of the tile lies inside the image
-                  if constexpr (!RSC) cs2[r] += f32x2{v[0], v[1]} + f32x2{v[2], v[3]};
+                  if constexpr (!RSC) {
+                    const f32x2 h2 = f32x2{v[0], v[1]} + f32x2{v[2], v[3]};
+                    cs2[r] += h2;
+                    if (b_tile) {      // (wave-uniform)
+                      if (gy0 + dy == 0) btop[r] += h2.x + h2.y;
+                      if (gy0 + dy == h - 1) bbot[r] += h2.x + h2.y;
+                      blft[r] += v[0];
+                      brgt[r] += v[3];
+                    }
+                  }
                   w6_st4(r_out, lane_off, (unsigned)r * plane_b + (unsigned)dy * row_b, o);
                 }
               }
@@ -971,6 +988,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino6_kernel(W4Args a) {
           const int co = cot * 64 + cb * 16 + 4 * kq + r;
           // (columns right of the image and channels >= cout are excluded here, rows below it above)
           csum[r] = (co < a.cout && gx < w) ? cs2[r].x + cs2[r].y : 0.f;
+        }
+        if constexpr (!RSC) {
+          if (b_tile) {      // (cout == 64 and one output-channel tile: the launcher checks)
+            const int txi = x0 / TOW, tyi = y0 / TOH;
+            float* bp = a.border + (size_t)bn * 4 * a.border_stride * 64 + cb * 16 + 4 * kq;
+            const bool has_top = gy0 == 0 && rows > 0, has_bot = gy0 <= h - 1 && h - 1 < gy0 + M;      // wave-uniform
+            if (has_top || has_bot) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float vt = gx < w ? btop[r] : 0.f, vb = gx < w ? bbot[r] : 0.f;
+                vt += __shfl_xor(vt, 8); vb += __shfl_xor(vb, 8);
+                vt += __shfl_xor(vt, 4); vb += __shfl_xor(vb, 4);
+                vt += __shfl_xor(vt, 2); vb += __shfl_xor(vb, 2);
+                vt += __shfl_xor(vt, 1); vb += __shfl_xor(vb, 1);
+                if (l15 == 0) {
+                  if (has_top) bp[(size_t)(0 * a.border_stride + txi) * 64 + r] = vt;
+                  if (has_bot) bp[(size_t)(1 * a.border_stride + txi) * 64 + r] = vb;
+                }
+              }
+            }
+            // column pieces: one per (tile row, wave row); a wave whose rows lie below the image contributes zeros
+            if (x0 == 0 && l15 == 0) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) bp[(size_t)(2 * a.border_stride + 2 * tyi + tg) * 64 + r] = blft[r];
+            }
+            if (x0 + TOW >= w && gx == w - 4) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) bp[(size_t)(3 * a.border_stride + 2 * tyi + tg) * 64 + r] = brgt[r];
+            }
+          }
         }
        }
       }
@@ -1278,6 +1325,15 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   a.act = d->act; a.slope = d->slope;
   a.out_shuffle = d->out_shuffle;
   a.res_scale = d->res_scale;
+  a.border = d->border_pieces;
+  a.border_stride = d->border_stride;
+  if (d->border_pieces != nullptr) {
+    EAVSR_REQUIRE(R == 3 && d->cout == 64 && d->out_shuffle == 0 && d->res_scale == nullptr && d->ca_scale == nullptr &&
+                      (d->cin / CK) % 2 == 0 && w6_grouped_schedule(), -2,
+                  "conv_wino6: border_pieces needs the grouped 3x3 kernel, 64 output channels, no shuffle / scaled residual / prologue");
+    EAVSR_REQUIRE(d->border_stride >= a.tiles_x && d->border_stride >= 2 * a.tiles_y, -1,
+                  "conv_wino6: border_stride %d < max(tiles_x %d, 2 tiles_y %d)", d->border_stride, a.tiles_x, 2 * a.tiles_y);
+  }
   EAVSR_REQUIRE(d->res_scale == nullptr || (R == 3 && d->residual != nullptr && d->out_shuffle == 0 && d->ca_scale == nullptr &&
                                             (d->cin / CK) % 2 == 0 && w6_grouped_schedule()), -2,
                 "conv_wino6: res_scale needs the (grouped) 3x3 kernel, a residual, no prologue, an even number of 4-channel chunks");
@@ -1353,6 +1409,12 @@ extern "C" int eavsr_pack_conv_weight_wino5x5(const float* weight, float* packed
 
 extern "C" int32_t eavsr_conv3x3_wino4_tiles(int32_t h, int32_t w) {
   return eavsr::cdiv(h, WCfg<3>::TOH) * eavsr::cdiv(w, WCfg<3>::TOW);
+}
+extern "C" int eavsr_conv3x3_wino4_border_pieces(int32_t h, int32_t w, int32_t* p_rows, int32_t* p_cols) {
+  EAVSR_REQUIRE(h > 0 && w > 0 && p_rows && p_cols, -1, "conv3x3_wino4_border_pieces: bad arguments");
+  *p_rows = eavsr::cdiv(w, WCfg<3>::TOW);
+  *p_cols = 2 * eavsr::cdiv(h, WCfg<3>::TOH);
+  return 0;
 }
 extern "C" int32_t eavsr_conv5x5_wino_tiles(int32_t h, int32_t w) {
   return eavsr::cdiv(h, WCfg<5>::TOH) * eavsr::cdiv(w, WCfg<5>::TOW);

@@ -357,8 +357,12 @@ class RCABlock(nn.Module):
             # channel sums of its input), `res * y + x` as that convolution's epilogue: no scale_residual launch (88 MB of HBM traffic
             # per block at 2 x 64 x 180 x 320)
             c1, c2 = self.res[0], self.res[2]
-            t, tpart = c1(x, act="relu", chan_partial=True)
-            scale = ops.ca_scale_pre(t, tpart, c2.weight, c2.bias, a.weight, a.bias, b.weight, b.bias)
+            # (this branch is inference-only: AG.needs_grad was checked above; the border pieces are a by-product of the first
+            # convolution's epilogue where the grouped F(4x4,3x3) kernel runs, None elsewhere: then ca_scale_pre sums the lines itself)
+            t, tpart, pieces = ops.conv2d(x, c1.weight, c1.bias, act="relu", chan_partial=True, border=True)
+            if not RCAB_PRE_PIECES:
+                pieces = None
+            scale = ops.ca_scale_pre(t, tpart, c2.weight, c2.bias, a.weight, a.bias, b.weight, b.bias, border=pieces)
             return ops.conv2d(t, c2.weight, c2.bias, residual=x, res_scale=scale)
         r, partial = _run_fused(self.res, x, chan_partial=True)     # conv-ReLU-conv, + channel sums
         if FUSE_CA_TAIL:
@@ -383,6 +387,9 @@ FUSE_CA_TAIL = _os.environ.get("EAVSR_FUSE_CA_TAIL", "0") == "1"
 # 16-bit modes): 217.0 / 218.0 -> 213.0 / 214.0 ms per configs[1] step in rotation on one box (tools/visits/r5_o.sh), timed output
 # bit-identical to the eager forward.  EAVSR_RCAB_PRE=0 keeps conv, conv, ca_scale, scale_residual (A/B switch).
 RCAB_PRE = _os.environ.get("EAVSR_RCAB_PRE", "1") == "1"
+# round 6: the border-line sums that ca_scale_pre needs come out of the first convolution's epilogue (desc.border_pieces) instead of a
+# launch of their own: one small launch per RCAB on the dependent chain instead of two.  EAVSR_RCAB_PRE_PIECES=0: A/B switch.
+RCAB_PRE_PIECES = _os.environ.get("EAVSR_RCAB_PRE_PIECES", "1") == "1"
 
 
 def set_rcab_pre(on: bool) -> None:

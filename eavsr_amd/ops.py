@@ -560,13 +560,34 @@ def dgrad_weight(w: Tensor) -> Tensor:
     return wt
 
 
-def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence[Tensor]],
+class BorderPieces:
+    """what conv2d(.., border=True) leaves beside the per-tile channel sums: `data` (n, 4, stride, 64) -- border 0 / 1 = image row 0 /
+    h - 1 (`p_rows` pieces), 2 / 3 = image column 0 / w - 1 (`p_cols` pieces) of the convolution's OUTPUT (desc.border_pieces)"""
+    __slots__ = ("data", "p_rows", "p_cols")
+
+    def __init__(self, data: Tensor, p_rows: int, p_cols: int):
+        self.data, self.p_rows, self.p_cols = data, int(p_rows), int(p_cols)
+
+
+def conv2d(srcs, weight, bias=None, act=None, slope: float = 0.0, residual=None, chan_partial: bool = False, ca=None, ca_out: bool = False,
+           pixel_shuffle2: bool = False, sigmoid_from=None, dgrad: bool = False, res_scale=None, border: bool = False):
+    """see _conv2d (the implementation); this shim only normalises the `border` result: routes that do not produce border pieces
+    return None in its place"""
+    r = _conv2d(srcs, weight, bias, act, slope, residual, chan_partial, ca, ca_out, pixel_shuffle2, sigmoid_from, dgrad, res_scale, border)
+    if border and not (isinstance(r, tuple) and len(r) >= 2 and (r[-1] is None or isinstance(r[-1], BorderPieces))):
+        r = (tuple(r) if isinstance(r, tuple) else (r,)) + (None,)
+    return r
+
+
+def _conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence[Tensor]],
            bias: Union[None, Tensor, Sequence[Optional[Tensor]]] = None, act: Optional[str] = None,
            slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False,
            ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False, pixel_shuffle2: bool = False,
-           sigmoid_from: Optional[int] = None, dgrad: bool = False, res_scale: Optional[Tensor] = None):
+           sigmoid_from: Optional[int] = None, dgrad: bool = False, res_scale: Optional[Tensor] = None, border: bool = False):
     """conv over the virtual channel-concatenation of `srcs`; `weight` may be a list of weights
     that are concatenated along cout (several heads in one launch).
+    border=True (with chan_partial=True): a third result, the sums of the output's four border lines per border tile
+    (`BorderPieces`, for ca_scale_pre(.., border=)) where the grouped F(4x4,3x3) kernel runs, None on every other route.
     res_scale (n, cout) with `residual`: out = residual + res_scale[n, co] * act(conv + bias) -- RCABlock's tail as the epilogue of
     the F(4x4,3x3) kernel (the attention from ca_scale_pre BEFORE the launch); other routes: the convolution, then scale_residual.
     dgrad=True: `weight` is ONE forward weight (cout_w, cin_w, k, k) and the call computes the input gradient of its stride-1
@@ -706,6 +727,14 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
     d.act = ACT[act]
     d.slope = float(slope)
     d.res_scale = _p(res_scale)
+    pieces = None
+    if (border and chan_partial and use_wino4 and cout == 64 and cin % 8 == 0 and ca is None and not pixel_shuffle2 and res_scale is None
+            and lib().eavsr_wino4_schedule() == 1):
+        pr, pc = C.c_int32(0), C.c_int32(0)
+        N.check(lib().eavsr_conv3x3_wino4_border_pieces(h, w, C.byref(pr), C.byref(pc)), "conv3x3_wino4_border_pieces")
+        stride = max(pr.value, pc.value)
+        pieces = BorderPieces(torch.empty((n, 4, stride, 64), device=out.device, dtype=torch.float32), pr.value, pc.value)
+        d.border_pieces, d.border_stride = _p(pieces.data), stride
     if pixel_shuffle2 and use_wino4:
         d.out_shuffle = 2
         out = out.view(n, cout // 4, 2 * h, 2 * w)      # the same buffer, written in the shuffled layout
@@ -742,7 +771,7 @@ def conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequence
         _launch(f"conv3x3_{cin}to{cout}_wino4" + ("_ca" if ca is not None else ""), 2.0 * cin * cout * 9 * px,
                 4.0 * px * (cin * (1 if ca is None else (3 if ca_out else 2)) + cout + (cout if residual is not None else 0)), out,
                 lambda: lib().eavsr_conv3x3_wino4_f32(C.byref(d), _p(wu), st), "conv3x3_wino4")
-        res = [out] + ([part] if chan_partial else []) + ([xs] if xs is not None else [])
+        res = [out] + ([part] if chan_partial else []) + ([xs] if xs is not None else []) + ([pieces] if border else [])
         return res[0] if len(res) == 1 else tuple(res)
     if use_wino:
         wu = _packed_wino(weights)
@@ -1871,6 +1900,9 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
     return (out, part) if chan_partial else out
 
 
+_ABLATE_CA_PRE = os.environ.get("EAVSR_ABLATE_CA_PRE", "0") == "1"      # measurement only
+
+
 def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Optional[Tensor], w1: Tensor, b1: Tensor,
                      w2: Tensor, b2: Tensor) -> Tensor:
     """The attention of an RCAB (CALayer, networks.py:444-447) BEFORE its second convolution runs: t = the 16-bit NHWC input of
@@ -1886,6 +1918,8 @@ def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias:
     w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
     cr = int(w1.shape[0])
     scale = torch.empty((n, 64), device=t.device, dtype=torch.float32)
+    if _ABLATE_CA_PRE:
+        return scale.fill_(0.5)
     ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
     st = _stream(t)
     _launch("ca_scale_pre_h16", 0.0, 4.0 * partial.numel(), t,
@@ -1895,7 +1929,7 @@ def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias:
 
 
 def ca_scale_pre(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Optional[Tensor], w1: Tensor, b1: Tensor,
-                 w2: Tensor, b2: Tensor) -> Tensor:
+                 w2: Tensor, b2: Tensor, border: Optional["BorderPieces"] = None) -> Tensor:
     """ca_scale_pre_h16 for the fp32 NCHW path: t (n, 64, h, w) = ReLU(conv1(x)), partial = its per-tile channel sums (the first
     convolution's chan_partial), conv_weight / conv_bias = the SECOND convolution's.  (n, 64) for conv2d(.., residual=, res_scale=)."""
     t, partial = _chk(t, "t"), _chk(partial, "partial")
@@ -1907,8 +1941,19 @@ def ca_scale_pre(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Opt
     w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
     cr = int(w1.shape[0])
     scale = torch.empty((n, 64), device=t.device, dtype=torch.float32)
-    ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
+    if _ABLATE_CA_PRE:      # timing ablation only (tools/visits/r6_f.sh): what the two small launches cost the STEP; results wrong
+        return scale.fill_(0.5)
     st = _stream(t)
+    if border is not None:      # the border lines as pieces from the first convolution's epilogue: ONE launch
+        bd = _chk(border.data, "border pieces")
+        if tuple(bd.shape[:2]) != (n, 4) or bd.shape[3] != 64 or bd.shape[2] < max(border.p_rows, border.p_cols):
+            raise ValueError("ca_scale_pre: border pieces must be (n, 4, stride >= max(p_rows, p_cols), 64)")
+        _launch("ca_scale_pre", 0.0, 4.0 * (partial.numel() + bd.numel()), t,
+                lambda: lib().eavsr_ca_scale_pre_pieces(_p(t), _p(partial), int(partial.shape[1]), _p(bd), border.p_rows, border.p_cols,
+                                                        int(bd.shape[2]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale),
+                                                        n, h, w, cr, 0, st), "ca_scale_pre_pieces")
+        return scale
+    ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
     _launch("ca_scale_pre", 0.0, 4.0 * partial.numel(), t,
             lambda: lib().eavsr_ca_scale_pre_f32(_p(t), _p(partial), int(partial.shape[1]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2),
                                                  _p(scale), _p(ws), n, h, w, cr, st), "ca_scale_pre")

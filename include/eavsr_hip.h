@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 28
+#define EAVSR_ABI_VERSION 29
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -199,6 +199,13 @@ typedef struct eavsr_conv2d_desc {
    * + bias) -- RCABlock's tail `res * y + x` (models/networks.py:463-464) as the second convolution's epilogue; the attention
    * comes from eavsr_ca_scale_pre_f32 BEFORE the launch.  Every other entry point returns -2 for a non-NULL value. */
   const float* res_scale;
+  /* NULL, or [n][4][border_stride][64] fp32 (ABI 29; eavsr_conv3x3_wino4_f32 only, 64 output channels): the epilogue also leaves the
+   * sums of the OUTPUT's border lines per border tile -- border 0 / 1 = image row 0 / h - 1, one piece per tile column
+   * (eavsr_conv3x3_wino4_border_pieces: p_rows); border 2 / 3 = image column 0 / w - 1, one piece per (tile row, wave row) (p_cols)
+   * -- for eavsr_ca_scale_pre_pieces: RCABlock's attention (models/networks.py:444-447) needs them of the second convolution's
+   * input, and summing them was a launch of its own on every block's dependent chain.  Every other entry point returns -2. */
+  float* border_pieces;
+  int32_t border_stride; /* >= max(p_rows, p_cols) */
 } eavsr_conv2d_desc;
 
 /* sizeof(eavsr_conv2d_desc) as THIS library was compiled (ABI 28): a binding compares it with its own struct at load time, so
@@ -216,6 +223,8 @@ int eavsr_conv2d_f32(const eavsr_conv2d_desc* desc, void* stream);
 int64_t eavsr_wino4_weight_elems(int32_t cout, int32_t cin);
 int eavsr_pack_conv_weight_wino4(const float* weight, float* weight_wino4, int32_t cout, int32_t cin, void* stream);
 int32_t eavsr_conv3x3_wino4_tiles(int32_t h, int32_t w);
+/* pieces per row border / per column border that desc.border_pieces receives for an (h, w) image */
+int eavsr_conv3x3_wino4_border_pieces(int32_t h, int32_t w, int32_t* p_rows, int32_t* p_cols);
 int eavsr_conv3x3_wino4_f32(const eavsr_conv2d_desc* desc, const float* weight_wino4, void* stream);
 
 /* 5x5 stride-1 "same" convolution by Winograd F(2x2, 5x5) - the same 6x6-tile pipeline (same points and input
@@ -514,6 +523,13 @@ int eavsr_ca_scale_pre_f32(const float* t, const float* chan_partial, int32_t ti
                            const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,
                            int32_t n, int32_t h, int32_t w, int32_t cr, void* stream);
 int64_t eavsr_ca_scale_pre_ws_floats(int32_t n);
+/* The same attention in ONE launch (ABI 29): the border lines of t come as the pieces the FIRST convolution's epilogue wrote
+ * (desc.border_pieces of eavsr_conv3x3_wino4_f32, layout [n][4][p_stride][64], p_rows / p_cols pieces per row / column border) instead
+ * of from a border-sum launch.  dtype 0: t fp32 NCHW; 1 / 2: fp16 / bf16 NHWC (only its four corner pixels are read). */
+int eavsr_ca_scale_pre_pieces(const void* t, const float* chan_partial, int32_t rows, const float* pieces, int32_t p_rows,
+                              int32_t p_cols, int32_t p_stride, const float* conv_weight, const float* conv_bias, const float* w1,
+                              const float* b1, const float* w2, const float* b2, float* scale, int32_t n, int32_t h, int32_t w,
+                              int32_t cr, int32_t dtype, void* stream);
 int eavsr_ca_scale_pre_h16(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight, const float* conv_bias,
                            const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,
                            int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream);

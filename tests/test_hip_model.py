@@ -82,9 +82,9 @@ def test_multiadstn_golden_in_every_dcn_mode(nets, cuda, preset, mode, fuse_leve
     m = load(Nw.MultiAdSTN(OPT, 64, 64, deformable_groups=8), sd, "g5.align.", cuda)
     nbr, ref, fp, flow = cases.g5_inputs()
     prev, prev_fl = ops.DCN_MODE, Nw.FUSE_FLOW_LEVEL
-    ops.set_dcn_mode(mode)
-    Nw.set_fuse_flow_level(fuse_level)
     try:
+        ops.set_dcn_mode(mode)
+        Nw.set_fuse_flow_level(fuse_level)      # (True: a lab-build kernel -- LabBuildRequired = skip, with the modes restored below)
         with torch.no_grad(), ops.profile() as prof:
             out = m(dev(nbr, cuda), dev(ref, cuda), fp.to(cuda), flow.to(cuda))
         names = set(prof.summary())

@@ -292,7 +292,7 @@ def test_conv3x3_small_launches_bf16x6_matches_fp64_and_the_fp32_kernel(ops, cud
         assert (outs["x6s"][r == 0] == 0).all()
 
 
-@pytest.mark.parametrize("shape", [(2, 180, 320), (1, 45, 80), (2, 19, 37), (1, 1, 8), (3, 5, 1)])
+@pytest.mark.parametrize("shape", [(2, 180, 320), (3, 133, 156), (8, 64, 128), (2, 3, 512), (1, 45, 80), (2, 19, 37), (1, 1, 8), (3, 5, 1)])
 def test_rcab_attention_before_the_second_convolution_fp32(ops, cuda, shape):
     """eavsr_ca_scale_pre_f32 + the scaled-residual epilogue of the F(4x4,3x3) kernel (desc.res_scale): the attention of an RCAB
     (CALayer, networks.py:444-447) from border-corrected channel sums of the second convolution's INPUT must equal the attention
@@ -314,9 +314,30 @@ def test_rcab_attention_before_the_second_convolution_fp32(ops, cuda, shape):
     t, tpart = ops.conv2d(gx, gw1, gb1, act="relu", chan_partial=True)
     scale = ops.ca_scale_pre(t, tpart, gw2, gb2, ga_w, ga_b, gc_w, gc_b)
     assert H.maxabs(scale.cpu().double(), s64) <= 2e-5
+    # round 6: the border-line sums as a by-product of the first convolution's epilogue (desc.border_pieces) instead of a launch of
+    # their own -- where the grouped F(4x4,3x3) kernel runs (None on every other route): same t, same plane sums, the same attention
+    # to summation order, and the pieces themselves equal the border lines of t (ragged heights / widths, single tile rows)
+    with ops.profile() as prof:
+        t2, tpart2, pieces = ops.conv2d(gx, gw1, gb1, act="relu", chan_partial=True, border=True)
+    assert torch.equal(t2, t) and torch.equal(tpart2, tpart)
+    if "conv3x3_64to64_wino4" in set(prof.summary()):
+        assert pieces is not None and (n, h, w) not in ((1, 45, 80), (2, 19, 37))
+        pd = pieces.data.cpu()
+        tc = t.cpu()
+        lines = [tc[:, :, 0, :].sum(-1), tc[:, :, h - 1, :].sum(-1), tc[:, :, :, 0].sum(-1), tc[:, :, :, w - 1].sum(-1)]
+        for bi, (want, cnt) in enumerate(zip(lines, (pieces.p_rows, pieces.p_rows, pieces.p_cols, pieces.p_cols))):
+            got = pd[:, bi, :cnt].sum(1)
+            assert H.maxabs(got, want) <= 1e-5 * max(1.0, want.abs().max().item()), (bi, H.maxabs(got, want))
+        with ops.profile() as prof2:
+            scale_p = ops.ca_scale_pre(t, tpart, gw2, gb2, ga_w, ga_b, gc_w, gc_b, border=pieces)
+        assert prof2.summary()["ca_scale_pre"]["calls"] == 1
+        assert H.maxabs(scale_p.cpu(), scale.cpu()) <= 2e-6
+        assert H.maxabs(scale_p.cpu().double(), s64) <= 2e-5
+    else:
+        assert pieces is None
     with ops.profile() as prof:
         y = ops.conv2d(t, gw2, gb2, residual=gx, res_scale=scale)
-    if (n, h, w) == (2, 180, 320):
+    if (n, h, w) in ((2, 180, 320), (3, 133, 156), (8, 64, 128)):
         assert list(prof.summary()) == ["conv3x3_64to64_wino4"]      # the epilogue form: one launch
     assert H.maxabs(y.cpu().double(), y64) <= 1e-4 * max(1.0, y64.abs().max().item())
     r, rpart = ops.conv2d(t, gw2, gb2, chan_partial=True)
