@@ -145,6 +145,8 @@ SIGNATURES = {
     "eavsr_ca_scale_pre_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, vp]),
     "eavsr_ca_scale_pre_ws_floats": (C.c_int64, [i32]),
     "eavsr_ca_scale_pre_h16": (C.c_int, [vp] * 11 + [i32, i32, i32, i32, i32, vp]),
+    "eavsr_conv_h16_border_pieces": (C.c_int, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "eavsr_conv3x3_c64_h16_b": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_c64_h16_act": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "eavsr_conv3x3_c64to3_h16": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_conv3x3_h16g_weight_bytes": (C.c_int64, [i32, i32]),

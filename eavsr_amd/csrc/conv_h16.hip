@@ -72,6 +72,8 @@ struct H16Args {
   // border-corrected channel sums of its INPUT (eavsr_ca_scale_pre_h16, csrc/ca.hip).  NULL: the plain epilogues.
   const void* res_x;         // (n, h, w, 64) 16-bit: the block's input (the skip path)
   const float* res_scale;    // (n, 64) fp32
+  float* border;      // NULL, or [n][4][border_stride][64] fp32: sums of the OUTPUT's border lines per border tile (round 6; with chan_partial):
+  int border_stride;  //   0 / 1 = image row 0 / h - 1, one piece per tile column; 2 / 3 = image column 0 / w - 1, one piece per (tile row, wave)
   int ps;             // 1: conv 64 -> 256 + PixelShuffle(2) as four 64 -> 64 slices (blockIdx.y = 2 dy + dx): slice k holds the output
                       // channels 4 c + k of the reference weight as its channel c, and its pixel (y, x) is output pixel (2 y + dy, 2 x + dx)
 };
@@ -120,8 +122,10 @@ __device__ __forceinline__ f32x16 mfma16(const f32x4& a, const f32x4& b, const f
 // RESK: the instantiation with the RCAB tail in the epilogue (a.res_x / a.res_scale) -- a kernel of its own so that its registers
 // do not weigh on the plain one (as one kernel with a run-time switch the patch offsets went to scratch and every patch request
 // waited for the previous one: s_waitcnt vmcnt(0) in front of each)
-template <bool BF16, bool RESK>
+// BORD: the instantiation that also writes the border pieces (a.border; the RCAB's first convolution) -- a kernel of its own, as RESK
+template <bool BF16, bool RESK, bool BORD = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
+  static_assert(!(RESK && BORD), "border pieces are written by the plain (sums) epilogue");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_w = smem;                                  // resident weights
   unsigned char* s_p = smem + HW_BYTES;                       // two patch stages, one per group
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
     return (unsigned)((r * w + c) * 128 + ((sb ^ ((c >> 1) & 7)) << 4));
   };
   unsigned rel_off[11];
-  if constexpr (!RESK) {
+  if constexpr (!RESK && !BORD) {      // (BORD recomputes them per tile as RESK does: with them resident the border code's registers spill)
 #pragma unroll
     for (int i = 0; i < 11; ++i) rel_off[i] = rel_off_of(i, lane);
   }
@@ -238,13 +242,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
         if (y0 >= 0 && x0 >= 0 && y0 + HP_H <= h && x0 + HP_W <= w) {      // interior tile (wave-uniform): no zero fills
           const char* org = xb + ((size_t)y0 * w + x0) * 128;
           int lane_o = lane;      // RESK: an opaque copy per tile, so that the offsets below are not hoisted back out of the tile loop
-          if constexpr (RESK) asm volatile("" : "+v"(lane_o));
+          if constexpr (RESK || BORD) asm volatile("" : "+v"(lane_o));
 #pragma unroll
           for (int i = 0; i < 11; ++i) {
             const int seg = i * 4 + w4;
 #ifndef EAVSR_H16_EXP_NO_DMA
             if (seg < HP_SEGS && (i < 10 || tail_lane))
-              __builtin_amdgcn_global_load_lds((gptr_t)(org + (RESK ? rel_off_of(i, lane_o) : rel_off[i])), (lptr_t)(pst + seg * 1024), 16, 0, 0);
+              __builtin_amdgcn_global_load_lds((gptr_t)(org + ((RESK || BORD) ? rel_off_of(i, lane_o) : rel_off[i])), (lptr_t)(pst + seg * 1024), 16, 0, 0);
 #endif
           }
         } else {
@@ -353,6 +357,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
           }
           H16_STAMP(5);     // bias / activation / rounding / output stores
           if (SUMS) {
+            // round 6: the sums of the output's border lines as a by-product (a.border; for eavsr_ca_scale_pre_pieces, which had a
+            // launch of its own for them on every RCAB's dependent chain).  Column 0 / w - 1 of the image: before the scan below a
+            // lane's csum is the sum over ITS pixel column of the wave's two rows -- the lane on the border column stores its 32
+            // values as the piece of (tile row, wave).  Rows: behind the scan (below).
+            if constexpr (BORD) {
+              const int cnt_last = (w - 1) - tx * HT_W;      // lane of image column w - 1 in this tile (>= 32: not in this tile)
+              float* bp = a.border + (size_t)bn * 4 * a.border_stride * 64;
+              if (tx == 0 && l31 == 0) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                  for (int qd = 0; qd < 4; ++qd)
+                    *reinterpret_cast<f32x4*>(bp + ((size_t)2 * a.border_stride + ty * 4 + w4) * 64 + m * 32 + 8 * qd + 4 * half) =
+                        f32x4{csum[m][4 * qd], csum[m][4 * qd + 1], csum[m][4 * qd + 2], csum[m][4 * qd + 3]};
+              }
+              if (cnt_last >= 0 && cnt_last < HT_W && l31 == cnt_last) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                  for (int qd = 0; qd < 4; ++qd)
+                    *reinterpret_cast<f32x4*>(bp + ((size_t)3 * a.border_stride + ty * 4 + w4) * 64 + m * 32 + 8 * qd + 4 * half) =
+                        f32x4{csum[m][4 * qd], csum[m][4 * qd + 1], csum[m][4 * qd + 2], csum[m][4 * qd + 3]};
+              }
+            }
             // channel sums over this wave's 64 pixels: 32 lanes hold the same channels -> five DPP adds per value (an inclusive
             // scan inside each row of 16 lanes, then row_bcast:15), totals in lanes 31 and 63; the four waves meet in LDS and
             // wave 0 of the group adds them up after the phase barrier (fixed order)
@@ -374,6 +402,51 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_h16_kernel(H16Args a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                   s_red[(grp * 4 + w4) * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * half] = csum[m][e];
+            }
+            // row 0 / h - 1 of the image, where this wave holds it (at most two waves of a border-row tile, wave-uniform): the row's
+            // 16-bit values once more from the accumulators (still live) into the registers the scan has just freed, the same scan,
+            // the totals of lanes 31 / 63 as the piece of this tile column.  No register, no LDS word beside what the sums use.
+            if constexpr (BORD) {
+#pragma unroll
+              for (int r = 0; r < 2; ++r) {
+                const int gy = ty * HT_H + 2 * w4 + r;
+                const bool is_top = gy == 0, is_bot = gy == h - 1;      // (wave-uniform)
+                if (is_top || is_bot) {
+                  const bool okx = tx * HT_W + l31 < w;
+#pragma unroll
+                  for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                      for (int e = 0; e < 4; ++e) {
+                        float v = acc[r][m][4 * qd + e] + bq4[m][qd][e];
+                        if (ACT == 1) v = fmaxf(v, 0.f);
+                        if (ACT == 2) v = fmaxf(v, v * slope);
+                        csum[m][4 * qd + e] = okx ? from_h16<BF16>(to_h16<BF16>(v)) : 0.f;
+                      }
+#define H16_DPP_STEP2(ctrl)                                    \
+  _Pragma("unroll") for (int m = 0; m < 2; ++m)                \
+      _Pragma("unroll") for (int e = 0; e < 16; ++e) H16_ADD_DPP(csum[m][e], ctrl);
+                  asm volatile("s_nop 1");
+                  H16_DPP_STEP2("row_shr:1")
+                  H16_DPP_STEP2("row_shr:2")
+                  H16_DPP_STEP2("row_shr:4")
+                  H16_DPP_STEP2("row_shr:8")
+                  H16_DPP_STEP2("row_bcast:15")
+#undef H16_DPP_STEP2
+                  if (l31 == 31) {
+                    float* bp = a.border + (size_t)bn * 4 * a.border_stride * 64;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                      for (int qd = 0; qd < 4; ++qd) {
+                        const f32x4 v4 = f32x4{csum[m][4 * qd], csum[m][4 * qd + 1], csum[m][4 * qd + 2], csum[m][4 * qd + 3]};
+                        if (is_top) *reinterpret_cast<f32x4*>(bp + ((size_t)0 * a.border_stride + tx) * 64 + m * 32 + 8 * qd + 4 * half) = v4;
+                        if (is_bot) *reinterpret_cast<f32x4*>(bp + ((size_t)1 * a.border_stride + tx) * 64 + m * 32 + 8 * qd + 4 * half) = v4;
+                      }
+                  }
+                }
+              }
             }
           }
         };
@@ -658,7 +731,7 @@ __global__ void pack_weight_h16_kernel(const float* __restrict__ w, unsigned sho
   p[i] = to_h16<BF16>(w[((size_t)co * 64 + ci) * 9 + tap]);
 }
 
-template <bool BF16, bool RESK = false>
+template <bool BF16, bool RESK = false, bool BORD = false>
 int launch_conv_h16(const H16Args& a, int blocks, int slices, hipStream_t st) {
   static eavsr::PerDeviceOnce once_pd;   // hipFuncSetAttribute is per device: once per (kernel, device)
   const int dev_ = eavsr::current_device();
@@ -666,14 +739,14 @@ int launch_conv_h16(const H16Args& a, int blocks, int slices, hipStream_t st) {
   static hipError_t attr_err_pd[eavsr::kMaxDevices] = {};
   hipError_t& attr_err = attr_err_pd[dev_];
   std::call_once(once, [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_h16_kernel<BF16, RESK>),
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_c64_h16_kernel<BF16, RESK, BORD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES);
   });
   if (attr_err != hipSuccess) {
     eavsr::set_error("conv3x3_c64_h16: hipFuncSetAttribute: %s", hipGetErrorString(attr_err));
     return (int)attr_err;
   }
-  hipLaunchKernelGGL((conv3x3_c64_h16_kernel<BF16, RESK>), dim3(blocks, slices), dim3(512), H_LDS_BYTES, st, a);
+  hipLaunchKernelGGL((conv3x3_c64_h16_kernel<BF16, RESK, BORD>), dim3(blocks, slices), dim3(512), H_LDS_BYTES, st, a);
   return eavsr::launch_status("conv3x3_c64_h16");
 }
 
@@ -714,7 +787,8 @@ extern "C" int eavsr_pack_conv3x3_c64_h16(const float* weight, void* packed, int
 
 static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, const float* bias, void* out, float* chan_partial,
                                   int32_t n, int32_t h, int32_t w, int32_t act, float slope, int32_t ps, int32_t dtype, void* stream,
-                                  const void* res_x = nullptr, const float* res_scale = nullptr);
+                                  const void* res_x = nullptr, const float* res_scale = nullptr, float* border = nullptr,
+                                  int32_t border_stride = 0);
 
 extern "C" int eavsr_conv3x3_c64_h16_res(const void* x, const void* weight_packed, const float* bias, void* out, const void* res_x,
                                          const float* res_scale, int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream) {
@@ -729,6 +803,22 @@ extern "C" int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, c
   return conv3x3_c64_h16_launch(x, weight_packed, bias, out, chan_partial, n, h, w, relu ? 1 : 0, 0.f, 0, dtype, stream);
 }
 
+// eavsr_conv3x3_c64_h16 that also leaves the sums of its OUTPUT's border lines per border tile (H16Args::border): p_rows = tiles_x
+// pieces per row border, p_cols = 4 tiles_y per column border (eavsr_conv_h16_border_pieces), layout [n][4][border_stride][64] fp32
+extern "C" int eavsr_conv_h16_border_pieces(int32_t h, int32_t w, int32_t* p_rows, int32_t* p_cols) {
+  EAVSR_REQUIRE(h > 0 && w > 0 && p_rows && p_cols, -1, "conv_h16_border_pieces: bad arguments");
+  *p_rows = eavsr::cdiv(w, HT_W);
+  *p_cols = 4 * eavsr::cdiv(h, HT_H);
+  return 0;
+}
+extern "C" int eavsr_conv3x3_c64_h16_b(const void* x, const void* weight_packed, const float* bias, void* out, float* chan_partial,
+                                       float* border_pieces, int32_t border_stride, int32_t n, int32_t h, int32_t w, int32_t relu,
+                                       int32_t dtype, void* stream) {
+  EAVSR_REQUIRE(border_pieces != nullptr, -1, "conv3x3_c64_h16_b: NULL border_pieces");
+  return conv3x3_c64_h16_launch(x, weight_packed, bias, out, chan_partial, n, h, w, relu ? 1 : 0, 0.f, 0, dtype, stream, nullptr, nullptr,
+                                border_pieces, border_stride);
+}
+
 extern "C" int eavsr_conv3x3_c64_h16_act(const void* x, const void* weight_packed, const float* bias, void* out, int32_t n, int32_t h,
                                          int32_t w, int32_t act, float slope, int32_t pixel_shuffle2, int32_t dtype, void* stream) {
   EAVSR_REQUIRE(act == EAVSR_ACT_NONE || act == EAVSR_ACT_RELU || act == EAVSR_ACT_LRELU, -1, "conv3x3_c64_h16_act: act %d", act);
@@ -739,7 +829,7 @@ extern "C" int eavsr_conv3x3_c64_h16_act(const void* x, const void* weight_packe
 
 static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, const float* bias, void* out, float* chan_partial,
                                   int32_t n, int32_t h, int32_t w, int32_t act, float slope, int32_t ps, int32_t dtype, void* stream,
-                                  const void* res_x, const float* res_scale) {
+                                  const void* res_x, const float* res_scale, float* border, int32_t border_stride) {
   EAVSR_REQUIRE(x && weight_packed && out, -1, "conv3x3_c64_h16: NULL pointer");
   EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "conv3x3_c64_h16: dtype %d (1 = f16, 2 = bf16)", dtype);
   EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0, -1, "conv3x3_c64_h16: bad dims");
@@ -752,6 +842,10 @@ static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, cons
   a.n = n; a.h = h; a.w = w;
   a.tiles_x = eavsr::cdiv(w, HT_W);
   a.tiles_y = eavsr::cdiv(h, HT_H);
+  a.border = border; a.border_stride = border_stride;
+  EAVSR_REQUIRE(border == nullptr || (chan_partial != nullptr && !ps && res_x == nullptr && border_stride >= a.tiles_x &&
+                                      border_stride >= 4 * a.tiles_y && (((uintptr_t)border) & 15) == 0), -1,
+                "conv3x3_c64_h16: border pieces need chan_partial, a 16-byte aligned buffer and border_stride >= max(tiles_x, 4 tiles_y)");
   const long tiles = (long)a.tiles_x * a.tiles_y * n;
   EAVSR_REQUIRE(tiles < (1L << 31), -1, "conv3x3_c64_h16: too many tiles");
   a.num_tiles = (int)tiles;
@@ -765,6 +859,9 @@ static int conv3x3_c64_h16_launch(const void* x, const void* weight_packed, cons
   if (res_x != nullptr)
     return dtype == 2 ? launch_conv_h16<true, true>(a, blocks, 1, eavsr::as_stream(stream))
                       : launch_conv_h16<false, true>(a, blocks, 1, eavsr::as_stream(stream));
+  if (border != nullptr)
+    return dtype == 2 ? launch_conv_h16<true, false, true>(a, blocks, 1, eavsr::as_stream(stream))
+                      : launch_conv_h16<false, false, true>(a, blocks, 1, eavsr::as_stream(stream));
   return dtype == 2 ? launch_conv_h16<true>(a, blocks, ps ? 4 : 1, eavsr::as_stream(stream))
                     : launch_conv_h16<false>(a, blocks, ps ? 4 : 1, eavsr::as_stream(stream));
 }

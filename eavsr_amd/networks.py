@@ -496,9 +496,12 @@ class RCAGroup(nn.Module):
             elif RCAB_H16_PRE and int(blk.ca.conv_du[0].weight.shape[0]) <= 8:      # (the kernel's hidden-unit bound)
                 # the attention BEFORE the second convolution (its output's channel means are linear in sums of its input), the
                 # tail `res * y + x` as that convolution's epilogue: no scale_residual launch (csrc/ca.hip, ops.ca_scale_pre_h16)
-                t, tpart = ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True, chan_partial=True)
+                # (round 6: the border-line sums the attention needs come out of the first convolution's epilogue: one small launch
+                # per block on the dependent chain instead of two; EAVSR_RCAB_PRE_PIECES=0 keeps the border-sum launch)
+                t, tpart, pieces = ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True, chan_partial=True, border=True) \
+                    if RCAB_PRE_PIECES else (*ops.conv3x3_c64_h16(xs, c1.weight, c1.bias, relu=True, chan_partial=True), None)
                 du_a, du_b = blk.ca.conv_du[0], blk.ca.conv_du[2]
-                scale = ops.ca_scale_pre_h16(t, tpart, c2.weight, c2.bias, du_a.weight, du_a.bias, du_b.weight, du_b.bias)
+                scale = ops.ca_scale_pre_h16(t, tpart, c2.weight, c2.bias, du_a.weight, du_a.bias, du_b.weight, du_b.bias, border=pieces)
                 xs = ops.conv3x3_c64_h16_res(t, c2.weight, c2.bias, xs, scale)
                 continue
             else:

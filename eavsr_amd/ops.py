@@ -1879,8 +1879,10 @@ def _packed_h16(weight: Tensor, code: int) -> Tensor:
     return packed
 
 
-def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool = False, chan_partial: bool = False):
-    """x: 16-bit NHWC (n,h,w,64); weight: the fp32 (64,64,3,3) parameter (packed + rounded once per version)"""
+def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: bool = False, chan_partial: bool = False,
+                    border: bool = False):
+    """x: 16-bit NHWC (n,h,w,64); weight: the fp32 (64,64,3,3) parameter (packed + rounded once per version).
+    border=True (with chan_partial): a third result, the `BorderPieces` of the output (for ca_scale_pre_h16(.., border=))."""
     x = _chk_h16(x, "x")
     n, h, w, c = x.shape
     if c != 64:
@@ -1894,6 +1896,15 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
         part = torch.empty((n, lib().eavsr_conv_h16_partial_rows(n, h, w), 64), device=x.device, dtype=torch.float32)
     st = _stream(x)
     px = float(n) * h * w
+    if border and chan_partial:
+        pr, pc = C.c_int32(0), C.c_int32(0)
+        N.check(lib().eavsr_conv_h16_border_pieces(h, w, C.byref(pr), C.byref(pc)), "conv_h16_border_pieces")
+        stride = max(pr.value, pc.value)
+        pieces = BorderPieces(torch.empty((n, 4, stride, 64), device=x.device, dtype=torch.float32), pr.value, pc.value)
+        _launch("conv3x3_64to64_h16", 2.0 * 64 * 64 * 9 * px, 2.0 * px * 128, x,
+                lambda: lib().eavsr_conv3x3_c64_h16_b(_p(x), _p(wp), _p(b), _p(out), _p(part), _p(pieces.data), stride, n, h, w,
+                                                      1 if relu else 0, code, st), "conv3x3_c64_h16_b")
+        return out, part, pieces
     _launch("conv3x3_64to64_h16", 2.0 * 64 * 64 * 9 * px, 2.0 * px * 128, x,
             lambda: lib().eavsr_conv3x3_c64_h16(_p(x), _p(wp), _p(b), _p(out), _p(part), n, h, w, 1 if relu else 0, code, st),
             "conv3x3_c64_h16")
@@ -1904,7 +1915,7 @@ _ABLATE_CA_PRE = os.environ.get("EAVSR_ABLATE_CA_PRE", "0") == "1"      # measur
 
 
 def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Optional[Tensor], w1: Tensor, b1: Tensor,
-                     w2: Tensor, b2: Tensor) -> Tensor:
+                     w2: Tensor, b2: Tensor, border: Optional["BorderPieces"] = None) -> Tensor:
     """The attention of an RCAB (CALayer, networks.py:444-447) BEFORE its second convolution runs: t = the 16-bit NHWC input of
     that convolution, partial = the per-tile channel sums of t from conv3x3_c64_h16(.., relu=True, chan_partial=True),
     conv_weight / conv_bias = the second convolution's parameters.  (n, 64) fp32 for conv3x3_c64_h16(.., skip=, scale=)."""
@@ -1920,8 +1931,17 @@ def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias:
     scale = torch.empty((n, 64), device=t.device, dtype=torch.float32)
     if _ABLATE_CA_PRE:
         return scale.fill_(0.5)
-    ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
     st = _stream(t)
+    if border is not None:      # the border lines as pieces from the first convolution's epilogue: ONE launch
+        bd = _chk(border.data, "border pieces")
+        if tuple(bd.shape[:2]) != (n, 4) or bd.shape[3] != 64 or bd.shape[2] < max(border.p_rows, border.p_cols):
+            raise ValueError("ca_scale_pre_h16: border pieces must be (n, 4, stride >= max(p_rows, p_cols), 64)")
+        _launch("ca_scale_pre_h16", 0.0, 4.0 * (partial.numel() + bd.numel()), t,
+                lambda: lib().eavsr_ca_scale_pre_pieces(_p(t), _p(partial), int(partial.shape[1]), _p(bd), border.p_rows, border.p_cols,
+                                                        int(bd.shape[2]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale),
+                                                        n, h, w, cr, code, st), "ca_scale_pre_pieces")
+        return scale
+    ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
     _launch("ca_scale_pre_h16", 0.0, 4.0 * partial.numel(), t,
             lambda: lib().eavsr_ca_scale_pre_h16(_p(t), _p(partial), int(partial.shape[1]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2),
                                                  _p(scale), _p(ws), n, h, w, cr, code, st), "ca_scale_pre_h16")

@@ -512,6 +512,14 @@ int eavsr_conv3x3_c64_h16(const void* x, const void* weight_packed, const float*
  * channel sums of its input.  res_x: the block's input, (n, h, w, 64) 16-bit. */
 int eavsr_conv3x3_c64_h16_res(const void* x, const void* weight_packed, const float* bias, void* out, const void* res_x,
                               const float* res_scale, int32_t n, int32_t h, int32_t w, int32_t dtype, void* stream);
+/* eavsr_conv3x3_c64_h16 that also leaves the sums of its OUTPUT's four border lines per border tile (ABI 29; the RCAB's first
+ * convolution: eavsr_ca_scale_pre_pieces takes them instead of a border-sum launch).  border_pieces: [n][4][border_stride][64] fp32,
+ * border 0 / 1 = image row 0 / h - 1 with p_rows pieces (one per 32-pixel tile column), 2 / 3 = image column 0 / w - 1 with p_cols
+ * pieces (one per (8-row tile, wave of two rows)); border_stride >= max(p_rows, p_cols); chan_partial required. */
+int eavsr_conv_h16_border_pieces(int32_t h, int32_t w, int32_t* p_rows, int32_t* p_cols);
+int eavsr_conv3x3_c64_h16_b(const void* x, const void* weight_packed, const float* bias, void* out, float* chan_partial,
+                            float* border_pieces, int32_t border_stride, int32_t n, int32_t h, int32_t w, int32_t relu,
+                            int32_t dtype, void* stream);
 /* scale[n][co] = sigmoid(W2 relu(W1 mean_hw(conv(t) + conv_bias) + b1) + b2) (CALayer, models/networks.py:444-447) from the per-tile
  * channel sums of t that eavsr_conv3x3_c64_h16(.., relu, chan_partial) left (rows = eavsr_conv_h16_partial_rows) and the border rows
  * / columns / corners of t (16-bit NHWC), WITHOUT running the convolution: sum_o conv(t)[co][o] = sum W[co][ci][ky][kx] (T[ci] -

@@ -370,6 +370,19 @@ def test_rcab_attention_before_the_second_convolution(ops, cuda, dt, shape):
     assert torch.equal(t2, t)
     scale_pre = ops.ca_scale_pre_h16(t2, tpart, w2, b2, a_w, a_b, c_w, c_b)
     y_pre = ops.conv3x3_c64_h16_res(t2, w2, b2, xh, scale_pre)
+    # round 6: the border-line sums as a by-product of the first convolution's epilogue (eavsr_conv3x3_c64_h16_b) instead of a launch
+    # of their own: same t and plane sums bit for bit, the pieces equal the border lines of t, the attention equal to summation order
+    t3, tpart3, pieces = ops.conv3x3_c64_h16(xh, w1, b1, relu=True, chan_partial=True, border=True)
+    assert torch.equal(t3, t) and torch.equal(tpart3, tpart)
+    tf, pd = t.float().cpu(), pieces.data.cpu()
+    lines = [tf[:, 0].sum(1), tf[:, h - 1].sum(1), tf[:, :, 0].sum(1), tf[:, :, w - 1].sum(1)]      # (n, 64) each
+    for bi, (want, cnt) in enumerate(zip(lines, (pieces.p_rows, pieces.p_rows, pieces.p_cols, pieces.p_cols))):
+        got = pd[:, bi, :cnt].sum(1)
+        assert H.maxabs(got, want) <= 2e-5 * max(1.0, want.abs().max().item()), (bi, H.maxabs(got, want))
+    with ops.profile() as prof:
+        scale_pc = ops.ca_scale_pre_h16(t2, tpart, w2, b2, a_w, a_b, c_w, c_b, border=pieces)
+    assert prof.summary()["ca_scale_pre_h16"]["calls"] == 1
+    assert H.maxabs(scale_pc.cpu(), scale_pre.cpu()) <= 2e-6
     # the means behind the two attentions: fp32 sums of the same products in another order (+ r's rounding in the old form)
     assert H.maxabs(scale_pre.cpu(), scale_post.cpu()) <= (3e-3 if dt == "bf16" else 5e-4)
     ref = xh.float() + r.float() * scale_post[:, None, None, :]      # what the old form rounds
