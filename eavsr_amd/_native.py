@@ -128,6 +128,10 @@ SIGNATURES = {
     "eavsr_conv_wgrad_multi_f32": (C.c_int, [vp, vp, i32, vp, vp] + [i32] * 11 + [vp]),
     "eavsr_conv_wgrad_span_f32": (C.c_int, [vp, vp, vp, vp] + [i32] * 9 + [vp]),
     "eavsr_conv_wgrad_bias_multi_f32": (C.c_int, [vp, vp, i32, vp, vp, vp] + [i32] * 11 + [vp]),
+    "eavsr_dcnv2_bwd_grid": (i32, [i32, i32, i32]),
+    "eavsr_dcnv2_bwd_workspace_floats": (C.c_int64, [i32, i32, i32]),
+    "eavsr_dcnv2_bwd_f32": (C.c_int, [vp] * 10 + [i32] * 7 + [vp]),
+    "eavsr_il8_to_nchw_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_im2col_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_dcnv2_col2im_f32": (C.c_int, [vp] * 7 + [i32, i32, i32, i32, i32, vp]),
     "eavsr_gconv3x3_fwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),

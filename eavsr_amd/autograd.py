@@ -311,8 +311,19 @@ class _DcnFn(Function):
         dg = ctx.dg
         dout = dout.contiguous()
         cout, cin = weight.shape[0], weight.shape[1]
-        col = ops.dcnv2_im2col(x, offset, mask, dg)                              # (n, cin*9, h, w)
         need_w, need_b = ctx.needs_input_grad[3], ctx.has_bias and ctx.needs_input_grad[4]
+        if ops.dcnv2_bwd_supported(x, weight, dg):
+            # round 6: the whole backward on the sampler's side (csrc/dcn_bwd.hip): no column tensor, no GEMM launches, no col2im
+            if need_w and (need_b or not ctx.has_bias) and grad_sink.eligible(ctx.params):
+                bufs, acc = grad_sink._active.raw(ctx.params)      # the uses of the weight across the frames add into one buffer
+                dx, doff, dmask, _ = ops.dcnv2_bwd(x, offset, mask, weight, dout, dg, need_dx=ctx.needs_input_grad[0], dweight=bufs[0],
+                                                   accumulate=acc)
+                if ctx.has_bias:
+                    ops.channel_sum(dout, out=bufs[1], accumulate=acc)
+                return dx, doff, dmask, None, None, None
+            dx, doff, dmask, dW = ops.dcnv2_bwd(x, offset, mask, weight, dout, dg, need_dx=ctx.needs_input_grad[0])
+            return dx, doff, dmask, (dW if need_w else None), (ops.channel_sum(dout) if need_b else None), None
+        col = ops.dcnv2_im2col(x, offset, mask, dg)                              # (n, cin*9, h, w)
         dW = db = None
         if need_w and (need_b or not ctx.has_bias) and grad_sink.eligible(ctx.params):
             # the uses of the weight across the frames add into one buffer (was: one ATen add per use and tensor)

@@ -1748,6 +1748,47 @@ def channel_sum_multi(tensors: Sequence[Tensor], out: Tensor, accumulate: bool =
     return out
 
 
+# DCNv2's backward: "sampler" = csrc/dcn_bwd.hip (one kernel, no column tensor; 64 -> 64 channels, 8 groups), "columns" = rounds 1-5
+# (im2col -> column tensor -> two GEMM launches -> col2im; any configuration).  EAVSR_DCN_BWD=columns: A/B switch.
+DCN_BWD = os.environ.get("EAVSR_DCN_BWD", "sampler")
+
+
+def dcnv2_bwd_supported(x: Tensor, weight: Tensor, dg: int) -> bool:
+    return (DCN_BWD == "sampler" and x.dim() == 4 and int(x.shape[1]) == 64 and tuple(weight.shape) == (64, 64, 3, 3) and dg == 8
+            and x.numel() < 2 ** 31)
+
+
+def dcnv2_bwd(x: Tensor, offset: Tensor, mask: Tensor, weight: Tensor, dy: Tensor, dg: int, need_dx: bool = True,
+              dweight: Optional[Tensor] = None, accumulate: bool = False):
+    """dx (NCHW or None), doffset, dmask, dweight of modulated_deform_conv2d(x, offset, mask, weight) for the upstream gradient dy, by
+    eavsr_dcnv2_bwd_f32 (csrc/dcn_bwd.hip): x goes to the IL8 layout, dx comes back from it.  `dweight` (64, 64, 3, 3): written or,
+    accumulate=True, added to (autograd.grad_sink); a new tensor when None."""
+    x, offset, mask, dy = _chk(x, "x"), _chk(offset, "offset"), _chk(mask, "mask"), _chk(dy, "dy")
+    w_ = _chk(weight.detach(), "weight")
+    n, c, h, w = x.shape
+    if not dcnv2_bwd_supported(x, weight, dg) or tuple(dy.shape) != (n, 64, h, w):
+        raise NotImplementedError("dcnv2_bwd: 64 -> 64 channels, 8 deformable groups, 3x3 (use dcnv2_im2col / dcnv2_col2im)")
+    xil = to_il8(x)
+    dxil = torch.zeros_like(xil) if need_dx else None
+    doff, dmask = torch.empty_like(offset), torch.empty_like(mask)
+    if dweight is None:
+        dweight, accumulate = torch.empty_like(w_), False
+    elif tuple(dweight.shape) != (64, 64, 3, 3) or not dweight.is_contiguous() or dweight.dtype != torch.float32:
+        raise ValueError("dcnv2_bwd: dweight must be a contiguous fp32 (64, 64, 3, 3) tensor")
+    ws = torch.empty(int(lib().eavsr_dcnv2_bwd_workspace_floats(n, h, w)), device=x.device, dtype=torch.float32)
+    st = _stream(x)
+    px = float(n) * h * w
+    _launch("dcnv2_bwd", 2.0 * 2.0 * 64 * 576 * px, 4.0 * px * (64 * 3 + 27 * dg * 2), x,
+            lambda: lib().eavsr_dcnv2_bwd_f32(_p(xil), _p(offset), _p(mask), _p(w_), _p(dy), _p(dxil), _p(doff), _p(dmask), _p(dweight),
+                                              _p(ws), n, c, h, w, 64, dg, int(accumulate), st), "dcnv2_bwd")
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        _launch("il8_to_nchw", 0.0, 8.0 * x.numel(), x,
+                lambda: lib().eavsr_il8_to_nchw_f32(_p(dxil), _p(dx), n, c, h, w, st), "il8_to_nchw")
+    return dx, doff, dmask, dweight
+
+
 def dcnv2_im2col(x: Tensor, offset: Tensor, mask: Tensor, dg: int) -> Tensor:
     x, offset, mask = _chk(x, "x"), _chk(offset, "offset"), _chk(mask, "mask")
     n, c, h, w = x.shape

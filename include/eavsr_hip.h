@@ -470,6 +470,21 @@ int eavsr_conv_wgrad_bias_multi_f32(const void* const* dy_list, const void* cons
 /* DCNv2 backward samplers (the two GEMMs run on eavsr_conv_wgrad_f32 / eavsr_conv2d_f32 with k = 1):
  * columns (n, c*9, h, w) = im2col(x, offset, mask);  from dcolumns: dx (pre-zeroed, atomics; NULL = skip),
  * doffset (n, dg*18, h, w), dmask (n, dg*9, h, w). */
+/* DCNv2 backward on the sampler's side (ABI 29; csrc/dcn_bwd.hip): the whole backward of modulated_deform_conv2d (models/networks.py:
+ * 627-630 under loss.backward(), models/eavsrp_model.py:109-119) as ONE kernel + a slab reduction -- no column tensor: the column
+ * gradient W^T . dY stays in the MFMA accumulators of a (deformable group, 4 x 16-pixel tile) unit, d_offset / d_mask are reduced over
+ * the group's 8 channels in the wave, dx accumulates in an LDS window before its global atomics, dW = dY . col^T runs on the same
+ * matrix instructions from a per-wave LDS tile of re-sampled columns.  64 -> 64 channels, 8 deformable groups, 3x3 (-2 otherwise:
+ * eavsr_dcnv2_im2col_f32 / eavsr_dcnv2_col2im_f32 below take any configuration).
+ * x_il8: the input in the IL8 layout (eavsr_nchw_to_il8_f32); dx_il8: pre-zeroed IL8 gradient buffer or NULL (eavsr_il8_to_nchw_f32
+ * turns it into NCHW); dweight (64, 64, 3, 3) written or, accumulate_dw != 0, added to; workspace: eavsr_dcnv2_bwd_workspace_floats
+ * floats.  The bias gradient is eavsr_channel_sum_f32 of dy. */
+int32_t eavsr_dcnv2_bwd_grid(int32_t n, int32_t h, int32_t w);
+int64_t eavsr_dcnv2_bwd_workspace_floats(int32_t n, int32_t h, int32_t w);
+int eavsr_dcnv2_bwd_f32(const float* x_il8, const float* offset, const float* mask, const float* weight, const float* dy, float* dx_il8,
+                        float* doffset, float* dmask, float* dweight, float* workspace, int32_t n, int32_t cin, int32_t h, int32_t w,
+                        int32_t cout, int32_t deform_groups, int32_t accumulate_dw, void* stream);
+int eavsr_il8_to_nchw_f32(const float* x_il8, float* out, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 int eavsr_dcnv2_im2col_f32(const float* x, const float* offset, const float* mask, float* columns, int32_t n,
                            int32_t c, int32_t h, int32_t w, int32_t deform_groups, void* stream);
 int eavsr_dcnv2_col2im_f32(const float* x, const float* offset, const float* mask, const float* dcolumns,

@@ -105,6 +105,36 @@ def test_dcnv2_backward(AG, cuda, shape, sigma):
     check(got, ref, 1e-4, ["x", "offset", "mask", "weight", "bias"])
 
 
+@pytest.mark.parametrize("shape,sigma", [((2, 96, 96), 1.0), ((2, 96, 96), 6.0), ((1, 45, 77), 2.0), ((3, 7, 5), 1.0), ((1, 4, 16), 0.3),
+                                         ((2, 33, 130), 12.0)])
+def test_dcnv2_backward_sampler_side_equals_the_column_path(AG, cuda, shape, sigma):
+    """round 6: eavsr_dcnv2_bwd_f32 (csrc/dcn_bwd.hip: column gradient in the MFMA accumulators, in-wave reduction of d_offset / d_mask,
+    dx through an LDS window, dW from re-sampled columns; no column tensor) against the rounds-1-5 path (im2col -> column tensor ->
+    two GEMM launches -> col2im) on the same inputs: the training crop, ragged tiles, single tiles, offsets that leave the dx window
+    (sigma = 6, 12: the direct global atomics) and the image; and the kernels that ran."""
+    from eavsr_amd import ops
+    n, h, w = shape
+    x, off = cases.randn(501, n, 64, h, w), cases.randn(502, n, 144, h, w, scale=sigma)
+    mask, wt = cases.rand(503, n, 72, h, w), cases.randn(504, 64, 64, 3, 3, scale=1.0 / 24)
+    b, G = cases.randn(505, 64, scale=0.1), cases.randn(506, n, 64, h, w)
+    res, names = {}, {}
+    prev = ops.DCN_BWD
+    try:
+        for mode in ("columns", "sampler"):
+            ops.DCN_BWD = mode
+            gl = [leaf(t, cuda) for t in (x, off, mask, wt, b)]
+            with ops.profile() as prof:
+                res[mode] = grads(AG.modulated_deform_conv2d(gl[0], gl[1], gl[2], gl[3], gl[4], 1, 1, 1, 1, 8), G.to(cuda), gl)
+            names[mode] = set(prof.summary())
+    finally:
+        ops.DCN_BWD = prev
+    assert "dcnv2_bwd" in names["sampler"] and not ({"dcnv2_im2col", "dcnv2_col2im"} & names["sampler"]), names["sampler"]
+    assert {"dcnv2_im2col", "dcnv2_col2im"} <= names["columns"]
+    for key, a, c in zip(("dx", "doffset", "dmask", "dweight", "dbias"), res["sampler"], res["columns"]):
+        sc = max(1e-6, c.abs().max().item())
+        assert H.maxabs(a.cpu(), c.cpu()) <= 2e-5 * sc, (key, H.maxabs(a.cpu(), c.cpu()), sc)
+
+
 @pytest.mark.parametrize("name", list(cases.G4_CASES))
 def test_dcnv2_backward_committed_gradients(AG, cuda, name):
     """fp64-autograd gradients of the DCNv2 known-answer cases, stored in tests/golden/g9_gradients.npz."""

@@ -392,6 +392,8 @@ def test_config3_gradients_at_the_bench_shape_match_oracle_autograd(cuda):
             loss.backward()
     names = set(prof.summary())
     assert {"conv3x3_64to64_x6s", "conv_wgrad3x3", "conv_wgrad5x5", "conv_wgrad1x1"} <= names, names
+    # round 6: DCNv2's backward runs on the sampler's side (csrc/dcn_bwd.hip) -- no column tensor, no im2col / col2im launches
+    assert "dcnv2_bwd" in names and not ({"dcnv2_im2col", "dcnv2_col2im"} & names), names
     assert ops.lib().eavsr_wgrad3_mode() == 1
     watch = ["conv_last.weight", "backbone.forward_2.main.2.rg.3.res.0.weight", "backbone.backward_1.main.2.rg.29.res.2.weight",
              "backbone.forward_1.main.2.rg.30.weight", "backbone.backward_2.main.0.weight", "fusion.backward_1.weight",
