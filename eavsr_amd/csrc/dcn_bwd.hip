@@ -58,7 +58,7 @@ struct BwdArgs {
   int n, h, w, tiles_x, tiles_y, ntiles, per, total;
 };
 
-// the forward's sampling rule (csrc/backward_dcn.hip make_samp; oracle/eavsr_oracle.py dcnv2): validity -1 < p < size, corner-wise
+// the forward's sampling rule (csrc/backward_dcn.hip make_samp; mmcv 1.x modulated_deform_conv as networks.py:627-630 uses it): validity -1 < p < size, corner-wise
 // zero padding, clamped corner indices (every read is in range; validity is applied to the values)
 struct BSamp {
   bool in, v1, v2, v3, v4;
