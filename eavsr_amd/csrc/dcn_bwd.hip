@@ -29,9 +29,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int B_C = 64, B_CO = 64, B_DG = 8;
 constexpr int B_TH = 4, B_TW = 16;              // tile: one 16-pixel row per wave, 4 waves
 constexpr int B_MT = 5;                          // 16-row blocks of a group's (tap, channel) rows: 72 -> 80
-constexpr int B_WY = 6, B_WX = 8;                // margins of the dx window around the tile
-constexpr int B_WH = B_TH + 2 * B_WY, B_WW = B_TW + 2 * B_WX;   // 16 x 32 cells x 8 channels
-constexpr int B_WIN = B_WH * B_WW * 8;           // 4096 floats
+constexpr int B_WY = 6, B_WX = 8;                // margins of a wave's dx window around its 16-pixel row
+constexpr int B_WH = 1 + 2 * B_WY, B_WW = B_TW + 2 * B_WX;      // 13 x 32 cells x 8 channels, one window PER WAVE
+constexpr int B_WIN = B_WH * B_WW * 8;           // 3328 floats
+constexpr int B_UH = B_TH + 2 * B_WY;            // rows of a unit's window (the four waves' windows, one row apart): 16
+constexpr int B_TAG = B_WH * B_WW * 2;           // one byte per (cell, channel half): who adds to it in this round
 constexpr int B_LD = 17;                         // row pitch of the per-wave 16-pixel tiles (bank spread)
 constexpr int B_COLB = 80 * B_LD, B_DYT = 64 * B_LD;
 constexpr int B_SLAB = 64 * 80;                  // one partial dW slab
@@ -55,6 +57,7 @@ struct BwdArgs {
   float* doff;           // (n, 144, h, w)
   float* dmask;          // (n, 72, h, w)
   float* slabs;          // [gridDim.x][2][64][80]
+  float* dxs;            // [total][16][32][8]: every unit's dx window (dcn_bwd_dx_gather adds them into dxil)
   int n, h, w, tiles_x, tiles_y, ntiles, per, total;
 };
 
@@ -64,6 +67,7 @@ struct BSamp {
   bool in, v1, v2, v3, v4;
   float w1, w2, w3, w4, hh, hw, lh, lw;
   int cy0, cy1, cx0, cx1;
+  int hl, wl;      // the top-left corner before clamping (-1 .. size - 1 when `in`)
 };
 __device__ __forceinline__ BSamp b_samp(float py, float px, int h, int w) {
   BSamp s;
@@ -78,6 +82,7 @@ __device__ __forceinline__ BSamp b_samp(float py, float px, int h, int w) {
   s.w3 = s.v3 ? s.lh * s.hw : 0.f; s.w4 = s.v4 ? s.lh * s.lw : 0.f;
   s.cy0 = min(max(hl, 0), h - 1); s.cy1 = min(max(hh_i, 0), h - 1);
   s.cx0 = min(max(wl, 0), w - 1); s.cx1 = min(max(wh_i, 0), w - 1);
+  s.hl = hl; s.wl = wl;
   return s;
 }
 
@@ -86,7 +91,8 @@ __device__ __forceinline__ BSamp b_samp(float py, float px, int h, int w) {
 // 96 x 96 launch, latency-bound at two waves per SIMD.  As two instantiations each keeps its requests one block ahead.
 template <bool DATA, bool WGT>
 __global__ __launch_bounds__(256, 2) void dcn_bwd_kernel(BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_win[DATA ? B_WIN : 8];
+  __shared__ __attribute__((aligned(16))) float s_win[DATA ? 4 * B_WIN : 8];
+  __shared__ unsigned char s_tag[DATA ? 4 * B_TAG : 4];
   __shared__ float s_colb[4][WGT ? B_COLB : 4];      // per wave: col[(tap, channel) row][pixel]; at a slab flush: the 64 x 80 combine buffer
   __shared__ float s_dyt[4][WGT ? B_DYT : 4];        // per wave: dY[co][pixel]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_kernel(BwdArgs a) {
   const int l15 = lane & 15, kq = lane >> 4;
   const int h = a.h, w = a.w, hw = h * w;
   if constexpr (DATA) {
-    for (int i = tid; i < B_WIN; i += 256) s_win[i] = 0.f;
+    for (int i = tid; i < 4 * B_WIN; i += 256) s_win[i] = 0.f;
     __syncthreads();
   }
 
@@ -229,6 +235,10 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_kernel(BwdArgs a) {
       const bool in = tv && sp.in;
       const size_t oi = ((size_t)(bn * B_DG + g) * 18 + 2 * (tap < 9 ? tap : 0)) * hw + p;
       const size_t mi = ((size_t)(bn * B_DG + g) * 9 + (tap < 9 ? tap : 0)) * hw + p;
+      bool part = false;      // this lane has something to add to dx
+      f32x4 dxv[4];           // [corner]: the four channels' contributions
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dxv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (tv) {
         const float m = p_m[mt];
         float dxc[4][4];      // [corner][channel]
@@ -246,32 +256,49 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_kernel(BwdArgs a) {
             dxc[0][c] = dv * sp.w1; dxc[1][c] = dv * sp.w2; dxc[2][c] = dv * sp.w3; dxc[3][c] = dv * sp.w4;
           }
         }
-        if (DATA && a.dxil != nullptr) {
+        if constexpr (DATA) {
+          part = a.dxil != nullptr && sp.in;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dxv[k] = f32x4{dxc[k][0], dxc[k][1], dxc[k][2], dxc[k][3]};
+        }
+      }
+      // ---- dx: the lane's four corners (by, bx) .. (by + 1, bx + 1) are added to the wave's own window without atomics (an LDS float
+      // atomic costs ~160 cycles per wave instruction on gfx950, sixteen of them per block: 215 of the kernel's 265 us).  A wave's LDS
+      // instructions execute in order, so a read-add-write is safe against every OTHER instruction of the wave; inside one
+      // instruction two lanes must not add to the same cell.  Valid corners are never clamped, so two lanes' k-th corners coincide
+      // exactly when their top-left corners do: one tag round per block finds those lanes (each writes its number at its top-left
+      // cell and reads it back; who reads another number waits for the next round).  An invalid corner carries a zero (weight 0).
+      if constexpr (DATA) {
+        const int by = sp.hl - (gy - B_WY), bx = sp.wl - (x0 - B_WX);
+        const bool fast = part && by >= 0 && by + 1 < B_WH && bx >= 0 && bx + 1 < B_WW;
+        if (part && !fast) {      // outside the window: straight to memory
           const bool cv[4] = {sp.v1, sp.v2, sp.v3, sp.v4};
           const int cy[4] = {sp.cy0, sp.cy0, sp.cy1, sp.cy1}, cx[4] = {sp.cx0, sp.cx1, sp.cx0, sp.cx1};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < 4; ++k)
             if (cv[k]) {
-              const int wy = cy[k] - wy0, wx = cx[k] - wx0;
-#ifdef EAVSR_DCNB_DIRECT      // no LDS window: every contribution straight to memory
-              if (false) {
-#else
-              if (wy >= 0 && wy < B_WH && wx >= 0 && wx < B_WW) {
-#endif
-#ifndef EAVSR_DCNB_EXP_NO_LDSATOM      // timing ablations (tools/visits/r6_m.sh): results wrong
-                float* q = s_win + (wy * B_WW + wx) * 8 + ch0;
+              float* q = a.dxil + ((size_t)(bn * B_DG + g) * hw + (size_t)cy[k] * w + cx[k]) * 8 + ch0;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) atomicAdd(q + c, dxc[k][c]);
-#else
-                if (dxc[k][0] == 1.2345f) s_win[0] = 1.f;
-#endif
-              } else {
-                float* q = a.dxil + ((size_t)(bn * B_DG + g) * hw + (size_t)cy[k] * w + cx[k]) * 8 + ch0;
+              for (int c = 0; c < 4; ++c) atomicAdd(q + c, dxv[k][c]);
+            }
+        }
+        const int cell = fast ? by * B_WW + bx : 0;
+        volatile unsigned char* tg = s_tag + wave * B_TAG + cell * 2 + (kq & 1);
+        float* q0 = s_win + wave * B_WIN + cell * 8 + ch0;
+        bool pend = fast;
+        while (__builtin_amdgcn_ballot_w64(pend) != 0) {
+          if (pend) *tg = (unsigned char)lane;
+          const bool win = pend && *tg == (unsigned char)lane;
+          if (win) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) atomicAdd(q + c, dxc[k][c]);
-              }
+            for (int k = 0; k < 4; ++k) {
+              f32x4* q = reinterpret_cast<f32x4*>(q0 + ((k >> 1) * B_WW + (k & 1)) * 8);
+              const f32x4 o = *q;
+              *q = o + dxv[k];
+              asm volatile("" ::: "memory");      // corner k + 1 of one lane is corner k of its neighbour: program order
             }
           }
+          pend = pend && !win;
         }
       }
       // the two lanes of a (pixel, tap) hold four channels each: one cross-lane add gives both the sums over the group's 8 channels
@@ -290,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_kernel(BwdArgs a) {
         for (int c = 0; c < 4; ++c) s_colb[wave][(16 * mt + 4 * kq + c) * B_LD + l15] = col4[c];
       }
     }
-    __syncthreads();      // the col / dY tiles of every wave are in LDS; every dx contribution of the unit is in the window
+    if constexpr (WGT) __syncthreads();      // the col / dY tiles of every wave are in LDS
     // ---- dW_g += dY . col^T over this wave's 16 pixels (k = pixel = 4 s + kq)
     if constexpr (WGT) {
 #pragma unroll
@@ -306,22 +333,31 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_kernel(BwdArgs a) {
           for (int nt = 0; nt < B_MT; ++nt) acc2[ct][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[ct], b2[nt], acc2[ct][nt], 0, 0, 0);
       }
     }
-    // ---- the dx window of this unit: one global atomic per touched cell and channel, then zero for the next unit
-#ifndef EAVSR_DCNB_EXP_NO_FLUSH
+    // ---- the unit's dx window (rows y0 - 6 .. y0 + 9, columns x0 - 8 .. x0 + 23): the four waves' windows added where they overlap
+    // and stored -- plain, coalesced -- as the unit's slab; the windows are zero again for the next unit.  (Adding the windows to dx
+    // with global atomics instead, one per touched cell and channel: 100 us of a 217 us call at 2 x 64 x 96 x 96, the rate of the
+    // L2's float atomics.)  dcn_bwd_dx_gather adds, for every dx cell, the eight slabs that cover it.
     if (DATA && a.dxil != nullptr) {
-      for (int i = tid; i < B_WIN; i += 256) {
-        const float v = s_win[i];
-        if (v != 0.f) {
-          const int ch = i & 7, cell = i >> 3;
-          const int wy = cell / B_WW, wx = cell - wy * B_WW;
-          const int yy = wy0 + wy, xx = wx0 + wx;      // (only cells inside the image were ever added to)
-          atomicAdd(a.dxil + ((size_t)(bn * B_DG + g) * hw + (size_t)yy * w + xx) * 8 + ch, v);
-          s_win[i] = 0.f;
+      __syncthreads();
+      float* dst = a.dxs + (size_t)u * (B_UH * B_WW * 8);
+#pragma unroll
+      for (int j = 0; j < B_UH / 4; ++j) {
+        const int r = wave + 4 * j;      // window row of this wave's 64 (column, channel half) entries
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          const int pr = r - wv;
+          if (pr >= 0 && pr < B_WH) {
+            f32x4* q = reinterpret_cast<f32x4*>(s_win + wv * B_WIN + pr * (B_WW * 8) + lane * 4);
+            v += *q;
+            *q = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
+        *reinterpret_cast<f32x4*>(dst + (r * (B_WW * 2) + lane) * 4) = v;
       }
+      __syncthreads();
     }
-#endif
-    __syncthreads();
+    if constexpr (WGT) __syncthreads();
   }
   if (cur_g >= 0) flush_slab();
 }
@@ -366,6 +402,37 @@ __global__ __launch_bounds__(256) void dcn_bwd_dw_reduce_kernel(const float* __r
   *q = accumulate ? *q + v : v;
 }
 
+// dx[bn][g][y][x][8] += the slabs of the (up to 4 x 2) units of group g whose window holds (y, x), in increasing unit order
+__global__ __launch_bounds__(256) void dcn_bwd_dx_gather_kernel(const float* __restrict__ dxs, float* __restrict__ dxil, int n, int h, int w,
+                                                                int tiles_x, int tiles_y, int ntiles) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;      // (bn, g, y, x, channel half)
+  if (idx >= (long)n * B_DG * h * w * 2) return;
+  const int half = (int)(idx & 1);
+  const long cell = idx >> 1;
+  const int x = (int)(cell % w), y = (int)((cell / w) % h), bg = (int)(cell / ((long)h * w));
+  const int bn = bg / B_DG, g = bg - bn * B_DG;
+  const int ty_lo = max((y - B_WY) >> 2, 0), ty_hi = min((y + B_WY) >> 2, tiles_y - 1);
+  const int tx_lo = max((x - B_WX) >> 4, 0), tx_hi = min((x + B_WX) >> 4, tiles_x - 1);
+  f32x4 t[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ty = ty_lo + i, tx = tx_lo + j;
+      t[2 * i + j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ty <= ty_hi && tx <= tx_hi) {
+        const long u = (long)g * ntiles + ((long)bn * tiles_y + ty) * tiles_x + tx;
+        const int r = y - B_TH * ty + B_WY, c = x - B_TW * tx + B_WX;
+        t[2 * i + j] = *reinterpret_cast<const f32x4*>(dxs + u * (B_UH * B_WW * 8) + ((r * B_WW + c) * 2 + half) * 4);
+      }
+    }
+  f32x4* q = reinterpret_cast<f32x4*>(dxil + idx * 4);
+  f32x4 v = *q;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v += t[k];
+  *q = v;
+}
+
 // dx in the IL8 layout the kernel accumulates in -> NCHW
 __global__ __launch_bounds__(256) void il8_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int c8, int hw) {
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -389,7 +456,9 @@ extern "C" int32_t eavsr_dcnv2_bwd_grid(int32_t n, int32_t h, int32_t w) {
   return (int32_t)(units < 512 ? units : 512);
 }
 extern "C" int64_t eavsr_dcnv2_bwd_workspace_floats(int32_t n, int32_t h, int32_t w) {
-  return (int64_t)eavsr_dcnv2_bwd_grid(n, h, w) * 2 * B_SLAB + (int64_t)B_DG * B_MT * 16 * 64;
+  if (n <= 0 || h <= 0 || w <= 0) return 0;
+  const int64_t units = (int64_t)B_DG * n * eavsr::cdiv(h, B_TH) * eavsr::cdiv(w, B_TW);
+  return (int64_t)eavsr_dcnv2_bwd_grid(n, h, w) * 2 * B_SLAB + (int64_t)B_DG * B_MT * 16 * 64 + units * (B_UH * B_WW * 8);
 }
 
 extern "C" int eavsr_dcnv2_bwd_f32(const float* x_il8, const float* offset, const float* mask, const float* weight, const float* dy,
@@ -400,7 +469,8 @@ extern "C" int eavsr_dcnv2_bwd_f32(const float* x_il8, const float* offset, cons
                 "dcnv2_bwd: 64 -> 64 channels in 8 deformable groups (got %d -> %d, %d groups): use eavsr_dcnv2_im2col / col2im", cin, cout,
                 deform_groups);
   EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && (long)n * h * w * 64 < (1L << 31), -1, "dcnv2_bwd: bad dims");
-  EAVSR_REQUIRE((((uintptr_t)x_il8) & 15) == 0, -1, "dcnv2_bwd: x_il8 must be 16-byte aligned");
+  EAVSR_REQUIRE(((((uintptr_t)x_il8) | ((uintptr_t)dx_il8) | ((uintptr_t)workspace)) & 15) == 0, -1,
+                "dcnv2_bwd: x_il8, dx_il8 and workspace must be 16-byte aligned");
   if (n == 0) return 0;
   hipStream_t st = eavsr::as_stream(stream);
   BwdArgs a;
@@ -409,6 +479,7 @@ extern "C" int eavsr_dcnv2_bwd_f32(const float* x_il8, const float* offset, cons
   float* wt = workspace + (size_t)grid * 2 * B_SLAB;
   a.xil = x_il8; a.offset = offset; a.mask = mask; a.dy = dy; a.wt = wt;
   a.dxil = dx_il8; a.doff = doffset; a.dmask = dmask;
+  a.dxs = wt + B_DG * B_MT * 16 * 64;
   a.n = n; a.h = h; a.w = w;
   a.tiles_x = eavsr::cdiv(w, B_TW);
   a.tiles_y = eavsr::cdiv(h, B_TH);
@@ -418,6 +489,9 @@ extern "C" int eavsr_dcnv2_bwd_f32(const float* x_il8, const float* offset, cons
   EAVSR_REQUIRE(a.per <= a.ntiles, -1, "dcnv2_bwd: internal: a workgroup would span more than two groups");
   hipLaunchKernelGGL(dcn_bwd_pack_kernel, dim3(eavsr::cdiv(B_DG * B_MT * 16 * 64, 256)), dim3(256), 0, st, weight, wt);
   hipLaunchKernelGGL((dcn_bwd_kernel<true, false>), dim3(grid), dim3(256), 0, st, a);
+  if (dx_il8 != nullptr)
+    hipLaunchKernelGGL(dcn_bwd_dx_gather_kernel, dim3((unsigned)(((long)n * B_DG * h * w * 2 + 255) / 256)), dim3(256), 0, st, a.dxs, dx_il8,
+                       n, h, w, a.tiles_x, a.tiles_y, a.ntiles);
   hipLaunchKernelGGL((dcn_bwd_kernel<false, true>), dim3(grid), dim3(256), 0, st, a);
   hipLaunchKernelGGL(dcn_bwd_dw_reduce_kernel, dim3(eavsr::cdiv(B_DG * 64 * 80, 256)), dim3(256), 0, st, a.slabs, dweight, grid, a.per,
                      a.ntiles, a.total, accumulate_dw);
