@@ -13,8 +13,12 @@
 //   2. The sampler: position, validity (-1 < p < size), the four corner weights as in the forward; four 16-byte corner reads; per
 //      channel the sample (-> dmask), its position derivative (-> doffset), dcol * mask * corner weight (-> dx).  The two lanes
 //      of a (pixel, tap) trade their 4-channel partial sums by one cross-lane add: d_offset / d_mask are reduced over the 8 channels
-//      of the group IN THE WAVE.  dx is accumulated in an LDS window around the tile (ds_add_f32) and flushed by one global atomic per
-//      touched window cell and channel (corners outside the window go out directly: rare at the alignment's offsets).
+//      of the group IN THE WAVE.  dx: every wave owns an LDS window (13 rows x 32 columns x 8 channels) around its pixel row and
+//      adds its lanes' corner contributions by plain read-add-write (a tag round per block finds lanes whose corners coincide;
+//      ds_add_f32 costs ~160 cycles per wave instruction on gfx950 and was 215 of the first version's 265 us).  At the end of the
+//      unit the four windows are added where they overlap and stored as the unit's 16 x 32-cell slab; dcn_bwd_dx_gather adds, per
+//      dx cell, the (up to eight) slabs that cover it -- no global atomics either (they cost 100 us per call at the rate of the L2's
+//      float atomic unit), except for corners outside the window (rare at the alignment's offsets).
 //   3. dW_g (64 x 80) += dY (64 x 16 px) . col^T (16 px x 80) on the same matrix instructions, col = sample * mask handed over through a
 //      per-wave LDS tile, accumulated in registers over the consecutive units of a workgroup (units are ordered group-major) and
 //      written as one partial slab per (workgroup, group); dcn_bwd_dw_reduce adds the slabs in a fixed order (no atomics).

@@ -471,14 +471,17 @@ int eavsr_conv_wgrad_bias_multi_f32(const void* const* dy_list, const void* cons
  * columns (n, c*9, h, w) = im2col(x, offset, mask);  from dcolumns: dx (pre-zeroed, atomics; NULL = skip),
  * doffset (n, dg*18, h, w), dmask (n, dg*9, h, w). */
 /* DCNv2 backward on the sampler's side (ABI 29; csrc/dcn_bwd.hip): the whole backward of modulated_deform_conv2d (models/networks.py:
- * 627-630 under loss.backward(), models/eavsrp_model.py:109-119) as ONE kernel + a slab reduction -- no column tensor: the column
- * gradient W^T . dY stays in the MFMA accumulators of a (deformable group, 4 x 16-pixel tile) unit, d_offset / d_mask are reduced over
- * the group's 8 channels in the wave, dx accumulates in an LDS window before its global atomics, dW = dY . col^T runs on the same
- * matrix instructions from a per-wave LDS tile of re-sampled columns.  64 -> 64 channels, 8 deformable groups, 3x3 (-2 otherwise:
- * eavsr_dcnv2_im2col_f32 / eavsr_dcnv2_col2im_f32 below take any configuration).
- * x_il8: the input in the IL8 layout (eavsr_nchw_to_il8_f32); dx_il8: pre-zeroed IL8 gradient buffer or NULL (eavsr_il8_to_nchw_f32
- * turns it into NCHW); dweight (64, 64, 3, 3) written or, accumulate_dw != 0, added to; workspace: eavsr_dcnv2_bwd_workspace_floats
- * floats.  The bias gradient is eavsr_channel_sum_f32 of dy. */
+ * 627-630 under loss.backward(), models/eavsrp_model.py:109-119) without a column tensor: the column gradient W^T . dY stays in the MFMA
+ * accumulators of a (deformable group, 4 x 16-pixel tile) unit, d_offset / d_mask are reduced over the group's 8 channels in the wave,
+ * dx is added -- without atomics -- into per-wave LDS windows that leave the unit as one 16 x 32-cell slab and are gathered per dx
+ * cell afterwards (samples further than 6 rows / 8 columns from their pixel go to dx_il8 by global atomics), dW = dY . col^T runs on
+ * the same matrix instructions from a per-wave LDS tile of re-sampled columns and is reduced from per-workgroup slabs in a fixed order.
+ * 64 -> 64 channels, 8 deformable groups, 3x3 (-2 otherwise: eavsr_dcnv2_im2col_f32 / eavsr_dcnv2_col2im_f32 below take any
+ * configuration).
+ * x_il8: the input in the IL8 layout (eavsr_nchw_to_il8_f32); dx_il8: IL8 gradient buffer, ADDED to (zero it for a plain gradient), or
+ * NULL (eavsr_il8_to_nchw_f32 turns it into NCHW); dweight (64, 64, 3, 3) written or, accumulate_dw != 0, added to; workspace:
+ * eavsr_dcnv2_bwd_workspace_floats floats, 16-byte aligned (dW slabs + packed W^T + 2 KB of dx slab per pixel).  The bias gradient is
+ * eavsr_channel_sum_f32 of dy. */
 int32_t eavsr_dcnv2_bwd_grid(int32_t n, int32_t h, int32_t w);
 int64_t eavsr_dcnv2_bwd_workspace_floats(int32_t n, int32_t h, int32_t w);
 int eavsr_dcnv2_bwd_f32(const float* x_il8, const float* offset, const float* mask, const float* weight, const float* dy, float* dx_il8,

@@ -16,13 +16,25 @@ x64 = r(n, 64, h, w)
 w33, b = r(64, 64, 3, 3) * 0.05, r(64) * 0.1
 if "conv" in which:
     for mode in ("winograd4", "winograd", "direct"):
-        ops.set_conv_mode(mode)
-        for _ in range(reps):
-            ops.conv2d(x64, w33, b, act="relu")
+        try:
+            ops.set_conv_mode(mode)
+            for _ in range(reps):
+                ops.conv2d(x64, w33, b, act="relu")
+        except ops.LabBuildRequired:      # F(2x2,3x3) exists in the lab library only (python -m eavsr_amd.build --lab)
+            pass
     ops.set_conv_mode("winograd4")
     w55, b120 = r(120, 64, 5, 5) * 0.02, r(120) * 0.1      # the predictor's 5x5 heads, F(2x2, 5x5)
     for _ in range(reps):
         ops.conv2d(x64, w55, b120)
+if "rcab" in which:
+    # one RCAB of the default fp32 path (networks.py RCABlock): conv + ReLU with channel sums and border pieces, the ONE small launch
+    # (attention before the second convolution), the second convolution with x + scale * r as its epilogue
+    wa, ba, wb, bb = r(4, 64, 1, 1) * 0.1, r(4) * 0.1, r(64, 4, 1, 1) * 0.1, r(64) * 0.1
+    w33b = r(64, 64, 3, 3) * 0.05
+    for _ in range(reps):
+        t, part, pieces = ops.conv2d(x64, w33, b, act="relu", chan_partial=True, border=True)
+        scale = ops.ca_scale_pre(t, part, w33b, b, wa, ba, wb, bb, border=pieces)
+        ops.conv2d(t, w33b, b, residual=x64, res_scale=scale)
 if "convhr" in which:
     hr = r(n, 64, 4 * h, 4 * w)
     for _ in range(2):
@@ -86,8 +98,11 @@ if "h16b" in which:
         for _ in range(reps):
             t16 = ops.conv3x3_c64_h16(x16, w33, b, relu=True)
             ops.conv3x3_c64_h16(t16, w33b, b, chan_partial=True)
-        for _ in range(reps):
-            ops.rcab_convs_h16(x16, w33, b, w33b, b, chan_partial=True)
+        try:
+            for _ in range(reps):
+                ops.rcab_convs_h16(x16, w33, b, w33b, b, chan_partial=True)
+        except ops.LabBuildRequired:      # the one-launch RCAB convolutions: lab library only
+            pass
 if "train" in which:
     # the training step's two dominant kernels at configs[3]'s launch shapes: the crop-sized 3x3 64 -> 64 convolution (2 x 64 x 96 x 96)
     # and the 3x3 weight gradient over the seven frames of a clip as segments of one launch

@@ -16,7 +16,7 @@ if stats:
     for r in rows[:16]:
         print(f"{float(r['Percentage']):6.2f}%  calls {int(r['Calls']):6d}  avg {float(r['AverageNs'])/1e3:10.1f} us  {r['Name'][:110]}")
 print()
-hot = ("conv_wino6_kernel<3, false", "conv_wino6_kernel<5, false", "conv_x6_kernel<5", "conv_x6_kernel<7", "conv3x3_wino_kernel", "conv2d_mfma_kernel", "dcnv2_grp_kernel", "dcnv2_il_kernel<6, true>", "dcnv2_il_kernel<6, false>", "dcnv2_il2_kernel<6, 1>", "dcnv2_il2_kernel<6, 0>", "dcnv2_il2_kernel<6, 2>", "flow_warp_kernel", "flow_warp_pair_kernel")
+hot = ("conv_wino6_kernel<3, false, true, false>", "conv_wino6_kernel<3, false, true, true>", "ca_scale_pre_kernel<0>", "conv_wino6_kernel<5, false", "conv_x6_kernel<5", "conv_x6_kernel<7", "conv3x3_wino_kernel", "conv2d_mfma_kernel", "dcnv2_grp_kernel", "dcnv2_il_kernel<6, true>", "dcnv2_il_kernel<6, false>", "dcnv2_il2_kernel<6, 1>", "dcnv2_il2_kernel<6, 0>", "dcnv2_il2_kernel<6, 2>", "flow_warp_kernel", "flow_warp_pair_kernel")
 if os.environ.get("HOT"):      # another set of kernels (tools/gpu_profile_h16.sh): substrings of the kernel names, ';'-separated
     hot = tuple(os.environ["HOT"].split(";"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
