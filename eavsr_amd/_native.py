@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
 
-ABI_VERSION = 30
+ABI_VERSION = 29
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -72,8 +72,7 @@ SIGNATURES = {
     "eavsr_dcnv2_il16": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "eavsr_wino4_schedule": (C.c_int, []),
     "eavsr_conv3x3_wino4_border_pieces": (C.c_int, [i32, i32, C.POINTER(i32), C.POINTER(i32)]),
-    "eavsr_ca_scale_pre_pieces": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
-    "eavsr_ca_scale_pre_sync_floats": (C.c_int64, []),
+    "eavsr_ca_scale_pre_pieces": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "eavsr_conv2d_f32": (C.c_int, [C.POINTER(ConvDesc), vp]),
     "eavsr_wino4_weight_elems": (C.c_int64, [i32, i32]),
     "eavsr_pack_conv_weight_wino4": (C.c_int, [vp, vp, i32, i32, vp]),

@@ -393,171 +393,6 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
   }
 }
 
-// ca_scale_pre_kernel over EIGHT workgroups per sample (round 6, late).  One workgroup per sample pulls everything the attention
-// needs -- the per-tile channel sums (up to 131 KB at 540 x 960), the border pieces, 147 KB of the second convolution's weights --
-// through ONE CU: 8.9 us per launch at two samples, 15.5 us at one 540 x 960 sample, on the dependent chain conv -> this -> conv of
-// every RCAB.  Here workgroup g of a sample takes the input channels 8 g .. 8 g + 7: their plane sums, border lines and corners (the
-// reductions are independent per channel), and the partial contraction  pm_g[co] = sum_{ci in slice, tap} W2[co][ci][tap] S[tap][ci]
-// over its 64 x 72 slice of the weights (18 KB, contiguous runs of 72 floats).  The eight partial vectors meet through `sync`:
-// each workgroup stores its vector, fences, and takes a ticket from the sample's counter; the workgroup that draws the LAST ticket
-// (ticket % 8 == 7: nobody waits for anybody, so the scheme cannot deadlock) adds the eight vectors in the fixed order g = 0 .. 7
-// and runs the MLP.  Tickets only ever grow: the buffer is zeroed once by the caller, never between launches.
-// sync: [64] unsigned tickets, then [n][8][64] partial vectors.
-constexpr int CPS_G = 8, CPS_CG = 8, CPS_MAXN = 64;
-template <int DT>
-__global__ __launch_bounds__(256) void ca_scale_pre_split_kernel(const float* __restrict__ partial, int rows, const float* __restrict__ border,
-                                                                  int p_rows, int p_cols, int p_stride, const void* __restrict__ t, int h,
-                                                                  int w, const float* __restrict__ wc, const float* __restrict__ bc,
-                                                                  const float* __restrict__ w1, const float* __restrict__ b1,
-                                                                  const float* __restrict__ w2, const float* __restrict__ b2,
-                                                                  float* __restrict__ scale, int cr, float* sync) {
-  constexpr int C = 64, CG = CPS_CG, NF4 = C * CG * 9 / 4;      // 1152 float4 of the weight slice
-  __shared__ float part[32][CG], Bq[8][4][CG], T[CG], B[4][CG], X[4][CG], S[9][CG], P[NF4], mean[C], hid[16];
-  __shared__ unsigned s_ticket;
-  const int g = blockIdx.x, bn = blockIdx.y, tid = threadIdx.x, c0 = g * CG;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  // ---- every request of the workgroup, up front
-  f32x4 wq[5];      // float4 f = tid + 256 k of the slice: output channel f / 18, elements 4 (f % 18) .. + 3 of its 72 (ci, tap) products
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int f = tid + 256 * k;
-    wq[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (f < NF4) wq[k] = *reinterpret_cast<const f32x4*>(wc + (size_t)(f / 18) * 576 + c0 * 9 + 4 * (f % 18));
-  }
-  float psum = 0.f;
-  {      // plane sums: thread (q, ch) adds the rows q, q + 32, ..; sixteen requests in flight
-    const int q = tid >> 3, ch = tid & 7;
-    const float* p = partial + (size_t)bn * rows * C + c0 + ch;
-    float s0 = 0.f, s1 = 0.f;
-    for (int r = q; r < rows; r += 16 * 32) {
-      float v[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        v[j] = 0.f;
-        if (r + 32 * j < rows) v[j] = p[(size_t)(r + 32 * j) * C];
-      }
-#pragma unroll
-      for (int j = 0; j < 16; j += 4) {
-        s0 += v[j] + v[j + 1];
-        s1 += v[j + 2] + v[j + 3];
-      }
-    }
-    psum = s0 + s1;
-  }
-  float bsum = 0.f;
-  {      // border pieces: thread (eighth qg, border b, ch) adds the pieces qg, qg + 8, ..
-    const int qg = tid >> 5, b = (tid >> 3) & 3, ch = tid & 7;
-    const int cnt = b < 2 ? p_rows : p_cols;
-    const float* p = border + (((size_t)bn * 4 + b) * p_stride) * C + c0 + ch;
-    float s0 = 0.f, s1 = 0.f;
-    for (int k = qg; k < cnt; k += 8 * 8) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = 0.f;
-        if (k + 8 * j < cnt) v[j] = p[(size_t)(k + 8 * j) * C];
-      }
-      s0 += (v[0] + v[1]) + (v[2] + v[3]);
-      s1 += (v[4] + v[5]) + (v[6] + v[7]);
-    }
-    bsum = s0 + s1;
-  }
-  float xc = 0.f;
-  if (tid < 4 * CG) {      // corners: 0 = (0, 0), 1 = (0, w - 1), 2 = (h - 1, 0), 3 = (h - 1, w - 1)
-    const int k = tid >> 3, ch = tid & 7;
-    xc = cp_load<DT>(t, bn, (k >> 1) ? h - 1 : 0, (k & 1) ? w - 1 : 0, c0 + ch, h, w);
-  }
-  // the MLP's parameters for whoever turns out to be last (2 KB: cheaper than a round trip behind the ticket)
-  const float bc_v = (bc && tid < C) ? bc[tid] : 0.f;
-  float w1_v[4], b1_v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int hj = wave + 4 * i;
-    w1_v[i] = hj < cr ? w1[hj * C + lane] : 0.f;
-    b1_v[i] = hj < cr ? b1[hj] : 0.f;
-  }
-  float w2_v[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) w2_v[j] = (tid < C && j < cr) ? w2[tid * cr + j] : 0.f;
-  const float b2_v = tid < C ? b2[tid] : 0.f;
-
-  part[tid >> 3][tid & 7] = psum;
-  Bq[tid >> 5][(tid >> 3) & 3][tid & 7] = bsum;
-  if (tid < 4 * CG) X[tid >> 3][tid & 7] = xc;
-  __syncthreads();
-  if (tid < CG) {
-    float v = 0.f;
-    for (int k = 0; k < 32; ++k) v += part[k][tid];
-    T[tid] = v;
-  } else if (tid >= 64 && tid < 64 + 4 * CG) {
-    const int b = (tid - 64) >> 3, ch = tid & 7;
-    float v = 0.f;
-    for (int k = 0; k < 8; ++k) v += Bq[k][b][ch];
-    B[b][ch] = v;
-  }
-  __syncthreads();
-  if (tid < 9 * CG) {      // S[tap][ci] = T - R(ky) - C(kx) + X(ky, kx)
-    const int tap = tid >> 3, ci = tid & 7, ky = tap / 3, kx = tap - 3 * ky;
-    const float R = ky == 0 ? B[1][ci] : ky == 2 ? B[0][ci] : 0.f;      // ky = 0 excludes the LAST row, ky = 2 the first
-    const float Cc = kx == 0 ? B[3][ci] : kx == 2 ? B[2][ci] : 0.f;
-    const float Xc = (ky == 1 || kx == 1) ? 0.f : X[(ky == 0 ? 2 : 0) + (kx == 0 ? 1 : 0)][ci];
-    S[tap][ci] = (T[ci] - R) - Cc + Xc;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int f = tid + 256 * k;
-    if (f < NF4) {
-      const int e0 = 4 * (f % 18);
-      float v = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = e0 + j, ci = e / 9, tap = e - 9 * ci;      // the weight's own order within a channel slice: ci * 9 + tap
-        v += (DT == 0 ? wq[k][j] : cp_round_h16<DT == 2>(wq[k][j])) * S[tap][ci];
-      }
-      P[f] = v;
-    }
-  }
-  __syncthreads();
-  float* pm = sync + CPS_MAXN + ((size_t)bn * CPS_G) * C;
-  if (tid < C) {
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < 18; ++i) v += P[tid * 18 + i];
-    pm[g * C + tid] = v;
-  }
-  __threadfence();      // the vector is visible device-wide before the ticket is
-  __syncthreads();
-  if (tid == 0) s_ticket = atomicAdd(reinterpret_cast<unsigned*>(sync) + bn, 1u);
-  __syncthreads();
-  if ((s_ticket % CPS_G) != CPS_G - 1) return;
-  __threadfence();      // (acquire: the other seven vectors)
-  if (tid < C) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < CPS_G; ++k) v += __hip_atomic_load(pm + k * C + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mean[tid] = bc_v + v / ((float)h * (float)w);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {      // hidden unit wave + 4 i: one product per lane and a shuffle tree
-    const int hj = wave + 4 * i;
-    if (hj < cr) {
-      float v = w1_v[i] * mean[lane];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) hid[hj] = fmaxf(v + b1_v[i], 0.f);
-    }
-  }
-  __syncthreads();
-  if (tid < C) {
-    float v = b2_v;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v += j < cr ? w2_v[j] * hid[j] : 0.f;
-    scale[(size_t)bn * C + tid] = 1.f / (1.f + expf(-v));
-  }
-}
-
 }  // namespace
 
 extern "C" int64_t eavsr_ca_scale_pre_ws_floats(int32_t n) { return n > 0 ? (int64_t)n * 4 * CP_SEGS * 64 : 0; }
@@ -567,14 +402,12 @@ extern "C" int64_t eavsr_ca_scale_pre_ws_floats(int32_t n) { return n > 0 ? (int
 static int ca_scale_pre_launch(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight, const float* conv_bias,
                                const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,
                                int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream,
-                               const float* pieces = nullptr, int32_t p_rows = 0, int32_t p_cols = 0, int32_t p_stride = 0,
-                               float* sync = nullptr) {
+                               const float* pieces = nullptr, int32_t p_rows = 0, int32_t p_cols = 0, int32_t p_stride = 0) {
   EAVSR_REQUIRE(t && chan_partial && conv_weight && w1 && b1 && w2 && b2 && scale && (workspace || pieces), -1, "ca_scale_pre: NULL pointer");
   EAVSR_REQUIRE(pieces == nullptr || (p_rows > 0 && p_cols > 0 && p_stride >= p_rows && p_stride >= p_cols), -1,
                 "ca_scale_pre: border pieces need 0 < p_rows, p_cols <= p_stride");
   EAVSR_REQUIRE(dtype >= 0 && dtype <= 2, -1, "ca_scale_pre: dtype %d (0 = f32 NCHW, 1 = f16, 2 = bf16 NHWC)", dtype);
   EAVSR_REQUIRE(n >= 0 && h > 0 && w > 0 && rows > 0 && cr > 0 && cr <= 8 && n <= 65535, -1, "ca_scale_pre: bad dims (1..8 hidden units)");
-  EAVSR_REQUIRE(sync == nullptr || (pieces != nullptr && n <= CPS_MAXN), -1, "ca_scale_pre: the split form takes border pieces and n <= %d", CPS_MAXN);
   EAVSR_REQUIRE(((uintptr_t)conv_weight & 15) == 0, -1, "ca_scale_pre: conv_weight must be 16-byte aligned");
   if (n == 0) return 0;
   hipStream_t st = eavsr::as_stream(stream);
@@ -584,9 +417,6 @@ static int ca_scale_pre_launch(const void* t, const float* chan_partial, int32_t
       hipLaunchKernelGGL(h16_border_sums_kernel<DT_>, dim3(CP_SEGS, 4, n), dim3(256), 0, st, t, workspace, h, w);                   \
       hipLaunchKernelGGL(ca_scale_pre_kernel<DT_>, dim3(n), dim3(1024), 0, st, chan_partial, rows, workspace, CP_SEGS, CP_SEGS,     \
                          CP_SEGS, t, h, w, conv_weight, conv_bias, w1, b1, w2, b2, scale, cr);                                     \
-    } else if (sync != nullptr) {                                                                                                  \
-      hipLaunchKernelGGL(ca_scale_pre_split_kernel<DT_>, dim3(CPS_G, n), dim3(256), 0, st, chan_partial, rows, pieces, p_rows,       \
-                         p_cols, p_stride, t, h, w, conv_weight, conv_bias, w1, b1, w2, b2, scale, cr, sync);                        \
     } else {                                                                                                                       \
       hipLaunchKernelGGL(ca_scale_pre_kernel<DT_>, dim3(n), dim3(1024), 0, st, chan_partial, rows, pieces, p_rows, p_cols,          \
                          p_stride, t, h, w, conv_weight, conv_bias, w1, b1, w2, b2, scale, cr);                                    \
@@ -688,11 +518,8 @@ extern "C" int eavsr_ca_tail_stats_f32(const float* r, const float* chan_partial
 extern "C" int eavsr_ca_scale_pre_pieces(const void* t, const float* chan_partial, int32_t rows, const float* pieces, int32_t p_rows,
                                          int32_t p_cols, int32_t p_stride, const float* conv_weight, const float* conv_bias,
                                          const float* w1, const float* b1, const float* w2, const float* b2, float* scale, int32_t n,
-                                         int32_t h, int32_t w, int32_t cr, int32_t dtype, float* sync, void* stream) {
+                                         int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream) {
   EAVSR_REQUIRE(pieces != nullptr, -1, "ca_scale_pre_pieces: NULL pieces");
   return ca_scale_pre_launch(t, chan_partial, rows, conv_weight, conv_bias, w1, b1, w2, b2, scale, nullptr, n, h, w, cr, dtype, stream,
-                             pieces, p_rows, p_cols, p_stride, sync);
+                             pieces, p_rows, p_cols, p_stride);
 }
-
-// floats of eavsr_ca_scale_pre_pieces' `sync` buffer (64 tickets + 64 samples x 8 partial vectors); zeroed ONCE by the caller
-extern "C" int64_t eavsr_ca_scale_pre_sync_floats(void) { return CPS_MAXN + (int64_t)CPS_MAXN * CPS_G * 64; }

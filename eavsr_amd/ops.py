@@ -1953,22 +1953,6 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
 
 
 _ABLATE_CA_PRE = os.environ.get("EAVSR_ABLATE_CA_PRE", "0") == "1"      # measurement only
-# eight workgroups per sample in ca_scale_pre_pieces (they meet through a ticket buffer; csrc/ca.hip ca_scale_pre_split_kernel);
-# EAVSR_CA_PRE_SPLIT=0: one workgroup per sample (the A/B switch)
-CA_PRE_SPLIT = os.environ.get("EAVSR_CA_PRE_SPLIT", "1") != "0"
-_CA_PRE_SYNC: dict = {}
-
-
-def _ca_pre_sync(t: Tensor, st, n: int) -> Optional[Tensor]:
-    """the ticket buffer of eavsr_ca_scale_pre_pieces for launches on stream `st`: zeroed when it is made, never again (tickets only
-    grow); one per (device, stream) because launches of DIFFERENT streams may overlap"""
-    if not CA_PRE_SPLIT or n > 64:
-        return None
-    key = (t.device.index, int(getattr(st, "value", st) or 0))
-    buf = _CA_PRE_SYNC.get(key)
-    if buf is None:
-        buf = _CA_PRE_SYNC[key] = torch.zeros(int(lib().eavsr_ca_scale_pre_sync_floats()), device=t.device, dtype=torch.float32)
-    return buf
 
 
 def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Optional[Tensor], w1: Tensor, b1: Tensor,
@@ -1993,11 +1977,10 @@ def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias:
         bd = _chk(border.data, "border pieces")
         if tuple(bd.shape[:2]) != (n, 4) or bd.shape[3] != 64 or bd.shape[2] < max(border.p_rows, border.p_cols):
             raise ValueError("ca_scale_pre_h16: border pieces must be (n, 4, stride >= max(p_rows, p_cols), 64)")
-        sync = _ca_pre_sync(t, st, n)
         _launch("ca_scale_pre_h16", 0.0, 4.0 * (partial.numel() + bd.numel()), t,
                 lambda: lib().eavsr_ca_scale_pre_pieces(_p(t), _p(partial), int(partial.shape[1]), _p(bd), border.p_rows, border.p_cols,
                                                         int(bd.shape[2]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale),
-                                                        n, h, w, cr, code, _p(sync), st), "ca_scale_pre_pieces")
+                                                        n, h, w, cr, code, st), "ca_scale_pre_pieces")
         return scale
     ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
     _launch("ca_scale_pre_h16", 0.0, 4.0 * partial.numel(), t,
@@ -2026,11 +2009,10 @@ def ca_scale_pre(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Opt
         bd = _chk(border.data, "border pieces")
         if tuple(bd.shape[:2]) != (n, 4) or bd.shape[3] != 64 or bd.shape[2] < max(border.p_rows, border.p_cols):
             raise ValueError("ca_scale_pre: border pieces must be (n, 4, stride >= max(p_rows, p_cols), 64)")
-        sync = _ca_pre_sync(t, st, n)
         _launch("ca_scale_pre", 0.0, 4.0 * (partial.numel() + bd.numel()), t,
                 lambda: lib().eavsr_ca_scale_pre_pieces(_p(t), _p(partial), int(partial.shape[1]), _p(bd), border.p_rows, border.p_cols,
                                                         int(bd.shape[2]), _p(cw), _p(cb), _p(w1), _p(b1), _p(w2), _p(b2), _p(scale),
-                                                        n, h, w, cr, 0, _p(sync), st), "ca_scale_pre_pieces")
+                                                        n, h, w, cr, 0, st), "ca_scale_pre_pieces")
         return scale
     ws = torch.empty(int(lib().eavsr_ca_scale_pre_ws_floats(n)), device=t.device, dtype=torch.float32)
     _launch("ca_scale_pre", 0.0, 4.0 * partial.numel(), t,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 30
+#define EAVSR_ABI_VERSION 29
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -551,15 +551,11 @@ int eavsr_ca_scale_pre_f32(const float* t, const float* chan_partial, int32_t ti
 int64_t eavsr_ca_scale_pre_ws_floats(int32_t n);
 /* The same attention in ONE launch (ABI 29): the border lines of t come as the pieces the FIRST convolution's epilogue wrote
  * (desc.border_pieces of eavsr_conv3x3_wino4_f32, layout [n][4][p_stride][64], p_rows / p_cols pieces per row / column border) instead
- * of from a border-sum launch.  dtype 0: t fp32 NCHW; 1 / 2: fp16 / bf16 NHWC (only its four corner pixels are read).
- * sync (ABI 30): NULL = one workgroup per sample; otherwise EIGHT workgroups per sample (one per 8 input channels of the second
- * convolution; n <= 64) that meet through `sync` -- eavsr_ca_scale_pre_sync_floats() floats, zeroed ONCE by the caller and from then
- * on handed only to this entry point, by one stream at a time (the launches of one stream may share it: tickets only grow). */
+ * of from a border-sum launch.  dtype 0: t fp32 NCHW; 1 / 2: fp16 / bf16 NHWC (only its four corner pixels are read). */
 int eavsr_ca_scale_pre_pieces(const void* t, const float* chan_partial, int32_t rows, const float* pieces, int32_t p_rows,
                               int32_t p_cols, int32_t p_stride, const float* conv_weight, const float* conv_bias, const float* w1,
                               const float* b1, const float* w2, const float* b2, float* scale, int32_t n, int32_t h, int32_t w,
-                              int32_t cr, int32_t dtype, float* sync, void* stream);
-int64_t eavsr_ca_scale_pre_sync_floats(void);
+                              int32_t cr, int32_t dtype, void* stream);
 int eavsr_ca_scale_pre_h16(const void* t, const float* chan_partial, int32_t rows, const float* conv_weight, const float* conv_bias,
                            const float* w1, const float* b1, const float* w2, const float* b2, float* scale, float* workspace,
                            int32_t n, int32_t h, int32_t w, int32_t cr, int32_t dtype, void* stream);

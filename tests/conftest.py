@@ -49,7 +49,7 @@ def _kernel_modes_do_not_leak():
     when the test started, whatever the test did -- also when it ended in the middle of a switch sequence (a lab-only mode on the
     default library raises between two set_* calls and the test is skipped)."""
     mods = {k: sys.modules.get(k) for k in ("eavsr_amd.ops", "eavsr_amd.networks")}
-    names = {"eavsr_amd.ops": ("CONV_MODE", "DCN_MODE", "DCN_IL_IMPL", "CONV5_MODE", "CONV7_MODE", "CONV3_SMALL", "CONV3_H16", "CA_PRE_SPLIT"),
+    names = {"eavsr_amd.ops": ("CONV_MODE", "DCN_MODE", "DCN_IL_IMPL", "CONV5_MODE", "CONV7_MODE", "CONV3_SMALL", "CONV3_H16"),
              "eavsr_amd.networks": ("FUSE_FLOW_LEVEL", "RCAB_H16_FUSED", "RCAB_PRE", "RCAB_PRE_PIECES", "RCAB_H16_PRE", "BACKBONE_DTYPE",
                                     "FUSE_CA_TAIL", "FUSE_CA_INTO_CONV")}
     before = {(m, n): getattr(mods[m], n) for m in mods if mods[m] is not None for n in names[m] if hasattr(mods[m], n)}

@@ -333,18 +333,6 @@ def test_rcab_attention_before_the_second_convolution_fp32(ops, cuda, shape):
         assert prof2.summary()["ca_scale_pre"]["calls"] == 1
         assert H.maxabs(scale_p.cpu(), scale.cpu()) <= 2e-6
         assert H.maxabs(scale_p.cpu().double(), s64) <= 2e-5
-        # the one launch as eight workgroups per sample that meet through a ticket buffer (the default) and as one workgroup per
-        # sample: the same attention; the tickets only grow, so launch after launch on one stream shares the buffer -- and every
-        # launch gives the same bits (the eight partial vectors are added in a fixed order whoever draws the last ticket)
-        assert ops.CA_PRE_SPLIT
-        again = [ops.ca_scale_pre(t, tpart, gw2, gb2, ga_w, ga_b, gc_w, gc_b, border=pieces) for _ in range(5)]
-        assert all(torch.equal(a, scale_p) for a in again)
-        ops.CA_PRE_SPLIT = False
-        try:
-            scale_1 = ops.ca_scale_pre(t, tpart, gw2, gb2, ga_w, ga_b, gc_w, gc_b, border=pieces)
-        finally:
-            ops.CA_PRE_SPLIT = True
-        assert H.maxabs(scale_1.cpu(), scale_p.cpu()) <= 2e-6
     else:
         assert pieces is None
     with ops.profile() as prof:
