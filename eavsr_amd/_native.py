@@ -11,9 +11,11 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(_HERE, "lib", "libeavsr_hip.so")   # EAVSR_LIB_PATH: A-B builds of the same ABI
+# EAVSR_LIB_PATH: A/B builds of the same ABI (the lab flavour eavsr_amd/lib/libeavsr_lab.so among them; EAVSR_BUILD_LAB=1 picks that one)
+LIB_PATH = os.environ.get("EAVSR_LIB_PATH") or os.path.join(
+    _HERE, "lib", "libeavsr_lab.so" if os.environ.get("EAVSR_BUILD_LAB", "0") == "1" else "libeavsr_hip.so")
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 p_f32 = C.c_void_p  # device pointers travel as integers
 i32 = C.c_int32
@@ -44,6 +46,7 @@ class ConvDesc(C.Structure):
         ("res_scale", vp),
         ("border_pieces", vp),
         ("border_stride", i32),
+        ("sum_mul", vp),
     ]
 
 
@@ -117,7 +120,7 @@ SIGNATURES = {
     "eavsr_channel_sum_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp]),
     "eavsr_channel_sum_multi_f32": (C.c_int, [vp, i32, vp, i32, i32, i32, i32, vp]),
     "eavsr_scale_residual_bwd_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
-    "eavsr_rcab_tail_bwd_f32": (C.c_int, [vp] * 13 + [i32] * 6 + [vp]),
+    "eavsr_rcab_tail_bwd_f32": (C.c_int, [vp] * 13 + [i32] * 7 + [vp]),
     "eavsr_ca_mlp_bwd_f32": (C.c_int, [vp] * 11 + [i32, i32, i32, vp]),
     "eavsr_flow_warp_bwd_f32": (C.c_int, [vp] * 6 + [i32, i32, i32, i32, vp]),
     "eavsr_resize_bilinear_ac_bwd_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]),

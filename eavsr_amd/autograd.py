@@ -11,6 +11,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple, Union
 
+import os
 import weakref
 
 import torch
@@ -61,6 +62,7 @@ class grad_sink:
         if et is None:
             self.flush()
         self.entries = {}
+        _chain.clear()      # (what consecutive RCABs handed each other during this forward / backward: see _Chain)
         return False
 
     @staticmethod
@@ -501,30 +503,34 @@ class _RcabFn(Function):
     convolutions and the four channel-attention parameters go through grad_sink when it is active."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, wa, ba, wb, bb):
+    def forward(ctx, x, r_prev, w1, b1, w2, b2, wa, ba, wb, bb):
         n, c, h, w = x.shape
         t = ops.conv2d([x], [w1], [b1], act="relu")
         r, partial = ops.conv2d([t], [w2], [b2], chan_partial=True)
         # the tail as ONE launch (every workgroup redoes the 64 -> 4 -> 64 MLP of its sample from the per-tile sums: 9 KB at a crop;
         # in the one-stream training graph the launch it saves is a pure gain -- unlike the two-stream inference step, DESIGN 3.4)
         out, scale, mean = ops.ca_tail(r, partial, wa, ba, wb, bb, x, with_stats=True)
-        ctx.save_for_backward(x, t, r, mean, scale, w1, w2, wa, ba, wb, bb)
+        ctx.save_for_backward(x, t, r, mean, scale, w1, w2, wa, ba, wb, bb, r_prev)
         ctx.params = ([w1], [b1], [w2], [b2], [wa, ba, wb, bb])      # the caller's tensor objects (grad_sink keys on them)
-        return out
+        ctx.mark_non_differentiable(r)
+        return out, r
 
     @staticmethod
-    def backward(ctx, d):
-        x, t, r, mean, scale, w1, w2, wa, ba, wb, bb = ctx.saved_tensors
+    def backward(ctx, d, _dr_unused=None):
+        x, t, r, mean, scale, w1, w2, wa, ba, wb, bb, r_prev = ctx.saved_tensors
         pw1, pb1, pw2, pb2, pca = ctx.params
         d = d.contiguous()
         sink = grad_sink._active if grad_sink.eligible(pw1 + pb1 + pw2 + pb2 + pca) else None
-        # tail: plane sums of d * r, then one launch (MLP backward, mean broadcast, dr; the mean came out of the forward's ca_scale)
+        # tail: the plane sums of d * r, then one launch (MLP backward, mean broadcast, dr; the mean came out of the forward's
+        # ca_scale).  Round 6: when d is what the NEXT block's backward returned (the same tensor object: nothing was added to it on
+        # the way), that block's last convolution already left the sums in per-tile rows (_chain below): no plane-sum launch
+        dsum = _chain.take_sums(d)
         if sink is not None:
             bufs, acc = sink.raw(pca)
-            dr = ops.rcab_tail_bwd(d, r, mean, scale, wa, ba, wb, bb, grads=tuple(bufs), accumulate=acc)[0]
+            dr = ops.rcab_tail_bwd(d, r, mean, scale, wa, ba, wb, bb, grads=tuple(bufs), accumulate=acc, dsum=dsum)[0]
             dca = (None, None, None, None)
         else:
-            dr, *dca = ops.rcab_tail_bwd(d, r, mean, scale, wa, ba, wb, bb)
+            dr, *dca = ops.rcab_tail_bwd(d, r, mean, scale, wa, ba, wb, bb, dsum=dsum)
         # second convolution
         if sink is not None:
             sink.add_use(pw2, pb2, 3, dr, [t])
@@ -539,8 +545,12 @@ class _RcabFn(Function):
             dW1 = db1 = None
         else:
             dW1, db1 = ops.conv_wgrad(g1, [x], 3), ops.channel_sum(g1)
-        dx = ops.conv2d(g1, w1, None, residual=d, dgrad=True)
-        return (dx, dW1, db1, dW2, db2) + tuple(dca)
+        if r_prev is not None and RCAB_CHAIN:      # x is the previous block's output: its backward starts with sum_hw dx * r_prev
+            dx, rows = ops.conv2d(g1, w1, None, residual=d, dgrad=True, sum_mul=r_prev)
+            _chain.put_sums(dx, rows)
+        else:
+            dx = ops.conv2d(g1, w1, None, residual=d, dgrad=True)
+        return (dx, None, dW1, db1, dW2, db2) + tuple(dca)
 
 
 def rcab_supported(x, params) -> bool:
@@ -550,8 +560,56 @@ def rcab_supported(x, params) -> bool:
             and ops.rcab_tail_bwd_supported(64, int(params[4].shape[0])))
 
 
+# EAVSR_RCAB_CHAIN=0: every block's backward takes its own plane sums (the A/B switch)
+RCAB_CHAIN = os.environ.get("EAVSR_RCAB_CHAIN", "1") != "0"
+
+
+class _Chain:
+    """What consecutive RCABs hand each other around autograd (round 6).  Forward: block k's `r` for block k + 1, found by the
+    IDENTITY of the tensor object that is block k's output and block k + 1's input.  Backward: the per-tile sums of dx * r_prev
+    that block k + 1's last input-gradient convolution left in its epilogue, found by the identity of the tensor that is its
+    returned dx and block k's incoming d.  Both tables hold strong references, so an id() cannot be reused while its entry lives;
+    an entry whose object is not the one asked about (autograd added another gradient to dx, a hook replaced it) is never used --
+    the consumer then takes its plane sums itself.  Entries are dropped when they are consumed and by clear()."""
+
+    def __init__(self):
+        self._r_of_out = {}
+        self._sums_of_dx = {}
+
+    def put_r(self, out, r):
+        if len(self._r_of_out) > 4096:      # (a forward without backward, over and over: keep the table bounded)
+            self._r_of_out.clear()
+        self._r_of_out[id(out)] = (out, r)
+
+    def r_behind(self, x):
+        ent = self._r_of_out.pop(id(x), None)
+        return ent[1] if ent is not None and ent[0] is x else None
+
+    def put_sums(self, dx, rows):
+        if len(self._sums_of_dx) > 4096:
+            self._sums_of_dx.clear()
+        self._sums_of_dx[id(dx)] = (dx, rows)
+
+    def take_sums(self, d):
+        ent = self._sums_of_dx.pop(id(d), None)
+        return ent[1] if ent is not None and ent[0] is d else None
+
+    def clear(self):
+        self._r_of_out.clear()
+        self._sums_of_dx.clear()
+
+
+_chain = _Chain()
+
+
 def rcab(x, w1, b1, w2, b2, wa, ba, wb, bb):
-    return _RcabFn.apply(x, w1, b1, w2, b2, wa, ba, wb, bb)
+    r_prev = _chain.r_behind(x) if RCAB_CHAIN else None
+    if r_prev is not None and r_prev.shape != x.shape:
+        r_prev = None
+    out, r = _RcabFn.apply(x, r_prev, w1, b1, w2, b2, wa, ba, wb, bb)
+    if RCAB_CHAIN:
+        _chain.put_r(out, r)
+    return out
 
 
 # the remaining ops have no trainable use on the path: forwarded as is

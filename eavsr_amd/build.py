@@ -2,7 +2,8 @@
 
     python -m eavsr_amd.build [--force] [--verbose] [--lab]
 
---lab (or EAVSR_BUILD_LAB=1) also compiles the retired schedules kept for A/B measurements (LAB_SOURCES below).
+--lab (or EAVSR_BUILD_LAB=1) builds eavsr_amd/lib/libeavsr_lab.so: the product library's sources plus the retired schedules kept
+for A/B measurements (LAB_SOURCES below); the product library is not touched.  EAVSR_LIB_PATH selects the file that is loaded.
 
 The shared object lands in eavsr_amd/lib/ (git-ignored, but it travels with gpurun snapshots).
 """
@@ -18,8 +19,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libeavsr_hip.so")
-OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = LIB_PRODUCT = os.path.join(LIBDIR, "libeavsr_hip.so")
+LIB_LAB = os.path.join(LIBDIR, "libeavsr_lab.so")
+OBJDIR = OBJDIR_PRODUCT = os.path.join(LIBDIR, "obj")
 ARCH = "gfx950"
 # -fno-slp-vectorize: the SLP vectorizer packs pairs of independent fp32 additions / multiplications into v_pk_add_f32 /
 # v_pk_mul_f32, which beside MFMAs are slower than the two plain instructions (MI355X_MICROARCH.md, "price of one filler beside
@@ -93,14 +95,18 @@ def lab_requested() -> bool:
 
 def build_native(force: bool = False, verbose: bool = False, extra_flags=(), lab=None) -> str:
     lab = lab_requested() if lab is None else bool(lab)
+    # the two flavours are two files: the lab build never replaces the product library (eavsr_amd/lib/libeavsr_lab.so, selected with
+    # EAVSR_LIB_PATH -- or by EAVSR_BUILD_LAB=1, which _native.py honours as well)
+    LIB = LIB_LAB if lab else LIB_PRODUCT
+    OBJDIR = OBJDIR_PRODUCT + ("_lab" if lab else "")
     os.makedirs(OBJDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "build.stamp")
+    stamp = os.path.join(LIBDIR, "build_lab.stamp" if lab else "build.stamp")
     dig = _digest(lab) + "|" + " ".join(extra_flags)
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = _hipcc()
     extra_flags = (*extra_flags, f"-DEAVSR_LAB={1 if lab else 0}")
-    for f in os.listdir(OBJDIR):      # objects of sources that are not part of this flavour must not be linked
+    for f in os.listdir(OBJDIR):      # objects of sources that are no longer part of the flavour must not be linked
         os.remove(os.path.join(OBJDIR, f))
 
     def compile_one(src):

@@ -217,7 +217,8 @@ struct RcabBwdArgs {
   const float* b1;       // (cr)
   const float* w2;       // (64, cr)
   const float* b2;       // (64)
-  const float* ds;       // (n, 64) sum_hw d * r
+  const float* ds;       // (n, 64) sum_hw d * r, or -- ds_rows > 0 -- (n, ds_rows, 64) partial sums (a convolution's per-tile rows)
+  int ds_rows;
   float* dr;             // (n, 64, hw)
   float* dw1; float* db1; float* dw2; float* db2;
   int n, cr, hw, accumulate;
@@ -238,6 +239,28 @@ __device__ __forceinline__ float rb_mean(const RcabBwdArgs& a, int b, int lane) 
   return (s0 + s1) * a.inv_hw;
 }
 
+// sum_hw d * r of channel `lane` of sample b for EVERY thread of the 256-thread workgroup (uniform call: two barriers when the sums
+// come as partial rows).  Rows: the four waves take the rows q, q + 4, .. with eight requests in flight each and meet in LDS -- one
+// round trip instead of a chain of them in one wave (36 rows per sample at a 96 x 96 crop: 4.4 us per launch when wave 0 walked them)
+__device__ __forceinline__ float rb_ds_block(const RcabBwdArgs& a, int b, float* sds /* [4][64] */, int tid) {
+  const int q = tid >> 6, lane = tid & 63;
+  if (a.ds_rows == 0) return a.ds[(size_t)b * 64 + lane];
+  const float* p = a.ds + (size_t)b * a.ds_rows * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  for (int r0 = q; r0 < a.ds_rows; r0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (r0 + 4 * j < a.ds_rows) ? p[(size_t)(r0 + 4 * j) * 64] : 0.f;
+    s0 += (v[0] + v[1]) + (v[2] + v[3]);
+    s1 += (v[4] + v[5]) + (v[6] + v[7]);
+  }
+  sds[q * 64 + lane] = s0 + s1;
+  __syncthreads();
+  const float r = (sds[lane] + sds[64 + lane]) + (sds[128 + lane] + sds[192 + lane]);
+  __syncthreads();
+  return r;
+}
+
 __device__ __forceinline__ float rb_wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -248,34 +271,30 @@ template <int CR>
 __global__ __launch_bounds__(256) void rcab_tail_bwd_kernel(RcabBwdArgs a) {
   constexpr int C = 64;
   __shared__ float sh[2 + 4 * C];
+  __shared__ float sds[4 * C];
   const int tid = threadIdx.x, lane = tid & 63;
   const int nplanes = a.n * C;
   if ((int)blockIdx.x < nplanes) {
     const int b = blockIdx.x / C, ch = blockIdx.x - b * C;
-    if (tid < 64) {      // wave 0: the MLP of sample b, lane = channel
-      const float m = rb_mean(a, b, lane), dsv = a.ds[(size_t)b * C + lane];
-      float hid[CR], z2 = a.b2[lane];
-#pragma unroll
-      for (int j = 0; j < CR; ++j) {
-        hid[j] = fmaxf(rb_wave_sum(a.w1[j * C + lane] * m) + a.b1[j], 0.f);
-        z2 += a.w2[lane * CR + j] * hid[j];
-      }
-      const float sg = 1.f / (1.f + expf(-z2));
-      const float dz2 = dsv * sg * (1.f - sg);
-      float dm = 0.f;
-#pragma unroll
-      for (int j = 0; j < CR; ++j) {
-        const float dz1 = hid[j] > 0.f ? rb_wave_sum(a.w2[lane * CR + j] * dz2) : 0.f;
-        dm += a.w1[j * C + lane] * dz1;
-      }
-      if (lane == ch) {
-        sh[0] = a.scale[(size_t)b * C + ch];
-        sh[1] = dm * a.inv_hw;
-      }
-    }
-    // the plane's first RB_PRE float4 per thread are requested BEFORE the barrier (they do not depend on the MLP that wave 0 is
-    // still computing), every pass issues all of its loads before its first store (d and dr may alias as far as the compiler knows:
+    // the plane's first RB_PRE float4 per thread are requested BEFORE the barriers (they depend neither on the row sums nor on the
+    // MLP that wave 0 computes), every pass issues all of its loads before its first store (d and dr may alias as far as the compiler knows:
     // load / store / load chains were nine dependent round trips per thread at a 96 x 96 crop)
+    // (the partial rows of sum_hw d r first: a wave's requests return in order, and these few lines are what the MLP waits for)
+    float dv[8];
+    if (a.ds_rows > 0) {
+      const float* p = a.ds + (size_t)b * a.ds_rows * 64 + lane;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dv[j] = ((tid >> 6) + 4 * j < a.ds_rows) ? p[(size_t)((tid >> 6) + 4 * j) * 64] : 0.f;
+    }
+    // (and everything the MLP reads: behind the row sums' barrier these were a second round trip)
+    const float pm = rb_mean(a, b, lane), pb2 = a.b2[lane];
+    float pw1[CR], pb1[CR], pw2[CR];
+#pragma unroll
+    for (int j = 0; j < CR; ++j) {
+      pw1[j] = a.w1[j * C + lane];
+      pb1[j] = a.b1[j];
+      pw2[j] = a.w2[lane * CR + j];
+    }
     constexpr int RB_PRE = 9;
     const size_t base = (size_t)blockIdx.x * a.hw;
     const bool vec = (a.hw & 3) == 0;
@@ -287,6 +306,44 @@ __global__ __launch_bounds__(256) void rcab_tail_bwd_kernel(RcabBwdArgs a) {
       for (int u = 0; u < RB_PRE; ++u) {
         const int i = tid + u * 256;
         pre[u] = i < q ? d4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float dsv;
+    if (a.ds_rows > 0) {      // (rb_ds_block with its first eight requests per thread issued above)
+      float s0 = (dv[0] + dv[1]) + (dv[2] + dv[3]), s1 = (dv[4] + dv[5]) + (dv[6] + dv[7]);
+      const float* p = a.ds + (size_t)b * a.ds_rows * 64 + lane;
+      for (int r0 = (tid >> 6) + 32; r0 < a.ds_rows; r0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (r0 + 4 * j < a.ds_rows) ? p[(size_t)(r0 + 4 * j) * 64] : 0.f;
+        s0 += (v[0] + v[1]) + (v[2] + v[3]);
+        s1 += (v[4] + v[5]) + (v[6] + v[7]);
+      }
+      sds[(tid >> 6) * 64 + lane] = s0 + s1;
+      __syncthreads();
+      dsv = (sds[lane] + sds[64 + lane]) + (sds[128 + lane] + sds[192 + lane]);
+    } else {
+      dsv = a.ds[(size_t)b * 64 + lane];
+    }
+    if (tid < 64) {      // wave 0: the MLP of sample b, lane = channel
+      const float m = pm;
+      float hid[CR], z2 = pb2;
+#pragma unroll
+      for (int j = 0; j < CR; ++j) {
+        hid[j] = fmaxf(rb_wave_sum(pw1[j] * m) + pb1[j], 0.f);
+        z2 += pw2[j] * hid[j];
+      }
+      const float sg = 1.f / (1.f + expf(-z2));
+      const float dz2 = dsv * sg * (1.f - sg);
+      float dm = 0.f;
+#pragma unroll
+      for (int j = 0; j < CR; ++j) {
+        const float dz1 = hid[j] > 0.f ? rb_wave_sum(pw2[j] * dz2) : 0.f;
+        dm += pw1[j] * dz1;
+      }
+      if (lane == ch) {
+        sh[0] = a.scale[(size_t)b * C + ch];
+        sh[1] = dm * a.inv_hw;
       }
     }
     __syncthreads();
@@ -321,42 +378,77 @@ __global__ __launch_bounds__(256) void rcab_tail_bwd_kernel(RcabBwdArgs a) {
   float* hidv = m + C;    // [CR] (C reserved)
   float* dz2 = hidv + C;  // [C]
   float* dz1 = dz2 + C;   // [CR]
+  const float qb2 = a.b2[lane];
+  float qw1[CR], qb1[CR], qw2[CR];
+#pragma unroll
+  for (int j = 0; j < CR; ++j) {
+    qw1[j] = a.w1[j * C + lane];
+    qb1[j] = a.b1[j];
+    qw2[j] = a.w2[lane * CR + j];
+  }
+  // what the four parameter gradients are added to (accumulate), requested before anything else; the sums over the samples in
+  // registers (sample order: deterministic)
+  constexpr int NU = (C * CR + 255) / 256;
+  float odw2[NU], odw1[NU], adw2[NU], adw1[NU], odb2 = 0.f, odb1 = 0.f, adb2 = 0.f, adb1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = tid + 256 * u;
+    odw2[u] = (a.accumulate && i < C * CR) ? a.dw2[i] : 0.f;
+    odw1[u] = (a.accumulate && i < C * CR) ? a.dw1[i] : 0.f;
+    adw2[u] = adw1[u] = 0.f;
+  }
+  if (a.accumulate && tid < C) odb2 = a.db2[tid];
+  if (a.accumulate && tid < CR) odb1 = a.db1[tid];
   for (int b = 0; b < a.n; ++b) {
-    const bool first = b == 0 && !a.accumulate;
-    if (tid < C) m[tid] = rb_mean(a, b, tid);
+    const float mv = rb_mean(a, b, lane);      // (requested in front of the row sums: one round trip for both)
+    const float dsv = rb_ds_block(a, b, sds, tid);
+    if (tid < C) m[tid] = mv;
     __syncthreads();
     if (tid < 64) {
-      float z2 = a.b2[lane];
+      float z2 = qb2;
 #pragma unroll
       for (int j = 0; j < CR; ++j) {
-        const float hj = fmaxf(rb_wave_sum(a.w1[j * C + lane] * m[lane]) + a.b1[j], 0.f);
+        const float hj = fmaxf(rb_wave_sum(qw1[j] * m[lane]) + qb1[j], 0.f);
         if (lane == 0) hidv[j] = hj;
-        z2 += a.w2[lane * CR + j] * hj;
+        z2 += qw2[j] * hj;
       }
       const float sg = 1.f / (1.f + expf(-z2));
-      const float g2 = a.ds[(size_t)b * C + lane] * sg * (1.f - sg);
+      const float g2 = dsv * sg * (1.f - sg);
       dz2[lane] = g2;
 #pragma unroll
       for (int j = 0; j < CR; ++j) {
-        const float t = rb_wave_sum(a.w2[lane * CR + j] * g2);
+        const float t = rb_wave_sum(qw2[j] * g2);
         if (lane == 0) dz1[j] = t;
       }
     }
     __syncthreads();
     if (tid < CR) dz1[tid] = hidv[tid] > 0.f ? dz1[tid] : 0.f;
     __syncthreads();
-    for (int i = tid; i < C * CR; i += 256) {
-      const int ci = i / CR, j = i - ci * CR;   // dw2[ci][j]
-      const float g2 = dz2[ci] * hidv[j];
-      a.dw2[i] = first ? g2 : a.dw2[i] + g2;
-      const int j1 = i / C, k = i - j1 * C;      // dw1[j1][k]
-      const float g1 = dz1[j1] * m[k];
-      a.dw1[i] = first ? g1 : a.dw1[i] + g1;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int i = tid + 256 * u;
+      if (i < C * CR) {
+        const int ci = i / CR, j = i - ci * CR;   // dw2[ci][j]
+        adw2[u] += dz2[ci] * hidv[j];
+        const int j1 = i / C, k = i - j1 * C;      // dw1[j1][k]
+        adw1[u] += dz1[j1] * m[k];
+      }
     }
-    if (tid < C) a.db2[tid] = first ? dz2[tid] : a.db2[tid] + dz2[tid];
-    if (tid < CR) a.db1[tid] = first ? dz1[tid] : a.db1[tid] + dz1[tid];
+    if (tid < C) adb2 += dz2[tid];
+    if (tid < CR) adb1 += dz1[tid];
     __syncthreads();
   }
+  // the samples' sums leave once (they were a store and a dependent load of the same address per sample)
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int i = tid + 256 * u;
+    if (i < C * CR) {
+      a.dw2[i] = odw2[u] + adw2[u];
+      a.dw1[i] = odw1[u] + adw1[u];
+    }
+  }
+  if (tid < C) a.db2[tid] = odb2 + adb2;
+  if (tid < CR) a.db1[tid] = odb1 + adb1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -572,16 +664,16 @@ extern "C" int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const fl
 extern "C" int eavsr_rcab_tail_bwd_f32(const float* d, const float* scale, const float* mean, const float* w1, const float* b1,
                                        const float* w2, const float* b2, const float* dscale, float* dr, float* dw1, float* db1,
                                        float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, int32_t hw, int32_t mean_rows,
-                                       int32_t accumulate, void* stream) {
+                                       int32_t dscale_rows, int32_t accumulate, void* stream) {
   EAVSR_REQUIRE(d && scale && mean && w1 && b1 && w2 && b2 && dscale && dr && dw1 && db1 && dw2 && db2, -1, "rcab_tail_bwd: NULL pointer");
   EAVSR_REQUIRE(c == 64 && (cr == 4 || cr == 8 || cr == 2 || cr == 1), -2,
                 "rcab_tail_bwd: %d channels / %d hidden units unsupported (64 channels, 1 / 2 / 4 / 8 hidden units)", c, cr);
-  EAVSR_REQUIRE(n >= 1 && hw > 0 && (long)n * c < 65535 && mean_rows >= 0, -1, "rcab_tail_bwd: bad dims");
+  EAVSR_REQUIRE(n >= 1 && hw > 0 && (long)n * c < 65535 && mean_rows >= 0 && dscale_rows >= 0, -1, "rcab_tail_bwd: bad dims");
   EAVSR_REQUIRE((((uintptr_t)d | (uintptr_t)dr) & 15) == 0 || (hw & 3), -2, "rcab_tail_bwd: d / dr must be 16-byte aligned");
   RcabBwdArgs a;
   a.d = d; a.scale = scale; a.mean = mean; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.ds = dscale; a.dr = dr;
   a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2;
-  a.n = n; a.cr = cr; a.hw = hw; a.accumulate = accumulate; a.inv_hw = 1.0f / (float)hw; a.rows = mean_rows;
+  a.n = n; a.cr = cr; a.hw = hw; a.accumulate = accumulate; a.inv_hw = 1.0f / (float)hw; a.rows = mean_rows; a.ds_rows = dscale_rows;
   hipStream_t st = eavsr::as_stream(stream);
   const dim3 grid(n * c + 1), block(256);
   switch (cr) {

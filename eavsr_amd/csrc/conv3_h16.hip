@@ -266,7 +266,7 @@ extern "C" int eavsr_conv3x3_h16g_f32(const eavsr_conv2d_desc* d, int32_t dtype,
   EAVSR_REQUIRE(d && d->out && d->weight_packed, -1, "conv3x3_h16g: NULL pointer");
   EAVSR_REQUIRE(dtype == 1 || dtype == 2, -1, "conv3x3_h16g: dtype %d (1 = f16, 2 = bf16)", dtype);
   EAVSR_REQUIRE(d->ksize == 3 && d->n_src >= 1 && d->n_src <= 5, -2, "conv3x3_h16g: 3x3, 1..5 sources");
-  EAVSR_REQUIRE(!d->residual && !d->chan_partial && !d->ca_scale && !d->ca_x && !d->ca_out && d->out_shuffle == 0 && !d->res_scale && !d->border_pieces, -2,
+  EAVSR_REQUIRE(!d->residual && !d->chan_partial && !d->ca_scale && !d->ca_x && !d->ca_out && d->out_shuffle == 0 && !d->res_scale && !d->border_pieces && !d->sum_mul, -2,
                 "conv3x3_h16g: plain convolution only (no residual / channel sums / channel-attention prologue / pixel shuffle)");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cout > 0 && d->w % 4 == 0, -2, "conv3x3_h16g: bad dims (w %% 4 == 0)");
   int cin = 0;

@@ -53,6 +53,7 @@ struct QArgs {
   const float* residual; // added to the output -- or, act == EAVSR_ACT_RELU_MASK, the mask source
   float* out;            // (n, cout, h, w)
   float* chan_partial;   // (n, tiles, cout) or NULL
+  const float* sum_mul;  // NULL, or (n, cout, h, w): chan_partial holds the per-tile sums of out * sum_mul (the STORED values) instead
   int n, cout, h, w, tiles_x, tiles_y;
   int wmt;               // 32-channel tiles per packed `cot` (1: cout <= 32, 2 otherwise)
   int act;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
       float v = acc[r];
       v = eavsr_act(v, act_s);      // branch-free: max(v, v s), 0 <= s <= 1
       vv[r] = v;
-      if (a.chan_partial) {
+      if (a.chan_partial && !a.sum_mul) {
         float sum = (pxok && co0 + cu < a.cout) ? v : 0.f;
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 8);
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
     const int q4 = lane & 7, rsub = lane >> 3;
     const int gx4 = x0 + 4 * q4;
     const bool pok4 = gx4 < w && gy < h;               // (w % 4 == 0: gx4 + 3 < w as well)
-    f32x4 rr4[4];
+    f32x4 rr4[4], mm4[4];
     size_t o4[4];
     bool ok4[4];
 #pragma unroll
@@ -355,8 +356,11 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
       o4[i] = ((size_t)bn * a.cout + co) * plane + (size_t)gy * w + gx4;
       rr4[i] = (a.residual && ok4[i]) ? *reinterpret_cast<const f32x4*>(a.residual + o4[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      mm4[i] = (a.sum_mul && ok4[i]) ? *reinterpret_cast<const f32x4*>(a.sum_mul + o4[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    if (a.chan_partial && tid < 32) {
+    if (a.chan_partial && !a.sum_mul && tid < 32) {
       const int co = cot * 32 + tid;
       if (co < a.cout) {
         float v = s_red[tid];
@@ -375,6 +379,25 @@ __global__ __launch_bounds__(512) void conv3x3_x6s_kernel(QArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) o[c] = a.act == EAVSR_ACT_RELU_MASK ? (rr4[i][c] > 0.f ? v[c] : 0.f) : v[c] + rr4[i][c];
       if (ok4[i]) *reinterpret_cast<f32x4*>(a.out + o4[i]) = o;
+      if (a.sum_mul) {      // sum over the wave's 32 pixels of stored value x multiplier, per channel (i, rsub): 4 in the lane, 8 lanes
+        float sm = (o[0] * mm4[i][0] + o[1] * mm4[i][1]) + (o[2] * mm4[i][2] + o[3] * mm4[i][3]);      // (a lane outside holds zeros in mm4)
+        sm += __shfl_xor(sm, 1);
+        sm += __shfl_xor(sm, 2);
+        sm += __shfl_xor(sm, 4);
+        if (q4 == 0) s_red[wave * 32 + i * 8 + rsub] = sm;
+      }
+    }
+    if (a.sum_mul) {      // the tile's eight pixel rows, in wave order (deterministic)
+      __syncthreads();
+      if (tid < 32) {
+        const int co = cot * 32 + tid;
+        if (co < a.cout) {
+          float v = s_red[tid];
+#pragma unroll
+          for (int k = 1; k < Q_NW; ++k) v += s_red[k * 32 + tid];
+          a.chan_partial[((size_t)bn * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx) * a.cout + co] = v;
+        }
+      }
     }
 #ifdef EAVSR_X6S_STAMPS
     Q_STAMP(4);      // epilogue issued
@@ -488,16 +511,19 @@ extern "C" int eavsr_conv3x3_f32x6s(const eavsr_conv2d_desc* d, const void* weig
                 "conv3x3_f32x6s: leaky-ReLU slope %g outside [0, 1] (the epilogue evaluates max(v, slope v))", (double)d->slope);
   EAVSR_REQUIRE(d->act != EAVSR_ACT_RELU_MASK || (d->residual != nullptr && d->chan_partial == nullptr), -1,
                 "conv3x3_f32x6s: EAVSR_ACT_RELU_MASK takes the mask source in `residual` (no channel sums)");
+  EAVSR_REQUIRE(d->sum_mul == nullptr || d->act != EAVSR_ACT_RELU_MASK, -1, "conv3x3_f32x6s: sum_mul with EAVSR_ACT_RELU_MASK");
   EAVSR_REQUIRE((long)d->h * d->w < (1L << 31), -1, "conv3x3_f32x6s: image plane too large for 32-bit pixel offsets");
   QArgs a;
   a.x = d->src[0]; a.wsplit = reinterpret_cast<const u32x4*>(weight_x6); a.bias = d->bias; a.residual = d->residual;
-  a.out = d->out; a.chan_partial = d->chan_partial;
+  a.out = d->out; a.chan_partial = d->chan_partial; a.sum_mul = d->sum_mul;
   a.n = d->n; a.cout = d->cout; a.h = d->h; a.w = d->w;
   a.tiles_x = eavsr::cdiv(d->w, Q_TW); a.tiles_y = eavsr::cdiv(d->h, Q_TH);
   a.wmt = d->cout > 32 ? 2 : 1;
   a.act = d->act; a.slope = d->slope;
   const bool vec = d->w % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.out) |
                                        reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0;
+  EAVSR_REQUIRE(a.sum_mul == nullptr || (a.chan_partial != nullptr && vec && (reinterpret_cast<uintptr_t>(a.sum_mul) & 15) == 0), -2,
+                "conv3x3_f32x6s: sum_mul needs chan_partial, w %% 4 == 0 and 16-byte aligned tensors");
 #ifdef EAVSR_X6S_NO_VEC
   return launch_q<8, false>(a, stream);
 #endif

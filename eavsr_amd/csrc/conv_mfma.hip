@@ -689,7 +689,7 @@ extern "C" int eavsr_conv2d_f32(const eavsr_conv2d_desc* d, void* stream) {
   EAVSR_REQUIRE(d->ksize == 1 || d->ksize == 3 || d->ksize == 5 || d->ksize == 7, -2,
                 "conv2d: kernel size %d unsupported (1,3,5,7)", d->ksize);
   EAVSR_REQUIRE(d->weight_packed && d->out, -1, "conv2d: NULL weight/out");
-  EAVSR_REQUIRE(d->out_shuffle == 0 && d->res_scale == nullptr && d->border_pieces == nullptr, -2, "conv2d: the pixel-shuffle and scaled-residual epilogues exist in eavsr_conv3x3_wino4_f32 only");
+  EAVSR_REQUIRE(d->out_shuffle == 0 && d->res_scale == nullptr && d->border_pieces == nullptr && d->sum_mul == nullptr, -2, "conv2d: the pixel-shuffle and scaled-residual epilogues exist in eavsr_conv3x3_wino4_f32 only");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv2d: bad dims");
   EAVSR_REQUIRE(d->act >= 0 && d->act <= EAVSR_ACT_RELU_MASK, -1, "conv2d: act %d", d->act);
   EAVSR_REQUIRE(d->act != EAVSR_ACT_RELU_MASK || (d->residual != nullptr && d->chan_partial == nullptr && d->ca_scale == nullptr), -1,

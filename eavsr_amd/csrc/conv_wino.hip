@@ -458,7 +458,7 @@ extern "C" int eavsr_conv3x3_wino_f32(const eavsr_conv2d_desc* d, const float* w
   EAVSR_REQUIRE(d->n_src >= 1 && d->n_src <= 5, -1, "conv3x3_wino: n_src %d not in 1..5", d->n_src);
   EAVSR_REQUIRE(d->ksize == 3, -2, "conv3x3_wino: kernel size %d (3 only)", d->ksize);
   EAVSR_REQUIRE(d->out, -1, "conv3x3_wino: NULL out");
-  EAVSR_REQUIRE(d->out_shuffle == 0 && d->res_scale == nullptr && d->border_pieces == nullptr, -2, "conv3x3_wino: the pixel-shuffle and scaled-residual epilogues exist in eavsr_conv3x3_wino4_f32 only");
+  EAVSR_REQUIRE(d->out_shuffle == 0 && d->res_scale == nullptr && d->border_pieces == nullptr && d->sum_mul == nullptr, -2, "conv3x3_wino: the pixel-shuffle and scaled-residual epilogues exist in eavsr_conv3x3_wino4_f32 only");
   EAVSR_REQUIRE(d->n >= 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, -1, "conv3x3_wino: bad dims");
   EAVSR_REQUIRE(d->act >= 0 && d->act <= 2, -1, "conv3x3_wino: act %d", d->act);
   EAVSR_REQUIRE(d->act != EAVSR_ACT_LRELU || (d->slope >= 0.f && d->slope <= 1.f), -2,

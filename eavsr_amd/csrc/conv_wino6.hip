@@ -1324,6 +1324,7 @@ int launch_wino6(const eavsr_conv2d_desc* d, const float* weight_wino, void* str
   a.tiles_y = eavsr::cdiv(d->h, C::TOH);
   a.act = d->act; a.slope = d->slope;
   a.out_shuffle = d->out_shuffle;
+  EAVSR_REQUIRE(d->sum_mul == nullptr, -2, "conv3x3_wino4: sum_mul exists in eavsr_conv3x3_f32x6s only");
   a.res_scale = d->res_scale;
   a.border = d->border_pieces;
   a.border_stride = d->border_stride;

@@ -570,10 +570,11 @@ class BorderPieces:
 
 
 def conv2d(srcs, weight, bias=None, act=None, slope: float = 0.0, residual=None, chan_partial: bool = False, ca=None, ca_out: bool = False,
-           pixel_shuffle2: bool = False, sigmoid_from=None, dgrad: bool = False, res_scale=None, border: bool = False):
+           pixel_shuffle2: bool = False, sigmoid_from=None, dgrad: bool = False, res_scale=None, border: bool = False, sum_mul=None):
     """see _conv2d (the implementation); this shim only normalises the `border` result: routes that do not produce border pieces
     return None in its place"""
-    r = _conv2d(srcs, weight, bias, act, slope, residual, chan_partial, ca, ca_out, pixel_shuffle2, sigmoid_from, dgrad, res_scale, border)
+    r = _conv2d(srcs, weight, bias, act, slope, residual, chan_partial, ca, ca_out, pixel_shuffle2, sigmoid_from, dgrad, res_scale, border,
+                sum_mul)
     if border and not (isinstance(r, tuple) and len(r) >= 2 and (r[-1] is None or isinstance(r[-1], BorderPieces))):
         r = (tuple(r) if isinstance(r, tuple) else (r,)) + (None,)
     return r
@@ -583,7 +584,8 @@ def _conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequenc
            bias: Union[None, Tensor, Sequence[Optional[Tensor]]] = None, act: Optional[str] = None,
            slope: float = 0.0, residual: Optional[Tensor] = None, chan_partial: bool = False,
            ca: Optional[Tuple[Tensor, Tensor]] = None, ca_out: bool = False, pixel_shuffle2: bool = False,
-           sigmoid_from: Optional[int] = None, dgrad: bool = False, res_scale: Optional[Tensor] = None, border: bool = False):
+           sigmoid_from: Optional[int] = None, dgrad: bool = False, res_scale: Optional[Tensor] = None, border: bool = False,
+           sum_mul: Optional[Tensor] = None):
     """conv over the virtual channel-concatenation of `srcs`; `weight` may be a list of weights
     that are concatenated along cout (several heads in one launch).
     border=True (with chan_partial=True): a third result, the sums of the output's four border lines per border tile
@@ -599,8 +601,15 @@ def _conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequenc
     runs (the upsampling tail, eavsrp_model.py:343-347), by torch otherwise.
     ca=(scale (n,c), x (n,c,h,w)): the conv input is srcs * scale[n,c] + x (RCABlock tail fused into this
     conv); with ca_out=True that effective input is also returned.
+    sum_mul=m (n, cout, h, w), with dgrad: also returns (n, rows, cout) partial sums over the plane of out * m -- `sum_hw d r`, what the
+    backward of the PREVIOUS RCAB's tail starts with -- from the epilogue of the small-launch bf16x6 kernel (desc.sum_mul), by a
+    plane-sum launch behind every other kernel (rows = 1).
     Returns out, then the per-tile channel sums when chan_partial=True, then the effective input when
     ca_out=True."""
+    if sum_mul is not None:
+        if not dgrad or chan_partial or ca is not None or pixel_shuffle2 or sigmoid_from is not None or res_scale is not None or act == "relu_mask":
+            raise ValueError("sum_mul: input-gradient convolutions only (dgrad=True; no channel sums / prologue / shuffle / sigmoid / mask)")
+        sum_mul = _chk(sum_mul, "sum_mul")
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     weights = [weight] if isinstance(weight, torch.Tensor) else list(weight)
@@ -623,7 +632,8 @@ def _conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequenc
         if not (CONV3_SMALL == "x6s" and CONV_MODE in ("winograd", "winograd4") and k_ == 3 and len(srcs) == 1 and cin == 64
                 and int(weights[0].shape[1]) not in (2, 3, 4, 6) and CONV3_H16 is None
                 and n * lib().eavsr_conv3x3_x6s_tiles(h, w) <= X6S_MAX_TILES):
-            return conv2d(srcs, dgrad_weight(weights[0]), None, act, slope, residual)
+            y = conv2d(srcs, dgrad_weight(weights[0]), None, act, slope, residual)
+            return y if sum_mul is None else (y, plane_sum(y, sum_mul).view(n, 1, -1))
     cout = sum(int(x.shape[0]) for x in weights) if not dgrad else int(weights[0].shape[1])
     k = int(weights[0].shape[-1])
     if not dgrad and any(int(x.shape[1]) != cin for x in weights):
@@ -700,10 +710,16 @@ def _conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequenc
     use_x6s = (CONV3_SMALL == "x6s" and CONV_MODE in ("winograd", "winograd4") and k == 3 and len(srcs) == 1 and cin == 64
                and ca is None and not pixel_shuffle2 and not use_wino
                and n * lib().eavsr_conv3x3_x6s_tiles(h, w) <= X6S_MAX_TILES)
+    if sum_mul is not None and not (use_x6s and w % 4 == 0 and tuple(sum_mul.shape) == (n, cout, h, w) and
+                                    all(t_ is None or t_.data_ptr() % 16 == 0 for t_ in (srcs[0], out, residual, sum_mul))):
+        y = conv2d(srcs, weights, None, act, slope, residual, dgrad=True)      # the kernel's epilogue form does not apply: a launch
+        return y, plane_sum(y, sum_mul).view(n, 1, -1)
     if dgrad and not use_x6s:      # (e.g. a large launch that the Winograd kernel takes)
         weights, dgrad = [dgrad_weight(weights[0])], False
     wp = None if use_x6s else pack_cache.get(weights)      # (the x6s kernel has its own packed form)
     part = None
+    if sum_mul is not None:      # (use_x6s holds)
+        part = torch.empty((n, lib().eavsr_conv3x3_x6s_tiles(h, w), cout), device=out.device, dtype=torch.float32)
     if chan_partial:
         tiles = (lib().eavsr_conv3x3_x6s_tiles(h, w) if use_x6s else lib().eavsr_conv5x5_wino_tiles(h, w) if use_wino5 else lib().eavsr_conv3x3_wino4_tiles(h, w) if use_wino4 else _wino_tiles(h, w) if use_wino
                  else lib().eavsr_conv2d_tiles(n, h, w, k))
@@ -727,6 +743,7 @@ def _conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequenc
     d.act = ACT[act]
     d.slope = float(slope)
     d.res_scale = _p(res_scale)
+    d.sum_mul = _p(sum_mul)
     pieces = None
     if (border and chan_partial and use_wino4 and cout == 64 and cin % 8 == 0 and ca is None and not pixel_shuffle2 and res_scale is None
             and lib().eavsr_wino4_schedule() == 1):
@@ -759,7 +776,7 @@ def _conv2d(srcs: Union[Tensor, Sequence[Tensor]], weight: Union[Tensor, Sequenc
         _launch(f"conv3x3_{cin}to{cout}_x6s", 2.0 * cin * cout * 9 * px,
                 4.0 * px * (cin + cout + (cout if residual is not None else 0)), out,
                 lambda: lib().eavsr_conv3x3_f32x6s(C.byref(d), _p(wq), st), "conv3x3_f32x6s")
-        return out if not chan_partial else (out, part)
+        return out if not (chan_partial or sum_mul is not None) else (out, part)
     if use_wino5:
         wu = _packed_wino(weights, kind="f5")
         _launch(f"conv5x5_{cin}to{cout}_wino", 2.0 * cin * cout * 25 * px,
@@ -1537,11 +1554,12 @@ def rcab_tail_bwd_supported(c: int, cr: int) -> bool:
 
 
 def rcab_tail_bwd(d: Tensor, r: Tensor, mean: Tensor, scale: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor,
-                  grads=None, accumulate: bool = False):
+                  grads=None, accumulate: bool = False, dsum: Optional[Tensor] = None):
     """Backward of out = r * sigmoid(W2 relu(W1 mean_hw(r) + b1) + b2) + x w.r.t. r and the four MLP parameters: the plane
     sums sum_hw d r, then ONE launch (eavsr_rcab_tail_bwd_f32) for the MLP's backward, the broadcast of the mean's gradient and
     dr = d * scale + dmean / hw.  `grads` = (dw1, db1, dw2, db2) buffers to write or, with `accumulate`, to add to; fresh ones
-    when None.  Returns (dr, dw1, db1, dw2, db2)."""
+    when None.  dsum: (n, rows, c) partial sums of d * r that the launch adds up itself (conv2d(.., dgrad=True, sum_mul=r) where d was
+    produced) -- then there is no plane-sum launch.  Returns (dr, dw1, db1, dw2, db2)."""
     d, r, mean, scale = _chk(d, "d"), _chk(r, "r"), _chk(mean, "mean"), _chk(scale, "scale")
     w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
     n, c, h, w = d.shape
@@ -1557,7 +1575,13 @@ def rcab_tail_bwd(d: Tensor, r: Tensor, mean: Tensor, scale: Tensor, w1: Tensor,
         mean_rows = 0
     else:
         raise ValueError("rcab_tail_bwd: mean must be (n, c) or (n, rows, c)")
-    dscale = plane_sum(d, r)
+    if dsum is not None:
+        dsum = _chk(dsum, "dsum")
+        if dsum.dim() != 3 or tuple(dsum.shape[::2]) != (n, c):
+            raise ValueError("rcab_tail_bwd: dsum must be (n, rows, c)")
+        dscale, ds_rows = dsum, int(dsum.shape[1])
+    else:
+        dscale, ds_rows = plane_sum(d, r), 0
     if grads is None:
         grads = (torch.empty_like(w1), torch.empty_like(b1), torch.empty_like(w2), torch.empty_like(b2))
         accumulate = False
@@ -1566,7 +1590,8 @@ def rcab_tail_bwd(d: Tensor, r: Tensor, mean: Tensor, scale: Tensor, w1: Tensor,
     st = _stream(d)
     _launch("rcab_tail_bwd", 2.0 * d.numel(), 8.0 * d.numel(), d,
             lambda: lib().eavsr_rcab_tail_bwd_f32(_p(d), _p(scale), _p(mean), _p(w1), _p(b1), _p(w2), _p(b2), _p(dscale), _p(dr),
-                                                  _p(dw1), _p(db1), _p(dw2), _p(db2), n, c, cr, h * w, mean_rows, int(accumulate), st),
+                                                  _p(dw1), _p(db1), _p(dw2), _p(db2), n, c, cr, h * w, mean_rows, ds_rows,
+                                                  int(accumulate), st),
             "rcab_tail_bwd")
     return dr, dw1, db1, dw2, db2
 

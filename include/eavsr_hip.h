@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EAVSR_ABI_VERSION 29
+#define EAVSR_ABI_VERSION 30
 
 /* activation codes for eavsr_conv2d_f32 */
 #define EAVSR_ACT_NONE 0
@@ -206,6 +206,12 @@ typedef struct eavsr_conv2d_desc {
    * input, and summing them was a launch of its own on every block's dependent chain.  Every other entry point returns -2. */
   float* border_pieces;
   int32_t border_stride; /* >= max(p_rows, p_cols) */
+  /* NULL, or (n, cout, h, w) fp32 (ABI 30; eavsr_conv3x3_f32x6s only, with chan_partial, w % 4 == 0, 16-byte aligned tensors):
+   * chan_partial then holds the per-tile channel sums of out * sum_mul -- of the values the launch STORES (after activation and
+   * residual) -- instead of the sums of act(conv + bias): the plane sums `sum_hw d r` that the backward of RCABlock's tail
+   * (models/networks.py:463-464) starts with, taken where d is produced (the previous block's input-gradient convolution) instead
+   * of by a launch of their own.  Every other entry point returns -2 for a non-NULL value. */
+  const float* sum_mul;
 } eavsr_conv2d_desc;
 
 /* sizeof(eavsr_conv2d_desc) as THIS library was compiled (ABI 28): a binding compares it with its own struct at load time, so
@@ -410,11 +416,13 @@ int eavsr_ca_mlp_bwd_f32(const float* mean, const float* w1, const float* b1, co
  * dmean[n,c] / hw with dmean from the MLP's backward, and the four parameter gradients summed over n in a fixed order, written
  * (accumulate = 0) or ADDED (accumulate != 0) to dw1 (cr, 64), db1 (cr), dw2 (64, cr), db2 (64).  c = 64, cr in {1, 2, 4, 8};
  * other shapes: eavsr_ca_mlp_bwd_f32 + eavsr_scale_residual_bwd_f32.  mean_rows = 0: `mean` is (n, 64); mean_rows > 0: `mean` is the
- * convolution epilogue's (n, mean_rows, 64) partial channel SUMS of r, added up and divided by hw here. */
+ * convolution epilogue's (n, mean_rows, 64) partial channel SUMS of r, added up and divided by hw here.  dscale_rows (ABI 30) = 0:
+ * `dscale` is (n, 64); > 0: `dscale` is (n, dscale_rows, 64) partial sums of d r -- the rows eavsr_conv3x3_f32x6s leaves with
+ * desc.sum_mul = r where it produces d -- added up here in row order: no plane-sum launch. */
 int eavsr_rcab_tail_bwd_f32(const float* d, const float* scale, const float* mean, const float* w1, const float* b1,
                             const float* w2, const float* b2, const float* dscale, float* dr, float* dw1, float* db1,
                             float* dw2, float* db2, int32_t n, int32_t c, int32_t cr, int32_t hw, int32_t mean_rows,
-                            int32_t accumulate, void* stream);
+                            int32_t dscale_rows, int32_t accumulate, void* stream);
 /* backward of eavsr_flow_warp_f32 (zeros padding, NCHW flow): dx (pre-zeroed, accumulated with float
  * atomics; NULL = skip) and dflow (n,2,h,w; NULL = skip).  flow2 as in the forward. */
 int eavsr_flow_warp_bwd_f32(const float* x, const float* flow, const float* flow2, const float* dout,

@@ -809,3 +809,81 @@ def test_propagate_partial_freeze_keeps_autograd(AG, cuda):
             assert H.maxabs(p.grad.cpu(), gf[k].grad.cpu()) <= 5e-3 * scale + 1e-4 * gmax, k
             checked += 1
     assert checked > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 96, 96), (1, 19, 37), (3, 40, 64), (2, 180, 320)])
+def test_input_gradient_convolution_leaves_the_next_tail_backwards_plane_sums(cuda, shape):
+    """conv2d(dY, W, dgrad=True, residual=d, sum_mul=m) (round 6; desc.sum_mul of eavsr_conv3x3_f32x6s): the same output bits as
+    without sum_mul, and rows whose sum over the plane's tiles is sum_hw out * m -- in the epilogue of the small-launch bf16x6
+    kernel at a training crop, by a plane-sum launch behind the kernels that take ragged widths / large launches"""
+    from eavsr_amd import ops
+    n, h, w = shape
+    dy, d, m = cases.randn(41, n, 64, h, w).to(cuda), cases.randn(42, n, 64, h, w).to(cuda), cases.randn(43, n, 64, h, w).to(cuda)
+    wt = cases.randn(44, 64, 64, 3, 3, scale=1.0 / 24).to(cuda)
+    ref = ops.conv2d(dy, wt, None, residual=d, dgrad=True)
+    with ops.profile() as prof:
+        out, rows = ops.conv2d(dy, wt, None, residual=d, dgrad=True, sum_mul=m)
+    assert torch.equal(out, ref)
+    assert rows.dim() == 3 and rows.shape[0] == n and rows.shape[2] == 64
+    want = (out.double() * m.double()).sum((2, 3))
+    got = rows.double().sum(1)
+    assert H.maxabs(got.cpu(), want.cpu()) <= 2e-6 * max(1.0, (out.double().abs() * m.double().abs()).sum((2, 3)).max().item())
+    names = set(prof.summary())
+    if shape == (2, 96, 96):
+        assert names == {"conv3x3_64to64_x6s"}, names      # the epilogue form: ONE launch
+    elif shape in ((1, 19, 37), (2, 180, 320)):
+        assert "plane_sum" in names, names
+    with pytest.raises(ValueError):
+        ops.conv2d(dy, wt, None, sum_mul=m)      # forward convolutions do not take it
+
+
+@pytest.mark.gpu
+def test_consecutive_rcabs_hand_the_plane_sums_over(AG, cuda):
+    """Four RCABs in a row (autograd._RcabFn): block k + 1's last input-gradient convolution leaves sum_hw dx * r_k in its epilogue,
+    block k's tail backward adds the rows up itself -- one plane-sum launch (the LAST block's, whose d comes from outside) instead
+    of four; gradients equal the unchained form's to rounding, and CPU autograd through the oracle's blocks; a block whose output
+    is used twice (autograd ADDS the two gradients: the tensor it receives is not the one its successor returned) falls back"""
+    from eavsr_amd import ops
+    sd = H.filled(H.rcagroup_shapes("g.", 4), "trained_like")
+    keys = [k for k in sd if k.startswith("g.rg.") and not k.startswith("g.rg.4.")]
+    x, G = cases.randn(51, 2, 64, 96, 96), cases.randn(52, 2, 64, 96, 96)
+
+    def run(chain, twice=False):
+        AG.RCAB_CHAIN = chain
+        gp = {k: torch.nn.Parameter(sd[k].to(cuda)) for k in keys}
+        gx = leaf(x, cuda)
+        with ops.profile() as prof:
+            with AG.grad_sink():
+                y, mid = gx * 1.0, None
+                for b in range(4):
+                    p = f"g.rg.{b}."
+                    y = AG.rcab(y, gp[p + "res.0.weight"], gp[p + "res.0.bias"], gp[p + "res.2.weight"], gp[p + "res.2.bias"],
+                                gp[p + "ca.conv_du.0.weight"], gp[p + "ca.conv_du.0.bias"], gp[p + "ca.conv_du.2.weight"],
+                                gp[p + "ca.conv_du.2.bias"])
+                    if b == 1:
+                        mid = y
+                loss = (y * G.to(cuda)).sum() + ((mid * mid).sum() * 0.5 if twice else 0.0)
+                loss.backward()
+        return [gx.grad] + [gp[k].grad for k in keys], prof.summary()
+
+    try:
+        got_c, prof_c = run(True)
+        got_u, prof_u = run(False)
+        got_t, prof_t = run(True, twice=True)
+        got_tu, _ = run(False, twice=True)
+    finally:
+        AG.RCAB_CHAIN = True
+    assert prof_u["plane_sum"]["calls"] == 4 and prof_c["plane_sum"]["calls"] == 1, (prof_u["plane_sum"], prof_c["plane_sum"])
+    assert prof_t["plane_sum"]["calls"] == 2      # block 1's output has two consumers: its d is a sum autograd made
+    for a, b, k in zip(got_c, got_u, ["x"] + keys):
+        assert H.maxabs(a.cpu(), b.cpu()) <= 2e-6 * max(1.0, b.abs().max().item()), k
+    for a, b, k in zip(got_t, got_tu, ["x"] + keys):
+        assert H.maxabs(a.cpu(), b.cpu()) <= 2e-6 * max(1.0, b.abs().max().item()), k
+    cp = {k: leaf(sd[k]) for k in keys}
+    cx = leaf(x)
+    y = cx
+    for b in range(4):
+        y = O.rcab({**sd, **cp}, f"g.rg.{b}.", y)
+    ref = grads(y, G, [cx] + [cp[k] for k in keys])
+    check(got_c, ref, 1e-4, ["x"] + keys)

@@ -395,6 +395,11 @@ def test_config3_gradients_at_the_bench_shape_match_oracle_autograd(cuda):
     # round 6: DCNv2's backward runs on the sampler's side (csrc/dcn_bwd.hip) -- no column tensor, no im2col / col2im launches
     assert "dcnv2_bwd" in names and not ({"dcnv2_im2col", "dcnv2_col2im"} & names), names
     assert ops.lib().eavsr_wgrad3_mode() == 1
+    # round 6 (late): consecutive RCABs hand the plane sums `sum_hw d r` over -- they leave the epilogue of the next block's last
+    # input-gradient convolution (desc.sum_mul); only a group's LAST block (its d comes from the group's closing convolution) still
+    # launches them
+    summ = prof.summary()
+    assert summ["plane_sum"]["calls"] * 10 <= summ["rcab_tail_bwd"]["calls"], (summ["plane_sum"]["calls"], summ["rcab_tail_bwd"]["calls"])
     watch = ["conv_last.weight", "backbone.forward_2.main.2.rg.3.res.0.weight", "backbone.backward_1.main.2.rg.29.res.2.weight",
              "backbone.forward_1.main.2.rg.30.weight", "backbone.backward_2.main.0.weight", "fusion.backward_1.weight",
              "deform_align.forward_1.weight", "deform_align.backward_2.adastn.mask_conv.bias",
