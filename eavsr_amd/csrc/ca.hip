@@ -118,6 +118,39 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
   float* s_scale = hid + cr;
   const int bn = blockIdx.y;
   const int tid = threadIdx.x;
+  // Training form (scale_out != NULL; round 6): everything the phases below read is requested HERE, in front of the first barrier --
+  // the MLP's parameters (64 channels, <= 8 hidden units) and the slice's first four pieces of r and x per thread.  Behind their
+  // barriers they were the second, third and fourth round trip of a launch that sits on every RCAB's dependent chain (9.0 us per
+  // launch at a 96 x 96 crop); the arithmetic and its order are unchanged.
+  const bool pre = scale_out != nullptr && c == 64 && cr <= 8;
+  float pw1[64], pw2[8], pb1 = 0.f, pb2 = 0.f;
+  f32x4 pa[4], pbx[4];
+  size_t po[4];
+  int pch[4];
+  const int p0_ = blockIdx.x * slice, len_ = min(slice, hw4 - p0_), total_ = len_ * c;
+  if (pre) {
+    if (tid < cr) {
+      pb1 = b1[tid];
+#pragma unroll
+      for (int k = 0; k < 64; ++k) pw1[k] = w1[tid * 64 + k];
+    }
+    if (tid < 64) {
+      pb2 = b2[tid];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pw2[j] = j < cr ? w2[tid * cr + j] : 0.f;
+    }
+    const f32x4* r4p = reinterpret_cast<const f32x4*>(r) + (size_t)bn * c * hw4 + p0_;
+    const f32x4* x4p = reinterpret_cast<const f32x4*>(x) + (size_t)bn * c * hw4 + p0_;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int f = tid + u * CT_THREADS;
+      const bool ok = f < total_;
+      pch[u] = ok ? f / len_ : 0;
+      po[u] = ok ? (size_t)pch[u] * hw4 + (f - pch[u] * len_) : 0;
+      pa[u] = r4p[po[u]];
+      pbx[u] = x4p[po[u]];
+    }
+  }
   // 1. mean + MLP (ca_scale_kernel's arithmetic, one logical thread at a time)
   for (int lt = tid; lt < Q * c; lt += CT_THREADS) {
     const int q = lt / c, ch = lt - q * c;
@@ -139,16 +172,33 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
     mean[ch] = s * inv_hw;
   }
   __syncthreads();
-  if (tid < cr) {
-    float v = b1[tid];
-    for (int k = 0; k < c; ++k) v += w1[tid * c + k] * mean[k];
-    hid[tid] = fmaxf(v, 0.f);
-  }
-  __syncthreads();
-  for (int ch = tid; ch < c; ch += CT_THREADS) {
-    float v = b2[ch];
-    for (int j = 0; j < cr; ++j) v += w2[ch * cr + j] * hid[j];
-    s_scale[ch] = 1.f / (1.f + expf(-v));
+  if (pre) {
+    if (tid < cr) {
+      float v = pb1;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) v += pw1[k] * mean[k];
+      hid[tid] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float v = pb2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < cr) v += pw2[j] * hid[j];
+      s_scale[tid] = 1.f / (1.f + expf(-v));
+    }
+  } else {
+    if (tid < cr) {
+      float v = b1[tid];
+      for (int k = 0; k < c; ++k) v += w1[tid * c + k] * mean[k];
+      hid[tid] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += CT_THREADS) {
+      float v = b2[ch];
+      for (int j = 0; j < cr; ++j) v += w2[ch * cr + j] * hid[j];
+      s_scale[ch] = 1.f / (1.f + expf(-v));
+    }
   }
   __syncthreads();
   // (training: the backward of CALayer needs the attention and the channel means -- written once per sample)
@@ -167,7 +217,21 @@ __global__ __launch_bounds__(CT_THREADS) void ca_tail_kernel(const float* __rest
   const int dch = CT_THREADS / len, dcol = CT_THREADS - dch * len;
   if (scale_out != nullptr) {
     // the training step's form (one stream, nothing to co-reside with): four pieces per thread in flight instead of one
-    for (int f = tid; f < total; f += 4 * CT_THREADS) {
+    int f_first = tid;
+    if (pre) {      // the first four pieces arrived while the phases above ran
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (tid + u * CT_THREADS < total) {
+          const float sv = s_scale[pch[u]];
+          f32x4 v;
+          v[0] = pa[u][0] * sv + pbx[u][0]; v[1] = pa[u][1] * sv + pbx[u][1]; v[2] = pa[u][2] * sv + pbx[u][2]; v[3] = pa[u][3] * sv + pbx[u][3];
+          o4[po[u]] = v;
+        }
+      f_first = tid + 4 * CT_THREADS;
+      ch = f_first / len;      // (ch, col) of piece f_first
+      col = f_first - ch * len;
+    }
+    for (int f = f_first; f < total; f += 4 * CT_THREADS) {
       f32x4 a[4], b[4];
       size_t o[4];
       float sv[4];
