@@ -99,6 +99,7 @@ SIGNATURES = {
     "eavsr_conv_weight_x6_bytes": (C.c_size_t, [i32, i32, i32]),
     "eavsr_pack_conv_weight_x6": (C.c_int, [vp, vp, i32, i32, i32, vp]),
     "eavsr_pack_conv_weight_x6_dgrad": (C.c_int, [vp, vp, i32, i32, i32, vp]),
+    "eavsr_pack_conv_weight_x6_multi": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_conv_f32x6": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp]),
     "eavsr_ca_scale_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "eavsr_ca_scale_mean_f32": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -412,6 +412,49 @@ __global__ void pack7_kernel(const float* __restrict__ wt, u32x4* __restrict__ p
   p[e] = o;
 }
 
+// pack7_kernel for up to PM_MAX weights of ONE shape in one launch (blockIdx.y = weight; pointers by value in the kernel arguments,
+// so that the launch captures into a HIP graph): the training step re-packs every 3x3 64 -> 64 weight and its input-gradient form
+// once per step -- 540 launches of 4.7 us on the step's one dependent chain as single-weight launches (round 6)
+constexpr int PM_MAX = 48;
+struct PackMultiArgs {
+  const float* src[PM_MAX];
+  u32x4* dst[PM_MAX];
+  unsigned long long tr_mask;      // bit t: weight t is packed transposed and flipped (its input-gradient form)
+};
+__global__ void pack7_multi_kernel(PackMultiArgs a, int cout, int cin, int kk, int mt_n, long total) {
+  const int t = blockIdx.y;
+  const int tr = (int)((a.tr_mask >> t) & 1ull);
+  const float* __restrict__ wt = a.src[t];
+  u32x4* __restrict__ p = a.dst[t];
+  const int ksteps = (kk + 1) / 2;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  long q = e;
+  const int lane = (int)(q % 64); q /= 64;
+  const int mt = (int)(q % mt_n); q /= mt_n;
+  const int pl = (int)(q % 3); q /= 3;
+  const int s = (int)(q % ksteps); q /= ksteps;
+  const int nch = cin / 8;
+  const int ch = (int)(q % nch);
+  const int cot = (int)(q / nch);
+  const int co = cot * 32 * mt_n + mt * 32 + (lane & 31);
+  const int tap = 2 * s + (lane >> 5);
+  u32x4 o;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ci = ch * 8 + 2 * c + u;
+      v[u] = (co < cout && tap < kk) ? (tr ? wt[((size_t)ci * cout + co) * kk + (kk - 1 - tap)] : wt[((size_t)co * cin + ci) * kk + tap]) : 0.f;
+    }
+    unsigned h2, m2, l2;
+    s_split2(v[0], v[1], h2, m2, l2);
+    o[c] = pl == 0 ? h2 : pl == 1 ? m2 : l2;
+  }
+  p[e] = o;
+}
+
 int mt_of(int cout) { return cout > 32 ? 2 : 1; }
 
 template <int KS, int MT, int NT, int WMT, int NP = 3, int DT = 0>
@@ -494,6 +537,31 @@ extern "C" int eavsr_pack_conv_weight_x6_dgrad(const float* weight, void* packed
   hipLaunchKernelGGL(pack7_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, eavsr::as_stream(stream), weight,
                      reinterpret_cast<u32x4*>(packed), cin_w, cout_w, ksize * ksize, mt_of(cin_w), total, 3, 0, 1);
   return eavsr::launch_status("pack_conv_weight_x6_dgrad");
+}
+
+// `count` weights of one SQUARE shape (c, c, ksize, ksize) in ceil(count / 48) launches: weights[t] -> packed[t], transposed[t] != 0:
+// the input-gradient form (eavsr_pack_conv_weight_x6_dgrad).  The three arrays are HOST arrays, read at the call.
+extern "C" int eavsr_pack_conv_weight_x6_multi(const float* const* weights, void* const* packed, const int32_t* transposed, int32_t count,
+                                               int32_t ksize, int32_t c, void* stream) {
+  EAVSR_REQUIRE(count >= 0 && (count == 0 || (weights && packed && transposed)), -1, "pack_conv_weight_x6_multi: NULL pointer");
+  EAVSR_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, -2, "pack_conv_weight_x6_multi: kernel size %d (3, 5 and 7 only)", ksize);
+  EAVSR_REQUIRE(c > 0 && c % 8 == 0, -1, "pack_conv_weight_x6_multi: %d channels must be a multiple of 8", c);
+  const long total = (long)(eavsr_conv_weight_x6_bytes(ksize, c, c) / 16);
+  for (int t0 = 0; t0 < count; t0 += PM_MAX) {
+    PackMultiArgs a;
+    a.tr_mask = 0ull;
+    const int m = count - t0 < PM_MAX ? count - t0 : PM_MAX;
+    for (int t = 0; t < PM_MAX; ++t) {
+      const int u = t < m ? t0 + t : t0;      // (unused slots repeat a valid pair; blockIdx.y never reaches them)
+      EAVSR_REQUIRE(weights[u] && packed[u], -1, "pack_conv_weight_x6_multi: NULL pointer in entry %d", u);
+      a.src[t] = weights[u];
+      a.dst[t] = reinterpret_cast<u32x4*>(packed[u]);
+      if (t < m && transposed[u]) a.tr_mask |= 1ull << t;
+    }
+    hipLaunchKernelGGL(pack7_multi_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)m), dim3(256), 0, eavsr::as_stream(stream), a, c, c,
+                       ksize * ksize, mt_of(c), total);
+  }
+  return eavsr::launch_status("pack_conv_weight_x6_multi");
 }
 
 extern "C" int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin,

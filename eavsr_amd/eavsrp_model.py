@@ -23,6 +23,9 @@ from . import autograd as AG
 from . import networks as N
 from . import ops
 
+# EAVSR_PREPACK=0: every weight's packed forms at their first use (the A/B switch of ops.prepack_conv3_x6)
+PREPACK = os.environ.get("EAVSR_PREPACK", "1") != "0"
+
 # In the 16-bit modes the upsampling tail (conv + PixelShuffle stages, conv_hr, conv_last) runs on the 16-bit kernels as well;
 # EAVSR_TAIL_16BIT=0 keeps it on the fp32 kernels (A/B switch).
 TAIL_IN_16BIT = os.environ.get("EAVSR_TAIL_16BIT", "1") == "1"
@@ -229,6 +232,10 @@ class EAVSRP(nn.Module):
         if not lrs.is_cuda:
             raise RuntimeError("eavsr_amd.EAVSRP runs on the GPU only (no CPU path); for a CPU reference use "
                                "the original repository with --gpu_ids -1")
+        if torch.is_grad_enabled() and PREPACK and ops.x6s_takes(n, h, w):
+            # training at a crop: the packed forms (forward + input-gradient) of every trainable 3x3 64 -> 64 weight in a handful of
+            # launches here instead of one launch per weight and form at its first use (ops.prepack_conv3_x6)
+            ops.prepack_conv3_x6([p_ for p_ in self.parameters() if p_.requires_grad and p_.dim() == 4 and tuple(p_.shape) == (64, 64, 3, 3)])
         # frame-major input so that every per-frame slice (of the input, the features, the flows) is contiguous
         lr_tm = lrs.transpose(0, 1).reshape(t * n, c, h, w)
         with torch.no_grad():

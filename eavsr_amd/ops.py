@@ -384,6 +384,45 @@ def _packed_conv_x6(weights: Sequence[Tensor], dgrad: bool = False) -> Tensor:
     return packed
 
 
+def prepack_conv3_x6(weights: Sequence[Tensor]) -> int:
+    """Both packed forms (forward and input-gradient) of every (64, 64, 3, 3) weight in `weights` that the cache does not hold at
+    the weight's current version, in ceil(count / 48) launches (eavsr_pack_conv_weight_x6_multi) instead of one launch per weight and
+    form at its first use: what the training step calls once, in front of its forward (540 launches of 4.7 us on its one dependent
+    chain otherwise).  Returns the number of forms packed."""
+    todo = []
+    for w in weights:
+        if tuple(w.shape) != (64, 64, 3, 3) or not w.is_cuda or not w.is_contiguous() or w.dtype != torch.float32:
+            continue
+        for dg in (False, True):
+            key = ((id(w), w._version),) + ((("dgrad", 0),) if dg else ())
+            hit = _conv7_pack_cache.get(key)
+            if hit is None or hit[0][0]() is not w:
+                todo.append((w, dg, key))
+    if not todo:
+        return 0
+    dev = todo[0][0].device
+    nbytes = int(lib().eavsr_conv_weight_x6_bytes(3, 64, 64))
+    store = torch.empty((len(todo), nbytes), device=dev, dtype=torch.uint8)
+    cnt = len(todo)
+    srcs = (C.c_void_p * cnt)(*[w.detach().data_ptr() for w, _, _ in todo])
+    dsts = (C.c_void_p * cnt)(*[store[i].data_ptr() for i in range(cnt)])
+    trs = (C.c_int32 * cnt)(*[int(dg) for _, dg, _ in todo])
+    with _DeviceOf(todo[0][0]):
+        N.check(lib().eavsr_pack_conv_weight_x6_multi(srcs, dsts, trs, cnt, 3, 64, _stream(todo[0][0])), "pack_conv_weight_x6_multi")
+    for i, (w, dg, key) in enumerate(todo):
+        for k_ in [k_ for k_ in _conv7_pack_cache if (k_[-1] == ("dgrad", 0)) == dg and any(i_ == id(w) for i_, _ in k_ if isinstance(i_, int))]:
+            _conv7_pack_cache.pop(k_, None)
+        refs = (weakref.ref(w, lambda _r, k_=key, c=_conv7_pack_cache: c.pop(k_, None)),)
+        _conv7_pack_cache[key] = (refs, store[i])
+    return cnt
+
+
+def x6s_takes(n: int, h: int, w: int) -> bool:
+    """a single-source 3x3 64 -> 64 launch of this size runs on eavsr_conv3x3_f32x6s (the crop-sized bf16x6 kernel) in the current mode"""
+    return (CONV3_SMALL == "x6s" and CONV_MODE in ("winograd", "winograd4") and CONV3_H16 is None
+            and n * lib().eavsr_conv3x3_x6s_tiles(h, w) <= X6S_MAX_TILES)
+
+
 def _conv_x6(x: Tensor, weights, biases, act, slope, sigmoid_from: int = -1):
     n, cin, h, w = x.shape
     cout = sum(int(w_.shape[0]) for w_ in weights)

@@ -291,6 +291,12 @@ int eavsr_pack_conv_weight_x6(const float* weight, void* packed, int32_t ksize, 
  * materialised copy (loss.backward() of every nn.Conv2d of RCABlock, models/networks.py:456-464; eavsrp_model.py:109-113).  The
  * result packs a (cin_w output, cout_w input)-channel convolution: eavsr_conv_weight_x6_bytes(ksize, cin_w, cout_w) bytes. */
 int eavsr_pack_conv_weight_x6_dgrad(const float* weight, void* packed, int32_t ksize, int32_t cout_w, int32_t cin_w, void* stream);
+/* `count` weights of one square shape (c, c, ksize, ksize) packed in ceil(count / 48) launches (ABI 30): weights[t] -> packed[t]
+ * (eavsr_conv_weight_x6_bytes(ksize, c, c) bytes each), transposed[t] != 0: the input-gradient form.  HOST arrays of device pointers,
+ * read at the call (pointers travel by value in the kernel arguments: the launch captures into a graph).  The training step's
+ * 3x3 64 -> 64 weights (models/networks.py:456-458) and their input-gradient forms, once per step. */
+int eavsr_pack_conv_weight_x6_multi(const float* const* weights, void* const* packed, const int32_t* transposed, int32_t count,
+                                    int32_t ksize, int32_t c, void* stream);
 int eavsr_conv_f32x6(const float* x, const void* weight_x6, const float* bias, float* out, int32_t n, int32_t cin, int32_t cout,
                      int32_t h, int32_t w, int32_t ksize, int32_t act, float slope, int32_t sigmoid_from, void* stream);
 /* The 3x3 form for SMALL launches (ABI 27): 64 input channels, one source, the same exact bf16x6 arithmetic; the descriptor's bias,

@@ -887,3 +887,26 @@ def test_consecutive_rcabs_hand_the_plane_sums_over(AG, cuda):
         y = O.rcab({**sd, **cp}, f"g.rg.{b}.", y)
     ref = grads(y, G, [cx] + [cp[k] for k in keys])
     check(got_c, ref, 1e-4, ["x"] + keys)
+
+
+def test_prepacked_weight_forms_equal_the_single_packs(cuda):
+    """ops.prepack_conv3_x6 (eavsr_pack_conv_weight_x6_multi: up to 48 weights per launch, pointers by value): the forward and the
+    input-gradient form of every weight equal the single-weight packs bit for bit, the cache serves them afterwards, a weight that
+    changed in place (its version moved) is packed again and only that one"""
+    from eavsr_amd import ops
+    from eavsr_amd.graph import clear_weight_caches
+    ws = [cases.randn(700 + i, 64, 64, 3, 3, scale=1.0 / 24).to(cuda) for i in range(50)]      # (> 48: two launches)
+    clear_weight_caches()
+    single = [(ops._packed_conv_x6([w]).clone(), ops._packed_conv_x6([w], dgrad=True).clone()) for w in ws]
+    clear_weight_caches()
+    assert ops.prepack_conv3_x6(ws + [cases.randn(9, 32, 64, 3, 3).to(cuda)]) == 100      # (another shape is left alone)
+    for w, (f, d) in zip(ws, single):
+        assert torch.equal(ops._packed_conv_x6([w]), f) and torch.equal(ops._packed_conv_x6([w], dgrad=True), d)
+    assert ops.prepack_conv3_x6(ws) == 0
+    ws[7].mul_(2.0)
+    assert ops.prepack_conv3_x6(ws) == 2
+    assert torch.equal(ops._packed_conv_x6([ws[7]]), ops._packed_conv_x6([ws[7].clone()]))
+    x = cases.randn(3, 2, 64, 96, 96).to(cuda)
+    y = ops.conv2d(x, ws[7], None)
+    clear_weight_caches()
+    assert torch.equal(ops.conv2d(x, ws[7], None), y)
