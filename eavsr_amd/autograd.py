@@ -513,12 +513,15 @@ class _RcabFn(Function):
         ctx.save_for_backward(x, t, r, mean, scale, w1, w2, wa, ba, wb, bb, r_prev)
         ctx.params = ([w1], [b1], [w2], [b2], [wa, ba, wb, bb])      # the caller's tensor objects (grad_sink keys on them)
         ctx.mark_non_differentiable(r)
+        ctx.set_materialize_grads(False)      # (autograd otherwise fills a zero gradient of r's size for the second output: 845 fills per step)
         return out, r
 
     @staticmethod
     def backward(ctx, d, _dr_unused=None):
         x, t, r, mean, scale, w1, w2, wa, ba, wb, bb, r_prev = ctx.saved_tensors
         pw1, pb1, pw2, pb2, pca = ctx.params
+        if d is None:      # (the block's output reached no loss term)
+            return (None,) * 10
         d = d.contiguous()
         sink = grad_sink._active if grad_sink.eligible(pw1 + pb1 + pw2 + pb2 + pca) else None
         # tail: the plane sums of d * r, then one launch (MLP backward, mean broadcast, dr; the mean came out of the forward's

@@ -28,5 +28,9 @@ for ev in prof.events():
         top = st[0] if st else (ev.stack[0] if ev.stack else "<no python frame: autograd engine>")
         shp = str(ev.input_shapes)[:60] if ev.input_shapes else ""
         cnt[(ev.name, top[-90:], shp)] += 1
-for (name, where, shp), c in cnt.most_common(60):
+import os
+only = os.environ.get('ONLY')
+for (name, where, shp), c in cnt.most_common(int(os.environ.get('TOP', '60'))):
+    if only and name not in only.split(','):
+        continue
     print(f"{c:5d}  {name:18s} {where}  {shp}")
