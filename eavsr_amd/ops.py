@@ -2016,7 +2016,6 @@ def conv3x3_c64_h16(x: Tensor, weight: Tensor, bias: Optional[Tensor], relu: boo
     return (out, part) if chan_partial else out
 
 
-_ABLATE_CA_PRE = os.environ.get("EAVSR_ABLATE_CA_PRE", "0") == "1"      # measurement only
 
 
 def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Optional[Tensor], w1: Tensor, b1: Tensor,
@@ -2034,8 +2033,6 @@ def ca_scale_pre_h16(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias:
     w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
     cr = int(w1.shape[0])
     scale = torch.empty((n, 64), device=t.device, dtype=torch.float32)
-    if _ABLATE_CA_PRE:
-        return scale.fill_(0.5)
     st = _stream(t)
     if border is not None:      # the border lines as pieces from the first convolution's epilogue: ONE launch
         bd = _chk(border.data, "border pieces")
@@ -2066,8 +2063,6 @@ def ca_scale_pre(t: Tensor, partial: Tensor, conv_weight: Tensor, conv_bias: Opt
     w1, b1, w2, b2 = (_chk(v.detach(), "param") for v in (w1, b1, w2, b2))
     cr = int(w1.shape[0])
     scale = torch.empty((n, 64), device=t.device, dtype=torch.float32)
-    if _ABLATE_CA_PRE:      # timing ablation only (tools/visits/r6_f.sh): what the two small launches cost the STEP; results wrong
-        return scale.fill_(0.5)
     st = _stream(t)
     if border is not None:      # the border lines as pieces from the first convolution's epilogue: ONE launch
         bd = _chk(border.data, "border pieces")

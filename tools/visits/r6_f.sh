@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 6: what do the two small launches per RCAB (border sums + ca_scale_pre) cost the STEP?  Ablation: the attention replaced by a
 # constant fill (one tiny launch instead of two dependent latency-bound ones; results wrong), per configuration, in rotation.
+# (EAVSR_ABLATE_CA_PRE existed in eavsr_amd/ops.py while this measurement was made; removed afterwards: the product has no switch that returns wrong results)
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r6f
 for rep in 1 2; do
