@@ -580,7 +580,7 @@ class _Chain:
         self._sums_of_dx = {}
 
     def put_r(self, out, r):
-        if len(self._r_of_out) > 4096:      # (a forward without backward, over and over: keep the table bounded)
+        if len(self._r_of_out) > 64:      # (forwards without a backward, over and over: only a group's LAST block stays unconsumed)
             self._r_of_out.clear()
         self._r_of_out[id(out)] = (out, r)
 
@@ -589,7 +589,7 @@ class _Chain:
         return ent[1] if ent is not None and ent[0] is x else None
 
     def put_sums(self, dx, rows):
-        if len(self._sums_of_dx) > 4096:
+        if len(self._sums_of_dx) > 64:
             self._sums_of_dx.clear()
         self._sums_of_dx[id(dx)] = (dx, rows)
 
