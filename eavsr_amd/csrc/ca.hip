@@ -336,7 +336,7 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
                                                             float* __restrict__ scale, int cr) {
   constexpr int C = 64, Q = 1024 / C;
   __shared__ float part[Q * C];
-  __shared__ float T[C], B[4][C], Bq[4][4][C], X[4][C], S[9][C], mean[C], hid[C];
+  __shared__ float T[C], B[4][C], Bq[16][C], X[4][C], S[9][C], mean[C], hid[C];
   const int bn = blockIdx.x, tid = threadIdx.x;
   // every parameter this thread will need, requested now (each was a round trip of its own behind a barrier)
   const float bc_v = bc ? bc[tid >> 4] : 0.f;
@@ -351,6 +351,13 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
     const float* p = partial + (size_t)bn * rows * C + ch;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int r = q;
+    for (; r + 31 * Q < rows; r += 32 * Q) {      // (512 per-workgroup rows at 540 x 960: one round trip instead of two)
+      float v[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) v[j] = p[(size_t)(r + j * Q) * C];
+#pragma unroll
+      for (int j = 0; j < 32; j += 4) { s0 += v[j]; s1 += v[j + 1]; s2 += v[j + 2]; s3 += v[j + 3]; }
+    }
     for (; r + 15 * Q < rows; r += 16 * Q) {
       float v[16];
 #pragma unroll
@@ -367,21 +374,23 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
   }
   // border lines: the pieces of border b (0 top row, 1 bottom row: p_rows pieces; 2 left column, 3 right column: p_cols pieces) -- the
   // segments of the border-sum launch, or what the first convolution's epilogue left per border tile (round 6) -- added in a fixed
-  // order: thread (quarter qg, border b, channel ch) takes the pieces k = qg, qg + 4, .. with eight requests in flight, the four
-  // quarters meet in LDS
+  // order: a wave takes a border (rows) or a seventh of one (columns), sixteen requests in flight per lane, the waves meet in LDS
   {
-    // (quarter and border are the same for a whole wave: the bounds below are scalar branches, a request that no lane needs is
-    // not issued -- sixteen exec-masked requests per wave cost the one memory pipe of the CU 2 us)
-    const int qg = __builtin_amdgcn_readfirstlane(tid >> 8), b = __builtin_amdgcn_readfirstlane((tid >> 6) & 3), ch = tid & 63;
+    // (border and part are the same for a whole wave: the bounds below are scalar branches, a request that no lane needs is not
+    // issued -- sixteen exec-masked requests per wave cost the one memory pipe of the CU 2 us.)  Waves 0 / 1 take the row borders
+    // whole, waves 2 .. 8 / 9 .. 15 a seventh of a column border each: at 540 x 960 a column border holds 272 pieces against 30 of
+    // a row border, and as four equal quarters per border (rounds 5-6) the columns were five request round trips; three now.
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ch = tid & 63;
+    const int b = wv < 2 ? wv : 2 + (wv - 2) / 7, part = wv < 2 ? 0 : (wv - 2) % 7, nparts = wv < 2 ? 1 : 7;
     const int cnt = b < 2 ? p_rows : p_cols;
     const float* p = border + (((size_t)bn * 4 + b) * p_stride) * C + ch;
     float s0 = 0.f, s1 = 0.f;
-    for (int k = qg; k < cnt; k += 64) {      // sixteen predicated requests at once: one round trip for up to 64 pieces per border
+    for (int k = part; k < cnt; k += 16 * nparts) {      // sixteen predicated requests at once
       float v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         v[j] = 0.f;
-        if (k + 4 * j < cnt) v[j] = p[(size_t)(k + 4 * j) * C];
+        if (k + nparts * j < cnt) v[j] = p[(size_t)(k + nparts * j) * C];
       }
 #pragma unroll
       for (int j = 0; j < 16; j += 4) {
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
         s1 += v[j + 2] + v[j + 3];
       }
     }
-    Bq[qg][b][ch] = s0 + s1;
+    Bq[wv][ch] = s0 + s1;
   }
   if (tid < 4 * C) {      // corners: 0 = (0, 0), 1 = (0, w - 1), 2 = (h - 1, 0), 3 = (h - 1, w - 1)
     const int k = tid >> 6, ch = tid & 63;
@@ -411,7 +420,15 @@ __global__ __launch_bounds__(1024) void ca_scale_pre_kernel(const float* __restr
     T[tid] = v;
   } else if (tid >= 4 * C && tid < 8 * C) {
     const int b = (tid >> 6) - 4, ch = tid & 63;
-    B[b][ch] = (Bq[0][b][ch] + Bq[1][b][ch]) + (Bq[2][b][ch] + Bq[3][b][ch]);
+    // (a border's waves in wave order: deterministic)
+    float v;
+    if (b < 2) {
+      v = Bq[b][ch];
+    } else {
+      const int w0 = 2 + 7 * (b - 2);
+      v = ((Bq[w0][ch] + Bq[w0 + 1][ch]) + (Bq[w0 + 2][ch] + Bq[w0 + 3][ch])) + ((Bq[w0 + 4][ch] + Bq[w0 + 5][ch]) + Bq[w0 + 6][ch]);
+    }
+    B[b][ch] = v;
   }
   __syncthreads();
   if (tid < 9 * C) {      // S[tap][ci] = T - R(ky) - C(kx) + X(ky, kx)
